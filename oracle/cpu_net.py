@@ -1,0 +1,235 @@
+"""
+TEST INFRASTRUCTURE — spec-driven CPU runner for whole networks on top of oracle/cpu_ref.py.
+
+Runs the reference's training step (Handlers/Trainer.py:28-35: forward, cost, zeroGrad, backward in
+accumulate mode, optimizer update) for a network given as plain data (a "spec": nested lists of
+tuples, see puzzlelib_amd/nets.py which builds the device graph from the very same data). Only tests,
+smoke() and bench.py's cpu_baseline leg may use it. It shares no code with the product path.
+
+Spec entries:
+  ("conv", name, cin, cout, size, stride, pad, bias)   Modules/ConvND.py:76-95
+  ("bn", name, maps)                                   Modules/BatchNormND.py:47-83
+  ("relu", name)                                       Modules/Activation.py:69-76
+  ("maxpool", name, size, stride, pad)                 Modules/MaxPool2D.py:32-47
+  ("avgpool", name, size, stride, pad)                 Modules/AvgPool2D.py:17-24 (includePad=True)
+  ("dropout", name, p)                                 Modules/Dropout.py:33-76 (mask words supplied by caller)
+  ("flatten", name)                                    Modules/Flatten.py:18-24
+  ("linear", name, nin, nout)                          Modules/Linear.py:36-54
+  ("softmax", name)                                    Modules/SoftMax.py:16-30
+  ("resid", branch_spec, shortcut_spec)                Replicate(2) + Parallel + Add, Models/Nets/ResNet.py:39-66
+"""
+import math
+import numpy as np
+
+try:
+	from . import cpu_ref as R
+except ImportError:
+	import cpu_ref as R
+
+
+class CpuNet:
+	def __init__(self, spec, params, attrs=None, bn_epsilon=1e-5, bn_init_factor=1.0, bn_min_factor=0.1):
+		"""params: {"<name>.W": ndarray, ...}; attrs: {"<name>.mean"/".var": ndarray} for BN running stats."""
+		self.spec = spec
+		self.params = {k: np.array(v, dtype=np.float32) for k, v in params.items()}
+		self.attrs = {k: np.array(v, dtype=np.float32) for k, v in (attrs or {}).items()}
+		self.grads = {k: np.zeros_like(v) for k, v in self.params.items()}
+
+		self.eps, self.initFactor, self.minFactor = bn_epsilon, bn_init_factor, bn_min_factor
+		self.numOfProps = {}
+		self.train = True
+		self.cache = {}
+		self.dropmasks = {}
+
+
+	# ---------------------------------------------------------------- forward
+	def forward(self, x, spec=None, prefix=""):
+		spec = self.spec if spec is None else spec
+
+		for i, layer in enumerate(spec):
+			kind, key = layer[0], "%s%d" % (prefix, i)
+
+			if kind == "conv":
+				_, name, _, _, _, stride, pad, bias = layer
+				self.cache[key] = x
+				x = R.conv2d_fwd(x, self.params[name + ".W"], self.params[name + ".b"] if bias else None, stride, pad)
+
+			elif kind == "bn":
+				name = layer[1]
+				scale, bias = self.params[name + ".scale"].ravel(), self.params[name + ".bias"].ravel()
+				mean, var = self.attrs[name + ".mean"], self.attrs[name + ".var"]
+
+				if self.train:
+					n = self.numOfProps.get(name, 0) + 1
+					self.numOfProps[name] = n
+					factor = max(self.initFactor / n, self.minFactor)
+
+					y, smean, sinv = R.bn_fwd_train(x, scale, bias, mean, var, self.eps, factor)
+					self.cache[key] = (x, smean, sinv)
+					x = y
+				else:
+					x = R.bn_fwd_infer(x, scale, bias, mean.ravel(), var.ravel(), self.eps)
+
+			elif kind == "relu":
+				x = R.relu(x)
+				self.cache[key] = x
+
+			elif kind in ("maxpool", "avgpool"):
+				_, name, size, stride, pad = layer
+				mode = R.POOL_MAX if kind == "maxpool" else R.POOL_AVG_WITH_PAD
+				y = R.pool2d_fwd(x, size, stride, pad, mode)
+				self.cache[key] = (x, y)
+				x = y
+
+			elif kind == "dropout":
+				_, name, p = layer
+				if self.train:
+					keep = 1.0 - p
+					v = int(keep * np.iinfo(np.uint32).max)
+					x = R.dropout(x, self.dropmasks[name], v, keep)
+					self.cache[key] = (v, keep)
+
+			elif kind == "flatten":
+				self.cache[key] = x.shape
+				x = x.reshape(x.shape[0], -1)
+
+			elif kind == "linear":
+				name = layer[1]
+				self.cache[key] = x
+				x = R.gemm(x, self.params[name + ".W"])
+				x = R.add_vec_to_mat(self.params[name + ".b"], x, axis=1)
+
+			elif kind == "softmax":
+				x = R.softmax_fwd(x.reshape(x.shape + (1, ) * (4 - x.ndim))).reshape(x.shape)
+				self.cache[key] = x
+
+			elif kind == "resid":
+				_, branch, shortcut = layer
+				yb = self.forward(x, branch, key + ".b.")
+				ys = self.forward(x, shortcut, key + ".s.") if len(shortcut) > 0 else x
+				x = (np.zeros_like(yb) + yb) + ys
+
+			else:
+				raise NotImplementedError(kind)
+
+		return x
+
+
+	# ---------------------------------------------------------------- backward (accumulate: scale=1, momentum=1)
+	def backward(self, g, spec=None, prefix="", scale=1.0, momentum=1.0):
+		spec = self.spec if spec is None else spec
+
+		for i in reversed(range(len(spec))):
+			layer = spec[i]
+			kind, key = layer[0], "%s%d" % (prefix, i)
+
+			if kind == "conv":
+				_, name, _, _, _, stride, pad, bias = layer
+				x, W = self.cache[key], self.params[name + ".W"]
+
+				dx = R.conv2d_bwd_data(g, W, x.shape, stride, pad)
+				R.conv2d_bwd_filter(
+					x, g, W.shape, stride, pad, withbias=bias, wgrad=self.grads[name + ".W"],
+					bgrad=self.grads[name + ".b"] if bias else None, scale=scale, momentum=momentum
+				)
+				g = dx
+
+			elif kind == "bn":
+				name = layer[1]
+				x, smean, sinv = self.cache[key]
+				g, dscale, dbias = R.bn_bwd(g, x, self.params[name + ".scale"].ravel(), smean, sinv)
+
+				for pname, d in ((".scale", dscale), (".bias", dbias)):
+					gr = self.grads[name + pname]
+					gr[...] = R.add_scaled(d.reshape(gr.shape), scale, gr, momentum)
+
+			elif kind == "relu":
+				g = R.relu_der(g, self.cache[key])
+
+			elif kind in ("maxpool", "avgpool"):
+				_, name, size, stride, pad = layer
+				x, y = self.cache[key]
+				mode = R.POOL_MAX if kind == "maxpool" else R.POOL_AVG_WITH_PAD
+				g = R.pool2d_bwd(g, x, y, size, stride, pad, mode)
+
+			elif kind == "dropout":
+				_, name, p = layer
+				if self.train:
+					v, keep = self.cache[key]
+					g = R.dropout(g, self.dropmasks[name], v, keep)
+
+			elif kind == "flatten":
+				g = g.reshape(self.cache[key])
+
+			elif kind == "linear":
+				name = layer[1]
+				x, W = self.cache[key], self.params[name + ".W"]
+
+				dx = R.gemm(g, W, transpB=True)
+				R.gemm(x, g, out=self.grads[name + ".W"], transpA=True, alpha=scale, beta=momentum)
+				R.matsum(g, axis=0, out=self.grads[name + ".b"], alpha=scale, beta=momentum)
+				g = dx
+
+			elif kind == "softmax":
+				y = self.cache[key]
+				shp = y.shape + (1, ) * (4 - y.ndim)
+				g = R.softmax_bwd(g.reshape(shp), y.reshape(shp)).reshape(y.shape)
+
+			elif kind == "resid":
+				_, branch, shortcut = layer
+				gb = self.backward(g, branch, key + ".b.", scale, momentum)
+				gs = self.backward(g, shortcut, key + ".s.", scale, momentum) if len(shortcut) > 0 else g
+				g = (np.zeros_like(gb) + gb) + gs
+
+			else:
+				raise NotImplementedError(kind)
+
+		return g
+
+
+	def zero_grads(self):
+		for g in self.grads.values():
+			g[...] = 0
+
+
+class CpuAdam:
+	"""Optimizers/Adam.py:35-43 on top of adamKer (bias-corrected rate computed on the host)."""
+	def __init__(self, net, alpha=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8):
+		self.net, self.alpha, self.beta1, self.beta2, self.epsilon = net, alpha, beta1, beta2, epsilon
+		self.t = 0
+		self.mg = {k: np.zeros_like(v) for k, v in net.params.items()}
+		self.ms = {k: np.zeros_like(v) for k, v in net.params.items()}
+
+	def update(self):
+		self.t += 1
+		fix1, fix2 = 1.0 - self.beta1**self.t, 1.0 - self.beta2**self.t
+		lr = self.alpha * math.sqrt(fix2) / fix1
+
+		for k, p in self.net.params.items():
+			R.adam(p, self.net.grads[k], self.mg[k], self.ms[k], lr, 1.0 - self.beta1, 1.0 - self.beta2, self.epsilon)
+
+
+class CpuMomentumSGD:
+	"""Optimizers/MomentumSGD.py:24-27 on top of classicMomSGDKer; optional WeightDecay hook (Optimizers/Hooks.py:11-19)."""
+	def __init__(self, net, learnRate=1e-3, momRate=0.9, weightDecay=0.0):
+		self.net, self.learnRate, self.momRate, self.weightDecay = net, learnRate, momRate, weightDecay
+		self.mom = {k: np.zeros_like(v) for k, v in net.params.items()}
+
+	def update(self):
+		for k, p in self.net.params.items():
+			if self.weightDecay > 0.0:
+				R.weight_decay(self.net.grads[k], p, self.weightDecay)
+			R.classic_mom_sgd(p, self.net.grads[k], self.mom[k], self.learnRate, self.momRate)
+
+
+def train_step(net, opt, data, labels):
+	"""Trainer.handleBatch — Handlers/Trainer.py:28-35. Returns (logits/probabilities, device-error value)."""
+	net.train = True
+	pred = net.forward(data)
+	err, grad = R.cross_entropy(pred, labels)
+
+	net.zero_grads()
+	net.backward(grad)
+	opt.update()
+
+	return pred, err

@@ -1,0 +1,586 @@
+"""
+TEST INFRASTRUCTURE — CPU oracle for the PuzzleLib operator hot path (numpy restatement).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module. Nothing under `puzzlelib_amd/` imports it; the product path has no CPU fallback.
+
+Every function restates the algorithm of a reference function and cites it
+(paths relative to the reference repo root, puzzlelib/PuzzleLib v1.0.2):
+
+* forward conv / pool / batch-norm inference / GEMM / column-sum follow the reference's numpy CPU
+  backend (CPU/Wrappers/NumpyDnn.py, CPU/Wrappers/NumpyBlas.py) — im2col via as_strided + np.dot;
+* element-wise and optimizer kernels follow CPU/Kernels/ElementWise.py (the gcc-JIT'd C loops);
+* ops the reference CPU backend does not implement (conv backward, pool backward, BN training
+  forward/backward, softmax, cross-entropy — see Backend/Dnn.py:341-371) follow the brute-force host
+  formulas inside the reference's own unit tests (Cuda/Wrappers/CuDnn.py, CuDnnNorm.py,
+  Cuda/Kernels/Costs.py, Modules/*.py), restated in vectorised form ("restatement-extended").
+
+Parity pinning: `oracle/make_golden.py` (runs in the build container only) checks this file against
+the imported reference CPU backend and against the reference's `bnd`-parameterised unit tests, and
+writes the fixtures in tests/golden/. One convention is not pinned by any reference test: the
+batch-norm *running variance* update (we use the cuDNN/MIOpen convention: unbiased batch variance).
+
+Arithmetic is float32 by default (like the reference); pass ``acc=np.float64`` for a tighter
+yardstick when checking long reductions.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------------
+
+def pair(v):
+	"""repeatValue(val, 2) — CPU/Wrappers/NumpyDnn.py:15-23"""
+	if isinstance(v, (int, np.integer)):
+		return int(v), int(v)
+	v = tuple(int(a) for a in v)
+	assert len(v) == 2
+	return v
+
+
+def conv_outshape(inhw, size, stride, pad, dilation):
+	"""outshape — CPU/Wrappers/NumpyDnn.py:26-36 (same formula as Modules/Conv2D.py:50-51)"""
+	(inh, inw), (fh, fw), (sh, sw), (ph, pw), (dh, dw) = inhw, size, stride, pad, dilation
+	outh = (inh + 2 * ph - dh * (fh - 1) - 1) // sh + 1
+	outw = (inw + 2 * pw - dw * (fw - 1) - 1) // sw + 1
+	return outh, outw
+
+
+def im2col(data, size, stride, pad, dilation, padval=0):
+	"""im2col — CPU/Wrappers/NumpyDnn.py:39-61: np.pad then as_strided to (N*P*Q, C*R*S)."""
+	fh, fw = size
+	sh, sw = stride
+	ph, pw = pad
+	dh, dw = dilation
+
+	n, c, inh, inw = data.shape
+	outh, outw = conv_outshape((inh, inw), size, stride, pad, dilation)
+
+	if ph > 0 or pw > 0:
+		data = np.pad(data, ((0, 0), (0, 0), (ph, ph), (pw, pw)), mode="constant", constant_values=padval)
+
+	st = data.strides
+	col = np.lib.stride_tricks.as_strided(
+		data, shape=(n, outh, outw, c, fh, fw),
+		strides=(st[0], sh * st[2], sw * st[3], st[1], st[2] * dh, st[3] * dw)
+	)
+	return col.reshape(n * outh * outw, c * fh * fw)
+
+
+def col2im(data, maps, shape):
+	"""col2im — CPU/Wrappers/NumpyDnn.py:64-71: (N*P*Q, K) -> NCHW."""
+	h, w = shape
+	return np.ascontiguousarray(np.moveaxis(data.reshape(-1, h, w, maps), 3, 1))
+
+
+# --------------------------------------------------------------------------------------------------
+# convolution (a1, a2, a3)
+# --------------------------------------------------------------------------------------------------
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, dilation=1, groups=1, acc=np.float32):
+	"""
+	y = x (*) w (+ b): NumpyDnn.conv2d — CPU/Wrappers/NumpyDnn.py:83-99 (groups=1);
+	groups>1 as the host loop of convGroupTest — Cuda/Wrappers/CuDnn.py:137-162.
+	bias may be shaped (K,) or (1,K,1,1).
+	"""
+	stride, pad, dilation = pair(stride), pair(pad), pair(dilation)
+	n, c, inh, inw = x.shape
+	k, cg, fh, fw = w.shape
+	assert c == cg * groups and k % groups == 0
+
+	outh, outw = conv_outshape((inh, inw), (fh, fw), stride, pad, dilation)
+	kg = k // groups
+	outs = []
+
+	for g in range(groups):
+		col = im2col(x[:, g * cg:(g + 1) * cg].astype(acc, copy=False), (fh, fw), stride, pad, dilation)
+		wmat = w[g * kg:(g + 1) * kg].reshape(kg, -1).T.astype(acc, copy=False)
+		outs.append(np.dot(col, wmat))
+
+	out = outs[0] if groups == 1 else np.concatenate(outs, axis=1)
+	if bias is not None:
+		out = out + np.asarray(bias, dtype=acc).reshape(1, k)
+
+	return col2im(out, k, (outh, outw)).astype(np.float32)
+
+
+def conv2d_bwd_data(dy, w, xshape, stride=1, pad=0, dilation=1, groups=1, acc=np.float32):
+	"""
+	dx[n,c,p*s+r*d-pad, ...] += w[k,c,r,s] * dy[n,k,p,q]: host loops of conv2dTest —
+	Cuda/Wrappers/CuDnn.py:51-65 and multiMapsWithPadsTest — Modules/Conv2D.py:215-230
+	(stride/pad/dilation); vectorised as dy_col . W followed by a scatter-add over the R*S taps.
+	"""
+	stride, pad, dilation = pair(stride), pair(pad), pair(dilation)
+	n, c, inh, inw = xshape
+	k, cg, fh, fw = w.shape
+	(sh, sw), (ph, pw), (dh, dw) = stride, pad, dilation
+	_, _, outh, outw = dy.shape
+	kg = k // groups
+
+	dxp = np.zeros((n, c, inh + 2 * ph, inw + 2 * pw), dtype=acc)
+
+	for g in range(groups):
+		dyg = np.moveaxis(dy[:, g * kg:(g + 1) * kg].astype(acc, copy=False), 1, 3).reshape(-1, kg)
+		wmat = w[g * kg:(g + 1) * kg].reshape(kg, -1).astype(acc, copy=False)
+
+		dcol = np.dot(dyg, wmat).reshape(n, outh, outw, cg, fh, fw)
+
+		for r in range(fh):
+			for s in range(fw):
+				tgt = dxp[:, g * cg:(g + 1) * cg, r * dh:r * dh + sh * outh:sh, s * dw:s * dw + sw * outw:sw]
+				tgt += np.moveaxis(dcol[:, :, :, :, r, s], 3, 1)
+
+	return np.ascontiguousarray(dxp[:, :, ph:ph + inh, pw:pw + inw]).astype(np.float32)
+
+
+def conv2d_bwd_filter(x, dy, wshape, stride=1, pad=0, dilation=1, groups=1, withbias=False,
+					  wgrad=None, bgrad=None, scale=1.0, momentum=0.0, acc=np.float32):
+	"""
+	dw[k,c,r,s] = sum x[n,c,p*s+r*d-pad,...] * dy[n,k,p,q]; db[k] = sum dy — host loops of conv2dTest
+	Cuda/Wrappers/CuDnn.py:67-80, Modules/Conv2D.py:232-248.
+	Accumulate contract (Hip/Wrappers/MIOpen.py:414-433,441-455): when wgrad is given and
+	(scale != 1 or momentum != 0): wgrad <- momentum*wgrad + scale*dw (same for bgrad); otherwise
+	wgrad <- dw. Returns wgrad or (wgrad, bgrad).
+	"""
+	stride, pad, dilation = pair(stride), pair(pad), pair(dilation)
+	k, cg, fh, fw = wshape
+	kg = k // groups
+	dws = []
+
+	for g in range(groups):
+		col = im2col(x[:, g * cg:(g + 1) * cg].astype(acc, copy=False), (fh, fw), stride, pad, dilation)
+		dyg = np.moveaxis(dy[:, g * kg:(g + 1) * kg].astype(acc, copy=False), 1, 3).reshape(-1, kg)
+		dws.append(np.dot(dyg.T, col).reshape(kg, cg, fh, fw))
+
+	dw = (dws[0] if groups == 1 else np.concatenate(dws, axis=0)).astype(np.float32)
+
+	def accumulate(dst, val):
+		if dst is not None and (scale != 1.0 or momentum != 0.0):
+			dst[...] = (np.float32(momentum) * dst + np.float32(scale) * val.reshape(dst.shape)).astype(np.float32)
+			return dst
+		if dst is None:
+			return val
+		dst[...] = val.reshape(dst.shape)
+		return dst
+
+	wgrad = accumulate(wgrad, dw)
+	if not withbias:
+		return wgrad
+
+	db = np.sum(dy, axis=(0, 2, 3), dtype=acc).astype(np.float32)
+	bgrad = accumulate(bgrad, db)
+	return wgrad, bgrad
+
+
+# --------------------------------------------------------------------------------------------------
+# GEMM / matrix-vector helpers (a4, a5)
+# --------------------------------------------------------------------------------------------------
+
+def gemm(A, B, out=None, transpA=False, transpB=False, alpha=1.0, beta=0.0, acc=np.float32):
+	"""
+	out = alpha*op(A)*op(B) + beta*out, row-major; NumpyBlas.mulMatrixOnMatrix —
+	CPU/Wrappers/NumpyBlas.py:66-91 (alpha=1, beta=0 there); alpha/beta semantics of BlasContext.gemm —
+	Cuda/Source/Libs/CuBlas.c:327-402 (not both transposed).
+	"""
+	assert not (transpA and transpB)
+	a = A.T if transpA else A
+	b = B.T if transpB else B
+	res = np.dot(a.astype(acc, copy=False), b.astype(acc, copy=False))
+
+	if alpha != 1.0:
+		res = acc(alpha) * res
+	if out is not None and beta != 0.0:
+		res = res + acc(beta) * out
+	res = res.astype(np.float32)
+
+	if out is None:
+		return res
+	out[...] = res
+	return out
+
+
+def add_vec_to_mat(vec, mat, axis=1, out=None):
+	"""
+	MatModule.addVecToMat — Cuda/Kernels/MatVec.py:346-374: axis=1 adds vec along columns (bias add; vec may
+	tile when mat width is a multiple of its length), axis=0 adds vec[row] to every row element.
+	Batched: mat (z,n,m), vec (z,len).
+	"""
+	if axis == 1:
+		reps = mat.shape[-1] // vec.shape[-1]
+		v = np.tile(vec, reps) if vec.ndim == 1 else np.tile(vec, (1, reps))
+		res = mat + (v[np.newaxis, :] if vec.ndim == 1 else v[:, np.newaxis, :])
+	else:
+		res = mat + (vec[:, np.newaxis] if vec.ndim == 1 else vec[:, :, np.newaxis])
+
+	if out is None:
+		return res.astype(np.float32)
+	out[...] = res
+	return out
+
+
+def matsum(tensor, axis=0, out=None, alpha=1.0, beta=0.0, acc=np.float32):
+	"""MatModule.matsum — Cuda/Kernels/MatVec.py:273-308; NumpyBlas.sumOnMatrix — CPU/Wrappers/NumpyBlas.py:7-22."""
+	s = np.sum(tensor, axis=axis, dtype=acc)
+	if out is None:
+		return (acc(alpha) * s).astype(np.float32)
+	out[...] = (acc(beta) * out + acc(alpha) * s).astype(np.float32)
+	return out
+
+
+def argmax(tensor, axis):
+	"""MatModule.argmax — Cuda/Kernels/MatVec.py:231-266 (first maximum wins on ties, as np.argmax)."""
+	return np.argmax(tensor, axis=axis).astype(np.int32)
+
+
+def dot(x, y):
+	"""NumpyBlas.dot — CPU/Wrappers/NumpyBlas.py:56-63"""
+	return float(np.vdot(x.ravel(), y.ravel()))
+
+
+def l1norm(x):
+	"""NumpyBlas.vectorL1Norm — CPU/Wrappers/NumpyBlas.py:48-53"""
+	return float(np.sum(np.abs(x.ravel())))
+
+
+# --------------------------------------------------------------------------------------------------
+# batch normalisation (a6, a7)
+# --------------------------------------------------------------------------------------------------
+
+def bn_fwd_infer(x, scale, bias, mean, var, epsilon=1e-5):
+	"""NumpyDnn.batchNorm2d — CPU/Wrappers/NumpyDnn.py:117-129: y = scale/sqrt(var+eps)*(x-mean)+bias."""
+	shp = (1, -1) + (1, ) * (x.ndim - 2)
+	s = scale.reshape(shp) / np.sqrt(var.reshape(shp) + np.float32(epsilon))
+	return (s * (x - mean.reshape(shp)) + bias.reshape(shp)).astype(np.float32)
+
+
+def bn_fwd_train(x, scale, bias, mean, var, epsilon=1e-5, factor=1.0, acc=np.float32):
+	"""
+	Spatial BN training forward as pinned by batchNorm2dTest — Cuda/Wrappers/CuDnnNorm.py:23-52 and
+	Modules/BatchNorm2D.py:34-59: biased variance for normalisation/saveinvvar; running stats updated
+	IN PLACE on `mean`/`var` as (1-f)*old + f*new (cuDNN/MIOpen contract, Cuda/Source/Libs/CuDnnNorm.c).
+	Running *variance* uses the unbiased batch variance (cuDNN convention; not pinned by a reference test).
+	Returns (y, savemean, saveinvvar) with stats shaped (C,).
+	"""
+	axes = (0, ) + tuple(range(2, x.ndim))
+	shp = (1, -1) + (1, ) * (x.ndim - 2)
+	norm = x.size // x.shape[1]
+
+	xa = x.astype(acc, copy=False)
+	mu = np.sum(xa, axis=axes, dtype=acc) / norm
+	v = np.sum((xa - mu.reshape(shp))**2, axis=axes, dtype=acc) / norm
+	rstd = 1.0 / np.sqrt(v + acc(epsilon))
+
+	y = (xa - mu.reshape(shp)) * rstd.reshape(shp) * scale.reshape(shp) + bias.reshape(shp)
+
+	f = acc(factor)
+	unbiased = v * norm / max(norm - 1, 1)
+	mean[...] = ((1 - f) * mean.reshape(-1) + f * mu).astype(np.float32).reshape(mean.shape)
+	var[...] = ((1 - f) * var.reshape(-1) + f * unbiased).astype(np.float32).reshape(var.shape)
+
+	return y.astype(np.float32), mu.astype(np.float32), rstd.astype(np.float32)
+
+
+def bn_bwd(dy, x, scale, savemean, saveinvvar, acc=np.float32):
+	"""
+	BN backward — formulas of batchNorm2dTest Cuda/Wrappers/CuDnnNorm.py:55-63 (== Modules/BatchNorm2D.py:61-82):
+	dscale = sum dy*xhat; dbias = sum dy; dx = dy*scale*rstd + (2*dvar*(x-mu) + dmean)/norm.
+	Returns (dx, dscale, dbias) with (C,) parameter grads.
+	"""
+	axes = (0, ) + tuple(range(2, x.ndim))
+	shp = (1, -1) + (1, ) * (x.ndim - 2)
+	norm = x.size // x.shape[1]
+
+	xa, dya = x.astype(acc, copy=False), dy.astype(acc, copy=False)
+	mu, rstd, sc = savemean.reshape(shp).astype(acc), saveinvvar.reshape(shp).astype(acc), scale.reshape(shp).astype(acc)
+
+	xc = xa - mu
+	dscale = np.sum(dya * xc * rstd, axis=axes, dtype=acc)
+	dbias = np.sum(dya, axis=axes, dtype=acc)
+
+	dmean = -rstd * dbias.reshape(shp) * sc
+	dvar = -0.5 * np.sum(dya * xc, axis=axes, dtype=acc).reshape(shp) * sc * rstd**3
+	dx = dya * sc * rstd + (2 * dvar * xc + dmean) / norm
+
+	return dx.astype(np.float32), dscale.astype(np.float32), dbias.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# pooling (a9)
+# --------------------------------------------------------------------------------------------------
+
+POOL_MAX, POOL_AVG_WITH_PAD, POOL_AVG_NO_PAD = 0, 1, 2
+
+
+def _pool_windows(x, size, stride, pad, padval):
+	n, c, inh, inw = x.shape
+	(fh, fw), (sh, sw), (ph, pw) = size, stride, pad
+	outh, outw = conv_outshape((inh, inw), size, stride, pad, (1, 1))
+
+	xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)), mode="constant", constant_values=padval) \
+		if (ph or pw) else x
+	st = xp.strides
+	win = np.lib.stride_tricks.as_strided(
+		xp, shape=(n, c, outh, outw, fh, fw), strides=(st[0], st[1], sh * st[2], sw * st[3], st[2], st[3])
+	)
+	return win, (outh, outw)
+
+
+def pool2d_fwd(x, size=2, stride=2, pad=0, mode=POOL_MAX):
+	"""
+	NumpyDnn.pool2d — CPU/Wrappers/NumpyDnn.py:102-114 (max: pads with -inf; avg only exact for pad=0 there).
+	avgWithPad divides by the full window (zero padding counted) as Modules/AvgPool2D.py:40-50;
+	avgNoPad divides by the number of in-bounds taps (MIOpen "miopenPoolingAverage").
+	"""
+	size, stride, pad = pair(size), pair(stride), pair(pad)
+
+	if mode == POOL_MAX:
+		win, _ = _pool_windows(x, size, stride, pad, -np.inf)
+		return win.max(axis=(4, 5)).astype(np.float32)
+
+	win, _ = _pool_windows(x, size, stride, pad, 0.0)
+	s = win.sum(axis=(4, 5), dtype=np.float32)
+
+	if mode == POOL_AVG_WITH_PAD:
+		return (s / np.float32(size[0] * size[1])).astype(np.float32)
+
+	ones, _ = _pool_windows(np.ones(x.shape[2:], dtype=np.float32)[None, None], size, stride, pad, 0.0)
+	return (s / ones.sum(axis=(4, 5))).astype(np.float32)
+
+
+def pool2d_bwd(dy, x, y, size=2, stride=2, pad=0, mode=POOL_MAX):
+	"""
+	Max: gradient goes to the arg-max tap of each window — maxpool2dTest Cuda/Wrappers/CuDnn.py:395-410.
+	The reference host loop credits *every* tap equal to the max; device libraries (and this build) credit
+	the FIRST maximum in row-major window order — identical on tie-free data, which is what tests use.
+	Avg: Modules/AvgPool2D.py:52-63 (dy / window for avgWithPad; dy / valid-count for avgNoPad).
+	"""
+	size, stride, pad = pair(size), pair(stride), pair(pad)
+	(fh, fw), (sh, sw), (ph, pw) = size, stride, pad
+	n, c, inh, inw = x.shape
+	_, _, outh, outw = dy.shape
+
+	dxp = np.zeros((n, c, inh + 2 * ph, inw + 2 * pw), dtype=np.float32)
+
+	if mode == POOL_MAX:
+		win, _ = _pool_windows(x, size, stride, pad, -np.inf)
+		flat = win.reshape(n, c, outh, outw, fh * fw)
+		idx = np.argmax(flat, axis=4)
+		r, s = idx // fw, idx % fw
+
+		nn, cc, pp, qq = np.meshgrid(np.arange(n), np.arange(c), np.arange(outh), np.arange(outw), indexing="ij")
+		np.add.at(dxp, (nn, cc, pp * sh + r, qq * sw + s), dy)
+
+	else:
+		if mode == POOL_AVG_WITH_PAD:
+			g = dy / np.float32(fh * fw)
+		else:
+			ones, _ = _pool_windows(np.ones((1, 1, inh, inw), dtype=np.float32), size, stride, pad, 0.0)
+			g = dy / ones.sum(axis=(4, 5))
+
+		for r in range(fh):
+			for s in range(fw):
+				dxp[:, :, r:r + sh * outh:sh, s:s + sw * outw:sw] += g
+
+	return np.ascontiguousarray(dxp[:, :, ph:ph + inh, pw:pw + inw])
+
+
+# --------------------------------------------------------------------------------------------------
+# softmax / cross-entropy / accuracy (a10, a11)
+# --------------------------------------------------------------------------------------------------
+
+def softmax_fwd(x):
+	"""Channel softmax over axis 1 ("accurate": max-subtracted) — softmax2dTest Cuda/Wrappers/CuDnn.py:454-470."""
+	e = np.exp(x - np.amax(x, axis=1, keepdims=True))
+	return (e / np.sum(e, axis=1, keepdims=True)).astype(np.float32)
+
+
+def softmax_bwd(dy, y):
+	"""dx = y*(dy - sum_c(y*dy)) — Cuda/Wrappers/CuDnn.py:472-485."""
+	return (y * (dy - np.sum(y * dy, axis=1, keepdims=True))).astype(np.float32)
+
+
+def cross_entropy(scores, labels, weights=None):
+	"""
+	CostModule.crossEntropy — Cuda/Kernels/Costs.py:79-106,213-247: p = softmax(scores) over axis 1;
+	grad = ((c==label) - p)/N (times weight[c] if given); error = sum(-log p[label])/spatial (weighted).
+	Returns (error, grad); error is the *unnormalised-by-batch* device accumulator value.
+	"""
+	n, ncls = scores.shape[:2]
+	spatial = int(np.prod(scores.shape[2:])) if scores.ndim > 2 else 1
+
+	s3 = scores.reshape(n, ncls, spatial)
+	p = softmax_fwd(s3)
+	lab = labels.reshape(n, spatial)
+
+	onehot = (np.arange(ncls)[None, :, None] == lab[:, None, :])
+	grad = (onehot.astype(np.float32) - p) / np.float32(n)
+
+	pl = np.take_along_axis(p, lab[:, None, :].astype(np.int64), axis=1)[:, 0, :]
+	if weights is None:
+		err = np.sum(-np.log(pl), dtype=np.float64) / spatial
+	else:
+		grad = grad * weights.reshape(1, ncls, 1)
+		err = np.sum(-weights[lab] * np.log(pl), dtype=np.float64) / spatial
+
+	return np.float32(err), grad.reshape(scores.shape).astype(np.float32)
+
+
+def count_neq(x, y):
+	"""calcAccuracy reduction — Cuda/Kernels/Costs.py:178-182: sum(x[i] != y[i]) as float32."""
+	return np.float32(np.sum(x.ravel() != y.ravel()))
+
+
+def mse(pred, target):
+	"""
+	MSE cost — Cost/MSE.py:8-21: grad = (target - pred)/numel; device error accumulator =
+	dot(grad,grad)*numel*batch/2 (so error/batch = sum(diff^2)/(2*numel)). Returns (devErr, grad).
+	"""
+	numel = pred.size
+	grad = ((target - pred) * np.float32(1.0 / numel)).astype(np.float32)
+	err = np.float32(np.dot(grad.ravel().astype(np.float64), grad.ravel().astype(np.float64)) * numel * pred.shape[0] / 2.0)
+	return err, grad
+
+
+# --------------------------------------------------------------------------------------------------
+# element-wise family (a8, a12, a13) — CPU/Kernels/ElementWise.py, loop bodies restated with ufuncs
+# --------------------------------------------------------------------------------------------------
+
+F = np.float32
+
+
+def sigmoid(x):            return (F(1) / (F(1) + np.exp(-x))).astype(F)             # ElementWise.py:9-16
+def sigmoid_der(g, y):     return (g * y * (F(1) - y)).astype(F)                      # :19-29
+def tanh(x):               return np.tanh(x).astype(F)                                # :32-39
+def tanh_der(g, y):        return (g * (F(1) - y * y)).astype(F)                      # :42-49
+def relu(x):               return (x * (x > 0)).astype(F)                             # :52-59
+def relu_der(g, y):        return (g * (y > 0)).astype(F)                             # :62-69
+def leaky_relu(x, a):      return (x * ((x > 0) + F(a) * (x <= 0))).astype(F)         # :72-79
+def leaky_relu_der(g, y, a): return (g * ((y > 0) + F(a) * (y <= 0))).astype(F)       # :82-89
+def elu(x, a):             return (x * (x > 0) + F(a) * (np.exp(x) - F(1)) * (x <= 0)).astype(F)   # :92-99
+def elu_der(g, y, a):      return (g * ((y > 0) + (y + F(a)) * (y <= 0))).astype(F)   # :102-109
+def softplus(x):           return np.log(F(1) + np.exp(x)).astype(F)                  # :112-119
+def softplus_der(g, y):    return (g * (F(1) - np.exp(-y))).astype(F)                 # :122-129
+
+
+def clip(x, a, b):                                                                    # :132-139
+	a, b = F(a), F(b)
+	return (x * ((x > a) & (x < b)) + a * (x <= a) + b * (x >= b)).astype(F)
+
+
+def clip_der(g, y, a, b):  return (g * ((y > F(a)) & (y < F(b)))).astype(F)           # :142-152
+
+
+def gelu(x):
+	"""Cuda/Kernels/ElementWise.py:427-456 (no CPU twin): 0.5*x*(1+erf(x/sqrt2))"""
+	from math import erf
+	return (F(0.5) * x * (F(1) + np.vectorize(erf)(x / np.sqrt(2.0)))).astype(F)
+
+
+def gelu_der(g, x):
+	"""Cuda/Kernels/ElementWise.py:459-492 — the reference's own formula (x/sqrt(pi) factor), restated as is."""
+	from math import erf
+	cdf = 0.5 * (1.0 + np.vectorize(erf)(x / np.sqrt(2.0)))
+	return (g * (cdf + x / np.sqrt(np.pi) * np.exp(-0.5 * x * x))).astype(F)
+
+
+def dropout(x, bits, v, p):
+	"""dropoutKer — CPU/Kernels/ElementWise.py:155-165: out = x*(b<v)/p with a uint32 mask stream."""
+	return (x * (bits.reshape(x.shape) < np.uint32(v)) / F(p)).astype(F)
+
+
+def dropout2d(x, bits, v, p, mapsize):
+	"""dropout2dKer — CPU/Kernels/ElementWise.py:168-179: one mask word per feature map."""
+	idx = np.arange(x.size) // mapsize
+	return (x.ravel() * (bits[idx] < np.uint32(v)) / F(p)).astype(F).reshape(x.shape)
+
+
+def axpy(y, x, alpha=1.0):
+	"""toVectorAddVectorKer — :182-189: y += alpha*x (in place)."""
+	y += x * F(alpha)
+	return y
+
+
+def add_scaled(x, alpha, y, beta, out=None):
+	"""addKer — :343-353 / Backend/Blas.py:51-58: out = alpha*x + beta*y."""
+	res = (F(alpha) * x + F(beta) * y).astype(F)
+	if out is None:
+		return res
+	out[...] = res
+	return out
+
+
+def mul(a, b):             return (a * b).astype(F)                                   # mulKer :356-363
+def linear(x, a, b):       return (F(a) * x + F(b)).astype(F)                         # linearKer :366-373
+def weight_decay(grad, param, rate):                                                  # weightDecayKer :383-387
+	grad -= F(rate) * param
+	return grad
+
+
+def adam(param, grad, mg, ms, learn_rate, fix1, fix2, epsilon):
+	"""adamKer — CPU/Kernels/ElementWise.py:235-249 (in place; update is +=)."""
+	mg += F(fix1) * (grad - mg)
+	ms += F(fix2) * (grad * grad - ms)
+	param += F(learn_rate) * mg / (np.sqrt(ms) + F(epsilon))
+
+
+def classic_mom_sgd(param, grad, mom, learn_rate, mom_rate):
+	"""classicMomSGDKer — :252-265"""
+	mom[...] = F(mom_rate) * mom + F(learn_rate) * grad
+	param += mom
+
+
+def nesterov_mom_sgd(param, grad, mom, learn_rate, mom_rate):
+	"""nesterovMomSGDKer — :268-282"""
+	m = mom.copy()
+	mom[...] = F(mom_rate) * m + F(learn_rate) * grad
+	param += F(mom_rate) * F(mom_rate) * m + (F(1) + F(mom_rate)) * F(learn_rate) * grad
+
+
+def rmsprop(param, grad, ms, learn_rate, factor, epsilon):
+	"""rmspropKer — :285-298"""
+	ms[...] = F(factor) * ms + (F(1) - F(factor)) * grad * grad
+	param += F(learn_rate) * grad / (np.sqrt(ms) + F(epsilon))
+
+
+def adagrad(param, grad, h, learn_rate, epsilon):
+	"""adagradKer — :219-232"""
+	h += grad * grad
+	param += F(learn_rate) * grad / (np.sqrt(h) + F(epsilon))
+
+
+def adadelta(param, grad, msg, msdx, rho, epsilon):
+	"""adadeltaKer — :201-216"""
+	msg += (F(1) - F(rho)) * (grad * grad - msg)
+	dx = np.sqrt((msdx + F(epsilon)) / (msg + F(epsilon))) * grad
+	msdx += (F(1) - F(rho)) * (dx * dx - msdx)
+	param += dx
+
+
+def rmsprop_graves(param, grad, mg, ms, delta, learn_rate, alpha, mom_rate, epsilon):
+	"""rmspropGravesKer — :301-317"""
+	ms[...] = F(alpha) * ms + (F(1) - F(alpha)) * grad * grad
+	mg[...] = F(alpha) * mg + (F(1) - F(alpha)) * grad
+	delta[...] = F(mom_rate) * delta + F(learn_rate) * grad / np.sqrt(ms - mg * mg + F(epsilon))
+	param += delta
+
+
+def smorms3(param, grad, mem, mg, ms, learn_rate, epsilon):
+	"""smorms3Ker — :320-340"""
+	r = F(1) / (mem + F(1))
+	mgi = (F(1) - r) * mg + r * grad
+	msi = (F(1) - r) * ms + r * grad * grad
+	x = mgi * mgi / (msi + F(epsilon))
+	mem[...] = F(1) + mem * (F(1) - x)
+	mg[...] = mgi
+	ms[...] = msi
+	param += grad * np.minimum(F(learn_rate), x) / (np.sqrt(msi) + F(epsilon))
+
+
+def grad_mean_allreduce(grads):
+	"""Data-parallel exchange — ParentNode.sumTensor Grid.py:123-135: g <- (g_0 + ... + g_{N-1}) / N for every rank."""
+	n = len(grads)
+	acc = grads[0].astype(np.float32) * F(1.0 / n)
+	for g in grads[1:]:
+		acc = acc + g * F(1.0 / n)
+	return acc
