@@ -1,0 +1,232 @@
+/*
+ * puzzle_mi355.h — C ABI of libpuzzle_mi355.so, the MI355X (gfx950 / CDNA4) operator backend that sits
+ * behind PuzzleLib's Backend/{gpuarray,Blas,Dnn,Kernels}.py dispatch surface.
+ *
+ * Conventions
+ *   - every entry returns an int status: 0 = OK, non-zero = failure; pz_last_error() returns a
+ *     thread-local, human readable message for the last failure on the calling thread;
+ *   - all tensors are fp32 (labels/indices int32, RNG words uint32), dense, C-contiguous, NCHW / KCRS;
+ *   - pointers are raw device pointers unless named h_*; no entry retains a pointer after it returns;
+ *   - every compute entry takes a stream (NULL = the device's default stream) and is asynchronous
+ *     with respect to the host; nothing here synchronises unless its name says so;
+ *   - no torch / Python types appear in any signature.
+ *
+ * Each group cites the reference interface it replaces (paths relative to puzzlelib/PuzzleLib).
+ */
+#ifndef PUZZLE_MI355_H
+#define PUZZLE_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pz_stream_t;   /* hipStream_t */
+typedef void *pz_event_t;    /* hipEvent_t  */
+typedef struct pz_pool *pz_pool_t;
+typedef struct pz_rng *pz_rng_t;
+typedef struct pz_comm *pz_comm_t;
+
+#define PZ_OK 0
+#define PZ_ERR_INVALID 1      /* bad argument / unsupported configuration (ValueError on the Python side) */
+#define PZ_ERR_HIP 2          /* a HIP runtime call failed                                              */
+#define PZ_ERR_NOMEM 3        /* device allocation failed                                               */
+#define PZ_ERR_COMM 4         /* RCCL failure / librccl not loadable                                    */
+
+/* ---- library / device: replaces Driver.Device (Cuda/Source/Core/Device.c:160-173) -------------- */
+int pz_version(void);
+const char *pz_last_error(void);
+int pz_init(int device);                                  /* hipSetDevice + arch check (gfx950)  */
+int pz_device_count(int *count);
+int pz_device_name(int device, char *buf, int buflen);
+int pz_device_arch(int device, char *buf, int buflen);
+int pz_device_sync(void);
+int pz_device_mem_info(size_t *free_bytes, size_t *total_bytes);
+int pz_device_num_cus(int device, int *cus);
+
+/* ---- memory: replaces Driver.Buffer / MemoryPool (Cuda/Source/Core/Buffer.c, Allocator.c:29-75,359-362)
+ * The pool is a size-class free list: a released block is held and handed out again for the next request
+ * of the same class (stream-ordered reuse on the compute stream).                                     */
+int pz_malloc(void **ptr, size_t nbytes);
+int pz_free(void *ptr);
+int pz_pool_create(pz_pool_t *pool);
+int pz_pool_destroy(pz_pool_t pool);
+int pz_pool_alloc(pz_pool_t pool, size_t nbytes, void **ptr);
+int pz_pool_release(pz_pool_t pool, void *ptr);
+int pz_pool_free_held(pz_pool_t pool);
+int pz_pool_stats(pz_pool_t pool, size_t *held_bytes, size_t *live_bytes, size_t *n_held, size_t *n_live);
+int pz_host_alloc_pinned(void **h_ptr, size_t nbytes);
+int pz_host_free_pinned(void *h_ptr);
+
+int pz_memcpy_h2d(void *dst, const void *h_src, size_t nbytes, pz_stream_t stream);   /* Buffer.set  Driver.h:80-106 */
+int pz_memcpy_d2h(void *h_dst, const void *src, size_t nbytes, pz_stream_t stream);   /* Buffer.get               */
+int pz_memcpy_d2d(void *dst, const void *src, size_t nbytes, pz_stream_t stream);     /* Buffer.copy              */
+int pz_memcpy_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width_bytes, size_t height,
+                 pz_stream_t stream);                                                  /* Driver.memcpy2D Cuda/GPUBackend.py:275-329 */
+int pz_memset_d32(void *dst, uint32_t value, size_t count, pz_stream_t stream);       /* Buffer.fillD32 Cuda/GPUArray.py:171-176 */
+/* generic strided gather/scatter of a <=6-d view (element size 4): GPUArray.get/set/copy of a non-contiguous view
+ * (Cuda/Source/Core/Array.c)                                                                           */
+int pz_strided_copy(void *dst, const int64_t *dst_strides, const void *src, const int64_t *src_strides,
+                    const int64_t *shape, int ndim, pz_stream_t stream);
+
+/* ---- streams / events: replaces Driver.Stream / Driver.Event (Cuda/Source/Core/Stream.c:101-239) ---- */
+int pz_stream_create(pz_stream_t *stream);
+int pz_stream_destroy(pz_stream_t stream);
+int pz_stream_sync(pz_stream_t stream);
+int pz_stream_wait_event(pz_stream_t stream, pz_event_t event);
+int pz_event_create(pz_event_t *event);
+int pz_event_destroy(pz_event_t event);
+int pz_event_record(pz_event_t event, pz_stream_t stream);
+int pz_event_sync(pz_event_t event);
+int pz_event_elapsed_ms(pz_event_t start, pz_event_t end, float *ms);
+
+/* ---- convolution: replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams
+ *      (Hip/Wrappers/MIOpen.py:333-462 over miopenConvolution{Forward,BackwardData,BackwardWeights,BackwardBias})
+ * Cross-correlation, NCHW x KCRS -> NKPQ, P = (H + 2*pad - dil*(R-1) - 1)/stride + 1.                  */
+typedef struct pz_conv_desc {
+	int n, c, h, w;                 /* input  (N, C, H, W)                      */
+	int k, r, s;                    /* filter (K, C/groups, R, S)               */
+	int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+	int groups;
+} pz_conv_desc;
+
+enum { PZ_CONV_ALGO_AUTO = -1, PZ_CONV_ALGO_DIRECT = 1, PZ_CONV_ALGO_IMPLICIT_GEMM = 5 };
+enum { PZ_CONV_FWD = 0, PZ_CONV_BWD_DATA = 1, PZ_CONV_BWD_FILTER = 2 };
+
+int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q);
+int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
+/* y = conv(x, w) (+ bias[k] when bias != NULL) */
+int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                  int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* dx = conv^T(dy, w); dx has the (n,c,h,w) of the descriptor */
+int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx,
+                       int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* dw <- beta*dw + alpha*sum(x (x) dy); db (optional) <- beta*db + alpha*sum(dy): the accumulate contract of
+ * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue.         */
+int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
+                         float alpha, float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
+/* ---- GEMM: replaces BlasContext.gemm (Cuda/Source/Libs/CuBlas.c:327-402); row-major,
+ *      C[M,N] = alpha*op(A)*op(B) + beta*C, lda/ldb/ldc = row pitches in elements.                    */
+int pz_gemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda,
+            const float *b, int ldb, float beta, float *c, int ldc, pz_stream_t stream);
+
+/* ---- batch normalisation (spatial): replaces DnnContext.batchNormNd / batchNormNdBackward
+ *      (Hip/Wrappers/MIOpen.py:634-688). x viewed as (n, c, hw). running stats updated in place:
+ *      run <- (1-factor)*run + factor*batch (variance: unbiased). ws: pz_bn_workspace_bytes.            */
+int pz_bn_workspace_bytes(int n, int c, int hw, size_t *nbytes);
+int pz_bn_fwd_train(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                    float *run_mean, float *run_var, float *save_mean, float *save_invvar,
+                    float epsilon, float factor, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                    const float *mean, const float *var, float epsilon, pz_stream_t stream);
+int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+              const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+              void *workspace, size_t ws_bytes, pz_stream_t stream);
+
+/* ---- pooling: replaces DnnContext.poolNd / poolNdBackward (Hip/Wrappers/MIOpen.py:549-598).
+ *      index workspace (uint8 per output element, window-local arg-max) is optional for forward (NULL in
+ *      test mode) and required for max backward.                                                        */
+typedef struct pz_pool_desc {
+	int n, c, h, w;
+	int size_h, size_w, stride_h, stride_w, pad_h, pad_w;
+	int mode;                       /* 0 max, 1 average incl. padding, 2 average excl. padding */
+} pz_pool_desc;
+
+int pz_pool2d_out_shape(const pz_pool_desc *d, int *p, int *q);
+int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *index_ws, pz_stream_t stream);
+/* x/y are only read for max pooling when index_ws == NULL (arg-max recomputed, first maximum wins) */
+int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const float *y, const uint8_t *index_ws,
+                  float *dx, pz_stream_t stream);
+
+/* ---- softmax / cross-entropy: replaces DnnContext.softmaxNd(+Backward) (MIOpen.py:601-631, channel mode,
+ *      "accurate") and CostModule.crossEntropy (Cuda/Kernels/Costs.py:79-106,213-247). Tensors (n, c, spatial). */
+int pz_softmax_fwd(const float *x, float *y, int n, int c, int spatial, pz_stream_t stream);
+int pz_softmax_bwd(const float *dy, const float *y, float *dx, int n, int c, int spatial, pz_stream_t stream);
+/* grad = w[c]*((c==label) - softmax(scores))/n ; *error = sum(-w*log p[label])/spatial (deterministic).
+ * workspace: n*spatial floats. weights may be NULL.                                                    */
+int pz_cross_entropy(const float *scores, const int32_t *labels, const float *weights, int n, int c, int spatial,
+                     float *grad, float *error, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
+/* ---- reductions / matrix-vector: replaces MatModule (Cuda/Kernels/MatVec.py:231-374), ReductionKernel users
+ *      (Cuda/GPUArray.py:80-103, Cuda/Kernels/Costs.py:178-182) and BlasContext.dot/l1norm (CuBlas.c:486-499). */
+int pz_reduce_sum_rows(const float *t, int rows, int cols, float *out, float alpha, float beta, pz_stream_t stream);
+int pz_reduce_sum_cols(const float *t, int z, int h, int w, float *out, float alpha, float beta, pz_stream_t stream);
+int pz_argmax_rows(const float *t, int rows, int cols, int32_t *out, pz_stream_t stream);
+int pz_argmax_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_t stream);
+int pz_bias_add(float *out, const float *mat, const float *vec, int z, int n, int m, int veclen, int axis,
+                pz_stream_t stream);
+int pz_count_neq_i32(const int32_t *x, const int32_t *y, size_t count, float *out, pz_stream_t stream);
+int pz_reduce_minmax_f32(const float *x, size_t count, int is_max, float *out, pz_stream_t stream);
+int pz_reduce_minmax_i32(const int32_t *x, size_t count, int is_max, int32_t *out, pz_stream_t stream);
+int pz_dot(const float *x, const float *y, size_t count, float *out, pz_stream_t stream);
+int pz_asum(const float *x, size_t count, float *out, pz_stream_t stream);
+
+/* ---- element-wise family: replaces the ElementwiseKernel objects of Cuda/Kernels/ElementWise.py (launched
+ *      through Cuda/SourceModule.py:176-226, incl. the `slice=` strided variant: start/stop/step; pass
+ *      start=0, stop=count, step=1 for the dense case). ptrs[0] is the output (or the in-place operand).
+ *      Operand/scalar order per op is the reference kernel's argument order and is listed next to each id. */
+enum pz_eltwise_op {
+	PZ_OP_SIGMOID = 0,        /* out, in                               */
+	PZ_OP_SIGMOID_DER,        /* ingrad, outgrad, outdata              */
+	PZ_OP_TANH, PZ_OP_TANH_DER,
+	PZ_OP_RELU, PZ_OP_RELU_DER,
+	PZ_OP_LEAKY_RELU, PZ_OP_LEAKY_RELU_DER,   /* + scalar a            */
+	PZ_OP_ELU, PZ_OP_ELU_DER,                 /* + scalar a            */
+	PZ_OP_SOFTPLUS, PZ_OP_SOFTPLUS_DER,
+	PZ_OP_CLIP, PZ_OP_CLIP_DER,               /* + scalars a, b        */
+	PZ_OP_GELU, PZ_OP_GELU_DER,               /* der: ingrad, outgrad, indata */
+	PZ_OP_DROPOUT,            /* out, in, bits(u32); scalars v(as float bits), p       */
+	PZ_OP_DROPOUT2D,          /* out, in, bits(u32); scalars v, p, mapsize(int bits)   */
+	PZ_OP_AXPY,               /* y, x; alpha          : y += alpha*x  (toVectorAddVectorKer) */
+	PZ_OP_ADD,                /* out, x, y; alpha, beta: out = alpha*x + beta*y (addKer)     */
+	PZ_OP_MUL,                /* out, a, b                                                     */
+	PZ_OP_LINEAR,             /* out, in; a, b        : out = a*in + b                         */
+	PZ_OP_ABS,                /* out, in                                                       */
+	PZ_OP_WEIGHT_DECAY,       /* grad, param; rate    : grad -= rate*param                     */
+	PZ_OP_L1_PENALTY,         /* outgrad, ingrad, data; a                                      */
+	PZ_OP_L1_GRAD,            /* grad, pred, target; norm                                      */
+	PZ_OP_RBM,                /* out, in, uni                                                  */
+	PZ_OP_ADAM,               /* param, grad, mg, ms; learnRate, fix1, fix2, epsilon           */
+	PZ_OP_CLASSIC_MOM_SGD,    /* param, grad, mom; learnRate, momRate                          */
+	PZ_OP_NESTEROV_MOM_SGD,   /* param, grad, mom; learnRate, momRate                          */
+	PZ_OP_RMSPROP,            /* param, grad, ms; learnRate, factor, epsilon                   */
+	PZ_OP_ADAGRAD,            /* param, grad, h; learnRate, epsilon                            */
+	PZ_OP_ADADELTA,           /* param, grad, msg, msdx; rho, epsilon                          */
+	PZ_OP_RMSPROP_GRAVES,     /* param, grad, mg, ms, delta; learnRate, alpha, momRate, epsilon*/
+	PZ_OP_SMORMS3,            /* param, grad, mem, mg, ms; learnRate, epsilon                  */
+	PZ_OP_ADD3,               /* out, a, b            : out = a + b (Add.updateData / Replicate.updateGrad fused) */
+	PZ_OP_IADD,               /* out, in              : out += in  (GPUArray.__iadd__)         */
+	PZ_OP_IMUL,               /* out, in              : out *= in                              */
+	PZ_OP_COUNT
+};
+
+int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *scalars, int nscalars,
+               int64_t start, int64_t stop, int64_t step, pz_stream_t stream);
+int pz_cast_i32_f32(float *out, const int32_t *in, size_t count, pz_stream_t stream);
+int pz_cast_f32_i32(int32_t *out, const float *in, size_t count, pz_stream_t stream);
+
+/* ---- RNG: replaces RandomNumberGenerator.fillInteger/fillUniform/fillNormal (Cuda/Source/Libs/CuRand.c:231-234).
+ *      Counter-based Philox4x32-10; statistical parity only (the reference's XORWOW stream is not reproduced). */
+int pz_rng_create(uint64_t seed, pz_rng_t *rng);
+int pz_rng_destroy(pz_rng_t rng);
+int pz_rng_fill_u32(pz_rng_t rng, uint32_t *out, size_t count, pz_stream_t stream);
+int pz_rng_fill_uniform(pz_rng_t rng, float *out, size_t count, pz_stream_t stream);           /* (0, 1] */
+int pz_rng_fill_normal(pz_rng_t rng, float *out, size_t count, float mean, float stddev, pz_stream_t stream);
+
+/* ---- data-parallel exchange: replaces NodeInfo.{sumTensor,broadcastBuffer} (Grid.py:54-63,103-157: IPC star)
+ *      with RCCL collectives over xGMI. One communicator per process (one process per GPU).             */
+#define PZ_COMM_ID_BYTES 128
+int pz_comm_unique_id(char id[PZ_COMM_ID_BYTES]);
+int pz_comm_init_rank(pz_comm_t *comm, int nranks, const char id[PZ_COMM_ID_BYTES], int rank);
+int pz_comm_destroy(pz_comm_t comm);
+int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, size_t count, pz_stream_t stream);
+int pz_comm_broadcast(pz_comm_t comm, void *buf, size_t nbytes, int root, pz_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PUZZLE_MI355_H */

@@ -1,0 +1,311 @@
+// Spatial batch normalisation for NCHW fp32 — HBM-bound kernels (forward-train 12 B/elem, backward 20 B/elem).
+// Replaces DnnContext.batchNormNd / batchNormNdBackward — Hip/Wrappers/MIOpen.py:634-688; formulas pinned by
+// Cuda/Wrappers/CuDnnNorm.py:23-77 (biased variance for normalisation, EMA running stats with `factor`).
+//
+// A channel's data are N slabs of hw contiguous floats (stride c*hw). A workgroup owns (channel, split): it walks
+// its share of the slabs either with all 256 threads on one slab (large hw) or with one wave per slab, reading
+// 16 B per lane after peeling each slab to 16-B alignment (hw = 55*55 or 7*7 is odd, so slab bases are not aligned).
+// Statistics are shifted sums (sum(x-K), sum((x-K)^2), K = first element of the channel) reduced per workgroup in
+// fp32 and merged across workgroups in fp64 in a fixed order -> deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+template <typename F4, typename F1>
+__device__ __forceinline__ void slab_foreach(const float *row, int len, int t, int nt, bool vec, F4 f4, F1 f1) {
+	if (!vec) {          // operands not congruent modulo 16 B (offset views): plain 4-B accesses
+		for (int j = t; j < len; j += nt) f1(j);
+		return;
+	}
+	const int mis = (int)(((uintptr_t)row >> 2) & 3);
+	int head = mis ? 4 - mis : 0;
+	head = head < len ? head : len;
+	if (t < head) f1(t);
+
+	const int n4 = (len - head) >> 2;
+	const float4 *r4 = reinterpret_cast<const float4 *>(row + head);
+	for (int i = t; i < n4; i += nt) f4(head + 4 * i, r4[i]);
+
+	const int tail0 = head + 4 * n4;
+	if (t < len - tail0) f1(tail0 + t);
+}
+
+struct BnGeom {
+	int n, c, hw, splits, nt;      // nt: threads cooperating on one slab (64 or 256)
+	bool vec;                      // all tensors of the call share the same address modulo 16 B
+};
+
+__host__ __device__ inline int bn_rows_per_pass(int nt) { return 256 / nt; }
+
+inline bool congruent16(const void *a, const void *b = nullptr, const void *c = nullptr) {
+	const uintptr_t m = (uintptr_t)a & 15;
+	return (!b || ((uintptr_t)b & 15) == m) && (!c || ((uintptr_t)c & 15) == m);
+}
+
+inline BnGeom bn_geom(int n, int c, int hw, bool vec = true) {
+	BnGeom g;
+	g.n = n, g.c = c, g.hw = hw, g.vec = vec;
+	g.nt = hw >= 2048 ? 256 : 64;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int row_groups = (n + rpp - 1) / rpp;
+	int s = (8 * pz::kNumCU + c - 1) / c;          // aim at >= 8 workgroups per CU across the whole launch
+	if (s > row_groups) s = row_groups;
+	if (s > 64) s = 64;
+	if (s < 1) s = 1;
+	g.splits = s;
+	return g;
+}
+
+// ---- forward statistics: ws[(ch*S + s)*2 + {0,1}] = {sum(x-K), sum((x-K)^2)}, wsK[ch] = K
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float *__restrict__ x, BnGeom g, float *__restrict__ part,
+                                                        float *__restrict__ shift) {
+	__shared__ float red[16];
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
+
+	const float K = x[(size_t)ch * g.hw];
+	float s1 = 0.f, s2 = 0.f;
+
+	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
+		const float *row = x + ((size_t)n * g.c + ch) * g.hw;
+		slab_foreach(
+		    row, g.hw, t, g.nt, g.vec,
+		    [&](int, float4 v) {
+			    const float a = v.x - K, b = v.y - K, c = v.z - K, d = v.w - K;
+			    s1 += (a + b) + (c + d);
+			    s2 += (a * a + b * b) + (c * c + d * d);
+		    },
+		    [&](int j) {
+			    const float a = row[j] - K;
+			    s1 += a;
+			    s2 += a * a;
+		    });
+	}
+
+	s1 = block_sum(s1, red);
+	s2 = block_sum(s2, red);
+	if (threadIdx.x == 0) {
+		part[((size_t)ch * g.splits + s) * 2 + 0] = s1;
+		part[((size_t)ch * g.splits + s) * 2 + 1] = s2;
+		if (s == 0) shift[ch] = K;
+	}
+}
+
+// merges the per-split partials of one channel (fixed order, fp64); every thread returns the same pair
+__device__ __forceinline__ void bn_merge(const float *part, int splits, int ch, double &a, double &b) {
+	a = 0.0, b = 0.0;
+	for (int i = 0; i < splits; ++i) {
+		a += (double)part[((size_t)ch * splits + i) * 2 + 0];
+		b += (double)part[((size_t)ch * splits + i) * 2 + 1];
+	}
+}
+
+__global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, float *y, BnGeom g,
+                                                              const float *__restrict__ part, const float *__restrict__ shift,
+                                                              const float *__restrict__ scale, const float *__restrict__ bias,
+                                                              float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                              float *__restrict__ save_mean, float *__restrict__ save_invvar,
+                                                              float eps, float factor) {
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
+
+	double S1, S2;
+	bn_merge(part, g.splits, ch, S1, S2);
+	const double cnt = (double)g.n * g.hw;
+	const double m1 = S1 / cnt;
+	double var = S2 / cnt - m1 * m1;
+	var = var > 0.0 ? var : 0.0;
+	const float mean = (float)((double)shift[ch] + m1);
+	const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+
+	if (s == 0 && threadIdx.x == 0) {
+		save_mean[ch] = mean;
+		save_invvar[ch] = rstd;
+		const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+		run_mean[ch] = (1.f - factor) * run_mean[ch] + factor * mean;
+		run_var[ch] = (1.f - factor) * run_var[ch] + factor * (float)unbiased;
+	}
+
+	const float a = rstd * scale[ch], b = bias[ch] - mean * a;
+
+	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
+		const size_t off = ((size_t)n * g.c + ch) * g.hw;
+		const float *row = x + off;
+		float *out = y + off;
+		slab_foreach(
+		    row, g.hw, t, g.nt, g.vec,
+		    [&](int j, float4 v) {
+			    *reinterpret_cast<float4 *>(out + j) = make_float4(v.x * a + b, v.y * a + b, v.z * a + b, v.w * a + b);
+		    },
+		    [&](int j) { out[j] = row[j] * a + b; });
+	}
+}
+
+__global__ void __launch_bounds__(256) bn_infer_kernel(const float *x, float *y, BnGeom g,
+                                                        const float *__restrict__ scale, const float *__restrict__ bias,
+                                                        const float *__restrict__ mean, const float *__restrict__ var, float eps) {
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
+
+	// NumpyDnn.batchNorm2d: scale / sqrt(var + eps) * (x - mean) + bias
+	const float a = scale[ch] / sqrtf(var[ch] + eps), mu = mean[ch], b = bias[ch];
+
+	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
+		const size_t off = ((size_t)n * g.c + ch) * g.hw;
+		const float *row = x + off;
+		float *out = y + off;
+		slab_foreach(
+		    row, g.hw, t, g.nt, g.vec,
+		    [&](int j, float4 v) {
+			    *reinterpret_cast<float4 *>(out + j) =
+			        make_float4(a * (v.x - mu) + b, a * (v.y - mu) + b, a * (v.z - mu) + b, a * (v.w - mu) + b);
+		    },
+		    [&](int j) { out[j] = a * (row[j] - mu) + b; });
+	}
+}
+
+// ---- backward: partials {sum dy, sum dy*(x-mean)} then dx
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ dy, BnGeom g,
+                                                            const float *__restrict__ save_mean, float *__restrict__ part) {
+	__shared__ float red[16];
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
+
+	const float mu = save_mean[ch];
+	float s1 = 0.f, s2 = 0.f;
+
+	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
+		const size_t off = ((size_t)n * g.c + ch) * g.hw;
+		const float *row = x + off, *grow = dy + off;
+		slab_foreach(
+		    row, g.hw, t, g.nt, g.vec,
+		    [&](int j, float4 v) {
+			    const float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    s1 += (gv.x + gv.y) + (gv.z + gv.w);
+			    s2 += (gv.x * (v.x - mu) + gv.y * (v.y - mu)) + (gv.z * (v.z - mu) + gv.w * (v.w - mu));
+		    },
+		    [&](int j) {
+			    const float gj = grow[j];
+			    s1 += gj;
+			    s2 += gj * (row[j] - mu);
+		    });
+	}
+
+	s1 = block_sum(s1, red);
+	s2 = block_sum(s2, red);
+	if (threadIdx.x == 0) {
+		part[((size_t)ch * g.splits + s) * 2 + 0] = s1;
+		part[((size_t)ch * g.splits + s) * 2 + 1] = s2;
+	}
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const float *dy,
+                                                            float *dx, BnGeom g, const float *__restrict__ part,
+                                                            const float *__restrict__ scale, const float *__restrict__ save_mean,
+                                                            const float *__restrict__ save_invvar, float *__restrict__ dscale,
+                                                            float *__restrict__ dbias) {
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const int rpp = bn_rows_per_pass(g.nt);
+	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
+
+	double S1, S2;
+	bn_merge(part, g.splits, ch, S1, S2);
+	const float mu = save_mean[ch], rstd = save_invvar[ch], sc = scale[ch];
+	const float db = (float)S1, ds = (float)(S2 * (double)rstd);      // dscale = rstd * sum dy*(x-mu)
+
+	if (s == 0 && threadIdx.x == 0) {
+		dscale[ch] = ds;
+		dbias[ch] = db;
+	}
+
+	// dx = sc*rstd*(dy - db/m - xhat*ds/m),  xhat = (x-mu)*rstd
+	const float inv_m = 1.f / ((float)g.n * (float)g.hw);
+	const float k0 = sc * rstd, k1 = db * inv_m, k2 = ds * inv_m * rstd;
+
+	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
+		const size_t off = ((size_t)n * g.c + ch) * g.hw;
+		const float *row = x + off, *grow = dy + off;
+		float *out = dx + off;
+		slab_foreach(
+		    row, g.hw, t, g.nt, g.vec,
+		    [&](int j, float4 v) {
+			    const float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    *reinterpret_cast<float4 *>(out + j) =
+			        make_float4(k0 * (gv.x - k1 - (v.x - mu) * k2), k0 * (gv.y - k1 - (v.y - mu) * k2),
+			                    k0 * (gv.z - k1 - (v.z - mu) * k2), k0 * (gv.w - k1 - (v.w - mu) * k2));
+		    },
+		    [&](int j) { out[j] = k0 * (grow[j] - k1 - (row[j] - mu) * k2); });
+	}
+}
+
+inline size_t bn_ws_bytes(const BnGeom &g) { return ((size_t)g.c * g.splits * 2 + g.c) * sizeof(float); }
+
+int bn_check(int n, int c, int hw) {
+	PZ_REQUIRE(n > 0 && c > 0 && hw > 0, "batchnorm: non-positive dimension (%d, %d, %d)", n, c, hw);
+	PZ_REQUIRE(c <= 65535 * 32, "batchnorm: too many channels");
+	return PZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pz_bn_workspace_bytes(int n, int c, int hw, size_t *nbytes) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	*nbytes = bn_ws_bytes(bn_geom(n, c, hw));
+	return PZ_OK;
+}
+
+int pz_bn_fwd_train(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
+                    float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor, void *workspace,
+                    size_t ws_bytes, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && y && scale && bias && run_mean && run_var && save_mean && save_invvar, "pz_bn_fwd_train: null tensor");
+	const BnGeom g = bn_geom(n, c, hw, congruent16(x, y));
+	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train: workspace too small");
+
+	float *part = (float *)workspace, *shift = part + (size_t)c * g.splits * 2;
+	hipStream_t st = pz::as_stream(stream);
+	dim3 grid(c, g.splits);
+
+	bn_stats_kernel<<<grid, 256, 0, st>>>(x, g, part, shift);
+	PZ_LAUNCH_CHECK();
+	bn_apply_train_kernel<<<grid, 256, 0, st>>>(x, y, g, part, shift, scale, bias, run_mean, run_var, save_mean, save_invvar,
+	                                            epsilon, factor);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias, const float *mean,
+                    const float *var, float epsilon, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && y && scale && bias && mean && var, "pz_bn_fwd_infer: null tensor");
+	const BnGeom g = bn_geom(n, c, hw, congruent16(x, y));
+	bn_infer_kernel<<<dim3(c, g.splits), 256, 0, pz::as_stream(stream)>>>(x, y, g, scale, bias, mean, var, epsilon);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *save_mean,
+              const float *save_invvar, float *dscale, float *dbias, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias, "pz_bn_bwd: null tensor");
+	const BnGeom g = bn_geom(n, c, hw, congruent16(x, dy, dx));
+	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_bwd: workspace too small");
+
+	float *part = (float *)workspace;
+	hipStream_t st = pz::as_stream(stream);
+	dim3 grid(c, g.splits);
+
+	bn_bwd_stats_kernel<<<grid, 256, 0, st>>>(x, dy, g, save_mean, part);
+	PZ_LAUNCH_CHECK();
+	bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, save_mean, save_invvar, dscale, dbias);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Shared host/device helpers for libpuzzle_mi355 (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/puzzle_mi355.h"
+
+namespace pz {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(pz_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNumXCD = 8;       // MI355X: 8 XCDs, block b is observed to land on XCD b % 8
+constexpr int kNumCU = 256;
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// grid for bandwidth kernels: enough workgroups to fill 256 CUs several times over, grid-stride the rest
+inline int stream_grid(size_t work_items, int per_block) {
+	size_t blocks = (work_items + per_block - 1) / per_block;
+	size_t cap = (size_t)kNumCU * 8;
+	return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+}  // namespace pz
+
+#define PZ_REQUIRE(cond, ...)                                   \
+	do {                                                        \
+		if (!(cond)) {                                          \
+			pz::set_error(__VA_ARGS__);                         \
+			return PZ_ERR_INVALID;                              \
+		}                                                       \
+	} while (0)
+
+#define PZ_HIP(call)                                                                         \
+	do {                                                                                     \
+		hipError_t e_ = (call);                                                              \
+		if (e_ != hipSuccess) {                                                              \
+			pz::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+			return e_ == hipErrorOutOfMemory ? PZ_ERR_NOMEM : PZ_ERR_HIP;                    \
+		}                                                                                    \
+	} while (0)
+
+#define PZ_LAUNCH_CHECK()                                                                    \
+	do {                                                                                     \
+		hipError_t e_ = hipGetLastError();                                                   \
+		if (e_ != hipSuccess) {                                                              \
+			pz::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+			return PZ_ERR_HIP;                                                               \
+		}                                                                                    \
+	} while (0)
+
+// ---- device-side wavefront helpers (64 lanes) ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+	return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+	return v;
+}
+
+// block-wide sum for blocks of up to 1024 threads; every thread gets the result. `smem` >= 16 floats.
+__device__ __forceinline__ float block_sum(float v, float *smem) {
+	v = wave_sum(v);
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+	__syncthreads();
+	if (lane == 0) smem[wid] = v;
+	__syncthreads();
+	float r = 0.f;
+	for (int i = 0; i < nw; ++i) r += smem[i];
+	return r;
+}

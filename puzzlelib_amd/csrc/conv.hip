@@ -1,0 +1,838 @@
+// fp32 convolution for gfx950 on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   forward      y[n,k,p,q]  = sum_{c,r,s} x[n,c,p*st+r*d-pad, ...] * w[k,c,r,s]        implicit GEMM  M=K  N=N*P*Q  Kred=C*R*S
+//   backward-data            = the same kernel run on dy with re-packed (flipped / stride-class) filters,
+//                              one launch per stride residue class, each writing its own output pixels
+//   backward-filter dw[k,crs]= sum_{n,p,q} dy[n,k,p,q] * x[n,c,...]                      implicit GEMM  M=K  N=C*R*S  Kred=N*P*Q
+//                              split over Kred across workgroups, deterministic slab reduce with the
+//                              beta*dw + alpha*sum epilogue (the reference's extra addKer pass, MIOpen.py:432-433, fused)
+//
+// Tiling (64-lane waves): a workgroup is 4 waves; each wave owns a (32*TM)x(32*TN) accumulator made of
+// 32x32 MFMA tiles. Operands are staged through LDS in layouts whose MFMA fragment reads (lane l reads
+// row/col l&31 at k = l>>5) hit 32 distinct banks: [k][m] for m-contiguous sources, [m][BK+1] for
+// k-contiguous ones. im2col never exists in memory: each lane owns one pixel column of the B tile, the
+// (c,r,s) -> address/offset decode is a per-k table read through the scalar cache.
+//
+// Replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams — Hip/Wrappers/MIOpen.py:333-462.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kPadTap = 0x7fff;   // table sentinel: pushes the bounds check out of range -> operand reads as 0
+
+// bijective XCD-aware remap (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles, so the
+// m-tiles that share one pixel panel are consumed back-to-back out of the same 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+	const int q = nblk / pz::kNumXCD, r = nblk % pz::kNumXCD;
+	const int xcd = bid % pz::kNumXCD, idx = bid / pz::kNumXCD;
+	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// filter packing + k-table (one tiny launch in front of every implicit-GEMM launch)
+// ------------------------------------------------------------------------------------------------
+struct PackArgs {
+	const float *w;      // (K, Cg, R, S)
+	float *wp;           // [groups][kred_pad][mpad]  (m contiguous)
+	int2 *tab;           // [kred_pad] {input offset of tap, (dh << 16) | dw}
+	int Kg, Cg, R, S, groups;
+	int mode;            // 0: forward (m = out channel, kred = (c, r, s));  1: backward-data class (m = in channel, kred = (k, r'', s''))
+	int M, mpad, kred, kred_pad;
+	int a_h, a_w, st_h, st_w, Rc, Sc;      // backward-data residue class: taps r = a + st*(Rc-1-r'')
+	int dil_h, dil_w;
+	int in_h, in_w;                         // spatial dims of the tensor the GEMM gathers from
+};
+
+__global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
+	const long total = (long)a.groups * a.kred_pad * a.mpad;
+	const int RS = a.mode == 0 ? a.R * a.S : a.Rc * a.Sc;
+	const int Sx = a.mode == 0 ? a.S : a.Sc;
+
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+		const int m = (int)(i % a.mpad);
+		const long t = i / a.mpad;
+		const int kr = (int)(t % a.kred_pad);
+		const int g = (int)(t / a.kred_pad);
+
+		float v = 0.f;
+		if (m < a.M && kr < a.kred) {
+			const int ch = kr / RS, rs = kr - ch * RS;
+			const int rr = rs / Sx, ss = rs - rr * Sx;
+
+			if (a.mode == 0) {
+				v = a.w[(((long)(g * a.Kg + m) * a.Cg + ch) * a.R + rr) * a.S + ss];
+			} else {
+				const int r = a.a_h + a.st_h * (a.Rc - 1 - rr), s = a.a_w + a.st_w * (a.Sc - 1 - ss);
+				v = a.w[(((long)(g * a.Kg + ch) * a.Cg + m) * a.R + r) * a.S + s];
+			}
+		}
+		a.wp[i] = v;
+
+		if (g == 0 && m == 0) {
+			int2 e = make_int2(0, (kPadTap << 16) | kPadTap);
+			if (kr < a.kred) {
+				const int ch = kr / RS, rs = kr - ch * RS;
+				const int rr = rs / Sx, ss = rs - rr * Sx;
+				const int dh = rr * a.dil_h, dw = ss * a.dil_w;
+				e = make_int2(ch * a.in_h * a.in_w + dh * a.in_w + dw, (dh << 16) | dw);
+			}
+			a.tab[kr] = e;
+		}
+	}
+}
+
+// table only (backward-filter: j = (c, r, s) column of the GEMM)
+__global__ void __launch_bounds__(256) build_tab_kernel(int2 *tab, int n, int npad, int R, int S, int dil_h, int dil_w,
+                                                        int in_h, int in_w) {
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= npad) return;
+	int2 e = make_int2(0, (kPadTap << 16) | kPadTap);
+	if (j < n) {
+		const int ch = j / (R * S), rs = j - ch * R * S;
+		const int rr = rs / S, ss = rs - rr * S;
+		e = make_int2(ch * in_h * in_w + rr * dil_h * in_w + ss * dil_w, ((rr * dil_h) << 16) | (ss * dil_w));
+	}
+	tab[j] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// implicit-GEMM forward / backward-data kernel
+// ------------------------------------------------------------------------------------------------
+struct IgemmArgs {
+	const float *x;       // gathered tensor (N, C_total, H, W)
+	const float *wp;      // packed filters [groups][kred_pad][mpad]
+	const int2 *tab;      // [kred_pad]
+	const float *bias;    // per output channel or NULL
+	float *y;             // (N, OC_total, OH, OW)
+	int C_total, H, W, Cg;
+	int M, mpad, kred_pad;
+	int Pv, Qv, npix;                      // virtual output grid, npix = N*Pv*Qv
+	int vs_h, vs_w, pad_h, pad_w;          // gather coordinate = p*vs - pad + dh
+	int OC_total, OH, OW, os_h, os_w, oo_h, oo_w;   // output coordinate = p*os + oo
+	int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
+	constexpr int BK = 16, NT = 256;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+
+	__shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+	__shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave / WN, wn = wave % WN;
+	const int g = blockIdx.z;
+
+	const int L = xcd_remap(blockIdx.x, gridDim.x);
+	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+
+	// ---- B (gathered pixels) loader: this thread owns one pixel column of the tile for the whole kernel
+	constexpr int NB = BK / (NT / BN);        // k rows per thread; a wave covers NB consecutive rows
+	const int jb = tid % BN;
+	const int kb0 = __builtin_amdgcn_readfirstlane(tid / BN);
+
+	const int pix = tn * BN + jb;
+	const bool pvalid = pix < a.npix;
+	int n_img = 0, pp = 0, qq = 0;
+	if (pvalid) {
+		const int pq_sz = a.Pv * a.Qv;
+		n_img = pix / pq_sz;
+		const int pq = pix - n_img * pq_sz;
+		pp = pq / a.Qv;
+		qq = pq - pp * a.Qv;
+	}
+	const int h0 = pvalid ? pp * a.vs_h - a.pad_h : -(1 << 20);     // invalid pixel: every tap fails the bounds check
+	const int w0 = qq * a.vs_w - a.pad_w;
+	const float *xb = a.x + ((size_t)n_img * a.C_total + (size_t)g * a.Cg) * a.H * a.W;
+	const int base_off = h0 * a.W + w0;
+
+	// ---- A (packed filters) loader: float4 per thread, m contiguous
+	constexpr int NA = (BK * BM / 4) / NT;
+	static_assert(NA >= 1, "A tile too small");
+	const float *wpg = a.wp + (size_t)g * a.kred_pad * a.mpad + (size_t)tm * BM;
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+	f32x4 ra[NA];
+	float rb[NB];
+	unsigned okmask = 0;
+
+	auto load_tile = [&](int kt) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const int f = tid + i * NT;
+			const int kk = f / (BM / 4), m4 = (f % (BM / 4)) * 4;
+			ra[i] = *reinterpret_cast<const f32x4 *>(wpg + (size_t)(kt * BK + kk) * a.mpad + m4);
+		}
+		// the NB table entries of this wave are contiguous: they arrive as one wide scalar load
+		int2 e[NB];
+#pragma unroll
+		for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];
+		okmask = 0;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int hh = h0 + (e[i].y >> 16), ww = w0 + (e[i].y & 0xffff);
+			const unsigned ok = (unsigned)((unsigned)hh < (unsigned)a.H) & (unsigned)((unsigned)ww < (unsigned)a.W);
+			rb[i] = xb[ok ? base_off + e[i].x : 0];     // branch-free: out-of-image taps read a safe address
+			okmask |= ok << i;                          // ... and are zeroed when the tile is parked in LDS
+		}
+	};
+
+	auto store_tile = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const int f = tid + i * NT;
+			const int kk = f / (BM / 4), m4 = (f % (BM / 4)) * 4;
+			*reinterpret_cast<f32x4 *>(&As[buf][kk][m4]) = ra[i];
+		}
+#pragma unroll
+		for (int i = 0; i < NB; ++i) Bs[buf][kb0 * NB + i][jb] = (okmask >> i) & 1u ? rb[i] : 0.f;
+	};
+
+	const int nk = a.kred_pad / BK;
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	load_tile(0);
+	store_tile(0);
+	__syncthreads();
+
+	for (int kt = 0; kt < nk; ++kt) {
+		const int buf = kt & 1;
+		if (kt + 1 < nk) load_tile(kt + 1);          // global loads in flight underneath the MFMAs below
+
+#pragma unroll
+		for (int ks = 0; ks < BK; ks += 2) {
+			float av[TM], bv[TN];
+#pragma unroll
+			for (int i = 0; i < TM; ++i) av[i] = As[buf][ks + lhi][wm * (32 * TM) + i * 32 + l31];
+#pragma unroll
+			for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][ks + lhi][wn * (32 * TN) + j * 32 + l31];
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+		}
+
+		if (kt + 1 < nk) store_tile(buf ^ 1);
+		__syncthreads();
+	}
+
+	// ---- epilogue: D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+#pragma unroll
+	for (int j = 0; j < TN; ++j) {
+		const int opix = tn * BN + wn * (32 * TN) + j * 32 + l31;
+		if (opix >= a.npix) continue;
+
+		const int pq_sz = a.Pv * a.Qv;
+		const int on = opix / pq_sz;
+		const int opq = opix - on * pq_sz;
+		const int op = opq / a.Qv, oq = opq - op * a.Qv;
+		const int oh = op * a.os_h + a.oo_h, ow = oq * a.os_w + a.oo_w;
+		if ((unsigned)oh >= (unsigned)a.OH || (unsigned)ow >= (unsigned)a.OW) continue;
+
+		const size_t plane = (size_t)a.OH * a.OW;
+		float *yb = a.y + ((size_t)on * a.OC_total + (size_t)g * a.M) * plane + (size_t)oh * a.OW + ow;
+
+#pragma unroll
+		for (int i = 0; i < TM; ++i) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int m = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+				if (m < a.M) {
+					float v = acc[i][j][r];
+					if (a.bias) v += a.bias[g * a.M + m];
+					yb[(size_t)m * plane] = v;
+				}
+			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward-filter kernel: acc[m = out channel][n = (c,r,s)] over kred = pixels, split along kred
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+	const float *x;       // (N, C_total, H, W)
+	const float *dy;      // (N, K_total, P, Q)
+	const int2 *tab;      // [ncrs_pad]
+	float *out;           // dw (splits == 1) or partial slabs [split][groups*Kg*ncrs]
+	int C_total, H, W, Cg;
+	int K_total, P, Q, Kg;
+	int ncrs;
+	int st_h, st_w, pad_h, pad_w;
+	int npix, steps_total, steps_per_split;
+	int tiles_m, tiles_n;
+	float alpha, beta;
+	int direct;           // 1: out = beta*out + alpha*acc ; 0: out[split] = acc
+	size_t slab;          // groups*Kg*ncrs
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
+	constexpr int BK = 32, LD = BK + 1;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	static_assert(WM * WN == 4, "4 waves per workgroup");
+
+	__shared__ float As[BM * LD];
+	__shared__ float Bs[BN * LD];
+	__shared__ int2 tabs[BN];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave / WN, wn = wave % WN;
+	const int g = blockIdx.z, split = blockIdx.y;
+
+	const int L = blockIdx.x;
+	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+
+	if (tid < BN) tabs[tid] = a.tab[tn * BN + tid];
+
+	const int kp = tid & 31, row0 = tid >> 5;         // pixel within the k-step, first row handled
+	constexpr int NA = BM / 8, NB = BN / 8;
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+	float ra[NA], rb[NB];
+	const int PQ = a.P * a.Q, HW = a.H * a.W;
+
+	__syncthreads();   // tabs visible
+
+	unsigned amask = 0, bmask = 0;
+
+	// branch-free gathers: masked-out elements read a safe address and are zeroed when parked in LDS,
+	// so all NA+NB loads of a step are issued back to back and stay in flight under the MFMAs
+	auto load_step = [&](int step) {
+		const int kpix = step * BK + kp;
+		const unsigned pv = kpix < a.npix;
+		const int kpc = pv ? kpix : 0;
+		const int n_img = kpc / PQ;
+		const int pq = kpc - n_img * PQ;
+		const int p = pq / a.Q, q = pq - p * a.Q;
+
+		const float *dyb = a.dy + ((size_t)n_img * a.K_total + (size_t)g * a.Kg) * PQ + pq;
+		amask = 0;
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const int m = tm * BM + row0 + 8 * i;
+			ra[i] = dyb[(size_t)min(m, a.Kg - 1) * PQ];
+			amask |= (pv & (unsigned)(m < a.Kg)) << i;
+		}
+
+		const int h0 = pv ? p * a.st_h - a.pad_h : -(1 << 20);
+		const int w0 = q * a.st_w - a.pad_w;
+		const float *xb = a.x + ((size_t)n_img * a.C_total + (size_t)g * a.Cg) * HW;
+		const int base_off = h0 * a.W + w0;
+		bmask = 0;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int2 e = tabs[row0 + 8 * i];
+			const int hh = h0 + (e.y >> 16), ww = w0 + (e.y & 0xffff);
+			const unsigned ok = (unsigned)((unsigned)hh < (unsigned)a.H) & (unsigned)((unsigned)ww < (unsigned)a.W);
+			rb[i] = xb[ok ? base_off + e.x : 0];
+			bmask |= ok << i;
+		}
+	};
+
+	const int s_begin = split * a.steps_per_split;
+	const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	if (s_begin < s_end) load_step(s_begin);
+
+	for (int step = s_begin; step < s_end; ++step) {
+		__syncthreads();                               // previous step's fragment reads are done
+#pragma unroll
+		for (int i = 0; i < NA; ++i) As[(row0 + 8 * i) * LD + kp] = (amask >> i) & 1u ? ra[i] : 0.f;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) Bs[(row0 + 8 * i) * LD + kp] = (bmask >> i) & 1u ? rb[i] : 0.f;
+		__syncthreads();
+
+		if (step + 1 < s_end) load_step(step + 1);
+
+#pragma unroll
+		for (int ks = 0; ks < BK; ks += 2) {
+			float av[TM], bv[TN];
+#pragma unroll
+			for (int i = 0; i < TM; ++i) av[i] = As[(wm * (32 * TM) + i * 32 + l31) * LD + ks + lhi];
+#pragma unroll
+			for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn * (32 * TN) + j * 32 + l31) * LD + ks + lhi];
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int j = 0; j < TN; ++j)
+					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+		}
+	}
+
+	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
+#pragma unroll
+	for (int j = 0; j < TN; ++j) {
+		const int col = tn * BN + wn * (32 * TN) + j * 32 + l31;
+		if (col >= a.ncrs) continue;
+#pragma unroll
+		for (int i = 0; i < TM; ++i) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int m = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+				if (m < a.Kg) {
+					float *o = outb + (size_t)m * a.ncrs + col;
+					const float v = acc[i][j][r];
+					if (a.direct)
+						*o = (a.beta == 0.f ? 0.f : a.beta * *o) + a.alpha * v;
+					else
+						*o = v;
+				}
+			}
+		}
+	}
+}
+
+// dw = beta*dw + alpha * sum_s slab[s]   (fixed summation order -> deterministic)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
+                                                            int splits, float alpha, float beta) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		float s = 0.f;
+		for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+		dw[i] = (beta == 0.f ? 0.f : beta * dw[i]) + alpha * s;
+	}
+}
+
+// db[k] = beta*db[k] + alpha * sum_{n,pq} dy[n,k,pq]   (one workgroup per channel)
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float *__restrict__ dy, float *__restrict__ db, int N, int K, int PQ,
+                                                         float alpha, float beta) {
+	__shared__ float red[16];
+	const int k = blockIdx.x;
+	float s = 0.f;
+	for (int n = 0; n < N; ++n) {
+		const float *row = dy + ((size_t)n * K + k) * PQ;
+		for (int i = threadIdx.x; i < PQ; i += blockDim.x) s += row[i];
+	}
+	s = block_sum(s, red);
+	if (threadIdx.x == 0) db[k] = (beta == 0.f ? 0.f : beta * db[k]) + alpha * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct (one thread per output) kernels: ConvFwdAlgo.direct and the fallback for configurations the
+// implicit-GEMM path does not take (stride > 1 together with dilation > 1 in backward-data)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) direct_fwd_kernel(pz_conv_desc d, int P, int Q, const float *__restrict__ x,
+                                                          const float *__restrict__ w, const float *__restrict__ bias,
+                                                          float *__restrict__ y) {
+	const int Cg = d.c / d.groups, Kg = d.k / d.groups;
+	const size_t total = (size_t)d.n * d.k * P * Q;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int q = i % Q, p = (i / Q) % P, k = (i / ((size_t)Q * P)) % d.k, n = i / ((size_t)Q * P * d.k);
+		const int g = k / Kg;
+		float s = bias ? bias[k] : 0.f;
+		for (int c = 0; c < Cg; ++c)
+			for (int r = 0; r < d.r; ++r) {
+				const int hh = p * d.stride_h - d.pad_h + r * d.dil_h;
+				if ((unsigned)hh >= (unsigned)d.h) continue;
+				for (int ss = 0; ss < d.s; ++ss) {
+					const int ww = q * d.stride_w - d.pad_w + ss * d.dil_w;
+					if ((unsigned)ww >= (unsigned)d.w) continue;
+					s += x[(((size_t)n * d.c + g * Cg + c) * d.h + hh) * d.w + ww] * w[(((size_t)k * Cg + c) * d.r + r) * d.s + ss];
+				}
+			}
+		y[i] = s;
+	}
+}
+
+__global__ void __launch_bounds__(256) direct_bwd_data_kernel(pz_conv_desc d, int P, int Q, const float *__restrict__ dy,
+                                                               const float *__restrict__ w, float *__restrict__ dx) {
+	const int Cg = d.c / d.groups, Kg = d.k / d.groups;
+	const size_t total = (size_t)d.n * d.c * d.h * d.w;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int ww = i % d.w, hh = (i / d.w) % d.h, c = (i / ((size_t)d.w * d.h)) % d.c, n = i / ((size_t)d.w * d.h * d.c);
+		const int g = c / Cg, cl = c - g * Cg;
+		float s = 0.f;
+		for (int r = 0; r < d.r; ++r) {
+			const int ph = hh + d.pad_h - r * d.dil_h;
+			if (ph < 0 || ph % d.stride_h) continue;
+			const int p = ph / d.stride_h;
+			if (p >= P) continue;
+			for (int ss = 0; ss < d.s; ++ss) {
+				const int qw = ww + d.pad_w - ss * d.dil_w;
+				if (qw < 0 || qw % d.stride_w) continue;
+				const int q = qw / d.stride_w;
+				if (q >= Q) continue;
+				for (int kl = 0; kl < Kg; ++kl) {
+					const int k = g * Kg + kl;
+					s += dy[(((size_t)n * d.k + k) * P + p) * Q + q] * w[(((size_t)k * Cg + cl) * d.r + r) * d.s + ss];
+				}
+			}
+		}
+		dx[i] = s;
+	}
+}
+
+// one workgroup per filter element
+__global__ void __launch_bounds__(256) direct_bwd_filter_kernel(pz_conv_desc d, int P, int Q, const float *__restrict__ x,
+                                                                 const float *__restrict__ dy, float *__restrict__ dw,
+                                                                 float alpha, float beta) {
+	__shared__ float red[16];
+	const int Cg = d.c / d.groups, Kg = d.k / d.groups;
+	const int e = blockIdx.x;
+	const int ss = e % d.s, r = (e / d.s) % d.r, cl = (e / (d.s * d.r)) % Cg, k = e / (d.s * d.r * Cg);
+	const int g = k / Kg;
+
+	float s = 0.f;
+	const int npq = d.n * P * Q;
+	for (int i = threadIdx.x; i < npq; i += blockDim.x) {
+		const int q = i % Q, p = (i / Q) % P, n = i / (Q * P);
+		const int hh = p * d.stride_h - d.pad_h + r * d.dil_h, ww = q * d.stride_w - d.pad_w + ss * d.dil_w;
+		if ((unsigned)hh < (unsigned)d.h && (unsigned)ww < (unsigned)d.w)
+			s += x[(((size_t)n * d.c + g * Cg + cl) * d.h + hh) * d.w + ww] * dy[(((size_t)n * d.k + k) * P + p) * Q + q];
+	}
+	s = block_sum(s, red);
+	if (threadIdx.x == 0) dw[e] = (beta == 0.f ? 0.f : beta * dw[e]) + alpha * s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct FwdPlan {
+	int bm, bn;                 // tile
+	int tiles_m, tiles_n, mpad, kred, kred_pad;
+	size_t wp_bytes, tab_bytes;
+};
+
+FwdPlan plan_igemm(int M, int kred, long npix) {
+	FwdPlan p;
+	p.bm = M <= 64 ? 64 : 128;
+	p.bn = M <= 64 ? 256 : 128;
+	p.tiles_m = pz::ceil_div(M, p.bm);
+	p.tiles_n = pz::ceil_div(npix, p.bn);
+	p.mpad = p.tiles_m * p.bm;
+	p.kred = kred;
+	p.kred_pad = pz::ceil_div(kred, 16) * 16;
+	return p;
+}
+
+int check_desc(const pz_conv_desc *d, int *P, int *Q) {
+	PZ_REQUIRE(d != nullptr, "conv: null descriptor");
+	PZ_REQUIRE(d->n > 0 && d->c > 0 && d->h > 0 && d->w > 0 && d->k > 0 && d->r > 0 && d->s > 0, "conv: non-positive dimension");
+	PZ_REQUIRE(d->groups >= 1 && d->c % d->groups == 0 && d->k % d->groups == 0,
+	           "conv: %d input / %d output maps not divisible by %d groups", d->c, d->k, d->groups);
+	PZ_REQUIRE(d->stride_h >= 1 && d->stride_w >= 1 && d->dil_h >= 1 && d->dil_w >= 1 && d->pad_h >= 0 && d->pad_w >= 0,
+	           "conv: invalid stride/dilation/pad");
+	const int eh = d->h + 2 * d->pad_h - d->dil_h * (d->r - 1) - 1, ew = d->w + 2 * d->pad_w - d->dil_w * (d->s - 1) - 1;
+	PZ_REQUIRE(eh >= 0 && ew >= 0, "conv: filter larger than padded input");
+	*P = eh / d->stride_h + 1;
+	*Q = ew / d->stride_w + 1;
+	PZ_REQUIRE((long)d->r * d->dil_h < kPadTap && (long)d->s * d->dil_w < kPadTap, "conv: filter extent too large");
+	PZ_REQUIRE((size_t)d->c * d->h * d->w < ((size_t)1 << 31) && (size_t)d->k * *P * *Q < ((size_t)1 << 31),
+	           "conv: one image exceeds 2^31 elements");
+	PZ_REQUIRE((size_t)d->n * *P * *Q < ((size_t)1 << 31) && (size_t)d->n * d->h * d->w < ((size_t)1 << 31),
+	           "conv: pixel count exceeds 2^31");
+	return PZ_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_igemm(const IgemmArgs &a, int groups, hipStream_t st) {
+	dim3 grid(a.tiles_m * a.tiles_n, 1, groups);
+	igemm_conv_kernel<BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+}
+
+void run_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
+	if (p.bm == 64)
+		launch_igemm<64, 256, 1, 4>(a, groups, st);
+	else
+		launch_igemm<128, 128, 2, 2>(a, groups, st);
+}
+
+// backward-data residue classes
+struct DgradClass {
+	int a_h, a_w, Rc, Sc, oo_h, oo_w, pad_h, pad_w, Pv, Qv;
+};
+
+int dgrad_classes(const pz_conv_desc *d, DgradClass *cls, bool *needs_zero) {
+	int n = 0;
+	*needs_zero = false;
+	for (int ah = 0; ah < d->stride_h; ++ah)
+		for (int aw = 0; aw < d->stride_w; ++aw) {
+			DgradClass c;
+			c.a_h = ah, c.a_w = aw;
+			c.Rc = ah < d->r ? (d->r - ah + d->stride_h - 1) / d->stride_h : 0;
+			c.Sc = aw < d->s ? (d->s - aw + d->stride_w - 1) / d->stride_w : 0;
+			c.oo_h = ((ah - d->pad_h) % d->stride_h + d->stride_h) % d->stride_h;
+			c.oo_w = ((aw - d->pad_w) % d->stride_w + d->stride_w) % d->stride_w;
+			c.Pv = c.oo_h < d->h ? (d->h - c.oo_h + d->stride_h - 1) / d->stride_h : 0;
+			c.Qv = c.oo_w < d->w ? (d->w - c.oo_w + d->stride_w - 1) / d->stride_w : 0;
+			if (c.Pv == 0 || c.Qv == 0) continue;               // no output pixel in this class
+			if (c.Rc == 0 || c.Sc == 0) {
+				*needs_zero = true;                              // pixels exist but no tap reaches them
+				continue;
+			}
+			const int delta_h = (c.oo_h + d->pad_h - ah) / d->stride_h, delta_w = (c.oo_w + d->pad_w - aw) / d->stride_w;
+			c.pad_h = (c.Rc - 1) * d->dil_h - delta_h;
+			c.pad_w = (c.Sc - 1) * d->dil_w - delta_w;
+			cls[n++] = c;
+		}
+	return n;
+}
+
+bool dgrad_uses_igemm(const pz_conv_desc *d) {
+	const bool strided = d->stride_h > 1 || d->stride_w > 1, dilated = d->dil_h > 1 || d->dil_w > 1;
+	return !(strided && dilated) && d->stride_h <= 4 && d->stride_w <= 4;
+}
+
+struct WgradPlan {
+	int bm, bn, tiles_m, tiles_n, ncrs, ncrs_pad, steps_total, steps_per_split, splits;
+	size_t tab_bytes, slab_elems;
+};
+
+WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
+	WgradPlan p;
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	p.ncrs = Cg * d->r * d->s;
+	p.bm = Kg <= 64 ? 64 : 128;
+	p.bn = p.ncrs <= 64 ? 64 : 128;
+	p.tiles_m = pz::ceil_div(Kg, p.bm);
+	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
+	p.ncrs_pad = p.tiles_n * p.bn;
+	const long npix = (long)d->n * P * Q;
+	p.steps_total = pz::ceil_div(npix, 32);
+
+	const int tiles = p.tiles_m * p.tiles_n * d->groups;
+	int splits = (4 * pz::kNumCU + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
+	const int max_by_work = p.steps_total / 8 > 0 ? p.steps_total / 8 : 1;   // >= 8 k-steps (256 pixels) per split
+	if (splits > max_by_work) splits = max_by_work;
+	if (splits < 1) splits = 1;
+	p.steps_per_split = pz::ceil_div(p.steps_total, splits);
+	p.splits = pz::ceil_div(p.steps_total, p.steps_per_split);
+	p.tab_bytes = align256((size_t)p.ncrs_pad * sizeof(int2));
+	p.slab_elems = (size_t)d->groups * Kg * p.ncrs;
+	return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q) { return check_desc(d, p, q); }
+
+int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_workspace_bytes: null output");
+	*nbytes = 0;
+	if (algo == PZ_CONV_ALGO_DIRECT) return PZ_OK;
+
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+
+	if (which == PZ_CONV_FWD) {
+		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q);
+		*nbytes = align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)) + align256((size_t)p.kred_pad * sizeof(int2));
+
+	} else if (which == PZ_CONV_BWD_DATA) {
+		if (!dgrad_uses_igemm(d)) return PZ_OK;
+		DgradClass cls[16];
+		bool nz;
+		const int nc = dgrad_classes(d, cls, &nz);
+		size_t total = 0;
+		for (int i = 0; i < nc; ++i) {
+			FwdPlan p = plan_igemm(Cg, Kg * cls[i].Rc * cls[i].Sc, (long)d->n * cls[i].Pv * cls[i].Qv);
+			total += align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)) + align256((size_t)p.kred_pad * sizeof(int2));
+		}
+		*nbytes = total;
+
+	} else if (which == PZ_CONV_BWD_FILTER) {
+		WgradPlan p = plan_wgrad(d, P, Q);
+		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);
+
+	} else {
+		PZ_REQUIRE(false, "pz_conv2d_workspace_bytes: unknown pass %d", which);
+	}
+	return PZ_OK;
+}
+
+int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, int algo,
+                  void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(x && w && y, "pz_conv2d_fwd: null tensor");
+	hipStream_t st = pz::as_stream(stream);
+
+	if (algo == PZ_CONV_ALGO_DIRECT) {
+		const size_t total = (size_t)d->n * d->k * P * Q;
+		direct_fwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(*d, P, Q, x, w, bias, y);
+		PZ_LAUNCH_CHECK();
+		return PZ_OK;
+	}
+
+	size_t need;
+	pz_conv2d_workspace_bytes(d, PZ_CONV_FWD, algo, &need);
+	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q);
+
+	float *wp = (float *)workspace;
+	int2 *tab = (int2 *)((char *)workspace + align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)));
+
+	PackArgs pa{};
+	pa.w = w, pa.wp = wp, pa.tab = tab;
+	pa.Kg = Kg, pa.Cg = Cg, pa.R = d->r, pa.S = d->s, pa.groups = d->groups, pa.mode = 0;
+	pa.M = Kg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
+	pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = d->h, pa.in_w = d->w;
+	const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
+	pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
+	PZ_LAUNCH_CHECK();
+
+	IgemmArgs a{};
+	a.x = x, a.wp = wp, a.tab = tab, a.bias = bias, a.y = y;
+	a.C_total = d->c, a.H = d->h, a.W = d->w, a.Cg = Cg;
+	a.M = Kg, a.mpad = p.mpad, a.kred_pad = p.kred_pad;
+	a.Pv = P, a.Qv = Q, a.npix = d->n * P * Q;
+	a.vs_h = d->stride_h, a.vs_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
+	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
+	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
+	run_igemm(p, a, d->groups, st);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx, int algo, void *workspace,
+                       size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(dy && w && dx, "pz_conv2d_bwd_data: null tensor");
+	hipStream_t st = pz::as_stream(stream);
+
+	if (algo == PZ_CONV_ALGO_DIRECT || !dgrad_uses_igemm(d)) {
+		const size_t total = (size_t)d->n * d->c * d->h * d->w;
+		direct_bwd_data_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(*d, P, Q, dy, w, dx);
+		PZ_LAUNCH_CHECK();
+		return PZ_OK;
+	}
+
+	size_t need;
+	pz_conv2d_workspace_bytes(d, PZ_CONV_BWD_DATA, algo, &need);
+	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	DgradClass cls[16];
+	bool needs_zero;
+	const int nc = dgrad_classes(d, cls, &needs_zero);
+
+	if (needs_zero) PZ_HIP(hipMemsetAsync(dx, 0, (size_t)d->n * d->c * d->h * d->w * sizeof(float), st));
+
+	char *wsp = (char *)workspace;
+	for (int i = 0; i < nc; ++i) {
+		const DgradClass &c = cls[i];
+		FwdPlan p = plan_igemm(Cg, Kg * c.Rc * c.Sc, (long)d->n * c.Pv * c.Qv);
+
+		float *wp = (float *)wsp;
+		wsp += align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float));
+		int2 *tab = (int2 *)wsp;
+		wsp += align256((size_t)p.kred_pad * sizeof(int2));
+
+		PackArgs pa{};
+		pa.w = w, pa.wp = wp, pa.tab = tab;
+		pa.Kg = Kg, pa.Cg = Cg, pa.R = d->r, pa.S = d->s, pa.groups = d->groups, pa.mode = 1;
+		pa.M = Cg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
+		pa.a_h = c.a_h, pa.a_w = c.a_w, pa.st_h = d->stride_h, pa.st_w = d->stride_w, pa.Rc = c.Rc, pa.Sc = c.Sc;
+		pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = P, pa.in_w = Q;
+		const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
+		pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
+		PZ_LAUNCH_CHECK();
+
+		IgemmArgs a{};
+		a.x = dy, a.wp = wp, a.tab = tab, a.bias = nullptr, a.y = dx;
+		a.C_total = d->k, a.H = P, a.W = Q, a.Cg = Kg;
+		a.M = Cg, a.mpad = p.mpad, a.kred_pad = p.kred_pad;
+		a.Pv = c.Pv, a.Qv = c.Qv, a.npix = d->n * c.Pv * c.Qv;
+		a.vs_h = 1, a.vs_w = 1, a.pad_h = c.pad_h, a.pad_w = c.pad_w;
+		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
+		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
+		a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
+		run_igemm(p, a, d->groups, st);
+		PZ_LAUNCH_CHECK();
+	}
+	return PZ_OK;
+}
+
+int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db, float alpha,
+                         float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(x && dy && dw, "pz_conv2d_bwd_filter: null tensor");
+	hipStream_t st = pz::as_stream(stream);
+
+	if (db) {
+		bias_grad_kernel<<<d->k, 256, 0, st>>>(dy, db, d->n, d->k, P * Q, alpha, beta);
+		PZ_LAUNCH_CHECK();
+	}
+
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+
+	if (algo == PZ_CONV_ALGO_DIRECT) {
+		direct_bwd_filter_kernel<<<d->k * Cg * d->r * d->s, 256, 0, st>>>(*d, P, Q, x, dy, dw, alpha, beta);
+		PZ_LAUNCH_CHECK();
+		return PZ_OK;
+	}
+
+	WgradPlan p = plan_wgrad(d, P, Q);
+	const size_t need = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);
+	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_filter: workspace %zu < required %zu bytes", ws_bytes, need);
+
+	int2 *tab = (int2 *)workspace;
+	float *slabs = (float *)((char *)workspace + p.tab_bytes);
+
+	build_tab_kernel<<<pz::ceil_div(p.ncrs_pad, 256), 256, 0, st>>>(tab, p.ncrs, p.ncrs_pad, d->r, d->s, d->dil_h, d->dil_w, d->h, d->w);
+	PZ_LAUNCH_CHECK();
+
+	WgradArgs a{};
+	a.x = x, a.dy = dy, a.tab = tab;
+	a.C_total = d->c, a.H = d->h, a.W = d->w, a.Cg = Cg;
+	a.K_total = d->k, a.P = P, a.Q = Q, a.Kg = Kg;
+	a.ncrs = p.ncrs;
+	a.st_h = d->stride_h, a.st_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
+	a.npix = d->n * P * Q, a.steps_total = p.steps_total, a.steps_per_split = p.steps_per_split;
+	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
+	a.alpha = alpha, a.beta = beta;
+	a.direct = p.splits == 1;
+	a.out = a.direct ? dw : slabs;
+	a.slab = p.slab_elems;
+
+	dim3 grid(p.tiles_m * p.tiles_n, p.splits, d->groups);
+	if (p.bm == 128 && p.bn == 128)
+		wgrad_conv_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(a);
+	else if (p.bm == 128 && p.bn == 64)
+		wgrad_conv_kernel<128, 64, 2, 2><<<grid, 256, 0, st>>>(a);
+	else if (p.bm == 64 && p.bn == 128)
+		wgrad_conv_kernel<64, 128, 2, 2><<<grid, 256, 0, st>>>(a);
+	else
+		wgrad_conv_kernel<64, 64, 2, 2><<<grid, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+
+	if (!a.direct) {
+		wgrad_reduce_kernel<<<pz::stream_grid(p.slab_elems, 256), 256, 0, st>>>(dw, slabs, p.slab_elems, p.splits, alpha, beta);
+		PZ_LAUNCH_CHECK();
+	}
+	return PZ_OK;
+}
+
+}  // extern "C"
