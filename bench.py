@@ -1,0 +1,179 @@
+"""
+bench.py — ResNet-50 (the reference's variant, Models/Nets/ResNet.py:69-121) training step on synthetic ImageNet-shaped
+fp32 data, batch 256 per GPU: forward + cross-entropy + zero-grad + backward + Adam (Handlers/Trainer.py:28-35), data
+already resident in HBM. One process per GPU; for N > 1 launch with
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(weak scaling: 256 images per GPU, gradients mean-all-reduced over RCCL, overlapped with backward).
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  roofline      dominant kernel family (fp32 MFMA implicit-GEMM convolution): algorithmic FLOP / measured launch time
+                (HIP events around every launch of the timed region, recorded on the launch stream) vs 157.3 TFLOP/s
+  cpu_baseline  the numpy oracle (a restatement of the reference's CPU algorithm, extended with backward) timed on this
+                host's cores on a bounded sample (rank 0, N == 1 only)
+"""
+import argparse, json, os, sys, time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 256
+FLOP_PER_IMAGE = 22.770e9        # fwd + dgrad + wgrad, conv1 dgrad excluded; reported, not used for `value`
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FAMILY = ["igemm_conv_kernel<128,128> (fwd + bwd-data)", "igemm_conv_kernel<64,256> (fwd + bwd-data)",
+		  "wgrad_conv_kernel (bwd-filter)"]
+
+
+def cpu_baseline(sample_batch=8):
+	"""Oracle ResNet-50 training step on the host (numpy im2col + sgemm, as the reference CPU backend does forward)."""
+	sys.path.insert(0, os.path.join(ROOT, "oracle"))
+	import cpu_net as N
+	from puzzlelib_amd import nets
+
+	spec = nets.resnet50_spec()
+	rng = np.random.RandomState(1234)
+	pshapes, ashapes = nets.spec_param_shapes(spec)
+
+	params = {}
+	for name, shape in pshapes.items():
+		if name.endswith(".W"):
+			fan = int(np.prod(shape[1:])) if len(shape) == 4 else shape[0]
+			params[name] = (rng.randn(*shape) * np.sqrt(2.0 / fan)).astype(np.float32)
+		elif name.endswith(".scale"):
+			params[name] = np.ones(shape, np.float32)
+		else:
+			params[name] = np.zeros(shape, np.float32)
+	attrs = {k: (np.zeros(s, np.float32) if k.endswith(".mean") else np.ones(s, np.float32)) for k, s in ashapes.items()}
+
+	net = N.CpuNet(spec, params, attrs)
+	opt = N.CpuAdam(net)
+	data = rng.randn(sample_batch, 3, 224, 224).astype(np.float32)
+	labels = rng.randint(0, 1000, size=(sample_batch, )).astype(np.int32)
+
+	t0 = time.perf_counter()
+	N.train_step(net, opt, data, labels)
+	dt = time.perf_counter() - t0
+
+	return {
+		"value": sample_batch / dt, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+		"sample": "1 training step (fwd+CE+bwd+Adam) of the same ResNet-50 at batch %d, %.1f s wall, numpy %s" % (
+			sample_batch, dt, np.__version__
+		)
+	}
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=10)
+	ap.add_argument("--warmup", type=int, default=3)
+	ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
+	ap.add_argument("--no-cpu-baseline", action="store_true")
+	args = ap.parse_args()
+
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	rank = int(os.environ.get("RANK", "0"))
+	local = int(os.environ.get("LOCAL_RANK", "0"))
+	assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+
+	from puzzlelib_amd.settings import Config
+	from puzzlelib_amd import grid
+
+	Config.deviceIdx = local
+	nodeinfo = grid.nodeFromEnv()
+
+	from puzzlelib_amd import nets, train, lib
+	from puzzlelib_amd.surface import bound
+	import ctypes
+
+	gpuarray = bound().gpuarray
+
+	np.random.seed(1234)                        # identical seeds -> identical initial parameters on every rank
+	net = nets.loadResNet(None, "50", initscheme="he")
+
+	rng = np.random.RandomState(1234 + rank)    # each rank trains on its own shard of the global mini-batch
+	data = gpuarray.to_gpu(rng.randn(args.batch, 3, 224, 224).astype(np.float32))
+	labels = gpuarray.to_gpu(rng.randint(0, 1000, size=(args.batch, )).astype(np.int32))
+
+	optimizer = train.Adam(alpha=1e-3, nodeinfo=nodeinfo)
+	optimizer.setupOn(net, useGlobalState=True)
+	if nodeinfo is not None:
+		grid.enableOverlap(optimizer, nodeinfo)
+
+	cost = train.CrossEntropy()
+	trainer = train.Trainer(net, cost, optimizer, batchsize=args.batch)
+	net.trainMode()
+
+	def step():
+		trainer.handleBatch([data, labels], 0, None)
+		net.reset()
+
+	for _ in range(args.warmup):
+		step()
+
+	lib.pz_device_sync()
+	grid.barrier()
+	lib.pz_conv_profile_enable(1)
+
+	t0 = time.perf_counter()
+	for _ in range(args.steps):
+		step()
+	lib.pz_device_sync()
+	grid.barrier()
+	elapsed = time.perf_counter() - t0
+
+	lib.pz_conv_profile_enable(0)
+	ms = (ctypes.c_double * 3)()
+	flops = (ctypes.c_double * 3)()
+	launches = (ctypes.c_longlong * 3)()
+	lib.pz_conv_profile_collect(ms, flops, launches)
+
+	elapsed = grid.maxOverRanks(elapsed)
+	loss = float(cost.getMeanError())
+
+	if rank != 0:
+		return
+
+	images_per_sec = world * args.batch * args.steps / elapsed
+
+	fams = []
+	for i in range(3):
+		if launches[i] > 0:
+			fams.append({
+				"kernel": FAMILY[i], "launches": int(launches[i]), "avg_launch_ms": ms[i] / launches[i],
+				"total_ms_per_step": ms[i] / args.steps, "achieved_tflops": flops[i] / (ms[i] * 1e-3) / 1e12
+			})
+	dom = max(range(3), key=lambda i: ms[i])
+	achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+
+	result = {
+		"metric": "images/sec fwd+bwd+Adam ResNet-50 224x224 fp32 b256 per GPU", "value": images_per_sec,
+		"unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+		"ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+		"dtype": "f32", "data": "synthetic",
+		"config": {
+			"workload": "ResNet-50 (PuzzleLib variant, 55x55 stage 2) synthetic ImageNet 224x224 fp32, batch %d per GPU, "
+						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights" % args.batch,
+			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
+			"grad_allreduce": "none" if world == 1 else "RCCL sum + 1/N, 25 MB buckets overlapped with backward"
+		},
+		"model_tflops_per_gpu": images_per_sec / world * FLOP_PER_IMAGE / 1e12,
+		"pct_of_f32_mfma_peak": images_per_sec / world * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,
+		"final_loss": loss,
+		"roofline": {
+			"kernel": FAMILY[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+			"frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+			"avg_launch_ms": ms[dom] / max(launches[dom], 1), "launches_in_timed_region": int(launches[dom])
+		},
+		"conv_kernel_families": fams,
+	}
+
+	if world == 1 and not args.no_cpu_baseline:
+		result["cpu_baseline"] = cpu_baseline()
+
+	print(json.dumps(result))
+
+
+if __name__ == "__main__":
+	main()

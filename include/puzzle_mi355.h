@@ -108,6 +108,15 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
                          float alpha, float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 
+/* Launch-level profiling of the convolution kernels (bench.py's roofline leg; the analogue of the reference's
+ * Driver timing hooks, Cuda/GPUBackend.py:332-368): while enabled, every MFMA convolution launch is bracketed by
+ * HIP events on the launch stream. collect() synchronises, sums per kernel family and resets.
+ * family: 0 = igemm 128x128 tile, 1 = igemm 64x256 tile, 2 = backward-filter (all tiles).                    */
+#define PZ_CONV_PROFILE_FAMILIES 3
+int pz_conv_profile_enable(int on);
+int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double total_flops[PZ_CONV_PROFILE_FAMILIES],
+                            long long launches[PZ_CONV_PROFILE_FAMILIES]);
+
 /* ---- GEMM: replaces BlasContext.gemm (Cuda/Source/Libs/CuBlas.c:327-402); row-major,
  *      C[M,N] = alpha*op(A)*op(B) + beta*C, lda/ldb/ldc = row pitches in elements.                    */
 int pz_gemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda,

@@ -1,0 +1,1069 @@
+"""
+The backend object of the MI355X operator backend — the thing `Backend.getBackend(deviceIdx, initmode, logger)` returns.
+
+It reproduces the object shape PuzzleLib's dispatch surface reads from `PuzzleLib.Hip.Backend`
+(Backend/gpuarray.py:60-113, Backend/Blas.py:43-102, Backend/Dnn.py:124-338, Backend/Kernels/*.py; the original is
+Hip/Backend.py:19-71 on top of Cuda/GPUBackend.py:17-433): GPUArray, memoryPool, blas, dnn, matmod, costmod, the
+`<name>Ker` kernel objects, enums, SharedArray, stream/event managers, RNG, copy/concatenate/split/tile, timeKernel.
+Underneath every entry is one or two calls into libpuzzle_mi355.so — no MIOpen, no rocBLAS, no JIT.
+"""
+import sys, time, ctypes
+from ctypes import byref, c_int, c_size_t, c_void_p
+from enum import Enum
+from collections import OrderedDict
+
+import numpy as np
+
+from puzzlelib_amd import lib, driver
+from puzzlelib_amd.lib import HipError, ConvDesc, PoolDesc
+from puzzlelib_amd.driver import streamHandle
+from puzzlelib_amd.gpuarray import GPUArray, prod, eltwise
+
+
+# ---------------------------------------------------------------------------------------------- enums
+class ConvFwdAlgo(Enum):              # Hip/Wrappers/MIOpen.py:24-31 (values are this library's algo ids)
+	auto = -1
+	gemm = 0
+	direct = 1
+	fft = 2
+	winograd = 3
+	implicitGemm = 5
+	staticGemm = 4
+
+
+class ConvBwdFilterAlgo(Enum):        # Hip/Wrappers/MIOpen.py:34-39
+	auto = -1
+	gemm = 0
+	direct = 1
+	winograd = 3
+	implicitGemm = 5
+
+
+class ConvBwdDataAlgo(Enum):          # Hip/Wrappers/MIOpen.py:42-49
+	auto = -1
+	gemm = 0
+	direct = 1
+	fft = 2
+	winograd = 3
+	transposeGemm = 4
+	implicitGemm = 5
+
+
+class PoolMode(Enum):                 # Hip/Wrappers/MIOpen.py:52-55
+	max = 0
+	avgWithPad = 1
+	avgNoPad = 2
+
+
+class SoftMaxMode(Enum):              # Hip/Wrappers/MIOpen.py:64-66
+	perActivation = 0
+	spatial = 1
+
+
+class BatchNormMode(Enum):            # Hip/Wrappers/MIOpen.py:69-71
+	perActivation = 0
+	spatial = 1
+
+
+class LRNMode(Enum):
+	map = 0
+	cross = 1
+
+
+class RNNMode(Enum):
+	relu = 0
+	tanh = 1
+	lstm = 2
+	gru = 3
+
+
+class DirectionMode(Enum):
+	uni = 0
+	bi = 1
+
+
+class RNNAlgo(Enum):
+	default = 0
+
+
+class GroupFormat(Enum):              # Hip/Backend.py:39-41
+	gbp = 0
+	bgp = 1
+
+
+class ConvPerf:                        # Hip/Wrappers/MIOpen.py:82-100
+	def __init__(self, algo, time, memory):
+		self.algo, self.time, self.memory = algo, time, memory
+
+	def toString(self):
+		return "%-40s %-25s %-28s" % (
+			"Algo %s" % self.algo, "time %.6f secs" % self.time, "memory %.6f mbytes" % (self.memory / 1024**2)
+		)
+
+	__str__ = __repr__ = toString
+
+
+def toAlgoId(algo):
+	"""Any of the reference's algo ids selects the MFMA implicit-GEMM path except `direct` (one thread per output)."""
+	algo = algo.value if isinstance(algo, Enum) else algo
+	return lib.CONV_ALGO_DIRECT if algo == 1 else lib.CONV_ALGO_AUTO
+
+
+def pair(v):
+	return (int(v), int(v)) if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
+
+
+def requireF32(*arrays):
+	for ary in arrays:
+		if ary is None:
+			continue
+		if ary.dtype != np.float32:
+			raise ValueError("float32 gpuarray expected, got %s" % ary.dtype)
+		if not ary.contiguous:
+			raise ValueError("gpuarray is not contiguous")
+
+
+def ptrOf(ary):
+	return None if ary is None else ary.ptr
+
+
+# ---------------------------------------------------------------------------------------------- BLAS
+class BlasContext:
+	"""gemm / dot / l1norm / l2norm — BlasContext of Cuda/Source/Libs/CuBlas.c:486-499 (RocBlas on HIP)."""
+
+	def __init__(self, backend):
+		self.backend = backend
+
+
+	def enableTensorOps(self, _):
+		return self
+
+
+	@staticmethod
+	def getVersion():
+		return "puzzle-mi355 mfma-f32 gemm %d" % lib.pz_version()
+
+
+	def gemm(self, A, B, out=None, transpA=False, transpB=False, alpha=1.0, beta=0.0, allocator=None):
+		requireF32(A, B, out)
+		if A.ndim != 2 or B.ndim != 2:
+			raise ValueError("gemm operands must be matrices")
+		if transpA and transpB:
+			raise ValueError("gemm with both operands transposed is not supported")
+
+		m, k = (A.shape[1], A.shape[0]) if transpA else A.shape
+		kb, n = (B.shape[1], B.shape[0]) if transpB else B.shape
+		if k != kb:
+			raise ValueError("gemm inner dimensions do not match (%d vs %d)" % (k, kb))
+
+		if out is None:
+			out = GPUArray.empty((m, n), dtype=A.dtype, allocator=allocator)
+		elif out.shape != (m, n):
+			raise ValueError("gemm output has shape %s, expected %s" % (out.shape, (m, n)))
+
+		lib.pz_gemm(
+			int(transpA), int(transpB), m, n, k, alpha, A.ptr, A.shape[1], B.ptr, B.shape[1], beta, out.ptr, n, None
+		)
+		return out
+
+
+	def gemmBatched(self, *args, **kwargs):
+		raise NotImplementedError("batched GEMM (GroupLinear) is outside the ResNet/NiN/LeNet operator path")
+
+
+	def scalarOut(self):
+		return GPUArray.empty((), dtype=np.float32, allocator=self.backend.memoryPool)
+
+
+	def dot(self, x, y):
+		requireF32(x, y)
+		out = self.scalarOut()
+		lib.pz_dot(x.ptr, y.ptr, x.size, out.ptr, None)
+		return float(out.get())
+
+
+	def l1norm(self, x):
+		requireF32(x)
+		out = self.scalarOut()
+		lib.pz_asum(x.ptr, x.size, out.ptr, None)
+		return float(out.get())
+
+
+	def l2norm(self, x):
+		return float(np.sqrt(self.dot(x, x)))
+
+
+# ---------------------------------------------------------------------------------------------- DNN
+class DnnContext:
+	"""conv / pool / softmax / batch-norm entry points with the signatures of Hip/Wrappers/MIOpen.py:333-751."""
+
+	def __init__(self, backend):
+		self.backend = backend
+
+
+	def enableTensorOps(self, _):
+		return self
+
+
+	@staticmethod
+	def getVersion():
+		return "puzzle-mi355 implicit-gemm conv %d" % lib.pz_version()
+
+
+	@staticmethod
+	def convDesc(dataShape, Wshape, stride, pad, dilation, groups):
+		if len(dataShape) != 4 or len(Wshape) != 4:
+			raise NotImplementedError("only 2-D convolution (4-d tensors) is implemented on this backend")
+
+		(sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dilation)
+		n, c, h, w = dataShape
+		k, _, r, s = Wshape
+		return ConvDesc(n, c, h, w, k, r, s, sh, sw, ph, pw, dh, dw, groups)
+
+
+	def workspace(self, nbytes, allocator):
+		if nbytes == 0:
+			return None
+		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
+
+
+	def convNd(self, data, W, bias=None, stride=1, pad=0, dilation=1, groups=1, algo=ConvFwdAlgo.auto.value,
+			   out=None, allocator=None):
+		assert data.ndim == W.ndim and data.shape[1] == W.shape[1] * groups
+		requireF32(data, W, bias, out)
+
+		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
+		p, q = c_int(0), c_int(0)
+		lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
+		outshape = (data.shape[0], W.shape[0], p.value, q.value)
+
+		out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator) if out is None else out
+		if out.shape != outshape:
+			raise ValueError("conv output has shape %s, expected %s" % (out.shape, outshape))
+
+		algo = toAlgoId(algo)
+		size = c_size_t(0)
+		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_FWD, algo, byref(size))
+		ws = self.workspace(size.value, allocator)
+
+		lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
+		return out
+
+
+	def convNdBackwardData(self, grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1,
+						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None):
+		assert grad.ndim == W.ndim and grad.shape[1] == W.shape[0]
+		requireF32(grad, W, bias, out)
+
+		(sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dilation)
+
+		if data is not None:
+			inshape = data.shape
+		else:
+			poh, pow_ = pair(postpad if postpad is not None else 0)
+			_, _, oh, ow = grad.shape
+			_, cg, r, s = W.shape
+			inshape = (
+				grad.shape[0], cg * groups, (oh - 1) * sh + dh * (r - 1) - 2 * ph + 1 + poh,
+				(ow - 1) * sw + dw * (s - 1) - 2 * pw + 1 + pow_
+			)
+
+		desc = self.convDesc(inshape, W.shape, stride, pad, dilation, groups)
+		p, q = c_int(0), c_int(0)
+		lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
+		if (p.value, q.value) != grad.shape[2:]:
+			raise ValueError("gradient maps %s do not match the convolution geometry %s" % (grad.shape[2:], (p.value, q.value)))
+
+		out = GPUArray.empty(inshape, dtype=grad.dtype, allocator=allocator) if out is None else out
+
+		algo = toAlgoId(algo)
+		size = c_size_t(0)
+		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_DATA, algo, byref(size))
+		ws = self.workspace(size.value, allocator)
+
+		lib.pz_conv2d_bwd_data(byref(desc), grad.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None)
+
+		if bias is not None:           # deconvolution forward: bias over the produced maps
+			self.backend.matmod.addVecToMat(
+				bias, out.reshape(out.shape[0], out.shape[1], prod(out.shape[2:])), axis=0, out=out.reshape(
+					out.shape[0], out.shape[1], prod(out.shape[2:])
+				), tiled=True
+			)
+
+		return out
+
+
+	def convNdBackwardParams(self, data, grad, W, stride=1, pad=0, dilation=1, groups=1, withbias=False, deconv=False,
+							 wgrad=None, bgrad=None, scale=1.0, momentum=0.0, algo=ConvBwdFilterAlgo.auto.value,
+							 allocator=None):
+		assert data.ndim == grad.ndim and grad.shape[1] == W.shape[0] and data.shape[1] == W.shape[1] * groups
+		requireF32(data, grad, wgrad, bgrad)
+		if deconv:
+			raise NotImplementedError("deconvolution parameter gradients are outside the implemented operator path")
+
+		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
+
+		# accumulate contract of Hip/Wrappers/MIOpen.py:414-433,441-455: a destination that was passed in AND
+		# (scale, momentum) != (1, 0) -> dst = momentum*dst + scale*d; otherwise dst = d
+		accumulate = scale != 1.0 or momentum != 0.0
+		wcoef = (scale, momentum) if (wgrad is not None and accumulate) else (1.0, 0.0)
+		bcoef = (scale, momentum) if (bgrad is not None and accumulate) else (1.0, 0.0)
+
+		wgrad = GPUArray.empty(W.shape, dtype=W.dtype, allocator=allocator) if wgrad is None else wgrad
+
+		algo = toAlgoId(algo)
+		size = c_size_t(0)
+		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_FILTER, algo, byref(size))
+		ws = self.workspace(size.value, allocator)
+
+		bg = None
+		if withbias:
+			bg = GPUArray.empty((grad.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
+
+		fused = withbias and bcoef == wcoef       # one library call reduces dw and db with the same (alpha, beta)
+		lib.pz_conv2d_bwd_filter(
+			byref(desc), data.ptr, grad.ptr, wgrad.ptr, ptrOf(bg) if fused else None, wcoef[0], wcoef[1], algo,
+			ptrOf(ws), size.value, None
+		)
+
+		if withbias and not fused:
+			n, k = grad.shape[:2]
+			persample = self.backend.matmod.matsum(grad.reshape(n * k, prod(grad.shape[2:])), axis=1, allocator=allocator)
+			self.backend.matmod.matsum(persample.reshape(n, k), axis=0, out=bg, alpha=bcoef[0], beta=bcoef[1])
+
+		return (wgrad, bg) if withbias else wgrad
+
+
+	def convNdbenchmark(self, datashape, Wshape, dtype, stride=1, pad=0, dilation=1, groups=1, algoCount=10,
+						exhaustive=False):
+		"""Times the two algorithms of each pass on scratch tensors: (algo id, seconds, workspace bytes) triples,
+		the result shape of Hip/Wrappers/MIOpen.py:465-519."""
+		bnd = self.backend
+		data = GPUArray.zeros(datashape, dtype=dtype, allocator=bnd.memoryPool)
+		W = GPUArray.zeros(Wshape, dtype=dtype, allocator=bnd.memoryPool)
+		desc = self.convDesc(datashape, Wshape, stride, pad, dilation, groups)
+
+		out = self.convNd(data, W, None, stride, pad, dilation, groups, allocator=bnd.memoryPool)
+		results = []
+
+		for which, run in (
+			(lib.CONV_FWD, lambda a: self.convNd(data, W, None, stride, pad, dilation, groups, a, None, bnd.memoryPool)),
+			(lib.CONV_BWD_DATA, lambda a: self.convNdBackwardData(
+				out, W, None, data, stride, pad, dilation, 0, groups, a, None, bnd.memoryPool
+			)),
+			(lib.CONV_BWD_FILTER, lambda a: self.convNdBackwardParams(
+				data, out, W, stride, pad, dilation, groups, False, False, None, None, 1.0, 0.0, a, bnd.memoryPool
+			)),
+		):
+			perfs = []
+			for algo in (ConvFwdAlgo.implicitGemm.value, ConvFwdAlgo.direct.value):
+				size = c_size_t(0)
+				lib.pz_conv2d_workspace_bytes(byref(desc), which, toAlgoId(algo), byref(size))
+				secs, _ = bnd.timeKernel(run, (algo, ), looplength=3, log=False, normalize=True)
+				perfs.append((algo, secs, size.value))
+
+			results.append(sorted(perfs, key=lambda perf: perf[1])[:algoCount])
+
+		return tuple(results)
+
+
+	@staticmethod
+	def poolDesc(shape, size, stride, pad, mode):
+		(fh, fw), (sh, sw), (ph, pw) = pair(size), pair(stride), pair(pad)
+		n, c, h, w = shape
+		return PoolDesc(n, c, h, w, fh, fw, sh, sw, ph, pw, mode)
+
+
+	def poolNd(self, data, size=2, stride=2, pad=0, mode=PoolMode.max.value, test=False, out=None, allocator=None):
+		assert data.ndim == 4
+		requireF32(data, out)
+
+		desc = self.poolDesc(data.shape, size, stride, pad, mode)
+		p, q = c_int(0), c_int(0)
+		lib.pz_pool2d_out_shape(byref(desc), byref(p), byref(q))
+		outshape = data.shape[:2] + (p.value, q.value)
+
+		out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator) if out is None else out
+
+		workspace = None
+		if not test:
+			# training mode returns the arg-max workspace (1 byte per output element; dummy for average pooling)
+			nbytes = prod(outshape) if mode == PoolMode.max.value else 4
+			workspace = GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
+
+		index = workspace.ptr if (workspace is not None and mode == PoolMode.max.value) else None
+		lib.pz_pool2d_fwd(byref(desc), data.ptr, out.ptr, index, None)
+
+		return out if test else (out, workspace)
+
+
+	def poolNdBackward(self, grad, indata, outdata, workspace, size=2, stride=2, pad=0, mode=PoolMode.max.value,
+					   out=None, allocator=None):
+		assert grad.ndim == 4
+		requireF32(grad, indata, outdata, out)
+
+		desc = self.poolDesc(indata.shape, size, stride, pad, mode)
+		out = GPUArray.empty(indata.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
+
+		index = workspace.ptr if (workspace is not None and mode == PoolMode.max.value) else None
+		lib.pz_pool2d_bwd(byref(desc), grad.ptr, indata.ptr, outdata.ptr, index, out.ptr, None)
+		return out
+
+
+	@staticmethod
+	def softmaxGeometry(data, mode):
+		n, c = data.shape[0], data.shape[1]
+		spatial = prod(data.shape[2:])
+
+		if mode == SoftMaxMode.perActivation.value:
+			c, spatial = c * spatial, 1
+
+		return n, c, spatial
+
+
+	def softmaxNd(self, data, mode=SoftMaxMode.spatial.value, algo=None, out=None, allocator=None):
+		requireF32(data, out)
+		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
+
+		n, c, spatial = self.softmaxGeometry(data, mode)
+		lib.pz_softmax_fwd(data.ptr, out.ptr, n, c, spatial, None)
+		return out
+
+
+	def softmaxNdBackward(self, grad, outdata, mode=SoftMaxMode.spatial.value, algo=None, out=None, allocator=None):
+		requireF32(grad, outdata, out)
+		out = GPUArray.empty(grad.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
+
+		n, c, spatial = self.softmaxGeometry(grad, mode)
+		lib.pz_softmax_bwd(grad.ptr, outdata.ptr, out.ptr, n, c, spatial, None)
+		return out
+
+
+	def bnWorkspace(self, n, c, hw, allocator):
+		size = c_size_t(0)
+		lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
+		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
+
+
+	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,
+					mode=BatchNormMode.spatial.value, out=None, allocator=None):
+		assert mean.ndim == 1 and var.ndim == 1 and scale.ndim == 1 and bias.ndim == 1
+		assert data.dimAt(1) == mean.dimAt(0)
+		requireF32(data, mean, var, scale, bias, out)
+		if mode != BatchNormMode.spatial.value:
+			raise NotImplementedError("per-activation batch normalisation is not implemented on this backend")
+
+		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
+		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
+
+		if test:
+			lib.pz_bn_fwd_infer(data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, epsilon, None)
+			return out
+
+		savemean = GPUArray.empty(mean.shape, dtype=data.dtype, allocator=allocator)
+		saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
+		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+
+		lib.pz_bn_fwd_train(
+			data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
+			epsilon, factor, ws.ptr, nbytes, None
+		)
+		return out, savemean, saveinvvar
+
+
+	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
+							mode=BatchNormMode.spatial.value, out=None, allocator=None):
+		assert data.ndim == grad.ndim
+		requireF32(grad, data, scale, savemean, saveinvvar, out)
+		if savemean is None or saveinvvar is None:
+			raise ValueError("batchNormNdBackward needs the saved mean / inverse variance of the forward pass")
+
+		out = GPUArray.empty(grad.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
+		scalegrad = GPUArray.empty(scale.shape, dtype=scale.dtype, allocator=allocator)
+		bgrad = GPUArray.empty(scale.shape, dtype=scale.dtype, allocator=allocator)
+
+		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
+		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+
+		lib.pz_bn_bwd(
+			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
+			ws.ptr, nbytes, None
+		)
+		return out, scalegrad, bgrad
+
+
+	def lrn(self, *args, **kwargs):
+		raise NotImplementedError("LRN is outside the implemented operator path")
+
+
+	lrnBackward = lrn
+
+
+# ---------------------------------------------------------------------------------------------- matrix-vector module
+class MatModule:
+	"""matsum / addVecToMat / argmax — Cuda/Kernels/MatVec.py:231-374."""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray = backend, backend.GPUArray
+
+
+	def matsum(self, tensor, axis=0, out=None, alpha=1.0, beta=0.0, allocator=None):
+		requireF32(tensor, out)
+		assert 0 <= axis < tensor.ndim
+
+		outshape = tensor.shape[:axis] + tensor.shape[axis + 1:]
+		if out is None:
+			out = GPUArray.zeros(outshape, dtype=tensor.dtype, allocator=allocator)
+		else:
+			assert out.shape == outshape
+
+		if axis == tensor.ndim - 1:
+			lib.pz_reduce_sum_rows(tensor.ptr, prod(tensor.shape[:-1]), tensor.shape[-1], out.ptr, alpha, beta, None)
+		else:
+			z, h, w = prod(tensor.shape[:axis]), tensor.shape[axis], prod(tensor.shape[axis + 1:])
+			lib.pz_reduce_sum_cols(tensor.ptr, z, h, w, out.ptr, alpha, beta, None)
+
+		return out
+
+
+	def argmax(self, tensor, axis=0, allocator=None):
+		requireF32(tensor)
+		assert 0 <= axis < tensor.ndim
+
+		idx = GPUArray.empty(tensor.shape[:axis] + tensor.shape[axis + 1:], dtype=np.int32, allocator=allocator)
+
+		if axis == tensor.ndim - 1:
+			lib.pz_argmax_rows(tensor.ptr, prod(tensor.shape[:-1]), tensor.shape[-1], idx.ptr, None)
+		else:
+			z, h, w = prod(tensor.shape[:axis]), tensor.shape[axis], prod(tensor.shape[axis + 1:])
+			lib.pz_argmax_cols(tensor.ptr, z, h, w, idx.ptr, None)
+
+		return idx
+
+
+	def argmin(self, tensor, axis=0, allocator=None):
+		raise NotImplementedError("argmin is not on the implemented operator path")
+
+
+	def matvec(self, *args, **kwargs):
+		raise NotImplementedError("matvec (GroupLinear) is outside the implemented operator path")
+
+
+	def addVecToMat(self, vec, mat, axis=0, out=None, allocator=None, tiled=False):
+		requireF32(vec, mat, out)
+		assert vec.ndim == mat.ndim - 1 and 0 <= axis < 2
+		assert mat.shape[:-2] == vec.shape[:-1] or tiled
+
+		out = GPUArray.empty(mat.shape, dtype=mat.dtype, allocator=allocator) if out is None else out
+		z = prod(mat.shape[:-2])
+		n, m = mat.shape[-2:]
+
+		if tiled:          # one vector shared by every matrix of the batch
+			for b in range(z):
+				lib.pz_bias_add(out.ptr + b * n * m * 4, mat.ptr + b * n * m * 4, vec.ptr, 1, n, m, vec.shape[-1], axis, None)
+			return out
+
+		if axis == 1:
+			assert mat.dimAt(-1) % vec.dimAt(-1) == 0
+		else:
+			assert mat.dimAt(-2) == vec.dimAt(-1)
+
+		lib.pz_bias_add(out.ptr, mat.ptr, vec.ptr, z, n, m, vec.dimAt(-1), axis, None)
+		return out
+
+
+# ---------------------------------------------------------------------------------------------- cost module
+class ReductionCallable:
+	def __init__(self, fn):
+		self.fn = fn
+
+	def __call__(self, *args, **kwargs):
+		return self.fn(*args, **kwargs)
+
+
+class CostModule:
+	"""crossEntropy + accuracy kernels — Cuda/Kernels/Costs.py:160-247."""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray, self.dnn = backend, backend.GPUArray, backend.dnn
+		self.accKernelCache = {}
+
+
+	def getAccuracyKernel(self, name):
+		krl = self.accKernelCache.get(name, None)
+
+		if krl is None:
+			if name != "calcAccuracy":
+				raise NotImplementedError(name)
+
+			def calcAccuracy(x, y, allocator=None):
+				assert x.dtype == np.int32 and y.dtype == np.int32 and x.size == y.size
+				out = GPUArray.empty((), dtype=np.float32, allocator=allocator)
+				lib.pz_count_neq_i32(x.ptr, y.ptr, x.size, out.ptr, None)
+				return out
+
+			krl = self.accKernelCache[name] = ReductionCallable(calcAccuracy)
+
+		return krl
+
+
+	def crossEntropy(self, scores, labels, weights=None, error=None, allocator=None):
+		assert scores.dtype == np.float32 and labels.dtype == np.int32
+		requireF32(scores, weights)
+
+		n, c = scores.shape[:2]
+		spatial = prod(scores.shape[2:])
+
+		grad = GPUArray.empty(scores.shape, dtype=np.float32, allocator=allocator)
+		if error is None:
+			error = GPUArray.empty((), dtype=np.float32, allocator=allocator)
+
+		ws = GPUArray.empty((n * spatial, ), dtype=np.float32, allocator=allocator)
+		lib.pz_cross_entropy(
+			scores.ptr, labels.ptr, ptrOf(weights), n, c, spatial, grad.ptr, error.ptr, ws.ptr, ws.nbytes, None
+		)
+		return error, grad
+
+
+	def svm(self, *args, **kwargs):
+		raise NotImplementedError("SVM cost is outside the implemented operator path")
+
+
+class StubModule:
+	def __init__(self, name):
+		self.stubName = name
+
+	def __getattr__(self, item):
+		def raiser(*args, **kwargs):
+			raise NotImplementedError("%s.%s is outside the implemented operator path" % (self.stubName, item))
+		return raiser
+
+
+# ---------------------------------------------------------------------------------------------- element-wise kernel objects
+class EltwiseKernel:
+	"""Callable with the launch signature of the reference kernel objects:
+	ker(*arrays_then_scalars, slice=None, stream=None) — Cuda/SourceModule.py:203-226."""
+
+	def __init__(self, op, narrays, nscalars, name, rawScalar=()):
+		self.op, self.narrays, self.nscalars, self.name = op, narrays, nscalars, name
+		self.rawScalar = rawScalar      # indices of scalars that are integers travelling as raw 32-bit words
+
+
+	def __call__(self, *args, **kwargs):
+		if len(args) != self.narrays + self.nscalars:
+			raise TypeError("%s expects %d arguments, got %d" % (self.name, self.narrays + self.nscalars, len(args)))
+
+		arrays, scalars = args[:self.narrays], args[self.narrays:]
+		for ary in arrays:
+			if not ary.contiguous:
+				raise ValueError("gpuarray is not contiguous")
+
+		words = np.empty(len(scalars), dtype=np.float32)
+		for i, value in enumerate(scalars):
+			if i in self.rawScalar:
+				words.view(np.uint32)[i] = np.uint32(int(value))
+			else:
+				words[i] = value
+
+		eltwise(self.op, arrays[0].size, arrays, words, slc=kwargs.get("slice", None), stream=kwargs.get("stream", None))
+
+
+def memoizedKernel(op, narrays, nscalars, name, rawScalar=()):
+	"""`ker(dtype) -> callable` factories (the @memoize'd kernels of Cuda/Kernels/ElementWise.py)."""
+	kernel = EltwiseKernel(op, narrays, nscalars, name, rawScalar)
+
+	def factory(dtype):
+		if np.dtype(dtype) != np.float32:
+			raise NotImplementedError("%s: dtype %s (this backend computes in float32)" % (name, dtype))
+		return kernel
+
+	factory.__name__ = name
+	return factory
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+class SharedArray:
+	"""Flat parameter/gradient arena — Cuda/Utils.py:19-64 (16-byte aligned blocks in registration order)."""
+	alignment = 16
+
+	def __init__(self, dtype=np.float32, allocator=None):
+		self.ary = None
+		self.blocks = OrderedDict()
+		self.dtype = np.dtype(dtype)
+		self.allocator = allocator
+
+
+	def register(self, shape, dtype, name):
+		assert name not in self.blocks
+		assert dtype == self.dtype
+		self.blocks[name] = (shape, prod(shape) * self.dtype.itemsize)
+
+
+	def build(self):
+		total = sum(self.align(nbytes) for _, nbytes in self.blocks.values())
+		self.ary = GPUArray.empty((total // self.dtype.itemsize, ), dtype=self.dtype, allocator=self.allocator)
+
+		blocks, offset = OrderedDict(), 0
+		for name, (shape, nbytes) in self.blocks.items():
+			blocks[name] = GPUArray(shape, self.dtype, gpudata=self.ary.gpudata[offset:offset + nbytes])
+			offset += self.align(nbytes)
+
+		self.blocks = blocks
+
+
+	def __getitem__(self, item):
+		return self.blocks[item]
+
+
+	@classmethod
+	def align(cls, nbytes):
+		return (nbytes + cls.alignment - 1) // cls.alignment * cls.alignment
+
+
+class QueueManager:
+	"""borrow/give pool of Stream or Event objects — Cuda/Utils.py:67-94."""
+
+	def __init__(self, objtype):
+		self.objtype, self.items = objtype, []
+
+	def reserve(self, nitems):
+		self.items.extend(self.objtype() for _ in range(nitems))
+
+	def borrow(self, nitems):
+		if len(self.items) < nitems:
+			self.reserve(nitems - len(self.items))
+		end = len(self.items) - nitems
+		borrowed, self.items = self.items[end:], self.items[:end]
+		return borrowed
+
+	def give(self, items):
+		self.items.extend(items)
+
+	def clear(self):
+		self.items.clear()
+
+
+class RandomNumberGenerator:
+	"""fillInteger / fillUniform / fillNormal — Cuda/Source/Libs/CuRand.c:231-234 (Philox here, XORWOW there)."""
+
+	def __init__(self, type=None, seed=0):
+		self.type, self.seed = "philox4x32-10", int(seed) & 0xffffffffffffffff
+		handle = c_void_p()
+		lib.pz_rng_create(self.seed, byref(handle))
+		self.handle = handle.value
+
+
+	def fillInteger(self, data):
+		assert data.contiguous and data.dtype.itemsize == 4
+		lib.pz_rng_fill_u32(self.handle, data.ptr, data.size, None)
+
+
+	def fillUniform(self, data):
+		requireF32(data)
+		lib.pz_rng_fill_uniform(self.handle, data.ptr, data.size, None)
+
+
+	def fillNormal(self, data, mean=0.0, stddev=1.0):
+		requireF32(data)
+		lib.pz_rng_fill_normal(self.handle, data.ptr, data.size, mean, stddev, None)
+
+
+	def __del__(self):
+		handle, self.handle = getattr(self, "handle", None), None
+		if handle is not None:
+			try:
+				lib.pz_rng_destroy(handle)
+			except Exception:
+				pass
+
+
+# ---------------------------------------------------------------------------------------------- the backend object
+class Mi355Backend:
+	BackendName = "Hip"
+
+	warpSize = 64
+	nthreads = 256
+
+	Driver = driver
+	GPUArray = GPUArray
+	Error = HipError
+	SharedArray = SharedArray
+
+	GroupFormat = GroupFormat
+	ConvPerf = ConvPerf
+	ConvFwdAlgo, ConvBwdDataAlgo, ConvBwdFilterAlgo = ConvFwdAlgo, ConvBwdDataAlgo, ConvBwdFilterAlgo
+	PoolMode, SoftMaxMode, BatchNormMode, LRNMode = PoolMode, SoftMaxMode, BatchNormMode, LRNMode
+	RNNAlgo, RNNMode, DirectionMode = RNNAlgo, RNNMode, DirectionMode
+
+
+	def __init__(self, deviceIdx, initmode=0, logger=None):
+		self.deviceIdx = deviceIdx
+
+		ndevices = driver.Device.count()
+		if ndevices == 0:
+			raise HipError("No %s enabled device found" % self.BackendName)
+		if deviceIdx >= ndevices:
+			raise HipError("Invalid %s config device index" % self.BackendName)
+
+		self.device = driver.Device(deviceIdx).set()
+
+		if logger is not None:
+			logger.info("Using device #%s (%s, %s)", deviceIdx, self.device.name(), self.device.arch())
+
+		self.memoryPool = driver.MemoryPool()
+		GPUArray.defaultAllocator = self.memoryPool
+
+		seed = int(np.random.randint(sys.maxsize, dtype=np.intp))
+		self.globalRng = RandomNumberGenerator(seed=seed)
+
+		self.streamManager = QueueManager(objtype=driver.Stream)
+		self.eventManager = QueueManager(objtype=driver.Event)
+
+		self.blas, self.dnn = None, None
+		self.costmod, self.matmod = None, None
+		self.ctcmod = self.embedmod = self.padmod = self.poolmod = self.prelumod = self.upsamplemod = self.memmod = None
+		self.getAccuracyKernel = None
+
+		self.initmode = 0
+		self.updateBackend(initmode, logger=logger)
+
+
+	def updateBackend(self, initmode, logger=None):
+		if initmode > 0 >= self.initmode:
+			self.initLibs(logger)
+		if initmode > 1 >= self.initmode:
+			self.initKernels()
+		self.initmode = max(initmode, self.initmode)
+
+
+	def initLibs(self, logger=None):
+		self.blas = BlasContext(self)
+		self.dnn = DnnContext(self)
+
+		if logger is not None:
+			logger.debug("Created blas/dnn contexts (%s; %s)", self.blas.getVersion(), self.dnn.getVersion())
+
+
+	def initKernels(self):
+		if self.dnn is None:
+			self.initLibs()
+
+		self.matmod = MatModule(self)
+		self.costmod = CostModule(self)
+		self.getAccuracyKernel = self.costmod.getAccuracyKernel
+
+		for name in ("ctcmod", "embedmod", "padmod", "poolmod", "prelumod", "upsamplemod", "memmod"):
+			setattr(self, name, StubModule(name))
+
+		K = memoizedKernel
+		self.sigmoidKer = K(lib.OP_SIGMOID, 2, 0, "sigmoidKer")
+		self.sigmoidDerKer = K(lib.OP_SIGMOID_DER, 3, 0, "sigmoidDerKer")
+		self.tanhKer = K(lib.OP_TANH, 2, 0, "tanhKer")
+		self.tanhDerKer = K(lib.OP_TANH_DER, 3, 0, "tanhDerKer")
+		self.reluKer = K(lib.OP_RELU, 2, 0, "reluKer")
+		self.reluDerKer = K(lib.OP_RELU_DER, 3, 0, "reluDerKer")
+		self.leakyReluKer = K(lib.OP_LEAKY_RELU, 2, 1, "leakyReluKer")
+		self.leakyReluDerKer = K(lib.OP_LEAKY_RELU_DER, 3, 1, "leakyReluDerKer")
+		self.eluKer = K(lib.OP_ELU, 2, 1, "eluKer")
+		self.eluDerKer = K(lib.OP_ELU_DER, 3, 1, "eluDerKer")
+		self.softPlusKer = K(lib.OP_SOFTPLUS, 2, 0, "softPlusKer")
+		self.softPlusDerKer = K(lib.OP_SOFTPLUS_DER, 3, 0, "softPlusDerKer")
+		self.clipKer = K(lib.OP_CLIP, 2, 2, "clipKer")
+		self.clipDerKer = K(lib.OP_CLIP_DER, 3, 2, "clipDerKer")
+		self.geluKer = K(lib.OP_GELU, 2, 0, "geluKer")
+		self.geluDerKer = K(lib.OP_GELU_DER, 3, 0, "geluDerKer")
+
+		self.dropoutKer = K(lib.OP_DROPOUT, 3, 2, "dropoutKer", rawScalar=(0, ))
+		self.dropout2dKer = K(lib.OP_DROPOUT2D, 3, 3, "dropout2dKer", rawScalar=(0, 2))
+		self.toVectorAddVectorKer = K(lib.OP_AXPY, 2, 1, "toVectorAddVectorKer")
+
+		self.classicMomSGDKer = K(lib.OP_CLASSIC_MOM_SGD, 3, 2, "classicMomSGDKer")
+		self.nesterovMomSGDKer = K(lib.OP_NESTEROV_MOM_SGD, 3, 2, "nesterovMomSGDKer")
+		self.rmspropKer = K(lib.OP_RMSPROP, 3, 3, "rmspropKer")
+		self.adamKer = K(lib.OP_ADAM, 4, 4, "adamKer")
+		self.rmspropGravesKer = K(lib.OP_RMSPROP_GRAVES, 5, 4, "rmspropGravesKer")
+		self.adagradKer = K(lib.OP_ADAGRAD, 3, 2, "adagradKer")
+		self.adadeltaKer = K(lib.OP_ADADELTA, 4, 2, "adadeltaKer")
+		self.smorms3Ker = K(lib.OP_SMORMS3, 5, 2, "smorms3Ker")
+
+		self.linearKer = K(lib.OP_LINEAR, 2, 2, "linearKer")
+		self.mulKer = K(lib.OP_MUL, 3, 0, "mulKer")
+		self.addKer = AddKernelFactory()
+
+		# direct callables (not factories) in the reference: Cuda/GPUBackend.py:169-172,194-195,207,211-215
+		self.rbmKer = EltwiseKernel(lib.OP_RBM, 3, 0, "rbmKer")
+		self.absKer = EltwiseKernel(lib.OP_ABS, 2, 0, "absKer")
+		self.weightDecayKer = EltwiseKernel(lib.OP_WEIGHT_DECAY, 2, 1, "weightDecayKer")
+		self.l1penaltyKer = EltwiseKernel(lib.OP_L1_PENALTY, 3, 1, "l1penaltyKer")
+		self.l1gradKer = EltwiseKernel(lib.OP_L1_GRAD, 3, 1, "l1gradKer")
+
+		def unsupported(*args, **kwargs):
+			raise NotImplementedError("this kernel is outside the implemented operator path (fp32-only backend)")
+
+		self.castFP16toFP32 = self.castFP32toFP16 = unsupported
+		self.bceKer = self.hingeKer = self.smoothL1Ker = self.l1HingeKer = unsupported
+
+		# fused residual sum / gradient fan-in (one 12 B/elem pass instead of memset + 2 axpy)
+		self.add3Ker = EltwiseKernel(lib.OP_ADD3, 3, 0, "add3Ker")
+
+
+	@staticmethod
+	def dtypesSupported():
+		return [(np.float32, 1e-5)]
+
+
+	@staticmethod
+	def copy(dest, source, allocator=None):
+		if dest is None:
+			return source.copy(allocator=allocator)
+		dest.set(source)
+		return dest
+
+
+	def fillUniform(self, data, minval=0.0, maxval=1.0, rng=None):
+		assert data.dtype == np.float32
+		rng = self.globalRng if rng is None else rng
+		rng.fillUniform(data)
+		self.linearKer(data.dtype)(data, data, maxval - minval, minval)
+
+
+	def fillNormal(self, data, mean=0.0, stddev=1.0, rng=None):
+		rng = self.globalRng if rng is None else rng
+		rng.fillNormal(data, mean=mean, stddev=stddev)
+
+
+	def concatenate(self, tup, axis, out=None, allocator=None):
+		ary = tup[0]
+		dtype, reduced = ary.dtype, ary.shape[:axis] + ary.shape[axis + 1:]
+		assert all(a.dtype == dtype and a.shape[:axis] + a.shape[axis + 1:] == reduced for a in tup[1:])
+
+		shape = reduced[:axis] + (sum(a.dimAt(axis) for a in tup), ) + reduced[axis:]
+		if out is None:
+			out = GPUArray.empty(shape, dtype=dtype, allocator=allocator)
+		else:
+			assert out.shape == shape and out.dtype == dtype
+
+		dstPitch = out.strideAt(axis - 1) if axis > 0 else out.nbytes
+		height, offset = prod(shape[:axis]), 0
+
+		for a in tup:
+			width = a.strideAt(axis - 1) if axis > 0 else a.nbytes
+			driver.memcpy2D(width, height, a.gpudata, width, out.gpudata, dstPitch, dstX=offset)
+			offset += width
+
+		return out
+
+
+	def split(self, ary, sections, axis, allocator=None):
+		shape = ary.shape
+		assert sum(sections) == shape[axis]
+
+		outs = [
+			GPUArray.empty(shape[:axis] + (sec, ) + shape[axis + 1:], dtype=ary.dtype, allocator=allocator)
+			for sec in sections
+		]
+
+		srcPitch = ary.strideAt(axis - 1) if axis > 0 else ary.nbytes
+		height, offset = prod(shape[:axis]), 0
+
+		for out in outs:
+			width = out.strideAt(axis - 1) if axis > 0 else out.nbytes
+			driver.memcpy2D(width, height, ary.gpudata, srcPitch, out.gpudata, width, srcX=offset)
+			offset += width
+
+		return outs
+
+
+	def tile(self, ary, repeats, axis, allocator=None):
+		return self.concatenate([ary] * repeats, axis=axis, allocator=allocator)
+
+
+	def timeKernel(self, func, args, kwargs=None, looplength=1000, log=True, logname=None, normalize=False,
+				   hotpass=True):
+		"""Event-pair timing of `looplength` back-to-back calls — Cuda/GPUBackend.py:332-368."""
+		kwargs = {} if kwargs is None else kwargs
+		if hotpass:
+			func(*args, **kwargs)
+
+		start, end = driver.Event(), driver.Event()
+
+		hostStart = time.time()
+		start.record()
+		for _ in range(looplength):
+			func(*args, **kwargs)
+		end.record()
+		hostEnd = time.time()
+
+		end.synchronize()
+		devsecs, hostsecs = start.timeTill(end) * 1e-3, hostEnd - hostStart
+
+		if normalize:
+			devsecs /= looplength
+			hostsecs /= looplength
+
+		if log:
+			logname = getattr(func, "__name__", func.__class__.__name__) if logname is None else logname
+			print("%s device time: %s secs" % (logname, devsecs))
+			print("%s host time: %s secs" % (logname, hostsecs))
+
+		return devsecs, hostsecs
+
+
+	def convNdbenchmark(self, datashape, Wshape, dtype, stride=1, pad=0, dilation=1, groups=1, algoCount=10):
+		results = self.dnn.convNdbenchmark(datashape, Wshape, dtype, stride, pad, dilation, groups, algoCount)
+		return tuple(
+			[ConvPerf(algotype(values[0]), *values[1:]) for values in sub] for algotype, sub in
+			zip((ConvFwdAlgo, ConvBwdDataAlgo, ConvBwdFilterAlgo), results)
+		)
+
+
+	def instanceNorm2d(self, *args, **kwargs):
+		raise NotImplementedError("instance normalisation is outside the implemented operator path")
+
+
+	instanceNorm2dBackward = instanceNorm2d
+
+
+	def createRnn(self, *args, **kwargs):
+		raise NotImplementedError("RNNs are outside the implemented operator path")
+
+
+	acquireRnnParams = updateRnnParams = createRnn
+
+
+	@staticmethod
+	def deviceSupportsBatchHint():
+		return False
+
+
+class AddKernelFactory:
+	"""addKer(dtype)(out, x, alpha, y, beta): out = alpha*x + beta*y — Cuda/Kernels/ElementWise.py:1017-1045
+	(note the interleaved array/scalar argument order)."""
+
+	def __call__(self, dtype):
+		if np.dtype(dtype) != np.float32:
+			raise NotImplementedError("addKer: dtype %s" % dtype)
+		return self.launch
+
+	@staticmethod
+	def launch(out, x, alpha, y, beta, slice=None, stream=None):
+		eltwise(lib.OP_ADD, out.size, (out, x, y), np.array([alpha, beta], dtype=np.float32), slc=slice, stream=stream)
+
+
+backendCache = {}
+
+
+def getDeviceCount():
+	return driver.Device.count()
+
+
+def getBackend(deviceIdx=0, initmode=0, logger=None):
+	bnd = backendCache.get(deviceIdx, None)
+
+	if bnd is None:
+		bnd = Mi355Backend(deviceIdx, initmode, logger=logger)
+		backendCache[deviceIdx] = bnd
+	else:
+		bnd.updateBackend(initmode, logger=logger)
+
+	return bnd

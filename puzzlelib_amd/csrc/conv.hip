@@ -16,10 +16,39 @@
 // Replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams — Hip/Wrappers/MIOpen.py:333-462.
 #include "common.h"
 
+#include <vector>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// ---- optional launch-level profiling (pz_conv_profile_*): event pairs around the MFMA launches only
+struct ProfRec {
+	hipEvent_t a, b;
+	int family;
+	double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+	hipStream_t st;
+	ProfRec rec;
+	bool on;
+	ProfScope(hipStream_t s, int family, double flops) : st(s), on(g_prof_on) {
+		if (!on) return;
+		rec.family = family, rec.flops = flops;
+		(void)hipEventCreate(&rec.a);
+		(void)hipEventCreate(&rec.b);
+		(void)hipEventRecord(rec.a, st);
+	}
+	~ProfScope() {
+		if (!on) return;
+		(void)hipEventRecord(rec.b, st);
+		g_prof.push_back(rec);
+	}
+};
 
 constexpr int kPadTap = 0x7fff;   // table sentinel: pushes the bounds check out of range -> operand reads as 0
 
@@ -555,7 +584,8 @@ void launch_igemm(const IgemmArgs &a, int groups, hipStream_t st) {
 	igemm_conv_kernel<BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
 }
 
-void run_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
+void run_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
+	ProfScope prof(st, p.bm == 64 ? 1 : 0, flops);
 	if (p.bm == 64)
 		launch_igemm<64, 256, 1, 4>(a, groups, st);
 	else
@@ -630,6 +660,28 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 }  // namespace
 
 extern "C" {
+
+int pz_conv_profile_enable(int on) {
+	g_prof_on = on != 0;
+	return PZ_OK;
+}
+
+int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double total_flops[PZ_CONV_PROFILE_FAMILIES],
+                            long long launches[PZ_CONV_PROFILE_FAMILIES]) {
+	PZ_HIP(hipDeviceSynchronize());
+	for (int f = 0; f < PZ_CONV_PROFILE_FAMILIES; ++f) total_ms[f] = 0.0, total_flops[f] = 0.0, launches[f] = 0;
+	for (ProfRec &r : g_prof) {
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, r.a, r.b);
+		total_ms[r.family] += ms;
+		total_flops[r.family] += r.flops;
+		launches[r.family] += 1;
+		(void)hipEventDestroy(r.a);
+		(void)hipEventDestroy(r.b);
+	}
+	g_prof.clear();
+	return PZ_OK;
+}
 
 int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q) { return check_desc(d, p, q); }
 
@@ -709,7 +761,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.vs_h = d->stride_h, a.vs_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
-	run_igemm(p, a, d->groups, st);
+	run_igemm(p, a, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
@@ -738,6 +790,11 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 	const int nc = dgrad_classes(d, cls, &needs_zero);
 
 	if (needs_zero) PZ_HIP(hipMemsetAsync(dx, 0, (size_t)d->n * d->c * d->h * d->w * sizeof(float), st));
+
+	// algorithmic work of backward-data = that of forward; shared out over the class launches by GEMM size
+	const double flops_total = 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s;
+	double gemm_total = 0.0;
+	for (int i = 0; i < nc; ++i) gemm_total += (double)cls[i].Pv * cls[i].Qv * cls[i].Rc * cls[i].Sc;
 
 	char *wsp = (char *)workspace;
 	for (int i = 0; i < nc; ++i) {
@@ -768,7 +825,7 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
 		a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
-		run_igemm(p, a, d->groups, st);
+		run_igemm(p, a, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;
@@ -818,6 +875,8 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	a.slab = p.slab_elems;
 
 	dim3 grid(p.tiles_m * p.tiles_n, p.splits, d->groups);
+	{
+	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	if (p.bm == 128 && p.bn == 128)
 		wgrad_conv_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(a);
 	else if (p.bm == 128 && p.bn == 64)
@@ -826,6 +885,7 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 		wgrad_conv_kernel<64, 128, 2, 2><<<grid, 256, 0, st>>>(a);
 	else
 		wgrad_conv_kernel<64, 64, 2, 2><<<grid, 256, 0, st>>>(a);
+	}
 	PZ_LAUNCH_CHECK();
 
 	if (!a.direct) {

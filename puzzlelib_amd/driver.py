@@ -1,0 +1,257 @@
+"""
+Device runtime objects of the MI355X backend: Device, Stream, Event, Buffer, MemoryPool, memcpy2D.
+
+Host-side mirror of the reference "Driver" extension module (Cuda/Source/Core/{Device,Stream,Buffer,Allocator,
+Driver}.c; method tables Device.c:160-173, Stream.c:101-239, Buffer.c:526-536, Allocator.c:359-362), implemented
+over the C ABI of libpuzzle_mi355.so. Ownership follows the reference: device memory is owned by Buffer objects,
+a pool-backed Buffer returns its block to the pool when the last Python reference dies, views (`buffer[a:b]`)
+keep their parent alive.
+"""
+import ctypes
+from ctypes import byref, c_int, c_size_t, c_void_p, c_float
+
+from puzzlelib_amd import lib
+from puzzlelib_amd.lib import HipError
+
+
+def getDriverVersion():
+	return lib.pz_version()
+
+
+class Device:
+	def __init__(self, index=0):
+		self.index = index
+
+
+	@staticmethod
+	def count():
+		n = c_int(0)
+		lib.pz_device_count(byref(n))
+		return n.value
+
+
+	def set(self):
+		lib.pz_init(self.index)
+		Device.current = self.index
+		return self
+
+
+	@staticmethod
+	def getCurrent():
+		return Device.current
+
+
+	@staticmethod
+	def synchronize():
+		lib.pz_device_sync()
+
+
+	def name(self):
+		buf = ctypes.create_string_buffer(256)
+		lib.pz_device_name(self.index, buf, 256)
+		return buf.value.decode()
+
+
+	def arch(self):
+		buf = ctypes.create_string_buffer(256)
+		lib.pz_device_arch(self.index, buf, 256)
+		return buf.value.decode()
+
+
+	def numCUs(self):
+		n = c_int(0)
+		lib.pz_device_num_cus(self.index, byref(n))
+		return n.value
+
+
+	@staticmethod
+	def memoryInfo():
+		free, total = c_size_t(0), c_size_t(0)
+		lib.pz_device_mem_info(byref(free), byref(total))
+		return free.value, total.value
+
+
+Device.current = 0
+
+
+class Stream:
+	def __init__(self):
+		handle = c_void_p()
+		lib.pz_stream_create(byref(handle))
+		self.handle = handle.value
+
+
+	def synchronize(self):
+		lib.pz_stream_sync(self.handle)
+
+
+	def waitEvent(self, event):
+		lib.pz_stream_wait_event(self.handle, event.handle)
+
+
+	def __del__(self):
+		handle, self.handle = getattr(self, "handle", None), None
+		if handle is not None:
+			try:
+				lib.pz_stream_destroy(handle)
+			except Exception:
+				pass
+
+
+class Event:
+	def __init__(self):
+		handle = c_void_p()
+		lib.pz_event_create(byref(handle))
+		self.handle = handle.value
+
+
+	def record(self, stream=None):
+		lib.pz_event_record(self.handle, streamHandle(stream))
+
+
+	def synchronize(self):
+		lib.pz_event_sync(self.handle)
+
+
+	def timeTill(self, end):
+		ms = c_float(0.0)
+		lib.pz_event_elapsed_ms(self.handle, end.handle, byref(ms))
+		return ms.value
+
+
+	def __del__(self):
+		handle, self.handle = getattr(self, "handle", None), None
+		if handle is not None:
+			try:
+				lib.pz_event_destroy(handle)
+			except Exception:
+				pass
+
+
+def streamHandle(stream):
+	return None if stream is None else stream.handle
+
+
+class Buffer:
+	"""A span of device memory. `parent` is the MemoryPool (or None for a raw allocation) for an owning buffer and
+	the sliced Buffer for a view — the same convention the reference uses (Cuda/GPUArray.py:146-154)."""
+	__slots__ = ["ptr", "size", "parent", "owner", "__weakref__"]
+
+
+	def __init__(self, ptr, size, parent=None, owner=False):
+		self.ptr, self.size, self.parent, self.owner = ptr, size, parent, owner
+
+
+	@classmethod
+	def allocate(cls, nbytes):
+		ptr = c_void_p()
+		lib.pz_malloc(byref(ptr), max(int(nbytes), 1))
+		return cls(ptr.value, int(nbytes), parent=None, owner=True)
+
+
+	def __getitem__(self, item):
+		if not isinstance(item, slice) or item.step not in (None, 1):
+			raise ValueError("buffer supports contiguous byte slices only")
+
+		start, stop, _ = item.indices(self.size)
+		if stop < start:
+			raise ValueError("invalid buffer slice")
+
+		return Buffer(self.ptr + start, stop - start, parent=self, owner=False)
+
+
+	def free(self):
+		if self.owner and self.ptr is not None:
+			ptr, self.ptr, self.owner = self.ptr, None, False
+
+			if isinstance(self.parent, MemoryPool):
+				self.parent.release(ptr)
+			else:
+				lib.pz_free(ptr)
+
+
+	def __del__(self):
+		try:
+			self.free()
+		except Exception:
+			pass
+
+
+	def fillD32(self, value, stream=None):
+		lib.pz_memset_d32(self.ptr, int(value) & 0xffffffff, self.size // 4, streamHandle(stream))
+		return self
+
+
+	def copy(self, dst=None, allocator=None, stream=None):
+		if dst is None:
+			dst = allocator.allocate(self.size) if allocator is not None else Buffer.allocate(self.size)
+		elif dst.size < self.size:
+			raise ValueError("destination buffer is too small")
+
+		lib.pz_memcpy_d2d(dst.ptr, self.ptr, self.size, streamHandle(stream))
+		return dst
+
+
+	def set(self, hostptr, nbytes, stream=None):
+		lib.pz_memcpy_h2d(self.ptr, hostptr, nbytes, streamHandle(stream))
+
+
+	def get(self, hostptr, nbytes, stream=None):
+		lib.pz_memcpy_d2h(hostptr, self.ptr, nbytes, streamHandle(stream))
+		lib.pz_stream_sync(streamHandle(stream))
+
+
+	def getIPCHandle(self):
+		raise NotImplementedError(
+			"IPC memory handles are replaced by RCCL collectives in this backend (see puzzlelib_amd.grid)"
+		)
+
+
+class MemoryPool:
+	"""Size-class free list living in the native library (pz_pool_*): allocate / freeHeld / getStats — the reference's
+	Driver.MemoryPool (Cuda/Source/Core/Allocator.c:29-75,359-362). Passed around as `allocator=`."""
+
+	def __init__(self):
+		handle = c_void_p()
+		lib.pz_pool_create(byref(handle))
+		self.handle = handle.value
+		self.holding = True
+
+
+	def allocate(self, nbytes):
+		nbytes = int(nbytes)
+		ptr = c_void_p()
+		lib.pz_pool_alloc(self.handle, max(nbytes, 1), byref(ptr))
+		return Buffer(ptr.value, nbytes, parent=self, owner=True)
+
+
+	def release(self, ptr):
+		if self.handle is not None:
+			lib.pz_pool_release(self.handle, ptr)
+			if not self.holding:
+				lib.pz_pool_free_held(self.handle)
+
+
+	def freeHeld(self):
+		lib.pz_pool_free_held(self.handle)
+
+
+	def stopHolding(self):
+		self.holding = False
+		self.freeHeld()
+
+
+	def getStats(self):
+		vals = [c_size_t(0) for _ in range(4)]
+		lib.pz_pool_stats(self.handle, *[byref(v) for v in vals])
+		return {"heldBytes": vals[0].value, "liveBytes": vals[1].value, "heldBlocks": vals[2].value,
+				"liveBlocks": vals[3].value}
+
+
+def memcpy2D(width, height, src, srcPitch, dst, dstPitch, srcX=0, dstX=0, stream=None):
+	"""Pitched device-to-device copy; argument order of Driver.memcpy2D as used by Cuda/GPUBackend.py:296,320."""
+	lib.pz_memcpy_2d(dst.ptr + dstX, dstPitch, src.ptr + srcX, srcPitch, width, height, streamHandle(stream))
+
+
+def allocateFromIPCHandle(handle, size):
+	raise NotImplementedError("IPC memory handles are replaced by RCCL collectives in this backend")

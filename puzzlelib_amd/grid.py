@@ -1,0 +1,306 @@
+"""
+Data-parallel training: one process per GPU, mini-batch sharded along N, mean all-reduce of the flat gradient arena.
+
+The reference (Grid.py:4-157) runs one multiprocessing.Process per GPU and reduces gradients through a star: the
+parent maps each child's flat gradient buffer by CUDA/HIP IPC handle, adds them one by one with an axpy kernel and
+copies the mean back — O(N) serial full-buffer passes, fully serialised with backward. Here the `nodeinfo` object the
+optimizers talk to (Optimizers/Optimizer.py:107-109,166-167: broadcastBuffer / sumTensor / meanValue) keeps its API
+but sits on RCCL collectives over xGMI:
+
+  broadcastBuffer(name, buffer)  ->  ncclBroadcast from rank 0 (initial parameter sync)
+  sumTensor(name, tensor)        ->  g <- (g_0 + ... + g_{N-1}) / N  via ncclAllReduce(sum) + one scale kernel
+  meanValue(value)               ->  scalar mean over ranks
+
+and the gradient exchange is bucketed and overlapped with backward: the flat arena is cut into buckets of ~25 MB
+(contiguous ranges, i.e. sets of variables); a module-level hook marks variables complete as backward produces them,
+and as soon as a bucket's completion set is full its all-reduce is queued on a dedicated communication stream behind
+an event recorded on the compute stream. `sumTensor` at update time only queues what is still missing, makes the
+compute stream wait for the communication stream and scales by 1/N.
+
+Processes are started by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT);
+torch.distributed's gloo group is used ONLY to hand the 128-byte RCCL unique id to the other ranks and for host scalars.
+"""
+import os
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------- bucket planning (pure host logic)
+class Bucket:
+	__slots__ = ["start", "stop", "names", "pending", "launched"]
+
+	def __init__(self, start, stop, names):
+		self.start, self.stop, self.names = start, stop, list(names)
+		self.pending, self.launched = set(names), False
+
+
+def planBuckets(blocks, bucketBytes):
+	"""blocks: ordered [(name, byteOffset, nbytes)] of the flat arena (registration order = sorted names, 16-B aligned,
+	Cuda/Utils.py:39-55). Returns contiguous buckets [(startByte, stopByte, [names])] of at least `bucketBytes`
+	(except the last), covering the arena from 0 to the end of the last block without gaps."""
+	buckets, names, start = [], [], 0
+	end = 0
+
+	for name, offset, nbytes in blocks:
+		names.append(name)
+		end = offset + nbytes
+
+		if end - start >= bucketBytes:
+			buckets.append((start, end, names))
+			names, start = [], end
+
+	if names:
+		buckets.append((start, end, names))
+
+	# a bucket's stop is the next bucket's start; gaps from alignment belong to the preceding bucket
+	fixed = []
+	for i, (bstart, bstop, bnames) in enumerate(buckets):
+		nxt = buckets[i + 1][0] if i + 1 < len(buckets) else bstop
+		fixed.append((bstart, max(bstop, nxt), bnames))
+
+	return fixed
+
+
+class GradReducer:
+	"""Completion-set bucketing of one flat gradient arena. Device work is delegated to `ops`:
+	  ops.markReady()                 record 'gradients up to here are final' on the compute stream -> token
+	  ops.allreduce(start, stop, tok) queue an in-place sum all-reduce of arena bytes [start, stop) after `tok`
+	  ops.finish(scale)               make compute wait for all queued collectives, then scale the arena by `scale`
+	"""
+
+	def __init__(self, blocks, ops, gridsize, bucketBytes=25 << 20):
+		self.ops, self.gridsize = ops, gridsize
+		self.buckets = [Bucket(*b) for b in planBuckets(blocks, bucketBytes)]
+		self.owner = {name: bucket for bucket in self.buckets for name in bucket.names}
+
+
+	def beginStep(self):
+		for bucket in self.buckets:
+			bucket.pending, bucket.launched = set(bucket.names), False
+
+
+	def variableReady(self, name):
+		bucket = self.owner.get(name, None)
+		if bucket is None or bucket.launched:
+			return
+
+		bucket.pending.discard(name)
+		if not bucket.pending:
+			self.launch(bucket)
+
+
+	def launch(self, bucket):
+		token = self.ops.markReady()
+		self.ops.allreduce(bucket.start, bucket.stop, token)
+		bucket.launched = True
+
+
+	def finishStep(self):
+		for bucket in self.buckets:
+			if not bucket.launched:
+				self.launch(bucket)
+
+		self.ops.finish(1.0 / self.gridsize)
+
+
+# ---------------------------------------------------------------------------------------------- nodeinfo API
+class NodeInfo:
+	def __init__(self, index, gridsize, device):
+		self.index, self.gridsize, self.device = index, gridsize, device
+
+	def close(self):
+		pass
+
+	def meanValue(self, value):
+		raise NotImplementedError()
+
+	def broadcastBuffer(self, name, buffer):
+		raise NotImplementedError()
+
+	def sumTensor(self, name, tensor):
+		raise NotImplementedError()
+
+
+class RcclNodeInfo(NodeInfo):
+	def __init__(self, index, gridsize, device, uniqueId, hostGroup=None, bucketBytes=25 << 20):
+		super().__init__(index, gridsize, device)
+		self.uniqueId, self.hostGroup, self.bucketBytes = uniqueId, hostGroup, bucketBytes
+
+		self.comm = None
+		self.commStream = None
+		self.reducers = {}
+		self.lastEvents = []
+
+
+	# ---- lazy device side (the backend must be bound to Config.deviceIdx == self.device first)
+	def ensureComm(self):
+		if self.comm is not None:
+			return
+
+		import ctypes
+		from puzzlelib_amd import lib, driver
+
+		handle = ctypes.c_void_p()
+		lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+
+		self.comm = handle.value
+		self.commStream = driver.Stream()
+
+
+	def close(self):
+		if self.comm is not None:
+			from puzzlelib_amd import lib
+			lib.pz_comm_destroy(self.comm)
+			self.comm = None
+
+
+	def meanValue(self, value):
+		if self.gridsize == 1:
+			return value
+
+		import torch, torch.distributed as dist
+		t = torch.tensor([float(value)], dtype=torch.float64)
+		dist.all_reduce(t, group=self.hostGroup)
+		return t.item() / self.gridsize
+
+
+	def broadcastBuffer(self, name, buffer):
+		from puzzlelib_amd import lib
+		self.ensureComm()
+		lib.pz_comm_broadcast(self.comm, buffer.ptr, buffer.size, 0, None)
+
+
+	# ---- gradient exchange
+	def attach(self, name, tensor, blocks):
+		"""Registers the flat arena `tensor` (1-d fp32 GPUArray) with its variable blocks for overlapped reduction."""
+		self.ensureComm()
+		self.reducers[name] = GradReducer(blocks, HipReduceOps(self, tensor), self.gridsize, self.bucketBytes)
+		return self.reducers[name]
+
+
+	def sumTensor(self, name, tensor):
+		reducer = self.reducers.get(name, None)
+
+		if reducer is None:
+			# no bucket plan registered: one collective over the whole tensor on the compute stream, then the mean
+			from puzzlelib_amd import lib
+			from puzzlelib_amd.gpuarray import eltwise
+			self.ensureComm()
+			lib.pz_comm_allreduce_sum_f32(self.comm, tensor.ptr, tensor.ptr, tensor.size, None)
+			eltwise(lib.OP_LINEAR, tensor.size, (tensor, tensor), np.array([1.0 / self.gridsize, 0.0], dtype=np.float32))
+			return
+
+		reducer.finishStep()
+		reducer.beginStep()
+
+
+class HipReduceOps:
+	def __init__(self, node, tensor):
+		self.node, self.tensor = node, tensor
+		self.events = []
+
+
+	def markReady(self):
+		from puzzlelib_amd import driver
+		event = driver.Event()
+		event.record(None)
+		return event
+
+
+	def allreduce(self, start, stop, token):
+		from puzzlelib_amd import lib, driver
+		node = self.node
+
+		node.commStream.waitEvent(token)
+		ptr = self.tensor.ptr + start
+		lib.pz_comm_allreduce_sum_f32(node.comm, ptr, ptr, (stop - start) // 4, node.commStream.handle)
+
+		done = driver.Event()
+		done.record(node.commStream)
+		self.events.append((token, done))
+
+
+	def finish(self, scale):
+		from puzzlelib_amd import lib
+		from puzzlelib_amd.gpuarray import eltwise
+
+		for _, done in self.events:
+			lib.pz_stream_wait_event(None, done.handle)
+		self.events = []
+
+		eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
+
+
+def arenaBlocks(sharedArray):
+	"""[(name, byteOffset, nbytes)] of a built SharedArray, in arena order."""
+	base = sharedArray.ary.ptr
+	return [(name, block.ptr - base, block.nbytes) for name, block in sharedArray.blocks.items()]
+
+
+def enableOverlap(optimizer, nodeinfo):
+	"""Wires the overlapped reducer into an optimizer in global-state mode: registers the flat fp32 gradient arena and
+	installs the module hook that reports finished variables during backward."""
+	from puzzlelib_amd import nn
+
+	shGrads = optimizer.shGrads[np.float32]
+	reducer = nodeinfo.attach("grad", shGrads.ary, arenaBlocks(shGrads))
+	reducer.beginStep()
+
+	# variable object -> arena name
+	names = {}
+	for var, varnames in optimizer.module.getVarTable().items():
+		names[id(var)] = varnames[0]
+
+	def onParamGrads(module):
+		for var in module.vars.values():
+			name = names.get(id(var), None)
+			if name is not None:
+				reducer.variableReady(name)
+
+	nn.Module.paramGradsHook = staticmethod(onParamGrads)
+	return reducer
+
+
+# ---------------------------------------------------------------------------------------------- process bootstrap
+def nodeFromEnv(bucketBytes=25 << 20):
+	"""Builds the NodeInfo of this rank from the torchrun environment. Returns None for a single-process run."""
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if world == 1:
+		return None
+
+	rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+
+	import torch.distributed as dist
+	if not dist.is_initialized():
+		dist.init_process_group(backend="gloo")
+
+	from puzzlelib_amd.settings import Config
+	Config.deviceIdx = local
+	Config.allowMultiContext = True
+
+	from puzzlelib_amd import lib
+	import ctypes
+
+	ids = [None]
+	if rank == 0:
+		buf = ctypes.create_string_buffer(lib.COMM_ID_BYTES)
+		lib.pz_comm_unique_id(buf)
+		ids = [buf.raw]
+
+	dist.broadcast_object_list(ids, src=0)
+	return RcclNodeInfo(rank, world, local, ids[0], bucketBytes=bucketBytes)
+
+
+def barrier():
+	import torch.distributed as dist
+	if dist.is_available() and dist.is_initialized():
+		dist.barrier()
+
+
+def maxOverRanks(value):
+	import torch, torch.distributed as dist
+	if not (dist.is_available() and dist.is_initialized()):
+		return value
+	t = torch.tensor([float(value)], dtype=torch.float64)
+	dist.all_reduce(t, op=dist.ReduceOp.MAX)
+	return t.item()

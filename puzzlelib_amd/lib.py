@@ -1,0 +1,202 @@
+"""
+ctypes binding of libpuzzle_mi355.so (C ABI declared in include/puzzle_mi355.h).
+
+The library is the ONLY compute path of this package: if it cannot be loaded, importing any device-facing
+module raises — there is no CPU or torch fallback. Status codes map to exceptions the way the reference's
+C extension and ctypes wrappers do (Cuda/Source/Core/Common.h:121-139 -> Python exceptions; ValueError for
+layout/dtype/dimension problems, e.g. Cuda/Source/Libs/CuBlas.c:350-354).
+"""
+import ctypes, os
+from ctypes import c_int, c_int32, c_int64, c_uint32, c_uint64, c_size_t, c_float, c_void_p, c_char_p, POINTER, byref
+
+LIBNAME = "libpuzzle_mi355.so"
+LIBPATH = os.environ.get("PUZZLE_MI355_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), LIBNAME))
+
+
+class HipError(RuntimeError):
+	pass
+
+
+class HipMemoryError(HipError, MemoryError):
+	pass
+
+
+class CommError(HipError):
+	pass
+
+
+class ConvDesc(ctypes.Structure):
+	_fields_ = [(name, c_int) for name in (
+		"n", "c", "h", "w", "k", "r", "s", "stride_h", "stride_w", "pad_h", "pad_w", "dil_h", "dil_w", "groups"
+	)]
+
+
+class PoolDesc(ctypes.Structure):
+	_fields_ = [(name, c_int) for name in (
+		"n", "c", "h", "w", "size_h", "size_w", "stride_h", "stride_w", "pad_h", "pad_w", "mode"
+	)]
+
+
+def _load():
+	if not os.path.exists(LIBPATH):
+		raise ImportError(
+			"%s not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+			"`make -C puzzlelib_amd/csrc` (hipcc --offload-arch=gfx950)" % (LIBNAME, LIBPATH)
+		)
+	return ctypes.CDLL(LIBPATH, mode=ctypes.RTLD_GLOBAL)
+
+
+_lib = _load()
+_lib.pz_last_error.restype = c_char_p
+
+P = c_void_p
+PP = POINTER(c_void_p)
+
+# name -> argtypes; every entry returns int status (checked by the generated wrapper)
+_PROTOS = {
+	"pz_init": [c_int],
+	"pz_device_count": [POINTER(c_int)],
+	"pz_device_name": [c_int, c_char_p, c_int],
+	"pz_device_arch": [c_int, c_char_p, c_int],
+	"pz_device_sync": [],
+	"pz_device_mem_info": [POINTER(c_size_t), POINTER(c_size_t)],
+	"pz_device_num_cus": [c_int, POINTER(c_int)],
+
+	"pz_malloc": [PP, c_size_t],
+	"pz_free": [P],
+	"pz_pool_create": [PP],
+	"pz_pool_destroy": [P],
+	"pz_pool_alloc": [P, c_size_t, PP],
+	"pz_pool_release": [P, P],
+	"pz_pool_free_held": [P],
+	"pz_pool_stats": [P, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t)],
+	"pz_host_alloc_pinned": [PP, c_size_t],
+	"pz_host_free_pinned": [P],
+
+	"pz_memcpy_h2d": [P, P, c_size_t, P],
+	"pz_memcpy_d2h": [P, P, c_size_t, P],
+	"pz_memcpy_d2d": [P, P, c_size_t, P],
+	"pz_memcpy_2d": [P, c_size_t, P, c_size_t, c_size_t, c_size_t, P],
+	"pz_memset_d32": [P, c_uint32, c_size_t, P],
+	"pz_strided_copy": [P, POINTER(c_int64), P, POINTER(c_int64), POINTER(c_int64), c_int, P],
+
+	"pz_stream_create": [PP],
+	"pz_stream_destroy": [P],
+	"pz_stream_sync": [P],
+	"pz_stream_wait_event": [P, P],
+	"pz_event_create": [PP],
+	"pz_event_destroy": [P],
+	"pz_event_record": [P, P],
+	"pz_event_sync": [P],
+	"pz_event_elapsed_ms": [P, P, POINTER(c_float)],
+
+	"pz_conv2d_out_shape": [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)],
+	"pz_conv2d_workspace_bytes": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
+	"pz_conv2d_fwd": [POINTER(ConvDesc), P, P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_bwd_data": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
+
+	"pz_conv_profile_enable": [c_int],
+	"pz_conv_profile_collect": [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_longlong)],
+
+	"pz_gemm": [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float, P, c_int, P],
+
+	"pz_bn_workspace_bytes": [c_int, c_int, c_int, POINTER(c_size_t)],
+	"pz_bn_fwd_train": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, P, c_size_t, P],
+	"pz_bn_fwd_infer": [P, P, c_int, c_int, c_int, P, P, P, P, c_float, P],
+	"pz_bn_bwd": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P],
+
+	"pz_pool2d_out_shape": [POINTER(PoolDesc), POINTER(c_int), POINTER(c_int)],
+	"pz_pool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
+	"pz_pool2d_bwd": [POINTER(PoolDesc), P, P, P, P, P, P],
+
+	"pz_softmax_fwd": [P, P, c_int, c_int, c_int, P],
+	"pz_softmax_bwd": [P, P, P, c_int, c_int, c_int, P],
+	"pz_cross_entropy": [P, P, P, c_int, c_int, c_int, P, P, P, c_size_t, P],
+
+	"pz_reduce_sum_rows": [P, c_int, c_int, P, c_float, c_float, P],
+	"pz_reduce_sum_cols": [P, c_int, c_int, c_int, P, c_float, c_float, P],
+	"pz_argmax_rows": [P, c_int, c_int, P, P],
+	"pz_argmax_cols": [P, c_int, c_int, c_int, P, P],
+	"pz_bias_add": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_count_neq_i32": [P, P, c_size_t, P, P],
+	"pz_reduce_minmax_f32": [P, c_size_t, c_int, P, P],
+	"pz_reduce_minmax_i32": [P, c_size_t, c_int, P, P],
+	"pz_dot": [P, P, c_size_t, P, P],
+	"pz_asum": [P, c_size_t, P, P],
+
+	"pz_eltwise": [c_int, c_size_t, PP, c_int, POINTER(c_float), c_int, c_int64, c_int64, c_int64, P],
+	"pz_cast_i32_f32": [P, P, c_size_t, P],
+	"pz_cast_f32_i32": [P, P, c_size_t, P],
+
+	"pz_rng_create": [c_uint64, PP],
+	"pz_rng_destroy": [P],
+	"pz_rng_fill_u32": [P, P, c_size_t, P],
+	"pz_rng_fill_uniform": [P, P, c_size_t, P],
+	"pz_rng_fill_normal": [P, P, c_size_t, c_float, c_float, P],
+
+	"pz_comm_unique_id": [c_char_p],
+	"pz_comm_init_rank": [PP, c_int, c_char_p, c_int],
+	"pz_comm_destroy": [P],
+	"pz_comm_allreduce_sum_f32": [P, P, P, c_size_t, P],
+	"pz_comm_broadcast": [P, P, c_size_t, c_int, P],
+}
+
+PZ_OK, PZ_ERR_INVALID, PZ_ERR_HIP, PZ_ERR_NOMEM, PZ_ERR_COMM = 0, 1, 2, 3, 4
+
+
+def lastError():
+	msg = _lib.pz_last_error()
+	return msg.decode(errors="replace") if msg else ""
+
+
+def _raise(status, name):
+	msg = "%s: %s" % (name, lastError())
+
+	if status == PZ_ERR_INVALID:
+		raise ValueError(msg)
+	elif status == PZ_ERR_NOMEM:
+		raise HipMemoryError(msg)
+	elif status == PZ_ERR_COMM:
+		raise CommError(msg)
+	else:
+		raise HipError(msg)
+
+
+def _bind(name, argtypes):
+	fn = getattr(_lib, name)
+	fn.argtypes = argtypes
+	fn.restype = c_int
+
+	def call(*args):
+		status = fn(*args)
+		if status != 0:
+			_raise(status, name)
+
+	call.__name__ = name
+	return call
+
+
+for _name, _argtypes in _PROTOS.items():
+	globals()[_name] = _bind(_name, _argtypes)
+
+pz_version = _lib.pz_version
+pz_version.restype = c_int
+
+COMM_ID_BYTES = 128
+
+# element-wise op ids (enum pz_eltwise_op)
+(
+	OP_SIGMOID, OP_SIGMOID_DER, OP_TANH, OP_TANH_DER, OP_RELU, OP_RELU_DER, OP_LEAKY_RELU, OP_LEAKY_RELU_DER,
+	OP_ELU, OP_ELU_DER, OP_SOFTPLUS, OP_SOFTPLUS_DER, OP_CLIP, OP_CLIP_DER, OP_GELU, OP_GELU_DER,
+	OP_DROPOUT, OP_DROPOUT2D, OP_AXPY, OP_ADD, OP_MUL, OP_LINEAR, OP_ABS, OP_WEIGHT_DECAY, OP_L1_PENALTY, OP_L1_GRAD,
+	OP_RBM, OP_ADAM, OP_CLASSIC_MOM_SGD, OP_NESTEROV_MOM_SGD, OP_RMSPROP, OP_ADAGRAD, OP_ADADELTA, OP_RMSPROP_GRAVES,
+	OP_SMORMS3, OP_ADD3, OP_IADD, OP_IMUL, OP_COUNT
+) = range(39)
+
+CONV_ALGO_AUTO, CONV_ALGO_DIRECT, CONV_ALGO_IMPLICIT_GEMM = -1, 1, 5
+CONV_FWD, CONV_BWD_DATA, CONV_BWD_FILTER = 0, 1, 2
+
+
+def declaredSymbols():
+	return sorted(list(_PROTOS.keys()) + ["pz_version", "pz_last_error"])

@@ -251,3 +251,27 @@ def loadResNet(modelpath=None, layers="50", actInplace=False, bnInplace=False, i
 		resnet_spec(stages), name="ResNet-%s" % layers if name is None else name, initscheme=initscheme,
 		actInplace=actInplace, bnInplace=bnInplace
 	)
+
+
+def namedVariables(net):
+	"""{"<module name>.<param>": Variable} — keys as used by the specs/oracle (module names are unique in these nets)."""
+	out = {}
+	for var, names in net.getVarTable().items():
+		for full in names:
+			parts = full.split(".")
+			out[".".join(parts[-2:])] = var
+	return out
+
+
+def namedAttrs(net, out=None):
+	"""{"<module name>.<attr>": GPUArray} for module attributes (batch-norm running mean / var)."""
+	from puzzlelib_amd import nn
+
+	out = {} if out is None else out
+	for mod in net.modules.values():
+		if isinstance(mod, nn.Container):
+			namedAttrs(mod, out)
+		else:
+			for attrName, attr in mod.attrs.items():
+				out["%s.%s" % (mod.name, attrName)] = attr
+	return out

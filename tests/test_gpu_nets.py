@@ -1,0 +1,199 @@
+"""
+GPU parity tests on whole networks through the module layer: LeNet b64 (config 1 — the forward logits in the fixture
+were computed by the REFERENCE's own CPU backend on the same seed), a two-stage mini-ResNet training step (conv, BN,
+ReLU, pooling, residual add, linear, cross-entropy, Adam; oracle fixture) and the Trainer/Validator loop.
+Tolerances: forward logits atol 1e-4; parameters after one step atol 2e-5 (updates are O(lr)); gradients rtol 1e-3.
+"""
+import numpy as np
+import pytest
+
+import cpu_ref as R
+import cpu_net as N
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lenet_reference_forward_and_step(bnd, lenet_golden):
+	from puzzlelib_amd import nets, train
+	from puzzlelib_amd.surface import bound
+
+	gpuarray = bound().gpuarray
+
+	np.random.seed(1234)                               # TestLib/CnnMnistLenet.py:18
+	net = nets.loadLeNet(None, initscheme=None)
+	data = np.random.randn(64, 1, 28, 28).astype(np.float32)
+	labels = np.random.randint(0, 10, size=(64, )).astype(np.int32)
+	assert np.array_equal(labels, lenet_golden["labels"])
+
+	variables = nets.namedVariables(net)
+	for name, var in variables.items():
+		head = var.data.get().ravel()[:64]
+		assert np.array_equal(head, lenet_golden["ref_init_head_" + name]), "same seed must give the reference's init: " + name
+
+	net.evalMode()
+	logits = net(gpuarray.to_gpu(data)).get()
+	assert_close(logits, lenet_golden["ref_logits"], atol=1e-4, rtol=1e-4, what="LeNet forward vs reference CPU backend")
+
+	optimizer = train.MomentumSGD(learnRate=0.1, momRate=0.9)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = train.CrossEntropy()
+	trainer = train.Trainer(net, cost, optimizer, batchsize=64)
+	trainer.train(gpuarray.to_gpu(data), gpuarray.to_gpu(labels), random=False)
+
+	assert np.isclose(cost.getMeanError() * 64, lenet_golden["orc_err"][0], rtol=1e-4)
+
+	for name, var in nets.namedVariables(net).items():
+		p, g = var.data.get().ravel(), var.grad.get().ravel()
+		assert_close(g[:256], lenet_golden["orc_grad_head_" + name], atol=1e-5, rtol=1e-3, what="grad " + name)
+		assert_close(p[:256], lenet_golden["orc_after_head_" + name], atol=2e-5, rtol=1e-4, what="param " + name)
+		ref_sum, ref_abs = lenet_golden["orc_after_sum_" + name]
+		assert abs(p.sum(dtype=np.float64) - ref_sum) <= 1e-3 + 1e-4 * ref_abs, "param checksum " + name
+
+
+def build_mini(mini_golden):
+	from puzzlelib_amd import nets
+	from puzzlelib_amd.surface import bound
+
+	spec = nets.resnet_spec(stages=((8, 1), (16, 2)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+
+	np.random.seed(7)
+	net = nets.build(spec, name="mini", initscheme="he")
+
+	for name, var in nets.namedVariables(net).items():
+		var.data.set(mini_golden["init_" + name])
+	return net, spec, bound().gpuarray
+
+
+def test_mini_resnet_training_step(bnd, mini_golden):
+	from puzzlelib_amd import nets, train
+
+	net, spec, gpuarray = build_mini(mini_golden)
+	data, labels = mini_golden["data"], mini_golden["labels"]
+
+	optimizer = train.Adam(alpha=1e-3)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = train.CrossEntropy()
+
+	net.trainMode()
+	pred = net(gpuarray.to_gpu(data))
+	assert_close(pred.get(), mini_golden["orc_logits"], atol=2e-4, rtol=1e-3, what="logits")
+
+	grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
+	assert np.isclose(cost.devErr.get(), mini_golden["orc_err"][0], rtol=1e-4)
+
+	optimizer.zeroGradParams()
+	net.backward(grad, updGrad=False)
+
+	for name, var in nets.namedVariables(net).items():
+		ref = mini_golden["orc_grad_" + name]
+		scale = np.abs(ref).max() + 1e-6
+		assert_close(var.grad.get(), ref, atol=2e-3 * scale, rtol=2e-3, what="grad " + name)
+
+	optimizer.update()
+
+	for name, var in nets.namedVariables(net).items():
+		assert_close(var.data.get(), mini_golden["orc_after_" + name], atol=3e-4, rtol=1e-4, what="param " + name)
+	for name, attr in nets.namedAttrs(net).items():
+		assert_close(attr.get(), mini_golden["orc_attr_" + name], atol=1e-5, rtol=1e-4, what="running stat " + name)
+
+
+def test_mini_resnet_matches_oracle_for_several_steps(bnd, mini_golden):
+	"""3 Adam steps on device vs 3 oracle steps (loss trajectory; Adam's sign-like first steps amplify tiny gradient
+	differences, hence the loose parameter tolerance — the loss is the invariant that is checked tightly)."""
+	from puzzlelib_amd import nets, train
+
+	net, spec, gpuarray = build_mini(mini_golden)
+	data, labels = mini_golden["data"], mini_golden["labels"]
+
+	params = {k[5:]: mini_golden[k] for k in mini_golden.keys() if k.startswith("init_")}
+	pshapes, ashapes = nets.spec_param_shapes(spec)
+	attrs = {k: (np.zeros(s, np.float32) if k.endswith(".mean") else np.ones(s, np.float32)) for k, s in ashapes.items()}
+	cnet = N.CpuNet(spec, params, attrs)
+	copt = N.CpuAdam(cnet, alpha=1e-3)
+
+	optimizer = train.Adam(alpha=1e-3)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = train.CrossEntropy()
+	trainer = train.Trainer(net, cost, optimizer, batchsize=4)
+
+	gdata, glabels = gpuarray.to_gpu(data), gpuarray.to_gpu(labels)
+	for step in range(3):
+		_, err = N.train_step(cnet, copt, data, labels)
+		trainer.train(gdata, glabels, random=False)
+		assert np.isclose(cost.getMeanError() * 4, err, rtol=2e-3), "step %d: device %s vs oracle %s" % (
+			step, cost.getMeanError() * 4, err
+		)
+
+
+def test_validator_and_eval_mode(bnd, mini_golden):
+	from puzzlelib_amd import train
+
+	net, spec, gpuarray = build_mini(mini_golden)
+	data, labels = mini_golden["data"], mini_golden["labels"]
+
+	validator = train.Validator(net, train.CrossEntropy(), batchsize=2)
+	err = validator.validate(gpuarray.to_gpu(data), gpuarray.to_gpu(labels))
+
+	params = {k[5:]: mini_golden[k] for k in mini_golden.keys() if k.startswith("init_")}
+	from puzzlelib_amd import nets
+	_, ashapes = nets.spec_param_shapes(spec)
+	attrs = {k: (np.zeros(s, np.float32) if k.endswith(".mean") else np.ones(s, np.float32)) for k, s in ashapes.items()}
+	cnet = N.CpuNet(spec, params, attrs)
+	cnet.train = False
+	pred = cnet.forward(data)
+	assert err == np.mean(np.argmax(pred, axis=1) != labels)
+
+
+def test_nin_forward_backward_runs_and_matches_oracle(bnd):
+	"""Config 3 (CIFAR-10 NiN): one training step with a fixed dropout mask on a reduced batch vs the oracle."""
+	from puzzlelib_amd import nets, train, nn
+	from puzzlelib_amd.surface import bound
+
+	gpuarray = bound().gpuarray
+	np.random.seed(1234)
+	net = nets.buildNiN()
+	spec = nets.nin_spec()
+
+	rng = np.random.RandomState(5)
+	data = rng.randn(8, 3, 32, 32).astype(np.float32)
+	labels = rng.randint(0, 10, size=(8, )).astype(np.int32)
+
+	params = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
+	cnet = N.CpuNet(spec, params)
+
+	# the device RNG is Philox, not the reference's XORWOW: parity is checked with the mask fed to the oracle
+	class FixedRng:
+		def __init__(self):
+			self.masks = {}
+		def fillInteger(self, ary):
+			bnd.globalRng.fillInteger(ary)
+			self.last = ary.get()
+
+	for mod in net.getAllByType(nn.Dropout):
+		mod.rng = FixedRng()
+
+	net.trainMode()
+	pred = net(gpuarray.to_gpu(data))
+	for mod in net.getAllByType(nn.Dropout):
+		cnet.dropmasks[mod.name] = mod.rng.last
+
+	cnet.train = True
+	pred_ref = cnet.forward(data)
+	assert_close(pred.get(), pred_ref, atol=1e-4, rtol=1e-3, what="NiN forward")
+
+	cost = train.CrossEntropy()
+	grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
+	err_ref, grad_ref = R.cross_entropy(pred_ref, labels)
+
+	for var in nets.namedVariables(net).values():
+		var.grad.fill(0)
+	net.backward(grad, updGrad=False)
+	cnet.zero_grads()
+	cnet.backward(grad_ref)
+
+	for name, var in nets.namedVariables(net).items():
+		ref = cnet.grads[name]
+		scale = np.abs(ref).max() + 1e-8
+		assert_close(var.grad.get(), ref, atol=2e-3 * scale, rtol=5e-3, what="NiN grad " + name)

@@ -1,0 +1,498 @@
+"""
+GPU parity tests: every operator of the hot path, called through the backend object (-> ctypes -> C ABI -> HIP kernels),
+against (1) the committed golden vectors — `ref_*` arrays were produced by the reference's own CPU backend, `orc_*` by
+the oracle after it was pinned to the reference — and (2) the oracle on fresh seeded inputs incl. awkward shapes.
+
+Stated tolerance (fp32): element-wise / optimizer kernels atol 1e-5 (the reference's own, CPU/Utils.py:36-37);
+reductions of length L (conv, GEMM, BN, sums): |err| <= 1e-5 + 1e-4*|ref| for L up to a few thousand (different
+summation order than numpy/OpenBLAS), checked against a float64 oracle where L is large.
+"""
+import numpy as np
+import pytest
+
+import cpu_ref as R
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+CONV_CASES = ["c0", "c1", "c2", "c3", "c4"]
+
+
+def gpu(bnd, a):
+	return bnd.GPUArray.toGpu(np.ascontiguousarray(a))
+
+
+# ------------------------------------------------------------------------------------------------ array type
+def test_gpuarray_roundtrip_views_arith(bnd):
+	rng = np.random.RandomState(0)
+	hostA = rng.randn(10, 10).astype(np.float32)
+	a = gpu(bnd, hostA)
+	assert np.array_equal(a.get(), hostA)
+
+	# Hip/GPUArray.py:22-46 memoryTest
+	b, hostB = a[:, :6], hostA[:, :6]
+	assert not b.contiguous
+	assert np.array_equal(hostB.reshape((2, 5, 6)), b.reshape(2, 5, 6).get())
+	assert np.array_equal(hostB.reshape((5, 2, 3, 2)), b.reshape(5, 2, 3, 2).get())
+	assert np.array_equal(hostB.reshape((10, 1, 6)), b.reshape(10, 1, 6).get())
+
+	hostC = rng.randn(10, 10, 10).astype(np.float32)
+	c = gpu(bnd, hostC)
+	v = c[:, :, :6]
+	assert np.array_equal(hostC[:, :, :6], v.get())
+	newv = rng.randn(*v.shape).astype(np.float32)
+	v.set(newv)
+	assert np.array_equal(newv, v.get())
+	assert np.array_equal(newv[:, :6, :6], c[:, :6, :6].get())
+
+
+	# Cuda/GPUArray.py:295-333 arithmTest
+	x, y = rng.randn(13, 15).astype(np.float32), rng.randn(13, 15).astype(np.float32)
+	gx, gy = gpu(bnd, x), gpu(bnd, y)
+	assert_close((gx + gy).get(), x + y)
+	assert_close((gx * gy).get(), x * y)
+	gx += gy
+	assert_close(gx.get(), x + y)
+	gx *= gy
+	assert_close(gx.get(), (x + y) * y)
+
+	assert gx.min().get() == ((x + y) * y).min() and gx.max().get() == ((x + y) * y).max()
+	assert np.array_equal(gpu(bnd, np.arange(7, dtype=np.int32)).astype(np.float32).get(), np.arange(7, dtype=np.float32))
+
+	f = bnd.GPUArray.empty((5, 7), dtype=np.float32).fill(3.5)
+	assert np.all(f.get() == 3.5)
+	z = bnd.GPUArray.zeros((1001, ), dtype=np.float32)
+	assert np.all(z.get() == 0)
+	e = bnd.GPUArray.empty((0, 3), dtype=np.float32)
+	assert e.get().shape == (0, 3)
+
+
+def test_concatenate_split_tile_sharedarray(bnd):
+	rng = np.random.RandomState(1)
+	src = rng.randn(4, 4, 4, 4).astype(np.float32)
+	a = rng.randn(4, 2, 4, 4).astype(np.float32)
+	b = rng.randn(4, 1, 4, 4).astype(np.float32)
+
+	out = bnd.concatenate((gpu(bnd, src), gpu(bnd, a), gpu(bnd, b)), axis=1)
+	assert np.array_equal(out.get(), np.concatenate((src, a, b), axis=1))
+
+	for axis in range(3):
+		outs = bnd.split(gpu(bnd, src), (1, 3), axis=axis)
+		exp = np.split(src, [1], axis=axis)
+		assert all(np.array_equal(o.get(), e) for o, e in zip(outs, exp))
+
+	assert np.array_equal(bnd.tile(gpu(bnd, b), 3, axis=1).get(), np.tile(b, (1, 3, 1, 1)))
+
+	sh = bnd.SharedArray(np.float32)
+	sh.register((3, 5), np.float32, "x")
+	sh.register((7, ), np.float32, "y")
+	sh.build()
+	sh["x"].set(np.ones((3, 5), np.float32))
+	sh["y"].set(np.full((7, ), 2.0, np.float32))
+	flat = sh.ary.get()
+	assert sh.ary.size == 16 + 8 and np.all(flat[:15] == 1) and np.all(flat[16:23] == 2)
+	assert (sh["y"].ptr - sh["x"].ptr) % 16 == 0
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+@pytest.mark.parametrize("algo", ["auto", "direct"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_golden(bnd, ops, case, algo):
+	x, w, b, dy = (ops["conv_%s_%s" % (case, k)] for k in ("x", "w", "b", "dy"))
+	sh, sw, ph, pw, dh, dw, groups = ops["conv_%s_cfg" % case]
+	kw = dict(stride=(sh, sw), pad=(ph, pw), dilation=(dh, dw), groups=int(groups))
+	fa = getattr(bnd.ConvFwdAlgo, algo).value
+
+	gx, gw, gb, gdy = gpu(bnd, x), gpu(bnd, w), gpu(bnd, b), gpu(bnd, dy)
+
+	y = bnd.dnn.convNd(gx, gw, gb, algo=fa, **kw)
+	assert_close(y.get(), ops["conv_%s_ref_y" % case], atol=1e-4, rtol=1e-4, what="fwd (reference output)")
+
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, data=gx, algo=fa, **kw)
+	assert_close(dx.get(), ops["conv_%s_orc_dx" % case], atol=1e-4, rtol=1e-4, what="bwd data")
+
+	wgrad, bgrad = bnd.dnn.convNdBackwardParams(gx, gdy, gw, withbias=True, algo=fa, **kw)
+	assert_close(wgrad.get(), ops["conv_%s_orc_dw" % case], atol=2e-4, rtol=1e-4, what="bwd filter")
+	assert_close(bgrad.get(), ops["conv_%s_orc_db" % case], atol=1e-4, rtol=1e-4, what="bias grad")
+
+	# accumulate contract: wgrad <- 0.5*wgrad + 2*dw (Hip/Wrappers/MIOpen.py:414-433)
+	wg, bg = gpu(bnd, ops["conv_%s_wg0" % case]), gpu(bnd, ops["conv_%s_bg0" % case])
+	bnd.dnn.convNdBackwardParams(gx, gdy, gw, withbias=True, wgrad=wg, bgrad=bg, scale=2.0, momentum=0.5, algo=fa, **kw)
+	assert_close(wg.get(), ops["conv_%s_orc_wgacc" % case], atol=4e-4, rtol=1e-4, what="bwd filter accumulate")
+	assert_close(bg.get(), ops["conv_%s_orc_bgacc" % case], atol=2e-4, rtol=1e-4, what="bias grad accumulate")
+
+
+def test_conv_groups_golden(bnd, ops):
+	x, w, dy = ops["conv_g2_x"], ops["conv_g2_w"], ops["conv_g2_dy"]
+	gx, gw, gdy = gpu(bnd, x), gpu(bnd, w), gpu(bnd, dy)
+	assert_close(bnd.dnn.convNd(gx, gw, groups=2).get(), ops["conv_g2_orc_y"], atol=1e-4, rtol=1e-4)
+	assert_close(bnd.dnn.convNdBackwardData(gdy, gw, groups=2).get(), ops["conv_g2_orc_dx"], atol=1e-4, rtol=1e-4)
+	assert_close(bnd.dnn.convNdBackwardParams(gx, gdy, gw, groups=2).get(), ops["conv_g2_orc_dw"], atol=1e-4, rtol=1e-4)
+
+
+# shapes that stress the tiling: K not a multiple of 64/128, C*R*S not a multiple of 16, pixels not a multiple of 128,
+# 1x1 stride 2 (ResNet shortcut), 7x7 stride 2 pad 3 (stem), 3x3 stride 2 with pad, dilation, groups
+FRESH = [
+	dict(n=3, c=5, h=17, w=13, k=70, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
+	dict(n=2, c=64, h=14, w=14, k=130, r=1, s=1, stride=1, pad=0, dil=1, groups=1),
+	dict(n=4, c=32, h=15, w=15, k=48, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	dict(n=2, c=3, h=37, w=41, k=64, r=7, s=7, stride=2, pad=3, dil=1, groups=1),
+	dict(n=2, c=16, h=19, w=20, k=24, r=3, s=3, stride=2, pad=1, dil=1, groups=1),
+	dict(n=2, c=8, h=16, w=16, k=12, r=3, s=3, stride=1, pad=2, dil=2, groups=1),
+	dict(n=2, c=8, h=12, w=12, k=8, r=3, s=2, stride=(2, 1), pad=(1, 0), dil=1, groups=4),
+	dict(n=1, c=4, h=9, w=9, k=6, r=3, s=3, stride=2, pad=1, dil=2, groups=1),       # strided+dilated: direct dgrad path
+	dict(n=5, c=130, h=7, w=7, k=200, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
+]
+
+
+@pytest.mark.parametrize("cs", FRESH, ids=lambda c: "n%(n)dc%(c)dk%(k)dr%(r)ds%(stride)sg%(groups)d" % c)
+def test_conv_fresh_vs_oracle(bnd, cs):
+	rng = np.random.RandomState(42)
+	g = cs["groups"]
+	x = rng.randn(cs["n"], cs["c"], cs["h"], cs["w"]).astype(np.float32)
+	w = (rng.randn(cs["k"], cs["c"] // g, cs["r"], cs["s"]) / np.sqrt(cs["c"] // g * cs["r"] * cs["s"])).astype(np.float32)
+	b = rng.randn(cs["k"]).astype(np.float32)
+	kw = dict(stride=cs["stride"], pad=cs["pad"], dilation=cs["dil"], groups=g)
+
+	y_ref = R.conv2d_fwd(x, w, b, acc=np.float64, **kw)
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+
+	gx, gw, gb, gdy = gpu(bnd, x), gpu(bnd, w), gpu(bnd, b), gpu(bnd, dy)
+	okw = dict(stride=cs["stride"], pad=cs["pad"], dilation=cs["dil"], groups=g)
+
+	assert_close(bnd.dnn.convNd(gx, gw, gb, **okw).get(), y_ref, atol=1e-4, rtol=1e-4, what="fwd")
+	assert_close(
+		bnd.dnn.convNdBackwardData(gdy, gw, data=gx, **okw).get(), R.conv2d_bwd_data(dy, w, x.shape, acc=np.float64, **kw),
+		atol=1e-4, rtol=1e-4, what="bwd data"
+	)
+
+	dw_ref, db_ref = R.conv2d_bwd_filter(x, dy, w.shape, withbias=True, acc=np.float64, **kw)
+	dw, db = bnd.dnn.convNdBackwardParams(gx, gdy, gw, withbias=True, **okw)
+	scale = np.sqrt(dy.size / cs["k"])          # wgrad sums N*P*Q products of O(1) terms
+	assert_close(dw.get(), dw_ref, atol=2e-6 * scale * 30, rtol=1e-4, what="bwd filter")
+	assert_close(db.get(), db_ref, atol=2e-6 * scale * 30, rtol=1e-4, what="bias grad")
+
+
+def test_conv_errors(bnd):
+	x = bnd.GPUArray.zeros((1, 4, 5, 5), dtype=np.float32)
+	w = bnd.GPUArray.zeros((6, 4, 7, 7), dtype=np.float32)
+	with pytest.raises(ValueError):
+		bnd.dnn.convNd(x, w)                                   # filter larger than input
+	with pytest.raises(ValueError):
+		bnd.dnn.convNd(x, bnd.GPUArray.zeros((6, 2, 3, 3), dtype=np.float32), groups=2, stride=0)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / matvec
+def test_gemm_golden_and_fresh(bnd, ops):
+	A, B, C0 = ops["gemm_A"], ops["gemm_B"], ops["gemm_C0"]
+	gA, gB = gpu(bnd, A), gpu(bnd, B)
+	assert_close(bnd.blas.gemm(gA, gB).get(), ops["gemm_ref_nn"], what="nn (reference output)")
+
+	out = gpu(bnd, C0)
+	bnd.blas.gemm(gA, gB, out=out, alpha=0.5, beta=2.0)
+	assert_close(out.get(), ops["gemm_orc_nn_ab"], what="nn alpha/beta")
+
+	out = gpu(bnd, C0)
+	bnd.blas.gemm(gA, gpu(bnd, B.T), out=out, transpB=True, alpha=-1.5, beta=1.0)
+	assert_close(out.get(), ops["gemm_orc_nt_ab"], what="nt alpha/beta")
+
+	out = gpu(bnd, C0)
+	bnd.blas.gemm(gpu(bnd, A.T), gB, out=out, transpA=True, alpha=1.0, beta=1.0)
+	assert_close(out.get(), ops["gemm_orc_tn_ab"], what="tn alpha/beta")
+
+	# Cuda/Wrappers/CuBlas.py:32-48 matrixTest + odd sizes around the 64x64x16 tile
+	rng = np.random.RandomState(3)
+	for m, n, k in ((5, 4, 3), (64, 64, 16), (65, 63, 17), (256, 1000, 2048), (64, 1024, 800), (130, 70, 333)):
+		a, b = rng.randn(m, k).astype(np.float32), rng.randn(k, n).astype(np.float32)
+		ref = a.astype(np.float64) @ b.astype(np.float64)
+		tol = dict(atol=1e-5 * np.sqrt(k) * 4, rtol=1e-4)
+		assert_close(bnd.blas.gemm(gpu(bnd, a), gpu(bnd, b)).get(), ref, what="nn %s" % ((m, n, k), ), **tol)
+		assert_close(bnd.blas.gemm(gpu(bnd, a), gpu(bnd, b.T), transpB=True).get(), ref, what="nt", **tol)
+		assert_close(bnd.blas.gemm(gpu(bnd, a.T), gpu(bnd, b), transpA=True).get(), ref, what="tn", **tol)
+
+	x, y = rng.randn(1000).astype(np.float32), rng.randn(1000).astype(np.float32)
+	assert np.isclose(bnd.blas.dot(gpu(bnd, x), gpu(bnd, y)), np.dot(x.astype(np.float64), y), rtol=1e-5, atol=1e-4)
+	assert np.isclose(bnd.blas.l1norm(gpu(bnd, x)), np.abs(x).sum(dtype=np.float64), rtol=1e-5)
+
+	with pytest.raises(ValueError):
+		bnd.blas.gemm(gA, gA)
+
+
+def test_matvec_golden_and_reference_cases(bnd, ops):
+	M, v = ops["mat_M"], ops["mat_v"]
+	gM, gv = gpu(bnd, M), gpu(bnd, v)
+
+	assert_close(bnd.matmod.matsum(gM, axis=0).get(), ops["mat_ref_colsum"], atol=1e-4, what="colsum (reference)")
+	assert_close(bnd.matmod.addVecToMat(gv, gM, axis=1).get(), ops["mat_ref_biasadd"], what="bias add (reference)")
+	assert np.array_equal(bnd.matmod.argmax(gM, axis=1).get(), ops["mat_ref_argmax"])
+
+	# Cuda/Kernels/MatVec.py:394-465 calcTest / batchCalcTest
+	rng = np.random.RandomState(5)
+	A = rng.randn(128, 500).astype(np.float32)
+	u, w = rng.randn(500).astype(np.float32), rng.randn(125).astype(np.float32)
+	col = rng.randn(128).astype(np.float32)
+	gA = gpu(bnd, A)
+
+	assert_close(bnd.matmod.addVecToMat(gpu(bnd, col), gA, axis=0).get(), A + col[:, None])
+	assert_close(bnd.matmod.addVecToMat(gpu(bnd, w), gA, axis=1).get(), A + np.tile(w, 4)[None, :])
+	assert_close(bnd.matmod.matsum(gA, axis=1).get(), A.sum(axis=1, dtype=np.float64), atol=1e-4)
+	assert_close(bnd.matmod.matsum(gA, axis=0).get(), A.sum(axis=0, dtype=np.float64), atol=1e-4)
+
+	out = gpu(bnd, u)
+	bnd.matmod.matsum(gA, axis=0, out=out, alpha=0.5, beta=2.0)
+	assert_close(out.get(), 2.0 * u + 0.5 * A.sum(axis=0, dtype=np.float64), atol=1e-4)
+
+	T = rng.randn(8, 32, 64).astype(np.float32)
+	gT = gpu(bnd, T)
+	assert_close(bnd.matmod.matsum(gT, axis=1).get(), T.sum(axis=1, dtype=np.float64), atol=1e-4)
+	assert_close(bnd.matmod.matsum(gT, axis=2).get(), T.sum(axis=2, dtype=np.float64), atol=1e-4)
+	assert_close(bnd.matmod.addVecToMat(gpu(bnd, T[:, :, 0].copy()), gT, axis=0).get(), T + T[:, :, :1])
+
+	big = (16.0 * rng.randn(129, 501)).astype(np.float32)
+	assert np.array_equal(bnd.matmod.argmax(gpu(bnd, big), axis=1).get(), np.argmax(big, axis=1))
+	assert np.array_equal(bnd.matmod.argmax(gpu(bnd, big), axis=0).get(), np.argmax(big, axis=0))
+	big3 = rng.normal(scale=16.0, size=(9, 33, 65)).astype(np.float32)
+	assert np.array_equal(bnd.matmod.argmax(gpu(bnd, big3), axis=1).get(), np.argmax(big3, axis=1))
+	assert np.array_equal(bnd.matmod.argmax(gpu(bnd, big3), axis=2).get(), np.argmax(big3, axis=2))
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+def test_batchnorm_golden(bnd, ops):
+	x, scale, bias, mean, var = (ops["bn_" + k] for k in ("x", "scale", "bias", "mean", "var"))
+	gx, gs, gb = gpu(bnd, x), gpu(bnd, scale), gpu(bnd, bias)
+
+	y = bnd.dnn.batchNormNd(gx, gpu(bnd, mean), gpu(bnd, var), gs, gb, 1e-5, 0, True)
+	assert_close(y.get(), ops["bn_ref_infer"], what="inference (reference output)")
+
+	rm, rv = gpu(bnd, mean), gpu(bnd, var)
+	y, smean, sinv = bnd.dnn.batchNormNd(gx, rm, rv, gs, gb, 1e-5, 0.25, False)
+	assert_close(y.get(), ops["bn_orc_train_y"], what="train y")
+	assert_close(smean.get(), ops["bn_orc_savemean"], what="save mean")
+	assert_close(sinv.get(), ops["bn_orc_saveinvvar"], what="save invvar")
+	assert_close(rm.get(), ops["bn_orc_runmean"], what="running mean")
+	assert_close(rv.get(), ops["bn_orc_runvar"], what="running var")
+
+	dx, dscale, dbias = bnd.dnn.batchNormNdBackward(gpu(bnd, ops["bn_dy"]), gx, gs, smean, sinv, 1e-5)
+	assert_close(dx.get(), ops["bn_orc_dx"], what="dx")
+	assert_close(dscale.get(), ops["bn_orc_dscale"], atol=1e-4, what="dscale")
+	assert_close(dbias.get(), ops["bn_orc_dbias"], atol=1e-4, what="dbias")
+
+
+@pytest.mark.parametrize("shape", [(4, 5, 2, 3), (16, 5, 4, 2), (3, 7, 55, 55), (5, 3, 7, 7), (2, 2, 56, 56), (8, 130, 14, 14)])
+def test_batchnorm_fresh(bnd, shape):
+	# Cuda/Wrappers/CuDnnNorm.py:23-77 batchNorm2dTest shapes + odd spatial sizes (55x55, 7x7: unaligned slabs)
+	rng = np.random.RandomState(7)
+	c = shape[1]
+	x = (3.0 + 2.0 * rng.randn(*shape)).astype(np.float32)         # non-zero mean: exercises the shifted sums
+	scale, bias = rng.randn(c).astype(np.float32), rng.randn(c).astype(np.float32)
+	dy = rng.randn(*shape).astype(np.float32)
+
+	rm0, rv0 = rng.randn(c).astype(np.float32), (1 + rng.rand(c)).astype(np.float32)
+	rm, rv = rm0.copy(), rv0.copy()
+	y_ref, sm_ref, si_ref = R.bn_fwd_train(x, scale, bias, rm, rv, 1e-5, 0.3, acc=np.float64)
+	dx_ref, ds_ref, db_ref = R.bn_bwd(dy, x, scale, sm_ref, si_ref, acc=np.float64)
+
+	gx, gs, gb, grm, grv = gpu(bnd, x), gpu(bnd, scale), gpu(bnd, bias), gpu(bnd, rm0), gpu(bnd, rv0)
+	y, sm, si = bnd.dnn.batchNormNd(gx, grm, grv, gs, gb, 1e-5, 0.3, False)
+
+	assert_close(sm.get(), sm_ref, atol=1e-5, what="mean")
+	assert_close(si.get(), si_ref, atol=1e-5, rtol=1e-4, what="invvar")
+	assert_close(y.get(), y_ref, atol=2e-5, rtol=1e-4, what="y")
+	assert_close(grm.get(), rm, atol=1e-5, what="running mean")
+	assert_close(grv.get(), rv, atol=1e-5, rtol=1e-4, what="running var")
+
+	dx, ds, db = bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, sm, si, 1e-5)
+	n = x.size // c
+	assert_close(ds.get(), ds_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="dscale")
+	assert_close(db.get(), db_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="dbias")
+	assert_close(dx.get(), dx_ref, atol=2e-5, rtol=1e-4, what="dx")
+
+	# in-place forward on a copy (batchNorm2dTest passes out=data)
+	gx2 = gpu(bnd, x)
+	y2, _, _ = bnd.dnn.batchNormNd(gx2, gpu(bnd, rm0), gpu(bnd, rv0), gs, gb, 1e-5, 0.3, False, out=gx2)
+	assert y2 is gx2
+	assert_close(y2.get(), y_ref, atol=2e-5, rtol=1e-4, what="in-place y")
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+@pytest.mark.parametrize("name", ["p0", "p1", "p2"])
+def test_pool_golden(bnd, ops, name):
+	x = ops["pool_x"]
+	fh, fw, sh, sw, ph, pw = (int(v) for v in ops["pool_%s_cfg" % name])
+	kw = dict(size=(fh, fw), stride=(sh, sw), pad=(ph, pw))
+	gx, gdy = gpu(bnd, x), gpu(bnd, ops["pool_%s_dy" % name])
+
+	y, ws = bnd.dnn.poolNd(gx, mode=bnd.PoolMode.max.value, test=False, **kw)
+	assert_close(y.get(), ops["pool_%s_ref_max" % name], what="max fwd (reference output)")
+	assert bnd.dnn.poolNd(gx, mode=bnd.PoolMode.max.value, test=True, **kw).shape == y.shape
+
+	dx = bnd.dnn.poolNdBackward(gdy, gx, y, ws, mode=bnd.PoolMode.max.value, **kw)
+	assert_close(dx.get(), ops["pool_%s_orc_maxbwd" % name], what="max bwd")
+	dx = bnd.dnn.poolNdBackward(gdy, gx, y, None, mode=bnd.PoolMode.max.value, **kw)      # arg-max recomputed
+	assert_close(dx.get(), ops["pool_%s_orc_maxbwd" % name], what="max bwd without workspace")
+
+	for mode, tag in ((bnd.PoolMode.avgWithPad, "avgp"), (bnd.PoolMode.avgNoPad, "avgn")):
+		y, ws = bnd.dnn.poolNd(gx, mode=mode.value, test=False, **kw)
+		assert_close(y.get(), ops["pool_%s_orc_%s" % (name, tag)], what=tag)
+		dx = bnd.dnn.poolNdBackward(gdy, gx, y, ws, mode=mode.value, **kw)
+		assert_close(dx.get(), ops["pool_%s_orc_%sbwd" % (name, tag)], what=tag + " bwd")
+
+
+def test_pool_resnet_shapes(bnd):
+	rng = np.random.RandomState(9)
+	x = rng.randn(2, 8, 112, 112).astype(np.float32)
+	gx = gpu(bnd, x)
+	y, ws = bnd.dnn.poolNd(gx, size=3, stride=2, pad=0, mode=bnd.PoolMode.max.value)
+	ref = R.pool2d_fwd(x, 3, 2, 0, R.POOL_MAX)
+	assert y.shape == (2, 8, 55, 55) and np.array_equal(y.get(), ref)
+	dy = rng.randn(*ref.shape).astype(np.float32)
+	assert_close(bnd.dnn.poolNdBackward(gpu(bnd, dy), gx, y, ws, size=3, stride=2, pad=0).get(),
+				 R.pool2d_bwd(dy, x, ref, 3, 2, 0, R.POOL_MAX))
+
+	x = rng.randn(3, 16, 7, 7).astype(np.float32)
+	y, ws = bnd.dnn.poolNd(gpu(bnd, x), size=7, stride=1, pad=0, mode=bnd.PoolMode.avgWithPad.value)
+	assert_close(y.get(), x.mean(axis=(2, 3), keepdims=True), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ softmax / cross-entropy
+def test_softmax_cross_entropy(bnd, ops):
+	gy = bnd.dnn.softmaxNd(gpu(bnd, ops["sm_x"]))
+	assert_close(gy.get(), ops["sm_orc_y"], what="softmax")
+	assert_close(bnd.dnn.softmaxNdBackward(gpu(bnd, ops["sm_g"]), gy).get(), ops["sm_orc_dx"], what="softmax bwd")
+
+	for tag in ("ce", "ce2"):
+		err, grad = bnd.costmod.crossEntropy(gpu(bnd, ops[tag + "_scores"]), gpu(bnd, ops[tag + "_labels"]))
+		assert_close(grad.get(), ops[tag + "_orc_grad"], atol=1e-6, what="CE grad")
+		assert np.isclose(err.get(), ops[tag + "_orc_err"][0], rtol=1e-5)
+
+	# 1000 classes (ResNet head) and class weights
+	rng = np.random.RandomState(11)
+	s = (4 * rng.randn(256, 1000)).astype(np.float32)
+	lab = rng.randint(0, 1000, size=(256, )).astype(np.int32)
+	wts = rng.rand(1000).astype(np.float32)
+	for w in (None, wts):
+		e_ref, g_ref = R.cross_entropy(s, lab, w)
+		err, grad = bnd.costmod.crossEntropy(gpu(bnd, s), gpu(bnd, lab), None if w is None else gpu(bnd, w))
+		assert_close(grad.get(), g_ref, atol=1e-6, rtol=1e-4)
+		assert np.isclose(err.get(), e_ref, rtol=1e-5)
+
+	a = rng.randint(0, 10, size=3001).astype(np.int32)
+	b = a.copy()
+	b[::7] += 1
+	acc = bnd.getAccuracyKernel("calcAccuracy")(gpu(bnd, a), gpu(bnd, b), allocator=bnd.memoryPool)
+	assert acc.get() == R.count_neq(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ element-wise family
+ACTS = {
+	"sigmoid": (), "tanh": (), "relu": (), "leakyRelu": (0.01, ), "elu": (1.0, ), "softPlus": (), "clip": (0.0, 6.0)
+}
+
+
+@pytest.mark.parametrize("name", sorted(ACTS))
+def test_activations_golden(bnd, ops, name):
+	x, g, args = ops["act_x"], ops["act_g"], ACTS[name]
+	out = bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	getattr(bnd, name + "Ker")(np.float32)(out, gpu(bnd, x), *args)
+	assert_close(out.get(), ops["act_ref_%s" % name], atol=1e-5, what=name)
+
+	ing = bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	getattr(bnd, name + "DerKer")(np.float32)(ing, gpu(bnd, g), gpu(bnd, ops["act_ref_%s" % name]), *args)
+	assert_close(ing.get(), ops["act_ref_%s_der" % name], atol=1e-5, what=name + " der")
+
+
+def test_eltwise_golden(bnd, ops):
+	x, g, y0 = ops["act_x"], ops["act_g"], ops["elt_y0"]
+
+	out = gpu(bnd, x)
+	bnd.reluKer(np.float32)(out, gpu(bnd, x), slice=slice(3, 900, 7))
+	assert_close(out.get(), ops["act_ref_relu_slice"], what="strided relu")
+
+	out = bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	bnd.dropoutKer(np.float32)(out, gpu(bnd, x), gpu(bnd, ops["drop_bits"]), int(ops["drop_v"][0]), 0.5)
+	assert_close(out.get(), ops["drop_ref"], what="dropout")
+
+	y = gpu(bnd, y0)
+	bnd.toVectorAddVectorKer(np.float32)(y, gpu(bnd, x), 0.3)
+	assert_close(y.get(), ops["elt_ref_axpy"], what="axpy")
+
+	out = bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	bnd.addKer(np.float32)(out, gpu(bnd, x), 0.7, gpu(bnd, y0), -1.1)
+	assert_close(out.get(), ops["elt_ref_add"], what="add")
+
+	bnd.linearKer(np.float32)(out, gpu(bnd, x), 1.5, -0.25)
+	assert_close(out.get(), ops["elt_ref_linear"], what="linear")
+
+	gr = gpu(bnd, g)
+	bnd.weightDecayKer(gr, gpu(bnd, x), 1e-2)
+	assert_close(gr.get(), ops["elt_ref_wd"], what="weight decay")
+
+	# sizes around the float4 body / tail split and an unaligned view
+	rng = np.random.RandomState(13)
+	for n in (1, 3, 4, 5, 1023, 1025):
+		a, b = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+		out = bnd.GPUArray.empty((n, ), dtype=np.float32)
+		bnd.add3Ker(out, gpu(bnd, a), gpu(bnd, b))
+		assert np.array_equal(out.get(), a + b)
+
+	base = gpu(bnd, rng.randn(1001).astype(np.float32))
+	view = base[1:]                      # 4-byte offset: not 16-B aligned
+	ref = R.relu(view.get())
+	outv = bnd.GPUArray.empty(view.shape, dtype=np.float32)
+	bnd.reluKer(np.float32)(outv, view.reshape(view.size))
+	assert np.array_equal(outv.get(), ref)
+
+
+OPTS = {
+	"adam": ("adamKer", 2), "classicMomSGD": ("classicMomSGDKer", 1), "nesterovMomSGD": ("nesterovMomSGDKer", 1),
+	"rmsprop": ("rmspropKer", 1), "adagrad": ("adagradKer", 1), "adadelta": ("adadeltaKer", 2),
+	"rmspropGraves": ("rmspropGravesKer", 3), "smorms3": ("smorms3Ker", 3)
+}
+
+
+@pytest.mark.parametrize("tag", sorted(OPTS))
+def test_optimizer_kernels_golden(bnd, ops, tag):
+	kername, nstates = OPTS[tag]
+	p = gpu(bnd, ops["opt_%s_p0" % tag])
+	st = [gpu(bnd, s) for s in ops["opt_%s_st0" % tag]]
+	scalars = [float(v) for v in ops["opt_%s_scalars" % tag]]
+
+	for g in ops["opt_%s_grads" % tag]:
+		getattr(bnd, kername)(np.float32)(p, gpu(bnd, g), *st, *scalars)
+
+	assert_close(p.get(), ops["opt_%s_ref_p" % tag], atol=1e-5, rtol=1e-5, what=tag + " param (reference output)")
+	for a, ref in zip(st, ops["opt_%s_ref_st" % tag]):
+		assert_close(a.get(), ref, atol=1e-5, rtol=1e-5, what=tag + " state")
+
+
+def test_rng_statistics(bnd):
+	n = 1 << 20
+	u = bnd.GPUArray.empty((n, ), dtype=np.float32)
+	bnd.fillUniform(u, -1.0, 3.0)
+	h = u.get()
+	assert h.min() >= -1.0 and h.max() <= 3.0 and abs(h.mean() - 1.0) < 0.01 and abs(h.std() - 4 / np.sqrt(12)) < 0.01
+
+	bnd.fillNormal(u, 2.0, 0.5)
+	h = u.get()
+	assert abs(h.mean() - 2.0) < 0.005 and abs(h.std() - 0.5) < 0.005
+
+	bits = bnd.GPUArray.empty((n + 3, ), dtype=np.uint32)
+	bnd.globalRng.fillInteger(bits)
+	b1 = bits.get()
+	bnd.globalRng.fillInteger(bits)
+	b2 = bits.get()
+	assert not np.array_equal(b1, b2)
+	assert abs((b1 < 2**31).mean() - 0.5) < 0.005
+	assert len(np.unique(b1)) > 0.999 * b1.size
+
+
+def test_timekernel_and_pool_stats(bnd):
+	x = bnd.GPUArray.zeros((1 << 16, ), dtype=np.float32)
+	dev, host = bnd.timeKernel(bnd.reluKer(np.float32), (x, x), looplength=10, log=False, normalize=True)
+	assert dev > 0 and host > 0
+
+	stats = bnd.memoryPool.getStats()
+	assert stats["liveBytes"] > 0
+	del x
+	bnd.memoryPool.freeHeld()
+	assert bnd.memoryPool.getStats()["heldBytes"] == 0
