@@ -406,7 +406,7 @@ def test_eltwise_golden(bnd, ops):
 
 	out = gpu(bnd, x)
 	bnd.reluKer(np.float32)(out, gpu(bnd, x), slice=slice(3, 900, 7))
-	assert_close(out.get(), ops["act_ref_relu_slice"], what="strided relu")
+	assert_close(out.get(), ops["act_orc_relu_slice"], what="strided relu (Cuda/SourceModule.py:216-226 semantics)")
 
 	out = bnd.GPUArray.empty(x.shape, dtype=np.float32)
 	bnd.dropoutKer(np.float32)(out, gpu(bnd, x), gpu(bnd, ops["drop_bits"]), int(ops["drop_v"][0]), 0.5)

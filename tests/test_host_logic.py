@@ -1,0 +1,189 @@
+"""
+CPU tests of the host logic: the C-ABI library loads and exports every symbol the header declares (no compute call is
+made without a GPU), GPUArray view/stride arithmetic, gradient-bucket planning and completion tracking, network specs,
+settings, and the loud failure when no device is present.
+"""
+import os, re, subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+	from puzzlelib_amd import lib
+
+	header = open(os.path.join(ROOT, "include", "puzzle_mi355.h")).read()
+	declared = set(re.findall(r"\b(pz_[a-z0-9_]+)\s*\(", header))
+	assert len(declared) >= 70
+
+	nm = subprocess.run(["nm", "-D", "--defined-only", lib.LIBPATH], check=True, capture_output=True, text=True).stdout
+	exported = set(re.findall(r" T (pz_[a-z0-9_]+)", nm))
+	assert declared <= exported, "not exported: %s" % sorted(declared - exported)
+	assert set(lib.declaredSymbols()) <= exported, "python binding names unknown symbols"
+	assert declared <= set(lib.declaredSymbols()), "header entries without a python binding: %s" % sorted(
+		declared - set(lib.declaredSymbols())
+	)
+	assert lib.pz_version() >= 100
+
+
+def test_struct_layouts_match_header():
+	import ctypes
+	from puzzlelib_amd.lib import ConvDesc, PoolDesc
+	assert ctypes.sizeof(ConvDesc) == 14 * 4 and ctypes.sizeof(PoolDesc) == 11 * 4
+	assert [f[0] for f in ConvDesc._fields_][:7] == ["n", "c", "h", "w", "k", "r", "s"]
+
+
+def test_error_mapping_and_descriptor_validation_without_device():
+	import ctypes
+	from puzzlelib_amd import lib
+	from puzzlelib_amd.lib import ConvDesc
+
+	bad = ConvDesc(1, 4, 5, 5, 6, 7, 7, 1, 1, 0, 0, 1, 1, 1)           # 7x7 filter on a 5x5 image
+	p, q = ctypes.c_int(), ctypes.c_int()
+	with pytest.raises(ValueError, match="filter larger"):
+		lib.pz_conv2d_out_shape(ctypes.byref(bad), ctypes.byref(p), ctypes.byref(q))
+
+	ok = ConvDesc(128, 64, 56, 56, 128, 3, 3, 1, 1, 1, 1, 1, 1, 1)      # config 2
+	lib.pz_conv2d_out_shape(ctypes.byref(ok), ctypes.byref(p), ctypes.byref(q))
+	assert (p.value, q.value) == (56, 56)
+
+	size = ctypes.c_size_t()
+	for which in (lib.CONV_FWD, lib.CONV_BWD_DATA, lib.CONV_BWD_FILTER):
+		lib.pz_conv2d_workspace_bytes(ctypes.byref(ok), which, lib.CONV_ALGO_AUTO, ctypes.byref(size))
+		assert 0 < size.value < 1 << 30
+
+	stem = ConvDesc(256, 3, 224, 224, 64, 7, 7, 2, 2, 3, 3, 1, 1, 1)
+	lib.pz_conv2d_out_shape(ctypes.byref(stem), ctypes.byref(p), ctypes.byref(q))
+	assert (p.value, q.value) == (112, 112)
+
+
+def test_no_device_fails_loudly():
+	from puzzlelib_amd import backend, driver
+	if driver.Device.count() > 0:
+		pytest.skip("a device is present")
+	with pytest.raises(backend.HipError, match="No Hip enabled device"):
+		backend.Mi355Backend(0, initmode=2)
+
+
+def test_view_strides_match_numpy():
+	from puzzlelib_amd.gpuarray import viewStridesForReshape, contiguousStrides
+
+	def check(shape, sl, new):
+		a = np.zeros(shape, np.float32)[sl]
+		try:
+			b = a.reshape(new)
+			expected = b.strides if np.shares_memory(a, b) and b.base is not None else None
+		except ValueError:
+			expected = None
+		if not a.flags.c_contiguous and expected is not None and not np.shares_memory(a, b):
+			expected = None
+		got = viewStridesForReshape(a.shape, a.strides, new)
+		if expected is not None:
+			assert got == expected, (shape, new, got, expected)
+
+	check((10, 10), (slice(None), slice(0, 6)), (2, 5, 6))
+	check((10, 10), (slice(None), slice(0, 6)), (5, 2, 3, 2))
+	check((10, 10), (slice(None), slice(0, 6)), (10, 1, 6))
+	check((4, 6, 8), (slice(None), slice(None), slice(0, 4)), (24, 4))
+	check((4, 6, 8), (slice(0, 2), ), (2, 48))
+	assert viewStridesForReshape((10, 6), (40, 4), (60, )) is None
+	assert contiguousStrides((2, 3, 4), 4) == (48, 16, 4)
+
+
+def test_bucket_planning_and_completion_tracking():
+	from puzzlelib_amd import grid
+
+	blocks, offset = [], 0
+	sizes = [100, 2000, 36, 5000, 12, 800, 64, 3000]
+	for i, n in enumerate(sizes):
+		blocks.append(("v%02d" % i, offset, n * 4))
+		offset += (n * 4 + 15) // 16 * 16
+
+	buckets = grid.planBuckets(blocks, 8000)
+	assert buckets[0][0] == 0 and buckets[-1][1] == blocks[-1][1] + blocks[-1][2]
+	for (s0, e0, _), (s1, _, _) in zip(buckets, buckets[1:]):
+		assert e0 == s1                                                   # contiguous cover, no gaps
+	assert sorted(n for _, _, names in buckets for n in names) == [b[0] for b in blocks]
+
+	class FakeOps:
+		def __init__(self):
+			self.log, self.tokens = [], 0
+		def markReady(self):
+			self.tokens += 1
+			return self.tokens
+		def allreduce(self, start, stop, token):
+			self.log.append(("ar", start, stop, token))
+		def finish(self, scale):
+			self.log.append(("finish", scale))
+
+	ops = FakeOps()
+	red = grid.GradReducer(blocks, ops, gridsize=4, bucketBytes=8000)
+	red.beginStep()
+
+	# backward produces variables in reverse order; a bucket launches exactly when its last variable lands
+	launched_after = {}
+	for name, _, _ in reversed(blocks):
+		before = len(ops.log)
+		red.variableReady(name)
+		if len(ops.log) > before:
+			launched_after[name] = ops.log[-1]
+
+	red.variableReady("v00")                                               # duplicate notifications are harmless
+	nb = len(red.buckets)
+	assert len([e for e in ops.log if e[0] == "ar"]) == nb
+	red.finishStep()
+	assert ops.log[-1] == ("finish", 0.25)
+	assert len([e for e in ops.log if e[0] == "ar"]) == nb                 # nothing is reduced twice
+
+	# a step in which some variables never report (frozen layers): finishStep flushes the rest
+	ops2 = FakeOps()
+	red2 = grid.GradReducer(blocks, ops2, gridsize=2, bucketBytes=8000)
+	red2.beginStep()
+	red2.variableReady("v07")
+	red2.finishStep()
+	ranges = sorted((e[1], e[2]) for e in ops2.log if e[0] == "ar")
+	assert ranges == sorted((b.start, b.stop) for b in red2.buckets)
+
+
+def test_network_specs():
+	from puzzlelib_amd import nets
+
+	params, attrs = nets.spec_param_shapes(nets.resnet50_spec())
+	assert sum(int(np.prod(s)) for s in params.values()) == 25557032
+	assert len([k for k in params if k.endswith(".W") and len(params[k]) == 4]) == 53
+	assert len(attrs) == 2 * 53
+	assert nets.spec_out_shape(nets.resnet50_spec(), (256, 3, 224, 224)) == (256, 1000)
+
+	# reference variant: MaxPool2D(3, 2) pad 0 -> 55x55 stage-2 maps (Models/Nets/ResNet.py:93)
+	assert nets.spec_out_shape(nets.resnet50_spec()[:4], (1, 3, 224, 224)) == (1, 64, 55, 55)
+
+	assert nets.spec_out_shape(nets.lenet_spec(), (64, 1, 28, 28)) == (64, 10)
+	assert nets.spec_out_shape(nets.nin_spec(), (128, 3, 32, 32)) == (128, 10)
+	lp, _ = nets.spec_param_shapes(nets.lenet_spec())
+	assert lp["7.W"] == (800, 1024) and lp["0.b"] == (1, 16, 1, 1)
+
+
+def test_settings_object():
+	from puzzlelib_amd.settings import Config, Backend, ConfigError
+	assert Config.backend == Backend.hip and Config.Backend.hip.value == 1
+	assert Config.shouldInit()
+
+	Config.backend = Backend.cpu
+	try:
+		with pytest.raises(ConfigError):
+			Config.requireHip()
+	finally:
+		Config.backend = Backend.hip
+
+	assert Config.getLogger() is Config.getLogger()
+
+
+def test_product_never_imports_the_oracle():
+	pkg = os.path.join(ROOT, "puzzlelib_amd")
+	for dirpath, _, files in os.walk(pkg):
+		for f in files:
+			if f.endswith(".py"):
+				text = open(os.path.join(dirpath, f)).read()
+				assert not re.search(r"^\s*(from|import)\s+(oracle|cpu_ref|cpu_net)\b", text, re.M), f
