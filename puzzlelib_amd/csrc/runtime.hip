@@ -55,7 +55,10 @@ int pz_init(int device) {
 int pz_device_name(int device, char *buf, int buflen) {
 	hipDeviceProp_t prop;
 	PZ_HIP(hipGetDeviceProperties(&prop, device));
-	snprintf(buf, buflen, "%s", prop.name);
+	if (prop.name[0])
+		snprintf(buf, buflen, "%s", prop.name);
+	else
+		snprintf(buf, buflen, "AMD Instinct (%s, %d CUs)", prop.gcnArchName, prop.multiProcessorCount);
 	return PZ_OK;
 }
 

@@ -979,6 +979,8 @@ class Container(Module):
 
 
 class Sequential(Container):
+	honourUpdGrad = True
+
 	def __init__(self, name=None):
 		super().__init__(name)
 		self.graph = []
@@ -1030,11 +1032,18 @@ class Sequential(Container):
 
 
 	def backward(self, grad, updParamGrads=True, updGrad=True, scale=1.0, momentum=1.0):
-		# accumulate mode by default (momentum=1.0); like the reference (Containers/Sequential.py:212-218) the data
-		# gradient of the first module is always computed
+		"""Accumulate mode by default (momentum=1.0), like Containers/Sequential.py:212-232. `updGrad=False` — what
+		Trainer.handleBatch passes (Handlers/Trainer.py:33) — skips the data gradient of the FIRST module, whose result
+		nobody consumes. The reference means to do the same but its branch is dead code (`i < len(self.graph)` is always
+		true, Sequential.py:215-218), so it always pays for conv1's backward-data; parameters, loss and every other
+		gradient are unaffected. Set Sequential.honourUpdGrad = False for the reference's literal behaviour."""
+		last = len(self.graph) - 1
+
 		for i, mod in enumerate(reversed(self.graph)):
+			first = i == last and Sequential.honourUpdGrad
 			try:
-				mod.backward(grad, updParamGrads=updParamGrads, scale=scale, momentum=momentum)
+				mod.backward(grad, updParamGrads=updParamGrads, updGrad=updGrad if first else True, scale=scale,
+							 momentum=momentum)
 			except ModuleError as e:
 				raise ModuleError("%s:\nGrad error in module %d (%s):\n%s" % (self, len(self.graph) - 1 - i, mod, e))
 			grad = mod.grad
