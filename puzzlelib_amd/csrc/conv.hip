@@ -50,7 +50,14 @@ struct ProfScope {
 	}
 };
 
-constexpr int kPadTap = 0x7fff;   // table sentinel: pushes the bounds check out of range -> operand reads as 0
+constexpr int kPadTap = 63;                 // table sentinel of padded k rows: tap bit 63 is never set -> operand reads as 0
+constexpr unsigned kOOB = 0xfffffff0u;      // buffer-load byte offset beyond every tensor: the hardware returns 0
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles, so the
 // m-tiles that share one pixel panel are consumed back-to-back out of the same 4 MiB L2.
@@ -66,7 +73,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 struct PackArgs {
 	const float *w;      // (K, Cg, R, S)
 	float *wp;           // [groups][kred_pad][mpad]  (m contiguous)
-	int2 *tab;           // [kred_pad] {input offset of tap, (dh << 16) | dw}
+	int2 *tab;           // [kred_pad] {byte offset of the tap inside one image, tap index r*S+s (63 = padding)}
 	int Kg, Cg, R, S, groups;
 	int mode;            // 0: forward (m = out channel, kred = (c, r, s));  1: backward-data class (m = in channel, kred = (k, r'', s''))
 	int M, mpad, kred, kred_pad;
@@ -101,12 +108,11 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
 		a.wp[i] = v;
 
 		if (g == 0 && m == 0) {
-			int2 e = make_int2(0, (kPadTap << 16) | kPadTap);
+			int2 e = make_int2(0, kPadTap);
 			if (kr < a.kred) {
 				const int ch = kr / RS, rs = kr - ch * RS;
 				const int rr = rs / Sx, ss = rs - rr * Sx;
-				const int dh = rr * a.dil_h, dw = ss * a.dil_w;
-				e = make_int2(ch * a.in_h * a.in_w + dh * a.in_w + dw, (dh << 16) | dw);
+				e = make_int2((ch * a.in_h * a.in_w + rr * a.dil_h * a.in_w + ss * a.dil_w) * 4, rs);
 			}
 			a.tab[kr] = e;
 		}
@@ -118,11 +124,11 @@ __global__ void __launch_bounds__(256) build_tab_kernel(int2 *tab, int n, int np
                                                         int in_h, int in_w) {
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= npad) return;
-	int2 e = make_int2(0, (kPadTap << 16) | kPadTap);
+	int2 e = make_int2(0, (31 << 8) | 31);       // padding column: row/col bit 31 is never set
 	if (j < n) {
 		const int ch = j / (R * S), rs = j - ch * R * S;
 		const int rr = rs / S, ss = rs - rr * S;
-		e = make_int2(ch * in_h * in_w + rr * dil_h * in_w + ss * dil_w, ((rr * dil_h) << 16) | (ss * dil_w));
+		e = make_int2((ch * in_h * in_w + rr * dil_h * in_w + ss * dil_w) * 4, (rr << 8) | ss);
 	}
 	tab[j] = e;
 }
@@ -139,7 +145,9 @@ struct IgemmArgs {
 	int C_total, H, W, Cg;
 	int M, mpad, kred_pad;
 	int Pv, Qv, npix;                      // virtual output grid, npix = N*Pv*Qv
-	int vs_h, vs_w, pad_h, pad_w;          // gather coordinate = p*vs - pad + dh
+	int vs_h, vs_w, pad_h, pad_w;          // gather coordinate = p*vs - pad + r*dil
+	int R, S, dil_h, dil_w;                // taps of the gathered problem (R*S <= 63)
+	unsigned x_bytes, wp_bytes;            // extents for the buffer descriptors
 	int OC_total, OH, OW, os_h, os_w, oo_h, oo_w;   // output coordinate = p*os + oo
 	int tiles_m, tiles_n;
 };
@@ -161,30 +169,44 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
 	const int L = xcd_remap(blockIdx.x, gridDim.x);
 	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
 
-	// ---- B (gathered pixels) loader: this thread owns one pixel column of the tile for the whole kernel
+	// ---- B (gathered pixels) loader: this thread owns one pixel column of the tile for the whole kernel.
+	// Gathers are buffer loads: 32-bit byte offsets, and a tap that falls outside the image (or a pixel outside the
+	// tensor) gets an out-of-range offset for which the hardware returns 0 — zero padding costs no select, no branch.
 	constexpr int NB = BK / (NT / BN);        // k rows per thread; a wave covers NB consecutive rows
 	const int jb = tid % BN;
 	const int kb0 = __builtin_amdgcn_readfirstlane(tid / BN);
 
-	const int pix = tn * BN + jb;
-	const bool pvalid = pix < a.npix;
-	int n_img = 0, pp = 0, qq = 0;
-	if (pvalid) {
-		const int pq_sz = a.Pv * a.Qv;
-		n_img = pix / pq_sz;
-		const int pq = pix - n_img * pq_sz;
-		pp = pq / a.Qv;
-		qq = pq - pp * a.Qv;
-	}
-	const int h0 = pvalid ? pp * a.vs_h - a.pad_h : -(1 << 20);     // invalid pixel: every tap fails the bounds check
-	const int w0 = qq * a.vs_w - a.pad_w;
-	const float *xb = a.x + ((size_t)n_img * a.C_total + (size_t)g * a.Cg) * a.H * a.W;
-	const int base_off = h0 * a.W + w0;
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, a.wp_bytes, 0x00020000);
 
-	// ---- A (packed filters) loader: float4 per thread, m contiguous
+	const int pix = tn * BN + jb;
+	unsigned long long tapmask = 0;           // bit r*S+s: tap (r, s) of this pixel lies inside the image
+	unsigned base_bytes = 0;
+	if (pix < a.npix) {
+		const int pq_sz = a.Pv * a.Qv;
+		const int n_img = pix / pq_sz;
+		const int pq = pix - n_img * pq_sz;
+		const int pp = pq / a.Qv, qq = pq - pp * a.Qv;
+		const int h0 = pp * a.vs_h - a.pad_h, w0 = qq * a.vs_w - a.pad_w;
+
+		for (int r = 0; r < a.R; ++r)
+			for (int t = 0; t < a.S; ++t) {
+				const bool ok = (unsigned)(h0 + r * a.dil_h) < (unsigned)a.H && (unsigned)(w0 + t * a.dil_w) < (unsigned)a.W;
+				tapmask |= (unsigned long long)ok << (r * a.S + t);
+			}
+		base_bytes = (unsigned)((((long)n_img * a.C_total + (long)g * a.Cg) * a.H + h0) * a.W + w0) * 4u;
+	}
+
+	// ---- A (packed filters) loader: 16 B per thread, m contiguous; the k-tile advance is a scalar offset
 	constexpr int NA = (BK * BM / 4) / NT;
 	static_assert(NA >= 1, "A tile too small");
-	const float *wpg = a.wp + (size_t)g * a.kred_pad * a.mpad + (size_t)tm * BM;
+	unsigned voffA[NA];
+#pragma unroll
+	for (int i = 0; i < NA; ++i) {
+		const int f = tid + i * NT;
+		const int kk = f / (BM / 4), m4 = (f % (BM / 4)) * 4;
+		voffA[i] = (unsigned)(((long)g * a.kred_pad + kk) * a.mpad + tm * BM + m4) * 4u;
+	}
 
 	f32x16 acc[TM][TN];
 #pragma unroll
@@ -196,26 +218,26 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
 
 	f32x4 ra[NA];
 	float rb[NB];
-	unsigned okmask = 0;
 
-	auto load_tile = [&](int kt) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	int2 e[NB];
+
+	// global -> register loads of k-tile `kt`, cut into BK/2 parts so that each part's address arithmetic and its
+	// load issue can sit in the shadow of one k2-step's MFMAs (the matrix pipe is busy 4 x 64 cycles per k2-step)
+	auto load_tab = [&](int kt) {
 #pragma unroll
-		for (int i = 0; i < NA; ++i) {
-			const int f = tid + i * NT;
-			const int kk = f / (BM / 4), m4 = (f % (BM / 4)) * 4;
-			ra[i] = *reinterpret_cast<const f32x4 *>(wpg + (size_t)(kt * BK + kk) * a.mpad + m4);
-		}
-		// the NB table entries of this wave are contiguous: they arrive as one wide scalar load
-		int2 e[NB];
+		for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];   // contiguous: one wide scalar load
+	};
+
+	auto load_part = [&](int kt, int j) {
+		constexpr int PER = NB / (BK / 2);          // gathers per k2-step
+		if (j < NA)
+			ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[j], (unsigned)(kt * BK * a.mpad) * 4u, 0));
 #pragma unroll
-		for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];
-		okmask = 0;
-#pragma unroll
-		for (int i = 0; i < NB; ++i) {
-			const int hh = h0 + (e[i].y >> 16), ww = w0 + (e[i].y & 0xffff);
-			const unsigned ok = (unsigned)((unsigned)hh < (unsigned)a.H) & (unsigned)((unsigned)ww < (unsigned)a.W);
-			rb[i] = xb[ok ? base_off + e[i].x : 0];     // branch-free: out-of-image taps read a safe address
-			okmask |= ok << i;                          // ... and are zeroed when the tile is parked in LDS
+		for (int t = 0; t < PER; ++t) {
+			const int i = j * PER + t;
+			const bool ok = (tapmask >> e[i].y) & 1ull;
+			rb[i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
 		}
 	};
 
@@ -227,37 +249,52 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
 			*reinterpret_cast<f32x4 *>(&As[buf][kk][m4]) = ra[i];
 		}
 #pragma unroll
-		for (int i = 0; i < NB; ++i) Bs[buf][kb0 * NB + i][jb] = (okmask >> i) & 1u ? rb[i] : 0.f;
+		for (int i = 0; i < NB; ++i) Bs[buf][kb0 * NB + i][jb] = rb[i];
 	};
 
-	const int nk = a.kred_pad / BK;
-	const int l31 = lane & 31, lhi = lane >> 5;
+	auto read_frag = [&](int buf, int ks, float (&av)[TM], float (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < TM; ++i) av[i] = As[buf][ks + lhi][wm * (32 * TM) + i * 32 + l31];
+#pragma unroll
+		for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][ks + lhi][wn * (32 * TN) + j * 32 + l31];
+	};
 
-	load_tile(0);
-	store_tile(0);
-	__syncthreads();
-
-	for (int kt = 0; kt < nk; ++kt) {
-		const int buf = kt & 1;
-		if (kt + 1 < nk) load_tile(kt + 1);          // global loads in flight underneath the MFMAs below
+	// one k-tile of MFMAs; fragments are double-buffered in registers (the LDS read of k2-step j+1 is issued before the
+	// MFMAs of step j), the next tile's global loads are interleaved one part per k2-step
+	auto compute_tile = [&](int buf, int kt_next, bool has_next) {
+		float av[2][TM], bv[2][TN];
+		read_frag(buf, 0, av[0], bv[0]);
+		if (has_next) load_tab(kt_next);
 
 #pragma unroll
-		for (int ks = 0; ks < BK; ks += 2) {
-			float av[TM], bv[TN];
-#pragma unroll
-			for (int i = 0; i < TM; ++i) av[i] = As[buf][ks + lhi][wm * (32 * TM) + i * 32 + l31];
-#pragma unroll
-			for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][ks + lhi][wn * (32 * TN) + j * 32 + l31];
+		for (int j = 0; j < BK / 2; ++j) {
+			if (j + 1 < BK / 2) read_frag(buf, 2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
+			if (has_next) load_part(kt_next, j);
+			__builtin_amdgcn_sched_barrier(0);        // keep this step's LDS reads / gather ahead of its MFMAs ...
 #pragma unroll
 			for (int i = 0; i < TM; ++i)
 #pragma unroll
-				for (int j = 0; j < TN; ++j)
-					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+				for (int jj = 0; jj < TN; ++jj)
+					acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);        // ... and the next step's behind them (they run in the MFMA shadow)
 		}
+	};
 
-		if (kt + 1 < nk) store_tile(buf ^ 1);
+	const int nk = a.kred_pad / BK;
+
+	load_tab(0);
+#pragma unroll
+	for (int j = 0; j < BK / 2; ++j) load_part(0, j);
+	store_tile(0);
+	__syncthreads();
+
+	for (int kt = 0; kt + 1 < nk; ++kt) {
+		const int buf = kt & 1;
+		compute_tile(buf, kt + 1, true);
+		store_tile(buf ^ 1);
 		__syncthreads();
 	}
+	compute_tile((nk - 1) & 1, 0, false);
 
 	// ---- epilogue: D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
 #pragma unroll
@@ -302,6 +339,8 @@ struct WgradArgs {
 	int K_total, P, Q, Kg;
 	int ncrs;
 	int st_h, st_w, pad_h, pad_w;
+	int R, S, dil_h, dil_w;
+	unsigned x_bytes, dy_bytes;
 	int npix, steps_total, steps_per_split;
 	int tiles_m, tiles_n;
 	float alpha, beta;
@@ -345,71 +384,104 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 
 	__syncthreads();   // tabs visible
 
-	unsigned amask = 0, bmask = 0;
+	const int l31 = lane & 31, lhi = lane >> 5;
 
-	// branch-free gathers: masked-out elements read a safe address and are zeroed when parked in LDS,
-	// so all NA+NB loads of a step are issued back to back and stay in flight under the MFMAs
-	auto load_step = [&](int step) {
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+
+	// per-step pixel decode (this thread's pixel of the k-step), then the step's NA + NB gathers cut into BK/2 parts that
+	// are issued one per k2-step in the shadow of the MFMAs. Gathers are buffer loads with 32-bit byte offsets; rows
+	// beyond Kg, pixels beyond the tensor and taps outside the image get an out-of-range offset -> the hardware returns 0.
+	unsigned rowmask = 0, colmask = 0;        // bit r / bit s: tap row / column of this step's pixel lies inside the image
+	unsigned dy_base = kOOB, x_base = 0;
+
+	auto load_head = [&](int step) {
 		const int kpix = step * BK + kp;
-		const unsigned pv = kpix < a.npix;
-		const int kpc = pv ? kpix : 0;
-		const int n_img = kpc / PQ;
-		const int pq = kpc - n_img * PQ;
-		const int p = pq / a.Q, q = pq - p * a.Q;
+		rowmask = colmask = 0;
+		dy_base = kOOB;
+		if (kpix < a.npix) {
+			const int n_img = kpix / PQ;
+			const int pq = kpix - n_img * PQ;
+			const int p = pq / a.Q, q = pq - p * a.Q;
+			const int h0 = p * a.st_h - a.pad_h, w0 = q * a.st_w - a.pad_w;
 
-		const float *dyb = a.dy + ((size_t)n_img * a.K_total + (size_t)g * a.Kg) * PQ + pq;
-		amask = 0;
-#pragma unroll
-		for (int i = 0; i < NA; ++i) {
-			const int m = tm * BM + row0 + 8 * i;
-			ra[i] = dyb[(size_t)min(m, a.Kg - 1) * PQ];
-			amask |= (pv & (unsigned)(m < a.Kg)) << i;
+			for (int r = 0; r < a.R; ++r) rowmask |= (unsigned)((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H) << r;
+			for (int t = 0; t < a.S; ++t) colmask |= (unsigned)((unsigned)(w0 + t * a.dil_w) < (unsigned)a.W) << t;
+
+			dy_base = (unsigned)(((long)n_img * a.K_total + (long)g * a.Kg) * PQ + pq) * 4u;
+			x_base = (unsigned)((((long)n_img * a.C_total + (long)g * a.Cg) * a.H + h0) * a.W + w0) * 4u;
 		}
+	};
 
-		const int h0 = pv ? p * a.st_h - a.pad_h : -(1 << 20);
-		const int w0 = q * a.st_w - a.pad_w;
-		const float *xb = a.x + ((size_t)n_img * a.C_total + (size_t)g * a.Cg) * HW;
-		const int base_off = h0 * a.W + w0;
-		bmask = 0;
+	auto load_part = [&](int j) {
+		constexpr int PA = NA / (BK / 2) > 0 ? NA / (BK / 2) : 1, PB = NB / (BK / 2) > 0 ? NB / (BK / 2) : 1;
 #pragma unroll
-		for (int i = 0; i < NB; ++i) {
-			const int2 e = tabs[row0 + 8 * i];
-			const int hh = h0 + (e.y >> 16), ww = w0 + (e.y & 0xffff);
-			const unsigned ok = (unsigned)((unsigned)hh < (unsigned)a.H) & (unsigned)((unsigned)ww < (unsigned)a.W);
-			rb[i] = xb[ok ? base_off + e.x : 0];
-			bmask |= ok << i;
+		for (int t = 0; t < PA; ++t) {
+			const int i = j * PA + t;
+			if (i < NA) {
+				const int m = tm * BM + row0 + 8 * i;
+				const bool ok = dy_base != kOOB && m < a.Kg;
+				ra[i] = buf_load_f32(dyr, ok ? dy_base + (unsigned)m * (unsigned)PQ * 4u : kOOB, 0);
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < PB; ++t) {
+			const int i = j * PB + t;
+			if (i < NB) {
+				const int2 e = tabs[row0 + 8 * i];
+				const bool ok = ((rowmask >> (e.y >> 8)) & (colmask >> (e.y & 0xff)) & 1u) != 0;
+				rb[i] = buf_load_f32(xr, ok ? x_base + (unsigned)e.x : kOOB, 0);
+			}
+		}
+	};
+
+	auto read_frag = [&](int ks, float (&av)[TM], float (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < TM; ++i) av[i] = As[(wm * (32 * TM) + i * 32 + l31) * LD + ks + lhi];
+#pragma unroll
+		for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn * (32 * TN) + j * 32 + l31) * LD + ks + lhi];
+	};
+
+	auto compute_step = [&](int next, bool has_next) {
+		float av[2][TM], bv[2][TN];
+		read_frag(0, av[0], bv[0]);
+		if (has_next) load_head(next);
+
+#pragma unroll
+		for (int j = 0; j < BK / 2; ++j) {
+			if (j + 1 < BK / 2) read_frag(2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
+			if (has_next) load_part(j);
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < TM; ++i)
+#pragma unroll
+				for (int jj = 0; jj < TN; ++jj)
+					acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
 		}
 	};
 
 	const int s_begin = split * a.steps_per_split;
 	const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
-	const int l31 = lane & 31, lhi = lane >> 5;
 
-	if (s_begin < s_end) load_step(s_begin);
+	if (s_begin < s_end) {
+		load_head(s_begin);
+#pragma unroll
+		for (int j = 0; j < BK / 2; ++j) load_part(j);
+	}
 
 	for (int step = s_begin; step < s_end; ++step) {
 		__syncthreads();                               // previous step's fragment reads are done
 #pragma unroll
-		for (int i = 0; i < NA; ++i) As[(row0 + 8 * i) * LD + kp] = (amask >> i) & 1u ? ra[i] : 0.f;
+		for (int i = 0; i < NA; ++i) As[(row0 + 8 * i) * LD + kp] = ra[i];
 #pragma unroll
-		for (int i = 0; i < NB; ++i) Bs[(row0 + 8 * i) * LD + kp] = (bmask >> i) & 1u ? rb[i] : 0.f;
+		for (int i = 0; i < NB; ++i) Bs[(row0 + 8 * i) * LD + kp] = rb[i];
 		__syncthreads();
 
-		if (step + 1 < s_end) load_step(step + 1);
-
-#pragma unroll
-		for (int ks = 0; ks < BK; ks += 2) {
-			float av[TM], bv[TN];
-#pragma unroll
-			for (int i = 0; i < TM; ++i) av[i] = As[(wm * (32 * TM) + i * 32 + l31) * LD + ks + lhi];
-#pragma unroll
-			for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn * (32 * TN) + j * 32 + l31) * LD + ks + lhi];
-#pragma unroll
-			for (int i = 0; i < TM; ++i)
-#pragma unroll
-				for (int j = 0; j < TN; ++j)
-					acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-		}
+		if (step + 1 < s_end)
+			compute_step(step + 1, true);
+		else
+			compute_step(0, false);
 	}
 
 	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
@@ -623,6 +695,13 @@ int dgrad_classes(const pz_conv_desc *d, DgradClass *cls, bool *needs_zero) {
 	return n;
 }
 
+// the MFMA kernels address tensors through buffer descriptors (32-bit byte offsets) and keep per-pixel tap masks in
+// registers: tensors must stay below 4 GiB and the filter below 64 taps (31 per side for backward-filter)
+bool igemm_eligible(const pz_conv_desc *d, int P, int Q) {
+	const size_t xb = (size_t)d->n * d->c * d->h * d->w * 4, yb = (size_t)d->n * d->k * P * Q * 4;
+	return xb < kOOB && yb < kOOB && d->r * d->s <= 63 && d->r <= 31 && d->s <= 31;
+}
+
 bool dgrad_uses_igemm(const pz_conv_desc *d) {
 	const bool strided = d->stride_h > 1 || d->stride_w > 1, dilated = d->dil_h > 1 || d->dil_w > 1;
 	return !(strided && dilated) && d->stride_h <= 4 && d->stride_w <= 4;
@@ -690,7 +769,7 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_workspace_bytes: null output");
 	*nbytes = 0;
-	if (algo == PZ_CONV_ALGO_DIRECT) return PZ_OK;
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) return PZ_OK;
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
@@ -727,7 +806,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	PZ_REQUIRE(x && w && y, "pz_conv2d_fwd: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
-	if (algo == PZ_CONV_ALGO_DIRECT) {
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
 		const size_t total = (size_t)d->n * d->k * P * Q;
 		direct_fwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(*d, P, Q, x, w, bias, y);
 		PZ_LAUNCH_CHECK();
@@ -759,6 +838,9 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.M = Kg, a.mpad = p.mpad, a.kred_pad = p.kred_pad;
 	a.Pv = P, a.Qv = Q, a.npix = d->n * P * Q;
 	a.vs_h = d->stride_h, a.vs_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
+	a.R = d->r, a.S = d->s, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
+	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
+	a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
 	run_igemm(p, a, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
@@ -773,7 +855,7 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 	PZ_REQUIRE(dy && w && dx, "pz_conv2d_bwd_data: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
-	if (algo == PZ_CONV_ALGO_DIRECT || !dgrad_uses_igemm(d)) {
+	if (algo == PZ_CONV_ALGO_DIRECT || !dgrad_uses_igemm(d) || !igemm_eligible(d, P, Q)) {
 		const size_t total = (size_t)d->n * d->c * d->h * d->w;
 		direct_bwd_data_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(*d, P, Q, dy, w, dx);
 		PZ_LAUNCH_CHECK();
@@ -822,6 +904,9 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.M = Cg, a.mpad = p.mpad, a.kred_pad = p.kred_pad;
 		a.Pv = c.Pv, a.Qv = c.Qv, a.npix = d->n * c.Pv * c.Qv;
 		a.vs_h = 1, a.vs_w = 1, a.pad_h = c.pad_h, a.pad_w = c.pad_w;
+		a.R = c.Rc, a.S = c.Sc, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
+		a.x_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
+		a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
 		a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
@@ -845,7 +930,7 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
-	if (algo == PZ_CONV_ALGO_DIRECT) {
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
 		direct_bwd_filter_kernel<<<d->k * Cg * d->r * d->s, 256, 0, st>>>(*d, P, Q, x, dy, dw, alpha, beta);
 		PZ_LAUNCH_CHECK();
 		return PZ_OK;
@@ -867,6 +952,9 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	a.K_total = d->k, a.P = P, a.Q = Q, a.Kg = Kg;
 	a.ncrs = p.ncrs;
 	a.st_h = d->stride_h, a.st_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
+	a.R = d->r, a.S = d->s, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
+	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
+	a.dy_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.npix = d->n * P * Q, a.steps_total = p.steps_total, a.steps_per_split = p.steps_per_split;
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
 	a.alpha = alpha, a.beta = beta;
