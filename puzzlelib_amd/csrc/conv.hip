@@ -18,6 +18,14 @@
 
 #include <vector>
 
+// ablation switches for kernel experiments (tools/ablate.sh builds variant libraries); 0 = the shipped kernel
+#ifndef PZ_ABL
+#define PZ_ABL 0
+#endif
+#ifndef PZ_LB
+#define PZ_LB 4
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -147,13 +155,58 @@ struct IgemmArgs {
 	int Pv, Qv, npix;                      // virtual output grid, npix = N*Pv*Qv
 	int vs_h, vs_w, pad_h, pad_w;          // gather coordinate = p*vs - pad + r*dil
 	int R, S, dil_h, dil_w;                // taps of the gathered problem (R*S <= 63)
-	unsigned x_bytes, wp_bytes;            // extents for the buffer descriptors
+	unsigned x_bytes, wp_bytes, y_bytes;   // extents for the buffer descriptors
 	int OC_total, OH, OW, os_h, os_w, oo_h, oo_w;   // output coordinate = p*os + oo
 	int tiles_m, tiles_n;
+	// tail balancing: the first `full_tiles` tiles are whole workgroups; each of the remaining tiles is cut into
+	// `tail_splits` k-slices whose partial accumulators go to `slabs` and are summed by igemm_tail_reduce_kernel
+	int full_tiles, tail_splits;
+	float *slabs;
 };
 
+// D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Buffer stores: the per-lane part of the address (pixel, lane half) is a 32-bit offset computed once per column block,
+// the channel row is a scalar offset -> no per-store address arithmetic; rows beyond M and pixels outside the output
+// get the out-of-range offset and are dropped by the hardware.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int tn, int g, int wm, int wn, int lane,
+                                                 f32x16 (&acc)[TM][TN]) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+	const unsigned plane_bytes = (unsigned)(a.OH * a.OW) * 4u;
+	const bool full_m = tm * BM + BM <= a.M;
+
+#pragma unroll
+	for (int j = 0; j < TN; ++j) {
+		const int opix = tn * BN + wn * (32 * TN) + j * 32 + l31;
+		unsigned voff = kOOB;
+		if (opix < a.npix) {
+			const int pq_sz = a.Pv * a.Qv;
+			const int on = opix / pq_sz;
+			const int opq = opix - on * pq_sz;
+			const int op = opq / a.Qv, oq = opq - op * a.Qv;
+			const int oh = op * a.os_h + a.oo_h, ow = oq * a.os_w + a.oo_w;
+			if ((unsigned)oh < (unsigned)a.OH && (unsigned)ow < (unsigned)a.OW)
+				voff = (unsigned)((((long)on * a.OC_total + (long)g * a.M + 4 * lhi) * a.OH + oh) * a.OW + ow) * 4u;
+		}
+
+#pragma unroll
+		for (int i = 0; i < TM; ++i) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int ms = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2);     // wave-uniform row (lane half adds 4)
+				float v = acc[i][j][r];
+				if (a.bias) v += a.bias[g * a.M + min(ms + 4 * lhi, a.M - 1)];
+				const unsigned vo = (full_m || ms + 4 * lhi < a.M) ? voff : kOOB;
+				__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, vo, (unsigned)ms * plane_bytes, 0);
+			}
+			__builtin_amdgcn_sched_barrier(0);      // one 32x32 tile (16 accumulator registers) in flight at a time
+		}
+	}
+}
+
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
+__global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 	constexpr int BK = 16, NT = 256;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
@@ -166,7 +219,15 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
 	const int wm = wave / WN, wn = wave % WN;
 	const int g = blockIdx.z;
 
-	const int L = xcd_remap(blockIdx.x, gridDim.x);
+	// whole tiles first (XCD-aware order), then the k-slices of the tail tiles
+	int L, kslice = -1;
+	if ((int)blockIdx.x < a.full_tiles) {
+		L = xcd_remap(blockIdx.x, a.full_tiles);
+	} else {
+		const int t = blockIdx.x - a.full_tiles;
+		L = a.full_tiles + t / a.tail_splits;
+		kslice = t % a.tail_splits;
+	}
 	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
 
 	// ---- B (gathered pixels) loader: this thread owns one pixel column of the tile for the whole kernel.
@@ -271,60 +332,94 @@ __global__ void __launch_bounds__(256) igemm_conv_kernel(IgemmArgs a) {
 			if (j + 1 < BK / 2) read_frag(buf, 2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
 			if (has_next) load_part(kt_next, j);
 			__builtin_amdgcn_sched_barrier(0);        // keep this step's LDS reads / gather ahead of its MFMAs ...
+#if PZ_ABL & 4
+			__builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
 			for (int i = 0; i < TM; ++i)
 #pragma unroll
 				for (int jj = 0; jj < TN; ++jj)
 					acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+#if PZ_ABL & 4
+			__builtin_amdgcn_s_setprio(0);
+#endif
 			__builtin_amdgcn_sched_barrier(0);        // ... and the next step's behind them (they run in the MFMA shadow)
 		}
 	};
 
-	const int nk = a.kred_pad / BK;
+	const int nk_all = a.kred_pad / BK;
+	int kt0 = 0, kt1 = nk_all;
+	if (kslice >= 0) {
+		kt0 = (int)((long)nk_all * kslice / a.tail_splits);
+		kt1 = (int)((long)nk_all * (kslice + 1) / a.tail_splits);
+	}
 
-	load_tab(0);
+	load_tab(kt0);
 #pragma unroll
-	for (int j = 0; j < BK / 2; ++j) load_part(0, j);
+	for (int j = 0; j < BK / 2; ++j) load_part(kt0, j);
 	store_tile(0);
 	__syncthreads();
 
-	for (int kt = 0; kt + 1 < nk; ++kt) {
-		const int buf = kt & 1;
+	for (int kt = kt0; kt + 1 < kt1; ++kt) {
+		const int buf = (kt - kt0) & 1;
+#if PZ_ABL & 1          // ablation: no global loads / LDS stores in the loop (wrong results, timing only)
+		compute_tile(buf, kt + 1, false);
+#else
 		compute_tile(buf, kt + 1, true);
 		store_tile(buf ^ 1);
+#endif
+#if !(PZ_ABL & 2)       // ablation: no barrier
 		__syncthreads();
+#endif
 	}
-	compute_tile((nk - 1) & 1, 0, false);
+	compute_tile((kt1 - 1 - kt0) & 1, 0, false);
 
-	// ---- epilogue: D[row][col]: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel)
+	if (kslice < 0) {
+		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+	} else {
+		// partial accumulators of a tail slice: slab[(tail tile, slice)][register][thread] — coalesced 256-B rows
+		float *slab = a.slabs + ((size_t)(blockIdx.x - a.full_tiles) + (size_t)g * (gridDim.x - a.full_tiles)) * (BM * BN);
 #pragma unroll
-	for (int j = 0; j < TN; ++j) {
-		const int opix = tn * BN + wn * (32 * TN) + j * 32 + l31;
-		if (opix >= a.npix) continue;
-
-		const int pq_sz = a.Pv * a.Qv;
-		const int on = opix / pq_sz;
-		const int opq = opix - on * pq_sz;
-		const int op = opq / a.Qv, oq = opq - op * a.Qv;
-		const int oh = op * a.os_h + a.oo_h, ow = oq * a.os_w + a.oo_w;
-		if ((unsigned)oh >= (unsigned)a.OH || (unsigned)ow >= (unsigned)a.OW) continue;
-
-		const size_t plane = (size_t)a.OH * a.OW;
-		float *yb = a.y + ((size_t)on * a.OC_total + (size_t)g * a.M) * plane + (size_t)oh * a.OW + ow;
-
+		for (int i = 0; i < TM; ++i)
 #pragma unroll
-		for (int i = 0; i < TM; ++i) {
+			for (int j = 0; j < TN; ++j)
 #pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				const int m = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-				if (m < a.M) {
-					float v = acc[i][j][r];
-					if (a.bias) v += a.bias[g * a.M + m];
-					yb[(size_t)m * plane] = v;
-				}
-			}
-		}
+				for (int r = 0; r < 16; ++r) slab[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
 	}
+}
+
+// sums the k-slices of one tail tile (fixed order) and writes it out like a whole tile
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_tail_reduce_kernel(IgemmArgs a) {
+	constexpr int NT = 256, TM = BM / WM / 32, TN = BN / WN / 32;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave / WN, wn = wave % WN;
+	const int g = blockIdx.z;
+
+	const int ntail = a.tiles_m * a.tiles_n - a.full_tiles;
+	const int L = a.full_tiles + blockIdx.x;
+	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+	for (int sl = 0; sl < a.tail_splits; ++sl) {
+		const float *slab = a.slabs + ((size_t)(blockIdx.x * a.tail_splits + sl) + (size_t)g * ntail * a.tail_splits) * (BM * BN);
+#pragma unroll
+		for (int i = 0; i < TM; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+#pragma unroll
+				for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((i * TN + j) * 16 + r) * NT + tid];
+	}
+
+	igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -413,17 +508,21 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 		}
 	};
 
+	const bool full_m = tm * BM + BM <= a.Kg;
+
 	auto load_part = [&](int j) {
 		constexpr int PA = NA / (BK / 2) > 0 ? NA / (BK / 2) : 1, PB = NB / (BK / 2) > 0 ? NB / (BK / 2) : 1;
+		// operand A rows row0 + 8*i: one per-lane offset for row0, the 8*i part is a scalar offset
+		const unsigned voffA = dy_base != kOOB ? dy_base + (unsigned)(tm * BM + row0) * (unsigned)PQ * 4u : kOOB;
 #pragma unroll
 		for (int t = 0; t < PA; ++t) {
 			const int i = j * PA + t;
 			if (i < NA) {
-				const int m = tm * BM + row0 + 8 * i;
-				const bool ok = dy_base != kOOB && m < a.Kg;
-				ra[i] = buf_load_f32(dyr, ok ? dy_base + (unsigned)m * (unsigned)PQ * 4u : kOOB, 0);
+				const bool ok = full_m || tm * BM + row0 + 8 * i < a.Kg;
+				ra[i] = buf_load_f32(dyr, ok ? voffA : kOOB, (unsigned)(8 * i) * (unsigned)PQ * 4u);
 			}
 		}
+		asm volatile("" ::: "memory");      // keep the table reads here (hoisting all NB entries costs 2*NB registers)
 #pragma unroll
 		for (int t = 0; t < PB; ++t) {
 			const int i = j * PB + t;
@@ -616,10 +715,11 @@ inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 struct FwdPlan {
 	int bm, bn;                 // tile
 	int tiles_m, tiles_n, mpad, kred, kred_pad;
-	size_t wp_bytes, tab_bytes;
+	int full_tiles, tail_splits, blocks;     // tail balancing (see IgemmArgs)
+	size_t wp_bytes, tab_bytes, slab_bytes;
 };
 
-FwdPlan plan_igemm(int M, int kred, long npix) {
+FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
 	FwdPlan p;
 	p.bm = M <= 64 ? 64 : 128;
 	p.bn = M <= 64 ? 256 : 128;
@@ -628,6 +728,28 @@ FwdPlan plan_igemm(int M, int kred, long npix) {
 	p.mpad = p.tiles_m * p.bm;
 	p.kred = kred;
 	p.kred_pad = pz::ceil_div(kred, 16) * 16;
+	p.wp_bytes = align256((size_t)groups * p.kred_pad * p.mpad * sizeof(float));
+	p.tab_bytes = align256((size_t)p.kred_pad * sizeof(int2));
+
+	// The matrix pipes bound the kernel, so a launch takes ceil(tiles / #CU) tile-times: a last round that fills only
+	// part of the chip is cut along k so that every CU gets an equal share of it (deterministic slab reduce).
+	const int tiles = p.tiles_m * p.tiles_n, nk = p.kred_pad / 16;
+	const int rem = (int)((long)tiles * groups % pz::kNumCU);
+	p.full_tiles = tiles, p.tail_splits = 1;
+	if (groups == 1 && rem != 0) {
+		// cost of the last round in tile-times: unsplit = 1; split s ways = ceil(rem*s / #CU) / s. Slices keep >= 4
+		// k-tiles and the slab stays <= 1024 tiles (64 MB).
+		int best = 1;
+		double best_cost = 0.92;                   // only split for a >= 8 % shorter last round
+		for (int sp = 2; sp <= nk / 4 && rem * sp <= 1024; ++sp) {
+			const double cost = (double)pz::ceil_div((long)rem * sp, pz::kNumCU) / sp;
+			if (cost < best_cost - 1e-9) best_cost = cost, best = sp;
+		}
+		if (best > 1) p.full_tiles = tiles - rem, p.tail_splits = best;
+	}
+	const int ntail = tiles - p.full_tiles;
+	p.blocks = p.full_tiles + ntail * p.tail_splits;
+	p.slab_bytes = p.tail_splits > 1 ? align256((size_t)ntail * p.tail_splits * p.bm * p.bn * sizeof(float)) : 0;
 	return p;
 }
 
@@ -651,17 +773,20 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 }
 
 template <int BM, int BN, int WM, int WN>
-void launch_igemm(const IgemmArgs &a, int groups, hipStream_t st) {
-	dim3 grid(a.tiles_m * a.tiles_n, 1, groups);
-	igemm_conv_kernel<BM, BN, WM, WN><<<grid, 256, 0, st>>>(a);
+void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
+	igemm_conv_kernel<BM, BN, WM, WN><<<dim3(p.blocks, 1, groups), 256, 0, st>>>(a);
+	if (p.tail_splits > 1)
+		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 256, 0, st>>>(a);
 }
 
-void run_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
+void run_igemm(const FwdPlan &p, IgemmArgs a, float *slabs, int groups, hipStream_t st, double flops) {
+	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
+	a.full_tiles = p.full_tiles, a.tail_splits = p.tail_splits, a.slabs = slabs;
 	ProfScope prof(st, p.bm == 64 ? 1 : 0, flops);
 	if (p.bm == 64)
-		launch_igemm<64, 256, 1, 4>(a, groups, st);
+		launch_igemm<64, 256, 1, 4>(p, a, groups, st);
 	else
-		launch_igemm<128, 128, 2, 2>(a, groups, st);
+		launch_igemm<128, 128, 2, 2>(p, a, groups, st);
 }
 
 // backward-data residue classes
@@ -725,7 +850,7 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	p.steps_total = pz::ceil_div(npix, 32);
 
 	const int tiles = p.tiles_m * p.tiles_n * d->groups;
-	int splits = (4 * pz::kNumCU + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
+	int splits = 4 * pz::kNumCU / tiles;                        // <= 4 workgroups per CU in total: one balanced round
 	const int max_by_work = p.steps_total / 8 > 0 ? p.steps_total / 8 : 1;   // >= 8 k-steps (256 pixels) per split
 	if (splits > max_by_work) splits = max_by_work;
 	if (splits < 1) splits = 1;
@@ -774,8 +899,8 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
 	if (which == PZ_CONV_FWD) {
-		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q);
-		*nbytes = align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)) + align256((size_t)p.kred_pad * sizeof(int2));
+		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups);
+		*nbytes = p.wp_bytes + p.tab_bytes + p.slab_bytes;
 
 	} else if (which == PZ_CONV_BWD_DATA) {
 		if (!dgrad_uses_igemm(d)) return PZ_OK;
@@ -784,8 +909,8 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 		const int nc = dgrad_classes(d, cls, &nz);
 		size_t total = 0;
 		for (int i = 0; i < nc; ++i) {
-			FwdPlan p = plan_igemm(Cg, Kg * cls[i].Rc * cls[i].Sc, (long)d->n * cls[i].Pv * cls[i].Qv);
-			total += align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)) + align256((size_t)p.kred_pad * sizeof(int2));
+			FwdPlan p = plan_igemm(Cg, Kg * cls[i].Rc * cls[i].Sc, (long)d->n * cls[i].Pv * cls[i].Qv, d->groups);
+			total += p.wp_bytes + p.tab_bytes + p.slab_bytes;
 		}
 		*nbytes = total;
 
@@ -818,10 +943,11 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
-	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q);
+	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups);
 
 	float *wp = (float *)workspace;
-	int2 *tab = (int2 *)((char *)workspace + align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float)));
+	int2 *tab = (int2 *)((char *)workspace + p.wp_bytes);
+	float *slabs = (float *)((char *)workspace + p.wp_bytes + p.tab_bytes);
 
 	PackArgs pa{};
 	pa.w = w, pa.wp = wp, pa.tab = tab;
@@ -841,9 +967,9 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.R = d->r, a.S = d->s, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
 	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 	a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
+	a.y_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
-	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
-	run_igemm(p, a, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
+	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
@@ -881,12 +1007,14 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 	char *wsp = (char *)workspace;
 	for (int i = 0; i < nc; ++i) {
 		const DgradClass &c = cls[i];
-		FwdPlan p = plan_igemm(Cg, Kg * c.Rc * c.Sc, (long)d->n * c.Pv * c.Qv);
+		FwdPlan p = plan_igemm(Cg, Kg * c.Rc * c.Sc, (long)d->n * c.Pv * c.Qv, d->groups);
 
 		float *wp = (float *)wsp;
-		wsp += align256((size_t)d->groups * p.kred_pad * p.mpad * sizeof(float));
+		wsp += p.wp_bytes;
 		int2 *tab = (int2 *)wsp;
-		wsp += align256((size_t)p.kred_pad * sizeof(int2));
+		wsp += p.tab_bytes;
+		float *slabs = (float *)wsp;
+		wsp += p.slab_bytes;
 
 		PackArgs pa{};
 		pa.w = w, pa.wp = wp, pa.tab = tab;
@@ -907,10 +1035,10 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.R = c.Rc, a.S = c.Sc, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
 		a.x_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 		a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
+		a.y_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
-		a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
-		run_igemm(p, a, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
+		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;

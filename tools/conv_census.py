@@ -28,6 +28,7 @@ def main():
 	ap.add_argument("--batch", type=int, default=256)
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--only", type=int, default=-1)
+	ap.add_argument("--passes", default="fwd,dgrad,wgrad")
 	args = ap.parse_args()
 
 	from puzzlelib_amd import backend, lib
@@ -62,10 +63,12 @@ def main():
 		p, q = y.shape[2:]
 		gflop = 2.0 * n * k * p * q * c * size * size / 1e9
 
-		tf = timed(lambda: bnd.dnn.convNd(x, W, None, stride, pad, allocator=bnd.memoryPool))
-		td = timed(lambda: bnd.dnn.convNdBackwardData(dy, W, None, x, stride, pad, allocator=bnd.memoryPool))
+		passes = args.passes.split(",")
+		tf = timed(lambda: bnd.dnn.convNd(x, W, None, stride, pad, allocator=bnd.memoryPool)) if "fwd" in passes else 1e9
+		td = timed(lambda: bnd.dnn.convNdBackwardData(dy, W, None, x, stride, pad, allocator=bnd.memoryPool)) \
+			if "dgrad" in passes else 1e9
 		tw = timed(lambda: bnd.dnn.convNdBackwardParams(x, dy, W, stride, pad, wgrad=wg, scale=1.0, momentum=1.0,
-													  allocator=bnd.memoryPool))
+													  allocator=bnd.memoryPool)) if "wgrad" in passes else 1e9
 
 		name = "(%d,%d,%d)->(%d,%dx%d,s%d,p%d)" % (c, h, w, k, size, size, stride, pad)
 		print("%-34s %5d | %9.3f %7.1f | %9.3f %7.1f | %9.3f %7.1f" % (
