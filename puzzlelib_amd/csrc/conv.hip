@@ -22,6 +22,14 @@
 #ifndef PZ_ABL
 #define PZ_ABL 0
 #endif
+#if PZ_ABL & 128        // ablation: fold every gather address into the first 64 KB of the tensor (cache-resident)
+#define PZ_ABL_NEAR(off) ((off) & 0xfffcu)
+#else
+#define PZ_ABL_NEAR(off) (off)
+#endif
+#ifndef PZ_WG_LOAD_RUNS
+#define PZ_WG_LOAD_RUNS 8
+#endif
 #ifndef PZ_LB
 #define PZ_LB 4
 #endif
@@ -436,35 +444,48 @@ struct WgradArgs {
 	int st_h, st_w, pad_h, pad_w;
 	int R, S, dil_h, dil_w;
 	unsigned x_bytes, dy_bytes;
-	int npix, steps_total, steps_per_split;
+	int npix, steps_total, steps_per_split;     // npix counts RUNS of 4 pixels: N * P * Q4
+	unsigned Q4, magic_q4, magic_p;             // Q4 = ceil(Q/4); magic = ceil(2^32 / d) for exact u / d by __umulhi
 	int tiles_m, tiles_n;
 	float alpha, beta;
 	int direct;           // 1: out = beta*out + alpha*acc ; 0: out[split] = acc
 	size_t slab;          // groups*Kg*ncrs
 };
 
-template <int BM, int BN, int WM, int WN>
+// The reduction axis is enumerated in RUNS of 4 consecutive output pixels of one output row (rows padded to a multiple
+// of 4): a run of dy is 16 contiguous bytes, and for stride-1 convolutions so is the matching run of x for any tap, so
+// both operands arrive as 16-byte loads (4-byte aligned is enough on gfx950). A k-step is 8 runs = 32 (padded) pixels.
+// LDS keeps a run as two 8-byte half-cells [run][half][row]{2 pixels}: the MFMA fragment of lane (row, half h) is
+// {pixel 2h, 2h+1} of its row, i.e. the k order inside a run is (0,2 | 1,3) for both operands.
+template <int BM, int BN, int WM, int WN, bool UNIT_W>
 __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
-	constexpr int BK = 32, LD = BK + 1;
+	constexpr int BK = 32, RUNS = BK / 4;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4, "4 waves per workgroup");
 
-	__shared__ float As[BM * LD];
-	__shared__ float Bs[BN * LD];
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	// double buffered (one barrier per k-step); row stride BM + 2 makes the 8-runs x 4-rows write pattern of half a wave
+	// and the 32-consecutive-rows read pattern both bank-conflict free
+	__shared__ __attribute__((aligned(16))) f32x2 As[2][RUNS][2][BM + 2];
+	__shared__ __attribute__((aligned(16))) f32x2 Bs[2][RUNS][2][BN + 2];
 	__shared__ int2 tabs[BN];
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave / WN, wn = wave % WN;
-	const int g = blockIdx.z, split = blockIdx.y;
+	const int g = blockIdx.z;
 
-	const int L = blockIdx.x;
+	// XCD-aware order: one XCD walks consecutive (split, tile) pairs, so the tiles that re-read one split's pixel range
+	// of dy and x find it in that XCD's L2
+	const int ntiles = a.tiles_m * a.tiles_n;
+	const int B = xcd_remap(blockIdx.x, gridDim.x);
+	const int split = B / ntiles, L = B - split * ntiles;
 	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
 
 	if (tid < BN) tabs[tid] = a.tab[tn * BN + tid];
 
-	const int kp = tid & 31, row0 = tid >> 5;         // pixel within the k-step, first row handled
-	constexpr int NA = BM / 8, NB = BN / 8;
+	const int run = tid % RUNS, row0 = tid / RUNS;    // this thread's run of the k-step, first tile row it loads (32 rows per pass)
+	constexpr int NA = BM / 32, NB = BN / 32;
 
 	f32x16 acc[TM][TN];
 #pragma unroll
@@ -474,88 +495,133 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-	float ra[NA], rb[NB];
-	const int PQ = a.P * a.Q, HW = a.H * a.W;
+	f32x4 ra[NA], rb[NB];
+	unsigned mb[NB];               // valid-pixel masks of the operand-B runs in flight
+	const int PQ = a.P * a.Q;
 
 	__syncthreads();   // tabs visible
+
+	// this thread gathers the same NB filter taps (rows of operand B) in every k-step: keep them decoded in registers,
+	// so the loop has no LDS read whose wait would also drain the fragment reads queued ahead of it
+	int tap_h[NB], tap_w[NB], tap_off[NB];
+#pragma unroll
+	for (int i = 0; i < NB; ++i) {
+		const int2 e = tabs[row0 + 32 * i];
+		tap_h[i] = (e.y >> 8) * a.dil_h, tap_w[i] = (e.y & 0xff) * a.dil_w, tap_off[i] = e.x >> 2;
+	}
 
 	const int l31 = lane & 31, lhi = lane >> 5;
 
 	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
-
-	// per-step pixel decode (this thread's pixel of the k-step), then the step's NA + NB gathers cut into BK/2 parts that
-	// are issued one per k2-step in the shadow of the MFMAs. Gathers are buffer loads with 32-bit byte offsets; rows
-	// beyond Kg, pixels beyond the tensor and taps outside the image get an out-of-range offset -> the hardware returns 0.
-	unsigned rowmask = 0, colmask = 0;        // bit r / bit s: tap row / column of this step's pixel lies inside the image
-	unsigned dy_base = kOOB, x_base = 0;
-
-	auto load_head = [&](int step) {
-		const int kpix = step * BK + kp;
-		rowmask = colmask = 0;
-		dy_base = kOOB;
-		if (kpix < a.npix) {
-			const int n_img = kpix / PQ;
-			const int pq = kpix - n_img * PQ;
-			const int p = pq / a.Q, q = pq - p * a.Q;
-			const int h0 = p * a.st_h - a.pad_h, w0 = q * a.st_w - a.pad_w;
-
-			for (int r = 0; r < a.R; ++r) rowmask |= (unsigned)((unsigned)(h0 + r * a.dil_h) < (unsigned)a.H) << r;
-			for (int t = 0; t < a.S; ++t) colmask |= (unsigned)((unsigned)(w0 + t * a.dil_w) < (unsigned)a.W) << t;
-
-			dy_base = (unsigned)(((long)n_img * a.K_total + (long)g * a.Kg) * PQ + pq) * 4u;
-			x_base = (unsigned)((((long)n_img * a.C_total + (long)g * a.Cg) * a.H + h0) * a.W + w0) * 4u;
-		}
-	};
-
 	const bool full_m = tm * BM + BM <= a.Kg;
 
+	// ---- per-step state of this thread's run: image / row / first column, number of real pixels in the run
+	unsigned dy_off = kOOB;        // byte offset of dy[n, g*Kg + tm*BM + row0, p, q0]
+	int x_img = 0;                 // element offset of x[n, g*Cg, hb, wb] (may point left of / above the image)
+	int hb = 0, wb = 0, nq = 0;    // input row/col of tap (0,0) for pixel q0; real pixels in the run (0..4)
+
+	auto load_head = [&](int step) {
+		const unsigned u = (unsigned)(step * RUNS + run);
+		nq = 0, dy_off = kOOB;
+		if (u < (unsigned)a.npix) {            // a.npix = N * P * Q4 runs
+			// multiply-high division, exact while u * divisor < 2^32 (igemm_eligible); divisor 1 has no 32-bit magic
+			const unsigned np = a.Q4 == 1u ? u : __umulhi(u, a.magic_q4), qb = u - np * a.Q4;
+			const unsigned n_img = a.P == 1 ? np : __umulhi(np, a.magic_p), p = np - n_img * a.P;
+			const int q0 = (int)qb * 4;
+			nq = min(4, a.Q - q0);
+			hb = (int)p * a.st_h - a.pad_h, wb = q0 * a.st_w - a.pad_w;
+			dy_off = ((((unsigned)n_img * a.K_total + (unsigned)(g * a.Kg + tm * BM + row0)) * a.P + p) * a.Q + q0) * 4u;
+			x_img = (int)(((unsigned)n_img * a.C_total + (unsigned)(g * a.Cg)) * (unsigned)(a.H * a.W)) + hb * a.W + wb;
+		}
+	};
+
+	// one part = one operand-A row pass or one operand-B row pass (each a 16-byte load per thread). Pixels beyond the
+	// row end (nq < 4) are zeroed in operand B only: operand A then holds finite data of the next row, times zero.
 	auto load_part = [&](int j) {
-		constexpr int PA = NA / (BK / 2) > 0 ? NA / (BK / 2) : 1, PB = NB / (BK / 2) > 0 ? NB / (BK / 2) : 1;
-		// operand A rows row0 + 8*i: one per-lane offset for row0, the 8*i part is a scalar offset
-		const unsigned voffA = dy_base != kOOB ? dy_base + (unsigned)(tm * BM + row0) * (unsigned)PQ * 4u : kOOB;
+		if (j < NA) {
+			const int i = j;
+			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + 32 * i < a.Kg);
+			ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(32 * i) * (unsigned)PQ * 4u, 0));
+		} else if (j < NA + NB) {
+			const int i = j - NA;
+			const int w0 = wb + tap_w[i];
+			const bool row_ok = nq > 0 && (unsigned)(hb + tap_h[i]) < (unsigned)a.H;
+			const int first = x_img + tap_off[i];        // element offset of the run's first input column inside the tensor
+
+			if constexpr (UNIT_W) {
+				// valid pixels of the run: q in [lo, hi)
+				const int lo = max(0, -w0), hi = row_ok ? min(nq, a.W - w0) : 0;
+				const unsigned m = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+
+				// A run that starts left of the tensor's first byte (first row of the first image, left padding) would wrap
+				// the 32-bit offset: such a lane loads nothing here and is flagged (bit 4) for store_step to gather it.
+				const bool far_left = first < 0 && m != 0u;
+				rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+				    xr, (m != 0u && first >= 0) ? PZ_ABL_NEAR((unsigned)first * 4u) : kOOB, 0, 0));
+				mb[i] = far_left ? (m | 16u) : m;      // the mask is applied when the run is parked in LDS: no wait on the load here
+			} else {
+				f32x4 v;
 #pragma unroll
-		for (int t = 0; t < PA; ++t) {
-			const int i = j * PA + t;
-			if (i < NA) {
-				const bool ok = full_m || tm * BM + row0 + 8 * i < a.Kg;
-				ra[i] = buf_load_f32(dyr, ok ? voffA : kOOB, (unsigned)(8 * i) * (unsigned)PQ * 4u);
-			}
-		}
-		asm volatile("" ::: "memory");      // keep the table reads here (hoisting all NB entries costs 2*NB registers)
-#pragma unroll
-		for (int t = 0; t < PB; ++t) {
-			const int i = j * PB + t;
-			if (i < NB) {
-				const int2 e = tabs[row0 + 8 * i];
-				const bool ok = ((rowmask >> (e.y >> 8)) & (colmask >> (e.y & 0xff)) & 1u) != 0;
-				rb[i] = buf_load_f32(xr, ok ? x_base + (unsigned)e.x : kOOB, 0);
+				for (int q = 0; q < 4; ++q) {
+					const bool ok = row_ok && q < nq && (unsigned)(w0 + q * a.st_w) < (unsigned)a.W;
+					v[q] = buf_load_f32(xr, ok ? (unsigned)(first + q * a.st_w) * 4u : kOOB, 0);
+				}
+				rb[i] = v, mb[i] = 0xfu;
 			}
 		}
 	};
 
-	auto read_frag = [&](int ks, float (&av)[TM], float (&bv)[TN]) {
+	auto store_step = [&](int buf) {
 #pragma unroll
-		for (int i = 0; i < TM; ++i) av[i] = As[(wm * (32 * TM) + i * 32 + l31) * LD + ks + lhi];
+		for (int i = 0; i < NA; ++i) {
+			As[buf][run][0][row0 + 32 * i] = f32x2{ra[i][0], ra[i][1]};
+			As[buf][run][1][row0 + 32 * i] = f32x2{ra[i][2], ra[i][3]};
+		}
 #pragma unroll
-		for (int j = 0; j < TN; ++j) bv[j] = Bs[(wn * (32 * TN) + j * 32 + l31) * LD + ks + lhi];
+		for (int i = 0; i < NB; ++i) {
+			const unsigned m = mb[i];
+			if (UNIT_W && (m & 16u)) {       // rare: run starting left of the tensor base, gathered element-wise (x_img is still this step's)
+				const int first = x_img + tap_off[i];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) rb[i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
+			}
+			Bs[buf][run][0][row0 + 32 * i] = f32x2{m & 1u ? rb[i][0] : 0.f, m & 2u ? rb[i][1] : 0.f};
+			Bs[buf][run][1][row0 + 32 * i] = f32x2{m & 4u ? rb[i][2] : 0.f, m & 8u ? rb[i][3] : 0.f};
+		}
 	};
 
-	auto compute_step = [&](int next, bool has_next) {
-		float av[2][TM], bv[2][TN];
-		read_frag(0, av[0], bv[0]);
+	// fragments of one run (2 k2-steps): lane (row, h) takes pixels {2h, 2h+1} of its row's cell
+	auto read_frag = [&](int buf, int rn, f32x2 (&av)[TM], f32x2 (&bv)[TN]) {
+#pragma unroll
+		for (int i = 0; i < TM; ++i)
+			av[i] = As[buf][rn][lhi][wm * (32 * TM) + i * 32 + l31];
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+			bv[j] = Bs[buf][rn][lhi][wn * (32 * TN) + j * 32 + l31];
+	};
+
+	auto compute_step = [&](int buf, int next, bool has_next) {
+		f32x2 av[2][TM], bv[2][TN];
+		read_frag(buf, 0, av[0], bv[0]);
 		if (has_next) load_head(next);
 
 #pragma unroll
-		for (int j = 0; j < BK / 2; ++j) {
-			if (j + 1 < BK / 2) read_frag(2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
-			if (has_next) load_part(j);
+		for (int rn = 0; rn < RUNS; ++rn) {
+			if (rn + 1 < RUNS) read_frag(buf, rn + 1, av[(rn + 1) & 1], bv[(rn + 1) & 1]);
+			if (has_next && rn < PZ_WG_LOAD_RUNS) {       // gathers go out early in the step: half a step of MFMAs covers their latency
+#pragma unroll
+				for (int j = 0; j < RUNS / PZ_WG_LOAD_RUNS; ++j) load_part(rn * (RUNS / PZ_WG_LOAD_RUNS) + j);
+			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int i = 0; i < TM; ++i)
+			for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-				for (int jj = 0; jj < TN; ++jj)
-					acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+				for (int i = 0; i < TM; ++i)
+#pragma unroll
+					for (int jj = 0; jj < TN; ++jj)
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rn & 1][i][sub], bv[rn & 1][jj][sub], acc[i][jj], 0, 0, 0);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 	};
@@ -566,21 +632,32 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 	if (s_begin < s_end) {
 		load_head(s_begin);
 #pragma unroll
-		for (int j = 0; j < BK / 2; ++j) load_part(j);
-	}
-
-	for (int step = s_begin; step < s_end; ++step) {
-		__syncthreads();                               // previous step's fragment reads are done
-#pragma unroll
-		for (int i = 0; i < NA; ++i) As[(row0 + 8 * i) * LD + kp] = ra[i];
-#pragma unroll
-		for (int i = 0; i < NB; ++i) Bs[(row0 + 8 * i) * LD + kp] = rb[i];
+		for (int j = 0; j < NA + NB; ++j) load_part(j);
+		store_step(0);
 		__syncthreads();
 
-		if (step + 1 < s_end)
-			compute_step(step + 1, true);
-		else
-			compute_step(0, false);
+		for (int step = s_begin; step + 1 < s_end; ++step) {
+			const int buf = (step - s_begin) & 1;
+#if PZ_ABL & 8          // ablation: no global loads / LDS stores in the loop (wrong results, timing only)
+			compute_step(buf, step + 1, false);
+#elif PZ_ABL & 32       // ablation: global loads, no LDS stores
+			compute_step(buf, step + 1, true);
+#pragma unroll
+			for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i]));
+#pragma unroll
+			for (int i = 0; i < NB; ++i) asm volatile("" :: "v"(rb[i]));
+#elif PZ_ABL & 64       // ablation: LDS stores, no global loads
+			compute_step(buf, step + 1, false);
+			store_step(buf ^ 1);
+#else
+			compute_step(buf, step + 1, true);
+			store_step(buf ^ 1);
+#endif
+#if !(PZ_ABL & 16)      // ablation: no barrier
+			__syncthreads();
+#endif
+		}
+		compute_step((s_end - 1 - s_begin) & 1, 0, false);
 	}
 
 	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
@@ -824,6 +901,9 @@ int dgrad_classes(const pz_conv_desc *d, DgradClass *cls, bool *needs_zero) {
 // registers: tensors must stay below 4 GiB and the filter below 64 taps (31 per side for backward-filter)
 bool igemm_eligible(const pz_conv_desc *d, int P, int Q) {
 	const size_t xb = (size_t)d->n * d->c * d->h * d->w * 4, yb = (size_t)d->n * d->k * P * Q * 4;
+	// the backward-filter kernel splits run indices by multiply-high division, exact while runs * divisor < 2^32
+	const unsigned long long runs = (unsigned long long)d->n * P * ((Q + 3) / 4);
+	if (runs * (unsigned long long)std::max(P, (Q + 3) / 4) >= (1ull << 32)) return false;
 	return xb < kOOB && yb < kOOB && d->r * d->s <= 63 && d->r <= 31 && d->s <= 31;
 }
 
@@ -846,11 +926,11 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	p.tiles_m = pz::ceil_div(Kg, p.bm);
 	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
 	p.ncrs_pad = p.tiles_n * p.bn;
-	const long npix = (long)d->n * P * Q;
-	p.steps_total = pz::ceil_div(npix, 32);
+	const long nruns = (long)d->n * P * ((Q + 3) / 4);         // reduction axis in runs of 4 pixels (rows padded to 4)
+	p.steps_total = pz::ceil_div(nruns, 8);
 
 	const int tiles = p.tiles_m * p.tiles_n * d->groups;
-	int splits = 4 * pz::kNumCU / tiles;                        // <= 4 workgroups per CU in total: one balanced round
+	int splits = 2 * pz::kNumCU / tiles;                        // 2 workgroups fit a CU (LDS): one balanced round
 	const int max_by_work = p.steps_total / 8 > 0 ? p.steps_total / 8 : 1;   // >= 8 k-steps (256 pixels) per split
 	if (splits > max_by_work) splits = max_by_work;
 	if (splits < 1) splits = 1;
@@ -1083,24 +1163,27 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	a.R = d->r, a.S = d->s, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
 	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 	a.dy_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
-	a.npix = d->n * P * Q, a.steps_total = p.steps_total, a.steps_per_split = p.steps_per_split;
+	a.npix = d->n * P * ((Q + 3) / 4), a.steps_total = p.steps_total, a.steps_per_split = p.steps_per_split;
+	a.Q4 = (unsigned)((Q + 3) / 4);
+	a.magic_q4 = (unsigned)((((unsigned long long)1 << 32) + a.Q4 - 1) / a.Q4);
+	a.magic_p = (unsigned)((((unsigned long long)1 << 32) + P - 1) / P);
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
 	a.alpha = alpha, a.beta = beta;
 	a.direct = p.splits == 1;
 	a.out = a.direct ? dw : slabs;
 	a.slab = p.slab_elems;
 
-	dim3 grid(p.tiles_m * p.tiles_n, p.splits, d->groups);
+	dim3 grid(p.tiles_m * p.tiles_n * p.splits, 1, d->groups);
 	{
 	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
-	if (p.bm == 128 && p.bn == 128)
-		wgrad_conv_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(a);
-	else if (p.bm == 128 && p.bn == 64)
-		wgrad_conv_kernel<128, 64, 2, 2><<<grid, 256, 0, st>>>(a);
-	else if (p.bm == 64 && p.bn == 128)
-		wgrad_conv_kernel<64, 128, 2, 2><<<grid, 256, 0, st>>>(a);
-	else
-		wgrad_conv_kernel<64, 64, 2, 2><<<grid, 256, 0, st>>>(a);
+	const bool unit_w = d->stride_w == 1;
+#define PZ_WGRAD_LAUNCH(BM_, BN_) \
+	(unit_w ? wgrad_conv_kernel<BM_, BN_, 2, 2, true><<<grid, 256, 0, st>>>(a) : wgrad_conv_kernel<BM_, BN_, 2, 2, false><<<grid, 256, 0, st>>>(a))
+	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128);
+	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64);
+	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128);
+	else PZ_WGRAD_LAUNCH(64, 64);
+#undef PZ_WGRAD_LAUNCH
 	}
 	PZ_LAUNCH_CHECK();
 

@@ -10,19 +10,21 @@ build() {   # name, extra flags
 	hipcc --offload-arch=gfx950 -shared -fPIC -o puzzlelib_amd/variants/lib_$name.so puzzlelib_amd/variants/conv_$name.o \
 		$(ls puzzlelib_amd/csrc/build/*.o | grep -v conv.o) -ldl
 }
+PASS=${PASS:-fwd}
 if [ "$1" = "build" ]; then
+	[ -n "$ONLY" ] && { build $ONLY $FLAGS; exit 0; }
 	build base
-	build noload -DPZ_ABL=1
-	build noload_nobar -DPZ_ABL=3
-	build setprio -DPZ_ABL=4
-	build lb2 -DPZ_LB=2
-	build lb3 -DPZ_LB=3
+	build noload -DPZ_ABL=9
+	build noload_nobar -DPZ_ABL=27
+	build loadonly -DPZ_ABL=32
+	build storeonly -DPZ_ABL=64
+	build nearloads -DPZ_ABL=128
 	ls -la puzzlelib_amd/variants/*.so
 else
-	for v in base noload noload_nobar setprio lb2 lb3; do
-		for layer in 6 12; do
+	for v in ${VARIANTS:-base noload noload_nobar loadonly storeonly nearloads}; do
+		for layer in 2 6 12; do
 			echo "== $v layer $layer"
-			PUZZLE_MI355_LIB=$PWD/puzzlelib_amd/variants/lib_$v.so python tools/conv_census.py --only $layer --passes fwd --reps 5 | sed -n 2p
+			PUZZLE_MI355_LIB=$PWD/puzzlelib_amd/variants/lib_$v.so python tools/conv_census.py --only $layer --passes $PASS --reps 5 | sed -n 2p
 		done
 	done
 fi
