@@ -25,7 +25,7 @@ FAMILY = ["igemm_conv_kernel<128,128> (fwd + bwd-data)", "igemm_conv_kernel<64,2
 		  "wgrad_conv_kernel (bwd-filter)"]
 
 
-def cpu_baseline(sample_batch=8):
+def cpu_baseline(sample_batch=32):
 	"""Oracle ResNet-50 training step on the host (numpy im2col + sgemm, as the reference CPU backend does forward)."""
 	sys.path.insert(0, os.path.join(ROOT, "oracle"))
 	import cpu_net as N
@@ -81,6 +81,13 @@ def main():
 	from puzzlelib_amd import grid
 
 	Config.deviceIdx = local
+
+	import logging                               # stdout carries the JSON line only; the backend's banner goes to stderr
+	log = logging.getLogger("puzzlelib_amd.bench")
+	log.setLevel(logging.INFO)
+	log.propagate = False
+	log.addHandler(logging.StreamHandler(stream=sys.stderr))
+	Config.logger = log
 	nodeinfo = grid.nodeFromEnv()
 
 	from puzzlelib_amd import nets, train, lib
@@ -90,7 +97,9 @@ def main():
 	gpuarray = bound().gpuarray
 
 	np.random.seed(1234)                        # identical seeds -> identical initial parameters on every rank
-	net = nets.loadResNet(None, "50", initscheme="he")
+	# actInplace=True is the reference's own flag (Models/Nets/ResNet.py:63): ReLUs overwrite their input, which lets
+	# this backend fold them into the neighbouring BatchNorm / Add / Replicate kernels (bit-identical results)
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="he")
 
 	rng = np.random.RandomState(1234 + rank)    # each rank trains on its own shard of the global mini-batch
 	data = gpuarray.to_gpu(rng.randn(args.batch, 3, 224, 224).astype(np.float32))
@@ -154,7 +163,7 @@ def main():
 		"dtype": "f32", "data": "synthetic",
 		"config": {
 			"workload": "ResNet-50 (PuzzleLib variant, 55x55 stage 2) synthetic ImageNet 224x224 fp32, batch %d per GPU, "
-						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights" % args.batch,
+						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True)" % args.batch,
 			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
 			"grad_allreduce": "none" if world == 1 else "RCCL sum + 1/N, 25 MB buckets overlapped with backward"
 		},

@@ -135,6 +135,18 @@ int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, 
               const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
               void *workspace, size_t ws_bytes, pz_stream_t stream);
 
+/* Backend-internal fusion of BatchNorm with a following in-place ReLU (Models/Nets/ResNet.py:30-33 builds exactly that
+ * pair): act = PZ_BN_ACT_RELU makes the forward write relu(bn(x)) and the backward gate dy with
+ * (bn(x) > 0), re-created from x, scale, bias and the saved statistics — reluDer's rule (Cuda/Kernels/ElementWise.py
+ * :119-172) without the two extra tensor passes. act = PZ_BN_ACT_NONE is pz_bn_fwd_train / pz_bn_bwd.            */
+enum pz_bn_act { PZ_BN_ACT_NONE = 0, PZ_BN_ACT_RELU = 1 };
+int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                        float *run_mean, float *run_var, float *save_mean, float *save_invvar,
+                        float epsilon, float factor, int act, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                  const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                  int act, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
 /* ---- pooling: replaces DnnContext.poolNd / poolNdBackward (Hip/Wrappers/MIOpen.py:549-598).
  *      index workspace (uint8 per output element, window-local arg-max) is optional for forward (NULL in
  *      test mode) and required for max backward.                                                        */
@@ -209,6 +221,9 @@ enum pz_eltwise_op {
 	PZ_OP_ADD3,               /* out, a, b            : out = a + b (Add.updateData / Replicate.updateGrad fused) */
 	PZ_OP_IADD,               /* out, in              : out += in  (GPUArray.__iadd__)         */
 	PZ_OP_IMUL,               /* out, in              : out *= in                              */
+	PZ_OP_ADD3_RELU,          /* out, a, b            : out = relu(a + b)  (Add followed by an in-place ReLU, fused) */
+	PZ_OP_ADD3_GATE,          /* out, a, b, y         : out = (a + b) * (y > 0)  (Replicate fan-in + reluDer of the
+	                             in-place ReLU that produced its input y, fused)                   */
 	PZ_OP_COUNT
 };
 

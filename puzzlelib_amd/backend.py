@@ -446,7 +446,9 @@ class DnnContext:
 
 
 	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,
-					mode=BatchNormMode.spatial.value, out=None, allocator=None):
+					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False):
+		"""`fuseRelu` (backend-internal, train mode only): write relu(bn(data)) — used by Sequential for a BatchNorm
+		followed by an in-place ReLU; the matching backward is batchNormNdBackward(..., bias=, fuseRelu=True)."""
 		assert mean.ndim == 1 and var.ndim == 1 and scale.ndim == 1 and bias.ndim == 1
 		assert data.dimAt(1) == mean.dimAt(0)
 		requireF32(data, mean, var, scale, bias, out)
@@ -464,17 +466,19 @@ class DnnContext:
 		saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
 		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 
-		lib.pz_bn_fwd_train(
+		lib.pz_bn_fwd_train_act(
 			data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
-			epsilon, factor, ws.ptr, nbytes, None
+			epsilon, factor, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE, ws.ptr, nbytes, None
 		)
 		return out, savemean, saveinvvar
 
 
 	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
-							mode=BatchNormMode.spatial.value, out=None, allocator=None):
+							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False):
 		assert data.ndim == grad.ndim
-		requireF32(grad, data, scale, savemean, saveinvvar, out)
+		requireF32(grad, data, scale, savemean, saveinvvar, out, bias)
+		if fuseRelu and bias is None:
+			raise ValueError("batchNormNdBackward: the fused ReLU gate needs the layer's bias")
 		if savemean is None or saveinvvar is None:
 			raise ValueError("batchNormNdBackward needs the saved mean / inverse variance of the forward pass")
 
@@ -485,9 +489,9 @@ class DnnContext:
 		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
 		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 
-		lib.pz_bn_bwd(
-			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
-			ws.ptr, nbytes, None
+		lib.pz_bn_bwd_act(
+			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr if fuseRelu else None, savemean.ptr,
+			saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE, ws.ptr, nbytes, None
 		)
 		return out, scalegrad, bgrad
 
@@ -905,6 +909,8 @@ class Mi355Backend:
 
 		# fused residual sum / gradient fan-in (one 12 B/elem pass instead of memset + 2 axpy)
 		self.add3Ker = EltwiseKernel(lib.OP_ADD3, 3, 0, "add3Ker")
+		self.add3ReluKer = EltwiseKernel(lib.OP_ADD3_RELU, 3, 0, "add3ReluKer")
+		self.add3GateKer = EltwiseKernel(lib.OP_ADD3_GATE, 4, 0, "add3GateKer")
 
 
 	@staticmethod

@@ -101,6 +101,20 @@ __device__ __forceinline__ void bn_merge(const float *part, int splits, int ch, 
 	}
 }
 
+// y = a*x + b with a = rstd*scale, b = bias - mean*a, both formed with explicit fma so that the backward kernels of the
+// fused BN+ReLU pair re-create bit-identical y (and hence the same ReLU mask) from x
+__device__ __forceinline__ void bn_affine(float rstd, float mean, float scale, float bias, float &a, float &b) {
+	a = rstd * scale;
+	b = __builtin_fmaf(-mean, a, bias);
+}
+
+template <bool RELU>
+__device__ __forceinline__ float bn_act(float x, float a, float b) {
+	const float y = __builtin_fmaf(x, a, b);
+	return RELU ? (y > 0.f ? y : 0.f) : y;
+}
+
+template <bool RELU>
 __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, float *y, BnGeom g,
                                                               const float *__restrict__ part, const float *__restrict__ shift,
                                                               const float *__restrict__ scale, const float *__restrict__ bias,
@@ -128,7 +142,8 @@ __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, flo
 		run_var[ch] = (1.f - factor) * run_var[ch] + factor * (float)unbiased;
 	}
 
-	const float a = rstd * scale[ch], b = bias[ch] - mean * a;
+	float a, b;
+	bn_affine(rstd, mean, scale[ch], bias[ch], a, b);
 
 	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
 		const size_t off = ((size_t)n * g.c + ch) * g.hw;
@@ -137,9 +152,10 @@ __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, flo
 		slab_foreach(
 		    row, g.hw, t, g.nt, g.vec,
 		    [&](int j, float4 v) {
-			    *reinterpret_cast<float4 *>(out + j) = make_float4(v.x * a + b, v.y * a + b, v.z * a + b, v.w * a + b);
+			    *reinterpret_cast<float4 *>(out + j) = make_float4(bn_act<RELU>(v.x, a, b), bn_act<RELU>(v.y, a, b),
+			                                                       bn_act<RELU>(v.z, a, b), bn_act<RELU>(v.w, a, b));
 		    },
-		    [&](int j) { out[j] = row[j] * a + b; });
+		    [&](int j) { out[j] = bn_act<RELU>(row[j], a, b); });
 	}
 }
 
@@ -167,15 +183,26 @@ __global__ void __launch_bounds__(256) bn_infer_kernel(const float *x, float *y,
 	}
 }
 
-// ---- backward: partials {sum dy, sum dy*(x-mean)} then dx
+// ---- backward: partials {sum dy, sum dy*(x-mean)} then dx. RELU: the layer's output went through a fused ReLU, so dy
+// is first masked with (y > 0), y re-created from x (Cuda/Kernels/ElementWise.py:119-172 reluDer uses the output sign)
+template <bool RELU>
+__device__ __forceinline__ float bn_gate(float dy, float x, float a, float b) {
+	return RELU ? (__builtin_fmaf(x, a, b) > 0.f ? dy : 0.f) : dy;
+}
+
+template <bool RELU>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ dy, BnGeom g,
-                                                            const float *__restrict__ save_mean, float *__restrict__ part) {
+                                                            const float *__restrict__ save_mean,
+                                                            const float *__restrict__ save_invvar, const float *__restrict__ scale,
+                                                            const float *__restrict__ bias, float *__restrict__ part) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
 	const int rpp = bn_rows_per_pass(g.nt);
 	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
 
 	const float mu = save_mean[ch];
+	float a = 0.f, b = 0.f;
+	if (RELU) bn_affine(save_invvar[ch], mu, scale[ch], bias[ch], a, b);
 	float s1 = 0.f, s2 = 0.f;
 
 	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
@@ -184,12 +211,14 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restri
 		slab_foreach(
 		    row, g.hw, t, g.nt, g.vec,
 		    [&](int j, float4 v) {
-			    const float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    gv.x = bn_gate<RELU>(gv.x, v.x, a, b), gv.y = bn_gate<RELU>(gv.y, v.y, a, b);
+			    gv.z = bn_gate<RELU>(gv.z, v.z, a, b), gv.w = bn_gate<RELU>(gv.w, v.w, a, b);
 			    s1 += (gv.x + gv.y) + (gv.z + gv.w);
 			    s2 += (gv.x * (v.x - mu) + gv.y * (v.y - mu)) + (gv.z * (v.z - mu) + gv.w * (v.w - mu));
 		    },
 		    [&](int j) {
-			    const float gj = grow[j];
+			    const float gj = bn_gate<RELU>(grow[j], row[j], a, b);
 			    s1 += gj;
 			    s2 += gj * (row[j] - mu);
 		    });
@@ -203,9 +232,11 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restri
 	}
 }
 
+template <bool RELU>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const float *dy,
                                                             float *dx, BnGeom g, const float *__restrict__ part,
-                                                            const float *__restrict__ scale, const float *__restrict__ save_mean,
+                                                            const float *__restrict__ scale, const float *__restrict__ bias,
+                                                            const float *__restrict__ save_mean,
                                                             const float *__restrict__ save_invvar, float *__restrict__ dscale,
                                                             float *__restrict__ dbias) {
 	const int ch = blockIdx.x, s = blockIdx.y;
@@ -225,6 +256,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 	// dx = sc*rstd*(dy - db/m - xhat*ds/m),  xhat = (x-mu)*rstd
 	const float inv_m = 1.f / ((float)g.n * (float)g.hw);
 	const float k0 = sc * rstd, k1 = db * inv_m, k2 = ds * inv_m * rstd;
+	float a = 0.f, b = 0.f;
+	if (RELU) bn_affine(rstd, mu, sc, bias[ch], a, b);
 
 	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
 		const size_t off = ((size_t)n * g.c + ch) * g.hw;
@@ -233,12 +266,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 		slab_foreach(
 		    row, g.hw, t, g.nt, g.vec,
 		    [&](int j, float4 v) {
-			    const float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    float4 gv = *reinterpret_cast<const float4 *>(grow + j);
+			    gv.x = bn_gate<RELU>(gv.x, v.x, a, b), gv.y = bn_gate<RELU>(gv.y, v.y, a, b);
+			    gv.z = bn_gate<RELU>(gv.z, v.z, a, b), gv.w = bn_gate<RELU>(gv.w, v.w, a, b);
 			    *reinterpret_cast<float4 *>(out + j) =
 			        make_float4(k0 * (gv.x - k1 - (v.x - mu) * k2), k0 * (gv.y - k1 - (v.y - mu) * k2),
 			                    k0 * (gv.z - k1 - (v.z - mu) * k2), k0 * (gv.w - k1 - (v.w - mu) * k2));
 		    },
-		    [&](int j) { out[j] = k0 * (grow[j] - k1 - (row[j] - mu) * k2); });
+		    [&](int j) { out[j] = k0 * (bn_gate<RELU>(grow[j], row[j], a, b) - k1 - (row[j] - mu) * k2); });
 	}
 }
 
@@ -260,11 +295,12 @@ int pz_bn_workspace_bytes(int n, int c, int hw, size_t *nbytes) {
 	return PZ_OK;
 }
 
-int pz_bn_fwd_train(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
-                    float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor, void *workspace,
-                    size_t ws_bytes, pz_stream_t stream) {
+int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                        float *run_mean, float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor,
+                        int act, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && y && scale && bias && run_mean && run_var && save_mean && save_invvar, "pz_bn_fwd_train: null tensor");
+	PZ_REQUIRE(act == PZ_BN_ACT_NONE || act == PZ_BN_ACT_RELU, "pz_bn_fwd_train: unknown fused activation %d", act);
 	const BnGeom g = bn_geom(n, c, hw, congruent16(x, y));
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train: workspace too small");
 
@@ -274,10 +310,21 @@ int pz_bn_fwd_train(const float *x, float *y, int n, int c, int hw, const float 
 
 	bn_stats_kernel<<<grid, 256, 0, st>>>(x, g, part, shift);
 	PZ_LAUNCH_CHECK();
-	bn_apply_train_kernel<<<grid, 256, 0, st>>>(x, y, g, part, shift, scale, bias, run_mean, run_var, save_mean, save_invvar,
-	                                            epsilon, factor);
+	if (act == PZ_BN_ACT_RELU)
+		bn_apply_train_kernel<true><<<grid, 256, 0, st>>>(x, y, g, part, shift, scale, bias, run_mean, run_var, save_mean,
+		                                                  save_invvar, epsilon, factor);
+	else
+		bn_apply_train_kernel<false><<<grid, 256, 0, st>>>(x, y, g, part, shift, scale, bias, run_mean, run_var, save_mean,
+		                                                   save_invvar, epsilon, factor);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
+}
+
+int pz_bn_fwd_train(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
+                    float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor, void *workspace,
+                    size_t ws_bytes, pz_stream_t stream) {
+	return pz_bn_fwd_train_act(x, y, n, c, hw, scale, bias, run_mean, run_var, save_mean, save_invvar, epsilon, factor,
+	                           PZ_BN_ACT_NONE, workspace, ws_bytes, stream);
 }
 
 int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias, const float *mean,
@@ -290,10 +337,12 @@ int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float 
 	return PZ_OK;
 }
 
-int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *save_mean,
-              const float *save_invvar, float *dscale, float *dbias, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *bias,
+                  const float *save_mean, const float *save_invvar, float *dscale, float *dbias, int act, void *workspace,
+                  size_t ws_bytes, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias, "pz_bn_bwd: null tensor");
+	PZ_REQUIRE(act == PZ_BN_ACT_NONE || (act == PZ_BN_ACT_RELU && bias), "pz_bn_bwd: fused activation %d needs the bias", act);
 	const BnGeom g = bn_geom(n, c, hw, congruent16(x, dy, dx));
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_bwd: workspace too small");
 
@@ -301,11 +350,23 @@ int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, 
 	hipStream_t st = pz::as_stream(stream);
 	dim3 grid(c, g.splits);
 
-	bn_bwd_stats_kernel<<<grid, 256, 0, st>>>(x, dy, g, save_mean, part);
-	PZ_LAUNCH_CHECK();
-	bn_bwd_apply_kernel<<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, save_mean, save_invvar, dscale, dbias);
+	if (act == PZ_BN_ACT_RELU) {
+		bn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(x, dy, g, save_mean, save_invvar, scale, bias, part);
+		PZ_LAUNCH_CHECK();
+		bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias);
+	} else {
+		bn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(x, dy, g, save_mean, save_invvar, scale, bias, part);
+		PZ_LAUNCH_CHECK();
+		bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias);
+	}
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
+}
+
+int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *save_mean,
+              const float *save_invvar, float *dscale, float *dbias, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	return pz_bn_bwd_act(x, dy, dx, n, c, hw, scale, nullptr, save_mean, save_invvar, dscale, dbias, PZ_BN_ACT_NONE, workspace,
+	                     ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -98,6 +98,10 @@ PZ_ELT(OpSmorms3, 5, 0b11111, 0b11101,                                          
        v[0] += g * fminf(s[0], x) / (sqrtf(msi) + s[1]);)
 
 PZ_ELT(OpAdd3, 3, 0b110, 0b001, v[0] = v[1] + v[2];)      // residual sum / gradient fan-in in one 12 B/elem pass
+// residual sum followed by an in-place ReLU, and gradient fan-in gated by that ReLU's output sign (reluKer / reluDerKer
+// rules, ElementWise.py:119-172) — one pass each instead of two
+PZ_ELT(OpAdd3Relu, 3, 0b110, 0b001, const float t = v[1] + v[2]; v[0] = t * gt0(t);)
+PZ_ELT(OpAdd3Gate, 4, 0b1110, 0b0001, v[0] = (v[1] + v[2]) * gt0(v[3]);)
 PZ_ELT(OpIadd, 2, 0b11, 0b01, v[0] += v[1];)              // Cuda/GPUArray.py:127-136 inplaceArithmKer
 PZ_ELT(OpImul, 2, 0b11, 0b01, v[0] *= v[1];)
 
@@ -256,6 +260,8 @@ int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *
 		PZ_CASE(PZ_OP_ADD3, OpAdd3, 0)
 		PZ_CASE(PZ_OP_IADD, OpIadd, 0)
 		PZ_CASE(PZ_OP_IMUL, OpImul, 0)
+		PZ_CASE(PZ_OP_ADD3_RELU, OpAdd3Relu, 0)
+		PZ_CASE(PZ_OP_ADD3_GATE, OpAdd3Gate, 0)
 
 		case PZ_OP_DROPOUT2D: {
 			PZ_REQUIRE(nptrs == 3 && nscalars >= 3 && dense, "pz_eltwise: dropout2d expects 3 operands, 3 scalars, no slice");

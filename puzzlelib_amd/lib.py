@@ -105,6 +105,8 @@ _PROTOS = {
 	"pz_bn_fwd_train": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, P, c_size_t, P],
 	"pz_bn_fwd_infer": [P, P, c_int, c_int, c_int, P, P, P, P, c_float, P],
 	"pz_bn_bwd": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P],
+	"pz_bn_fwd_train_act": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
+	"pz_bn_bwd_act": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, c_size_t, P],
 
 	"pz_pool2d_out_shape": [POINTER(PoolDesc), POINTER(c_int), POINTER(c_int)],
 	"pz_pool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
@@ -191,11 +193,12 @@ COMM_ID_BYTES = 128
 	OP_ELU, OP_ELU_DER, OP_SOFTPLUS, OP_SOFTPLUS_DER, OP_CLIP, OP_CLIP_DER, OP_GELU, OP_GELU_DER,
 	OP_DROPOUT, OP_DROPOUT2D, OP_AXPY, OP_ADD, OP_MUL, OP_LINEAR, OP_ABS, OP_WEIGHT_DECAY, OP_L1_PENALTY, OP_L1_GRAD,
 	OP_RBM, OP_ADAM, OP_CLASSIC_MOM_SGD, OP_NESTEROV_MOM_SGD, OP_RMSPROP, OP_ADAGRAD, OP_ADADELTA, OP_RMSPROP_GRAVES,
-	OP_SMORMS3, OP_ADD3, OP_IADD, OP_IMUL, OP_COUNT
-) = range(39)
+	OP_SMORMS3, OP_ADD3, OP_IADD, OP_IMUL, OP_ADD3_RELU, OP_ADD3_GATE, OP_COUNT
+) = range(41)
 
 CONV_ALGO_AUTO, CONV_ALGO_DIRECT, CONV_ALGO_IMPLICIT_GEMM = -1, 1, 5
 CONV_FWD, CONV_BWD_DATA, CONV_BWD_FILTER = 0, 1, 2
+BN_ACT_NONE, BN_ACT_RELU = 0, 1
 
 
 def declaredSymbols():

@@ -453,6 +453,7 @@ class BatchNorm2D(Module):
 
 		self.scale = self.bias = self.mean = self.var = None
 		self.savemean = self.saveinvvar = self.scalegrad = self.biasgrad = None
+		self.fusedRelu = False       # set per forward pass by Sequential (planFusion): output is relu(bn(x))
 
 		if empty:
 			return
@@ -478,7 +479,7 @@ class BatchNorm2D(Module):
 			factor = max(self.initFactor / self.numOfProps, self.minFactor)
 
 			self.data, self.savemean, self.saveinvvar = dnn.batchNormNd(
-				data, self.scale, self.bias, self.mean, self.var, self.epsilon, factor, False
+				data, self.scale, self.bias, self.mean, self.var, self.epsilon, factor, False, fuseRelu=self.fusedRelu
 			)
 		else:
 			self.data = dnn.batchNormNd(
@@ -488,7 +489,10 @@ class BatchNorm2D(Module):
 
 
 	def updateGrad(self, grad):
-		tup = S().Dnn.batchNormNdBackward(self.inData, grad, self.scale, self.savemean, self.saveinvvar, self.epsilon)
+		tup = S().Dnn.batchNormNdBackward(
+			self.inData, grad, self.scale, self.savemean, self.saveinvvar, self.epsilon,
+			bias=self.bias if self.fusedRelu else None, fuseRelu=self.fusedRelu
+		)
 		if self.affine:
 			self.grad, self.scalegrad, self.biasgrad = tup
 		else:
@@ -564,6 +568,14 @@ class Activation(Module):
 		self.actFuncDer = getattr(kernels, "%sDerKer" % self.activation.value)
 		self.actArgs = tuple(args) if len(args) > 0 else self.defaultArgs.get(self.activation, ())
 
+		# set per forward pass by Sequential (planFusion) for in-place ReLUs only:
+		self.dataFused = False       # the producer (BatchNorm2D / Add) already wrote relu(.) into `data`
+		self.gradFused = False       # the ReLU derivative is applied by the producer's or the consumer's backward
+
+
+	def fusable(self):
+		return self.activation == ActivationType.relu and self.inplace and self.slc is None
+
 
 	def allocLike(self, ary):
 		gpuarray = S().gpuarray
@@ -571,11 +583,19 @@ class Activation(Module):
 
 
 	def updateData(self, data):
+		if self.dataFused:
+			self.data = data
+			return
+
 		self.data = data if self.inplace else self.allocLike(data)
 		self.actFunc(data.dtype)(self.data, data, *self.actArgs, slice=self.slc)
 
 
 	def updateGrad(self, grad):
+		if self.gradFused:
+			self.grad = grad
+			return
+
 		self.grad = grad if self.inplace else self.allocLike(grad)
 		self.actFuncDer(grad.dtype)(self.grad, grad, self.data, *self.actArgs, slice=self.slc)
 
@@ -659,13 +679,22 @@ class AvgPool2D(Pool2D):
 		self.mode = PoolMode.avgWithPad if includePad else PoolMode.avgNoPad
 
 
-def sumTensors(tensors):
+def sumTensors(tensors, relu=False, gate=None):
 	"""memset + one axpy per input in the reference (Modules/Add.py:15-22, Replicate.py:22-29: 28 B/elem for two
 	inputs); here the first two inputs are summed by one 3-operand kernel (12 B/elem), further ones by axpy.
-	0 + a + b == a + b exactly in fp32, so results are bit-identical."""
+	0 + a + b == a + b exactly in fp32, so results are bit-identical.
+	Two-input sums can absorb a neighbouring in-place ReLU: relu=True gives relu(a + b), gate=y gives (a + b)*(y > 0)."""
 	surf = S()
 	first = tensors[0]
 	out = surf.gpuarray.empty(first.shape, dtype=first.dtype, allocator=surf.gpuarray.memoryPool)
+
+	if relu or gate is not None:
+		assert len(tensors) == 2
+		if relu:
+			surf.ElementWise.add3ReluKer(out, tensors[0], tensors[1])
+		else:
+			surf.ElementWise.add3GateKer(out, tensors[0], tensors[1], gate)
+		return out
 
 	if len(tensors) == 1:
 		out.set(first)
@@ -682,10 +711,15 @@ class Add(Module):
 	def __init__(self, name=None):
 		super().__init__(name)
 		self.movesGrad = True
+		self.fusedRelu = False       # set per forward pass by Sequential (planFusion)
 
 
 	def updateData(self, data):
-		self.data = sumTensors(data)
+		if self.fusedRelu and len(data) != 2:
+			self.data = sumTensors(data)
+			S().ElementWise.reluKer(self.data.dtype)(self.data, self.data)
+		else:
+			self.data = sumTensors(data, relu=self.fusedRelu)
 
 
 	def updateGrad(self, grad):
@@ -711,6 +745,7 @@ class Replicate(Module):
 		super().__init__(name)
 		self.movesData = True
 		self.times = times
+		self.gateGrad = False        # set per forward pass by Sequential (planFusion): input is an in-place ReLU's output
 
 
 	def updateData(self, data):
@@ -718,7 +753,7 @@ class Replicate(Module):
 
 
 	def updateGrad(self, grad):
-		self.grad = sumTensors(grad)
+		self.grad = sumTensors(grad, gate=self.inData if self.gateGrad else None)
 
 
 	def dataShapeFrom(self, shape):
@@ -980,10 +1015,49 @@ class Container(Module):
 
 class Sequential(Container):
 	honourUpdGrad = True
+	fuseInplaceRelu = True       # backend-internal fusion around in-place ReLUs (see planFusion)
 
 	def __init__(self, name=None):
 		super().__init__(name)
 		self.graph = []
+
+
+	def planFusion(self):
+		"""Marks, for the coming forward/backward pass, the neighbours that absorb an in-place ReLU
+		(Activation(relu, inplace=True), e.g. Models/Nets/ResNet.py:33,58 with actInplace=True). With the in-place flag
+		the pre-activation values are overwritten in the reference as well, so no observable buffer changes:
+		  BatchNorm2D (train) -> ReLU : BN writes relu(bn(x)); its backward gates the incoming grad with (bn(x) > 0)
+		  Add (2 inputs)      -> ReLU : the sum kernel writes relu(a + b)
+		  ReLU -> Replicate(2)        : the fan-in kernel writes (g0 + g1) * (y > 0), y = the ReLU's output
+		The ReLU module itself then only forwards data / grad. Values are bit-identical to the unfused sequence."""
+		graph, on = self.graph, Sequential.fuseInplaceRelu
+
+		for mod in graph:
+			if isinstance(mod, Activation):
+				mod.dataFused = mod.gradFused = False
+			elif isinstance(mod, (BatchNorm2D, Add)):
+				mod.fusedRelu = False
+			elif isinstance(mod, Replicate):
+				mod.gateGrad = False
+
+		if not on:
+			return
+
+		for i, mod in enumerate(graph):
+			if not (isinstance(mod, Activation) and mod.fusable() and i > 0):
+				continue
+
+			prev = graph[i - 1]
+			nxt = graph[i + 1] if i + 1 < len(graph) else None
+
+			if isinstance(prev, BatchNorm2D) and prev.train:
+				prev.fusedRelu = mod.dataFused = mod.gradFused = True
+
+			elif isinstance(prev, Add):
+				prev.fusedRelu = mod.dataFused = True
+
+			if not mod.gradFused and isinstance(nxt, Replicate) and nxt.times == 2:
+				nxt.gateGrad = mod.gradFused = True
 
 
 	def append(self, mod, acquire=True):
@@ -1021,6 +1095,8 @@ class Sequential(Container):
 
 
 	def updateData(self, data):
+		self.planFusion()
+
 		for i, mod in enumerate(self.graph):
 			try:
 				mod(data)

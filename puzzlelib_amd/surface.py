@@ -98,11 +98,12 @@ def bind():
 	def poolNdBackward(indata, outdata, grad, workspace, size, stride, pad, mode):
 		return dnn.poolNdBackward(grad, indata, outdata, workspace, size, stride, pad, mode.value, None, memoryPool)
 
-	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None):
+	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None,
+					fuseRelu=False):
 		shape = scale.shape
 		result = dnn.batchNormNd(
 			data, mean.ravel(), var.ravel(), scale.ravel(), bias.ravel(), epsilon, factor, test, mode.value, out=out,
-			allocator=memoryPool
+			allocator=memoryPool, fuseRelu=fuseRelu
 		)
 		if test:
 			return result
@@ -110,10 +111,12 @@ def bind():
 		outdata, savemean, saveinvvar = result
 		return outdata, savemean.reshape(shape), saveinvvar.reshape(shape)
 
-	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial):
+	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial,
+							bias=None, fuseRelu=False):
 		shape = scale.shape
 		ingrad, scalegrad, bgrad = dnn.batchNormNdBackward(
-			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool
+			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool,
+			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu
 		)
 		return ingrad, scalegrad.reshape(shape), bgrad.reshape(shape)
 
@@ -145,7 +148,8 @@ def bind():
 		"leakyReluDerKer", "eluKer", "eluDerKer", "softPlusKer", "softPlusDerKer", "clipKer", "clipDerKer", "geluKer",
 		"geluDerKer", "dropoutKer", "dropout2dKer", "toVectorAddVectorKer", "classicMomSGDKer", "nesterovMomSGDKer",
 		"rmspropKer", "adamKer", "rmspropGravesKer", "adagradKer", "adadeltaKer", "smorms3Ker", "addKer", "mulKer",
-		"linearKer", "rbmKer", "absKer", "weightDecayKer", "l1penaltyKer", "l1gradKer", "add3Ker"
+		"linearKer", "rbmKer", "absKer", "weightDecayKer", "l1penaltyKer", "l1gradKer", "add3Ker", "add3ReluKer",
+		"add3GateKer"
 	]
 	ElementWise = SimpleNamespace(**{name: getattr(bnd, name) for name in kernelNames})
 

@@ -127,6 +127,71 @@ def test_mini_resnet_matches_oracle_for_several_steps(bnd, mini_golden):
 		)
 
 
+def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golden):
+	"""actInplace=True (Models/Nets/ResNet.py:33,58) lets Sequential fold every ReLU into its neighbours (BN+ReLU,
+	Add+ReLU, ReLU-derivative into the Replicate fan-in or the BN backward). One Adam step must give the same bits as
+	the unfused module sequence, and the oracle's loss / parameters within the usual tolerances."""
+	from puzzlelib_amd import nets, train, nn
+	from puzzlelib_amd.surface import bound
+
+	gpuarray = bound().gpuarray
+	spec = nets.resnet_spec(stages=((8, 1), (16, 2)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	data, labels = mini_golden["data"], mini_golden["labels"]
+
+	results = {}
+	for fused in (False, True):
+		nn.Sequential.fuseInplaceRelu = fused
+		try:
+			np.random.seed(7)
+			net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+			for name, var in nets.namedVariables(net).items():
+				var.data.set(mini_golden["init_" + name])
+
+			optimizer = train.Adam(alpha=1e-3)
+			optimizer.setupOn(net, useGlobalState=True)
+			cost = train.CrossEntropy()
+			net.trainMode()
+
+			pred = net(gpuarray.to_gpu(data))
+			logits = pred.get()
+			grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
+			optimizer.zeroGradParams()
+			net.backward(grad, updGrad=False)
+			grads = {name: var.grad.get() for name, var in nets.namedVariables(net).items()}
+			optimizer.update()
+			params = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
+
+			if fused:
+				acts = [m for m in allModules(net) if isinstance(m, nn.Activation)]
+				assert acts and all(m.dataFused and m.gradFused for m in acts[:-1]), "every inner ReLU must have been absorbed"
+				assert acts[-1].dataFused          # last block's ReLU: forward fused into Add, derivative computed by itself
+
+			results[fused] = (logits, float(cost.devErr.get()), grads, params)
+		finally:
+			nn.Sequential.fuseInplaceRelu = True
+
+	(l0, e0, g0, p0), (l1, e1, g1, p1) = results[False], results[True]
+	assert np.array_equal(l0, l1) and e0 == e1
+	for name in g0:
+		assert np.array_equal(g0[name], g1[name]), "grad " + name
+		assert np.array_equal(p0[name], p1[name]), "param " + name
+
+	assert_close(l1, mini_golden["orc_logits"], atol=2e-4, rtol=1e-3, what="logits")
+	assert np.isclose(e1, mini_golden["orc_err"][0], rtol=1e-4)
+	for name in p1:
+		assert_close(p1[name], mini_golden["orc_after_" + name], atol=3e-4, rtol=1e-4, what="param " + name)
+
+
+def allModules(container):
+	from puzzlelib_amd import nn
+	for mod in (container.graph if hasattr(container, "graph") else container.modules.values()):
+		if isinstance(mod, nn.Container):
+			yield from allModules(mod)
+		else:
+			yield mod
+
+
 def test_validator_and_eval_mode(bnd, mini_golden):
 	from puzzlelib_amd import train
 

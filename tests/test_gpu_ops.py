@@ -314,6 +314,70 @@ def test_batchnorm_fresh(bnd, shape):
 	assert_close(y2.get(), y_ref, atol=2e-5, rtol=1e-4, what="in-place y")
 
 
+@pytest.mark.parametrize("shape", [(4, 5, 2, 3), (3, 7, 55, 55), (5, 3, 7, 7), (8, 130, 14, 14)])
+def test_batchnorm_fused_relu_is_the_unfused_sequence(bnd, shape):
+	"""BN + in-place ReLU fused inside the backend. Forward must equal reluKer(batchNormNd(x)) and backward
+	batchNormNdBackward(reluDerKer(dy, y)) BIT FOR BIT (the gate is re-created from x with the forward's own fma), and
+	both must match the oracle."""
+	rng = np.random.RandomState(11)
+	c = shape[1]
+	x = (0.5 + 2.0 * rng.randn(*shape)).astype(np.float32)
+	scale, bias = rng.randn(c).astype(np.float32), rng.randn(c).astype(np.float32)
+	dy = rng.randn(*shape).astype(np.float32)
+	rm0, rv0 = rng.randn(c).astype(np.float32), (1 + rng.rand(c)).astype(np.float32)
+
+	gx, gs, gb = gpu(bnd, x), gpu(bnd, scale), gpu(bnd, bias)
+
+	# unfused sequence
+	y, sm, si = bnd.dnn.batchNormNd(gx, gpu(bnd, rm0), gpu(bnd, rv0), gs, gb, 1e-5, 0.3, False)
+	bnd.reluKer(np.float32)(y, y)
+	gdy = gpu(bnd, dy)
+	bnd.reluDerKer(np.float32)(gdy, gdy, y)
+	dx, ds, db = bnd.dnn.batchNormNdBackward(gdy, gx, gs, sm, si, 1e-5)
+
+	# fused
+	grm, grv = gpu(bnd, rm0), gpu(bnd, rv0)
+	yf, smf, sif = bnd.dnn.batchNormNd(gx, grm, grv, gs, gb, 1e-5, 0.3, False, fuseRelu=True)
+	dxf, dsf, dbf = bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, smf, sif, 1e-5, bias=gb, fuseRelu=True)
+
+	assert np.array_equal(yf.get(), y.get())
+	assert np.array_equal(smf.get(), sm.get()) and np.array_equal(sif.get(), si.get())
+	assert np.array_equal(dxf.get(), dx.get())
+	assert np.array_equal(dsf.get(), ds.get()) and np.array_equal(dbf.get(), db.get())
+
+	# oracle
+	rm, rv = rm0.copy(), rv0.copy()
+	y_ref, sm_ref, si_ref = R.bn_fwd_train(x, scale, bias, rm, rv, 1e-5, 0.3, acc=np.float64)
+	near_zero = np.abs(y_ref) < 1e-4                   # the gate of such elements may legitimately differ from float64's
+	y_relu = R.relu(y_ref)
+	dy_gated = np.where(near_zero, dy * (yf.get() > 0), R.relu_der(dy, y_relu)).astype(np.float32)
+	dx_ref, ds_ref, db_ref = R.bn_bwd(dy_gated, x, scale, sm_ref, si_ref, acc=np.float64)
+
+	n = x.size // c
+	assert_close(yf.get(), y_relu, atol=2e-5, rtol=1e-4, what="fused y")
+	assert_close(grm.get(), rm, atol=1e-5, what="running mean")
+	assert_close(dxf.get(), dx_ref, atol=2e-5, rtol=1e-4, what="fused dx")
+	assert_close(dsf.get(), ds_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="fused dscale")
+	assert_close(dbf.get(), db_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="fused dbias")
+
+	with pytest.raises(ValueError):
+		bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, smf, sif, 1e-5, fuseRelu=True)      # gate needs the bias
+
+
+@pytest.mark.parametrize("n", [1, 5, 1024, 4 * 3025 + 3])
+def test_fused_residual_kernels(bnd, n):
+	rng = np.random.RandomState(n)
+	a, b, y = (rng.randn(n).astype(np.float32) for _ in range(3))
+	ga, gb_, gy = gpu(bnd, a), gpu(bnd, b), gpu(bnd, y)
+
+	out = bnd.GPUArray.empty((n, ), dtype=np.float32)
+	bnd.add3ReluKer(out, ga, gb_)
+	assert np.array_equal(out.get(), R.relu(a + b))
+
+	bnd.add3GateKer(out, ga, gb_, gy)
+	assert np.array_equal(out.get(), R.relu_der(a + b, y))
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 @pytest.mark.parametrize("name", ["p0", "p1", "p2"])
 def test_pool_golden(bnd, ops, name):
