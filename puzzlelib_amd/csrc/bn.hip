@@ -2,51 +2,30 @@
 // Replaces DnnContext.batchNormNd / batchNormNdBackward — Hip/Wrappers/MIOpen.py:634-688; formulas pinned by
 // Cuda/Wrappers/CuDnnNorm.py:23-77 (biased variance for normalisation, EMA running stats with `factor`).
 //
-// A channel's data are N slabs of hw contiguous floats (stride c*hw). A workgroup owns (channel, split): it walks
-// its share of the slabs either with all 256 threads on one slab (large hw) or with one wave per slab, reading
-// 16 B per lane after peeling each slab to 16-B alignment (hw = 55*55 or 7*7 is odd, so slab bases are not aligned).
+// A channel's data are N slabs of hw contiguous floats (stride c*hw). A workgroup owns (channel, split); T = 16..256
+// threads (the power of two covering hw/4) walk one slab with 16-byte accesses, 256/T slabs side by side. The accesses are
+// only 4-byte aligned (hw = 55*55 or 7*7 is odd, so slab bases are not 16-B aligned) — gfx950 takes unaligned dwordx4
+// — and every thread keeps U of them in flight before touching the data: an HBM-bound stream needs ~10 MB in flight across
+// the chip, which one dependent load per thread does not give. The hw % 4 trailing floats of each slab go scalar.
 // Statistics are shifted sums (sum(x-K), sum((x-K)^2), K = first element of the channel) reduced per workgroup in
 // fp32 and merged across workgroups in fp64 in a fixed order -> deterministic, no atomics.
 #include "common.h"
 
 namespace {
 
-template <typename F4, typename F1>
-__device__ __forceinline__ void slab_foreach(const float *row, int len, int t, int nt, bool vec, F4 f4, F1 f1) {
-	if (!vec) {          // operands not congruent modulo 16 B (offset views): plain 4-B accesses
-		for (int j = t; j < len; j += nt) f1(j);
-		return;
-	}
-	const int mis = (int)(((uintptr_t)row >> 2) & 3);
-	int head = mis ? 4 - mis : 0;
-	head = head < len ? head : len;
-	if (t < head) f1(t);
-
-	const int n4 = (len - head) >> 2;
-	const float4 *r4 = reinterpret_cast<const float4 *>(row + head);
-	for (int i = t; i < n4; i += nt) f4(head + 4 * i, r4[i]);
-
-	const int tail0 = head + 4 * n4;
-	if (t < len - tail0) f1(tail0 + t);
-}
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte access, 4-byte alignment
 
 struct BnGeom {
-	int n, c, hw, splits, nt;      // nt: threads cooperating on one slab (64 or 256)
-	bool vec;                      // all tensors of the call share the same address modulo 16 B
+	int n, c, hw, splits, nt;      // nt: threads cooperating on one slab (16..256)
 };
 
-__host__ __device__ inline int bn_rows_per_pass(int nt) { return 256 / nt; }
-
-inline bool congruent16(const void *a, const void *b = nullptr, const void *c = nullptr) {
-	const uintptr_t m = (uintptr_t)a & 15;
-	return (!b || ((uintptr_t)b & 15) == m) && (!c || ((uintptr_t)c & 15) == m);
-}
-
-inline BnGeom bn_geom(int n, int c, int hw, bool vec = true) {
+inline BnGeom bn_geom(int n, int c, int hw) {
 	BnGeom g;
-	g.n = n, g.c = c, g.hw = hw, g.vec = vec;
-	g.nt = hw >= 2048 ? 256 : 64;
-	const int rpp = bn_rows_per_pass(g.nt);
+	g.n = n, g.c = c, g.hw = hw;
+	const int n4 = hw >> 2;
+	g.nt = 16;
+	while (g.nt < 256 && g.nt < n4) g.nt <<= 1;
+	const int rpp = 256 / g.nt;
 	const int row_groups = (n + rpp - 1) / rpp;
 	int s = (8 * pz::kNumCU + c - 1) / c;          // aim at >= 8 workgroups per CU across the whole launch
 	if (s > row_groups) s = row_groups;
@@ -56,32 +35,59 @@ inline BnGeom bn_geom(int n, int c, int hw, bool vec = true) {
 	return g;
 }
 
+// Visits this workgroup's share of channel `ch`: vec(u, off) is called for U independent 4-float groups at element
+// offsets `off` (loads only), then use(u, off) for the same groups (arithmetic / stores), then one(off) for the
+// trailing scalars.
+template <int U, typename Vec, typename Use, typename One>
+__device__ __forceinline__ void channel_foreach(const BnGeom &g, int ch, int split, Vec vec, Use use, One one) {
+	const int t = threadIdx.x & (g.nt - 1), ty = threadIdx.x / g.nt, rpp = 256 / g.nt;
+	const int n4 = g.hw >> 2, rem = g.hw & 3;
+	const int first = split * rpp + ty, stride = g.splits * rpp;
+	const size_t slab = (size_t)g.c * g.hw, chan = (size_t)ch * g.hw;
+
+	if (t < n4) {
+		int n = first, v = t;
+		while (n < g.n) {
+			size_t off[U];
+			bool ok[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				ok[u] = n < g.n;
+				off[u] = (size_t)n * slab + chan + 4 * v;
+				if (ok[u]) vec(u, off[u]);
+				v += g.nt;
+				if (v >= n4) v = t, n += stride;
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				if (ok[u]) use(u, off[u]);
+		}
+	}
+	if (t < rem)
+		for (int n = first; n < g.n; n += stride) one((size_t)n * slab + chan + 4 * n4 + t);
+}
+
 // ---- forward statistics: ws[(ch*S + s)*2 + {0,1}] = {sum(x-K), sum((x-K)^2)}, wsK[ch] = K
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float *__restrict__ x, BnGeom g, float *__restrict__ part,
                                                         float *__restrict__ shift) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
-	const int rpp = bn_rows_per_pass(g.nt);
-	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
-
 	const float K = x[(size_t)ch * g.hw];
 	float s1 = 0.f, s2 = 0.f;
+	f4u xv[4];
 
-	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
-		const float *row = x + ((size_t)n * g.c + ch) * g.hw;
-		slab_foreach(
-		    row, g.hw, t, g.nt, g.vec,
-		    [&](int, float4 v) {
-			    const float a = v.x - K, b = v.y - K, c = v.z - K, d = v.w - K;
-			    s1 += (a + b) + (c + d);
-			    s2 += (a * a + b * b) + (c * c + d * d);
-		    },
-		    [&](int j) {
-			    const float a = row[j] - K;
-			    s1 += a;
-			    s2 += a * a;
-		    });
-	}
+	channel_foreach<4>(
+	    g, ch, s, [&](int u, size_t off) { xv[u] = *reinterpret_cast<const f4u *>(x + off); },
+	    [&](int u, size_t) {
+		    const float a = xv[u][0] - K, b = xv[u][1] - K, c = xv[u][2] - K, d = xv[u][3] - K;
+		    s1 += (a + b) + (c + d);
+		    s2 += (a * a + b * b) + (c * c + d * d);
+	    },
+	    [&](size_t off) {
+		    const float a = x[off] - K;
+		    s1 += a;
+		    s2 += a * a;
+	    });
 
 	s1 = block_sum(s1, red);
 	s2 = block_sum(s2, red);
@@ -122,8 +128,6 @@ __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, flo
                                                               float *__restrict__ save_mean, float *__restrict__ save_invvar,
                                                               float eps, float factor) {
 	const int ch = blockIdx.x, s = blockIdx.y;
-	const int rpp = bn_rows_per_pass(g.nt);
-	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
 
 	double S1, S2;
 	bn_merge(part, g.splits, ch, S1, S2);
@@ -144,43 +148,33 @@ __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, flo
 
 	float a, b;
 	bn_affine(rstd, mean, scale[ch], bias[ch], a, b);
+	f4u xv[4];
 
-	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
-		const size_t off = ((size_t)n * g.c + ch) * g.hw;
-		const float *row = x + off;
-		float *out = y + off;
-		slab_foreach(
-		    row, g.hw, t, g.nt, g.vec,
-		    [&](int j, float4 v) {
-			    *reinterpret_cast<float4 *>(out + j) = make_float4(bn_act<RELU>(v.x, a, b), bn_act<RELU>(v.y, a, b),
-			                                                       bn_act<RELU>(v.z, a, b), bn_act<RELU>(v.w, a, b));
-		    },
-		    [&](int j) { out[j] = bn_act<RELU>(row[j], a, b); });
-	}
+	channel_foreach<4>(
+	    g, ch, s, [&](int u, size_t off) { xv[u] = *reinterpret_cast<const f4u *>(x + off); },
+	    [&](int u, size_t off) {
+		    *reinterpret_cast<f4u *>(y + off) = f4u{bn_act<RELU>(xv[u][0], a, b), bn_act<RELU>(xv[u][1], a, b),
+		                                            bn_act<RELU>(xv[u][2], a, b), bn_act<RELU>(xv[u][3], a, b)};
+	    },
+	    [&](size_t off) { y[off] = bn_act<RELU>(x[off], a, b); });
 }
 
 __global__ void __launch_bounds__(256) bn_infer_kernel(const float *x, float *y, BnGeom g,
                                                         const float *__restrict__ scale, const float *__restrict__ bias,
                                                         const float *__restrict__ mean, const float *__restrict__ var, float eps) {
 	const int ch = blockIdx.x, s = blockIdx.y;
-	const int rpp = bn_rows_per_pass(g.nt);
-	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
 
 	// NumpyDnn.batchNorm2d: scale / sqrt(var + eps) * (x - mean) + bias
 	const float a = scale[ch] / sqrtf(var[ch] + eps), mu = mean[ch], b = bias[ch];
+	f4u xv[4];
 
-	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
-		const size_t off = ((size_t)n * g.c + ch) * g.hw;
-		const float *row = x + off;
-		float *out = y + off;
-		slab_foreach(
-		    row, g.hw, t, g.nt, g.vec,
-		    [&](int j, float4 v) {
-			    *reinterpret_cast<float4 *>(out + j) =
-			        make_float4(a * (v.x - mu) + b, a * (v.y - mu) + b, a * (v.z - mu) + b, a * (v.w - mu) + b);
-		    },
-		    [&](int j) { out[j] = a * (row[j] - mu) + b; });
-	}
+	channel_foreach<4>(
+	    g, ch, s, [&](int u, size_t off) { xv[u] = *reinterpret_cast<const f4u *>(x + off); },
+	    [&](int u, size_t off) {
+		    *reinterpret_cast<f4u *>(y + off) =
+		        f4u{a * (xv[u][0] - mu) + b, a * (xv[u][1] - mu) + b, a * (xv[u][2] - mu) + b, a * (xv[u][3] - mu) + b};
+	    },
+	    [&](size_t off) { y[off] = a * (x[off] - mu) + b; });
 }
 
 // ---- backward: partials {sum dy, sum dy*(x-mean)} then dx. RELU: the layer's output went through a fused ReLU, so dy
@@ -197,32 +191,32 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restri
                                                             const float *__restrict__ bias, float *__restrict__ part) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
-	const int rpp = bn_rows_per_pass(g.nt);
-	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
 
 	const float mu = save_mean[ch];
 	float a = 0.f, b = 0.f;
 	if (RELU) bn_affine(save_invvar[ch], mu, scale[ch], bias[ch], a, b);
 	float s1 = 0.f, s2 = 0.f;
+	f4u xv[4], gv[4];
 
-	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
-		const size_t off = ((size_t)n * g.c + ch) * g.hw;
-		const float *row = x + off, *grow = dy + off;
-		slab_foreach(
-		    row, g.hw, t, g.nt, g.vec,
-		    [&](int j, float4 v) {
-			    float4 gv = *reinterpret_cast<const float4 *>(grow + j);
-			    gv.x = bn_gate<RELU>(gv.x, v.x, a, b), gv.y = bn_gate<RELU>(gv.y, v.y, a, b);
-			    gv.z = bn_gate<RELU>(gv.z, v.z, a, b), gv.w = bn_gate<RELU>(gv.w, v.w, a, b);
-			    s1 += (gv.x + gv.y) + (gv.z + gv.w);
-			    s2 += (gv.x * (v.x - mu) + gv.y * (v.y - mu)) + (gv.z * (v.z - mu) + gv.w * (v.w - mu));
-		    },
-		    [&](int j) {
-			    const float gj = bn_gate<RELU>(grow[j], row[j], a, b);
-			    s1 += gj;
-			    s2 += gj * (row[j] - mu);
-		    });
-	}
+	channel_foreach<4>(
+	    g, ch, s,
+	    [&](int u, size_t off) {
+		    xv[u] = *reinterpret_cast<const f4u *>(x + off);
+		    gv[u] = *reinterpret_cast<const f4u *>(dy + off);
+	    },
+	    [&](int u, size_t) {
+		    const f4u v = xv[u];
+		    f4u q = gv[u];
+#pragma unroll
+		    for (int e = 0; e < 4; ++e) q[e] = bn_gate<RELU>(q[e], v[e], a, b);
+		    s1 += (q[0] + q[1]) + (q[2] + q[3]);
+		    s2 += (q[0] * (v[0] - mu) + q[1] * (v[1] - mu)) + (q[2] * (v[2] - mu) + q[3] * (v[3] - mu));
+	    },
+	    [&](size_t off) {
+		    const float gj = bn_gate<RELU>(dy[off], x[off], a, b);
+		    s1 += gj;
+		    s2 += gj * (x[off] - mu);
+	    });
 
 	s1 = block_sum(s1, red);
 	s2 = block_sum(s2, red);
@@ -240,8 +234,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
                                                             const float *__restrict__ save_invvar, float *__restrict__ dscale,
                                                             float *__restrict__ dbias) {
 	const int ch = blockIdx.x, s = blockIdx.y;
-	const int rpp = bn_rows_per_pass(g.nt);
-	const int t = threadIdx.x % g.nt, ty = threadIdx.x / g.nt;
 
 	double S1, S2;
 	bn_merge(part, g.splits, ch, S1, S2);
@@ -258,23 +250,22 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 	const float k0 = sc * rstd, k1 = db * inv_m, k2 = ds * inv_m * rstd;
 	float a = 0.f, b = 0.f;
 	if (RELU) bn_affine(rstd, mu, sc, bias[ch], a, b);
+	f4u xv[4], gv[4];
 
-	for (int n = s * rpp + ty; n < g.n; n += g.splits * rpp) {
-		const size_t off = ((size_t)n * g.c + ch) * g.hw;
-		const float *row = x + off, *grow = dy + off;
-		float *out = dx + off;
-		slab_foreach(
-		    row, g.hw, t, g.nt, g.vec,
-		    [&](int j, float4 v) {
-			    float4 gv = *reinterpret_cast<const float4 *>(grow + j);
-			    gv.x = bn_gate<RELU>(gv.x, v.x, a, b), gv.y = bn_gate<RELU>(gv.y, v.y, a, b);
-			    gv.z = bn_gate<RELU>(gv.z, v.z, a, b), gv.w = bn_gate<RELU>(gv.w, v.w, a, b);
-			    *reinterpret_cast<float4 *>(out + j) =
-			        make_float4(k0 * (gv.x - k1 - (v.x - mu) * k2), k0 * (gv.y - k1 - (v.y - mu) * k2),
-			                    k0 * (gv.z - k1 - (v.z - mu) * k2), k0 * (gv.w - k1 - (v.w - mu) * k2));
-		    },
-		    [&](int j) { out[j] = k0 * (bn_gate<RELU>(grow[j], row[j], a, b) - k1 - (row[j] - mu) * k2); });
-	}
+	channel_foreach<4>(
+	    g, ch, s,
+	    [&](int u, size_t off) {
+		    xv[u] = *reinterpret_cast<const f4u *>(x + off);
+		    gv[u] = *reinterpret_cast<const f4u *>(dy + off);
+	    },
+	    [&](int u, size_t off) {
+		    const f4u v = xv[u];
+		    f4u q = gv[u];
+#pragma unroll
+		    for (int e = 0; e < 4; ++e) q[e] = k0 * (bn_gate<RELU>(q[e], v[e], a, b) - k1 - (v[e] - mu) * k2);
+		    *reinterpret_cast<f4u *>(dx + off) = q;
+	    },
+	    [&](size_t off) { dx[off] = k0 * (bn_gate<RELU>(dy[off], x[off], a, b) - k1 - (x[off] - mu) * k2); });
 }
 
 inline size_t bn_ws_bytes(const BnGeom &g) { return ((size_t)g.c * g.splits * 2 + g.c) * sizeof(float); }
@@ -301,7 +292,7 @@ int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const fl
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && y && scale && bias && run_mean && run_var && save_mean && save_invvar, "pz_bn_fwd_train: null tensor");
 	PZ_REQUIRE(act == PZ_BN_ACT_NONE || act == PZ_BN_ACT_RELU, "pz_bn_fwd_train: unknown fused activation %d", act);
-	const BnGeom g = bn_geom(n, c, hw, congruent16(x, y));
+	const BnGeom g = bn_geom(n, c, hw);
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train: workspace too small");
 
 	float *part = (float *)workspace, *shift = part + (size_t)c * g.splits * 2;
@@ -331,7 +322,7 @@ int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float 
                     const float *var, float epsilon, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && y && scale && bias && mean && var, "pz_bn_fwd_infer: null tensor");
-	const BnGeom g = bn_geom(n, c, hw, congruent16(x, y));
+	const BnGeom g = bn_geom(n, c, hw);
 	bn_infer_kernel<<<dim3(c, g.splits), 256, 0, pz::as_stream(stream)>>>(x, y, g, scale, bias, mean, var, epsilon);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
@@ -343,7 +334,7 @@ int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int 
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias, "pz_bn_bwd: null tensor");
 	PZ_REQUIRE(act == PZ_BN_ACT_NONE || (act == PZ_BN_ACT_RELU && bias), "pz_bn_bwd: fused activation %d needs the bias", act);
-	const BnGeom g = bn_geom(n, c, hw, congruent16(x, dy, dx));
+	const BnGeom g = bn_geom(n, c, hw);
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_bwd: workspace too small");
 
 	float *part = (float *)workspace;
