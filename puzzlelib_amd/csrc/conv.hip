@@ -851,7 +851,8 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
-	igemm_conv_kernel<BM, BN, WM, WN><<<dim3(p.blocks, 1, groups), 256, 0, st>>>(a);
+	static const int lds_pad = getenv("PZ_IGEMM_LDS_PAD") ? atoi(getenv("PZ_IGEMM_LDS_PAD")) : 0;     // experiment: cap co-residency
+	igemm_conv_kernel<BM, BN, WM, WN><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
 	if (p.tail_splits > 1)
 		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 256, 0, st>>>(a);
 }

@@ -8,46 +8,62 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) pool_fwd_kernel(pz_pool_desc d, int P, int Q, const float *__restrict__ x,
-                                                        float *__restrict__ y, uint8_t *__restrict__ idx) {
-	const size_t total = (size_t)d.n * d.c * P * Q;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-		const int q = (int)(i % Q), p = (int)((i / Q) % P);
-		const size_t nc = i / ((size_t)Q * P);
-		const float *img = x + nc * d.h * d.w;
-		const int h0 = p * d.stride_h - d.pad_h, w0 = q * d.stride_w - d.pad_w;
+// One workgroup owns `group` consecutive (image, channel) planes (several when a plane has fewer outputs than threads),
+// so all index arithmetic is 32-bit and a wave's accesses stay inside neighbouring rows of one plane.
+struct PoolGeom {
+	int P, Q, group;
+	unsigned planes;
+};
 
-		if (d.mode == 0) {
-			float best = -FLT_MAX;
+// SZ / ST: square window size / stride known at compile time (0 = read from the descriptor): the common 2x2/2, 3x3/2
+// and 3x3/1 windows get unrolled taps and shift/multiply index arithmetic — the generic loops are ALU-bound
+template <int MODE, int SZ, int ST>
+__global__ void __launch_bounds__(256) pool_fwd_kernel(pz_pool_desc d, PoolGeom g, const float *__restrict__ x,
+                                                        float *__restrict__ y, uint8_t *__restrict__ idx) {
+	if (SZ) d.size_h = d.size_w = SZ;
+	if (ST) d.stride_h = d.stride_w = ST;
+	const unsigned PQ = (unsigned)(g.P * g.Q), HW = (unsigned)(d.h * d.w);
+	const unsigned plane0 = blockIdx.x * (unsigned)g.group;
+	const unsigned nplanes = min((unsigned)g.group, g.planes - plane0);
+
+	for (unsigned j = threadIdx.x; j < nplanes * PQ; j += 256) {
+		const unsigned pl = j / PQ, i = j - pl * PQ;
+		const int p = (int)(i / (unsigned)g.Q), q = (int)(i - (unsigned)p * g.Q);
+		const float *img = x + (size_t)(plane0 + pl) * HW;
+		const size_t o = (size_t)(plane0 + pl) * PQ + i;
+		const int h0 = p * d.stride_h - d.pad_h, w0 = q * d.stride_w - d.pad_w;
+		const int r_lo = h0 < 0 ? -h0 : 0, r_hi = min(d.size_h, d.h - h0);
+		const int s_lo = w0 < 0 ? -w0 : 0, s_hi = min(d.size_w, d.w - w0);
+
+		if (MODE == 0) {
+			float best = -INFINITY;                    // NumpyDnn.pool2d pads with -inf
 			int bi = 0;
 			bool found = false;
-			for (int r = 0; r < d.size_h; ++r) {
-				const int hh = h0 + r;
-				if ((unsigned)hh >= (unsigned)d.h) continue;
-				for (int s = 0; s < d.size_w; ++s) {
-					const int ww = w0 + s;
-					if ((unsigned)ww >= (unsigned)d.w) continue;
-					const float v = img[hh * d.w + ww];
-					if (!found || v > best) { best = v; bi = r * d.size_w + s; found = true; }
-				}
+			if constexpr (SZ != 0) {
+#pragma unroll
+				for (int r = 0; r < SZ; ++r)
+#pragma unroll
+					for (int t = 0; t < SZ; ++t) {
+						if (r < r_lo || r >= r_hi || t < s_lo || t >= s_hi) continue;
+						const float v = img[(h0 + r) * d.w + w0 + t];
+						if (!found || v > best) best = v, bi = r * SZ + t, found = true;       // first maximum in window order
+					}
+			} else {
+				for (int r = r_lo; r < r_hi; ++r)
+					for (int t = s_lo; t < s_hi; ++t) {
+						const float v = img[(h0 + r) * d.w + w0 + t];
+						if (!found || v > best) best = v, bi = r * d.size_w + t, found = true;
+					}
 			}
-			y[i] = found ? best : -INFINITY;          // NumpyDnn.pool2d pads with -inf
-			if (idx) idx[i] = (uint8_t)bi;
+			y[o] = best;
+			if (idx) idx[o] = (uint8_t)bi;
 		} else {
-			float s = 0.f;
-			int cnt = 0;
-			for (int r = 0; r < d.size_h; ++r) {
-				const int hh = h0 + r;
-				if ((unsigned)hh >= (unsigned)d.h) continue;
-				for (int t = 0; t < d.size_w; ++t) {
-					const int ww = w0 + t;
-					if ((unsigned)ww >= (unsigned)d.w) continue;
-					s += img[hh * d.w + ww];
-					++cnt;
-				}
-			}
-			const float div = d.mode == 1 ? (float)(d.size_h * d.size_w) : (float)(cnt > 0 ? cnt : 1);
-			y[i] = s / div;
+			float sum = 0.f;
+			for (int r = r_lo; r < r_hi; ++r)
+				for (int t = s_lo; t < s_hi; ++t) sum += img[(h0 + r) * d.w + w0 + t];
+			const int cnt = max(r_hi - r_lo, 0) * max(s_hi - s_lo, 0);
+			const float div = MODE == 1 ? (float)(d.size_h * d.size_w) : (float)(cnt > 0 ? cnt : 1);
+			y[o] = sum / div;
 		}
 	}
 }
@@ -61,40 +77,46 @@ __device__ __forceinline__ int valid_taps(const pz_pool_desc &d, int p, int q) {
 	return a > 0 && b > 0 ? a * b : 1;
 }
 
-__global__ void __launch_bounds__(256) pool_bwd_kernel(pz_pool_desc d, int P, int Q, const float *__restrict__ dy,
+// backward: a gather over the (few) windows covering each input pixel
+template <int MODE, bool HAS_IDX, int SZ, int ST>
+__global__ void __launch_bounds__(256) pool_bwd_kernel(pz_pool_desc d, PoolGeom g, const float *__restrict__ dy,
                                                         const float *__restrict__ x, const uint8_t *__restrict__ idx,
                                                         float *__restrict__ dx) {
-	const size_t total = (size_t)d.n * d.c * d.h * d.w;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-		const int ww = (int)(i % d.w), hh = (int)((i / d.w) % d.h);
-		const size_t nc = i / ((size_t)d.w * d.h);
-		const float *gimg = dy + nc * P * Q;
+	if (SZ) d.size_h = d.size_w = SZ;
+	if (ST) d.stride_h = d.stride_w = ST;
+	const unsigned PQ = (unsigned)(g.P * g.Q), HW = (unsigned)(d.h * d.w);
+	const unsigned plane0 = blockIdx.x * (unsigned)g.group;
+	const unsigned nplanes = min((unsigned)g.group, g.planes - plane0);
+
+	for (unsigned j = threadIdx.x; j < nplanes * HW; j += 256) {
+		const unsigned pl = j / HW, i = j - pl * HW;
+		const int hh = (int)(i / (unsigned)d.w), ww = (int)(i - (unsigned)hh * d.w);
+		const size_t plane = plane0 + pl;
+		const float *gimg = dy + plane * PQ;
 
 		// windows p with p*stride - pad <= hh < p*stride - pad + size
 		const int hp = hh + d.pad_h, wp = ww + d.pad_w;
 		int p_lo = hp - d.size_h + 1;
 		p_lo = p_lo <= 0 ? 0 : (p_lo + d.stride_h - 1) / d.stride_h;
-		int p_hi = hp / d.stride_h;
-		p_hi = p_hi >= P ? P - 1 : p_hi;
+		const int p_hi = min(hp / d.stride_h, g.P - 1);
 		int q_lo = wp - d.size_w + 1;
 		q_lo = q_lo <= 0 ? 0 : (q_lo + d.stride_w - 1) / d.stride_w;
-		int q_hi = wp / d.stride_w;
-		q_hi = q_hi >= Q ? Q - 1 : q_hi;
+		const int q_hi = min(wp / d.stride_w, g.Q - 1);
 
-		float s = 0.f;
+		float sum = 0.f;
 		for (int p = p_lo; p <= p_hi; ++p)
 			for (int q = q_lo; q <= q_hi; ++q) {
-				const float g = gimg[p * Q + q];
-				if (d.mode == 0) {
+				const float gv = gimg[p * g.Q + q];
+				if (MODE == 0) {
 					const int r = hp - p * d.stride_h, t = wp - q * d.stride_w;
 					int win;
-					if (idx) {
-						win = idx[nc * P * Q + p * Q + q];
+					if (HAS_IDX) {
+						win = idx[plane * PQ + p * g.Q + q];
 					} else {
 						// recompute the first maximum of the window
-						const float *img = x + nc * d.h * d.w;
+						const float *img = x + plane * HW;
 						const int h0 = p * d.stride_h - d.pad_h, w0 = q * d.stride_w - d.pad_w;
-						float best = -FLT_MAX;
+						float best = -INFINITY;
 						bool found = false;
 						win = 0;
 						for (int rr = 0; rr < d.size_h; ++rr)
@@ -102,18 +124,59 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(pz_pool_desc d, int P, in
 								const int a = h0 + rr, b = w0 + tt;
 								if ((unsigned)a >= (unsigned)d.h || (unsigned)b >= (unsigned)d.w) continue;
 								const float v = img[a * d.w + b];
-								if (!found || v > best) { best = v; win = rr * d.size_w + tt; found = true; }
+								if (!found || v > best) best = v, win = rr * d.size_w + tt, found = true;
 							}
 					}
-					if (win == r * d.size_w + t) s += g;
-				} else if (d.mode == 1) {
-					s += g / (float)(d.size_h * d.size_w);
+					if (win == r * d.size_w + t) sum += gv;
+				} else if (MODE == 1) {
+					sum += gv / (float)(d.size_h * d.size_w);
 				} else {
-					s += g / (float)valid_taps(d, p, q);
+					sum += gv / (float)valid_taps(d, p, q);
 				}
 			}
-		dx[i] = s;
+		dx[plane * HW + i] = sum;
 	}
+}
+
+// average over the whole plane (window = plane, no padding, one output): one wave per plane, coalesced, shuffle-reduced
+__global__ void __launch_bounds__(256) pool_global_avg_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                   unsigned planes, int hw) {
+	const unsigned plane = blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (plane >= planes) return;
+	const float *img = x + (size_t)plane * hw;
+	float s = 0.f;
+	for (int i = threadIdx.x & 63; i < hw; i += 64) s += img[i];
+	s = wave_sum(s);
+	if ((threadIdx.x & 63) == 0) y[plane] = s / (float)hw;
+}
+
+__global__ void __launch_bounds__(256) pool_global_avg_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
+                                                                   size_t total, int hw) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+		dx[i] = dy[(unsigned)(i / (unsigned)hw)] / (float)hw;
+}
+
+inline bool pool_is_global_avg(const pz_pool_desc *d, int P, int Q) {
+	return d->mode != 0 && P == 1 && Q == 1 && d->pad_h == 0 && d->pad_w == 0 && d->size_h == d->h && d->size_w == d->w &&
+	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32);
+}
+
+// compile-time window variants
+#define PZ_POOL_SPECIALISE(LAUNCH)                                                             \
+	do {                                                                                       \
+		const bool sq = d->size_h == d->size_w && d->stride_h == d->stride_w;                  \
+		if (sq && d->size_h == 3 && d->stride_h == 2) { LAUNCH(3, 2); }                        \
+		else if (sq && d->size_h == 2 && d->stride_h == 2) { LAUNCH(2, 2); }                   \
+		else if (sq && d->size_h == 3 && d->stride_h == 1) { LAUNCH(3, 1); }                   \
+		else { LAUNCH(0, 0); }                                                                 \
+	} while (0)
+
+PoolGeom pool_geom(const pz_pool_desc *d, int P, int Q, size_t per_plane) {
+	PoolGeom g;
+	g.P = P, g.Q = Q;
+	g.planes = (unsigned)((size_t)d->n * d->c);
+	g.group = per_plane >= 256 ? 1 : (int)(256 / per_plane);
+	return g;
 }
 
 int pool_check(const pz_pool_desc *d, int *P, int *Q) {
@@ -123,6 +186,7 @@ int pool_check(const pz_pool_desc *d, int *P, int *Q) {
 	           "pool: invalid window/stride/pad");
 	PZ_REQUIRE(d->size_h * d->size_w <= 256, "pool: window larger than 256 taps");
 	PZ_REQUIRE(d->mode >= 0 && d->mode <= 2, "pool: unknown mode %d", d->mode);
+	PZ_REQUIRE((size_t)d->h * d->w < (1u << 30) && (size_t)d->n * d->c < (1u << 31), "pool: plane or plane count beyond 32-bit indexing");
 	PZ_REQUIRE(d->h + 2 * d->pad_h >= d->size_h && d->w + 2 * d->pad_w >= d->size_w, "pool: window larger than padded input");
 	*P = (d->h + 2 * d->pad_h - d->size_h) / d->stride_h + 1;
 	*Q = (d->w + 2 * d->pad_w - d->size_w) / d->stride_w + 1;
@@ -139,8 +203,20 @@ int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *inde
 	int P, Q;
 	if (int rc = pool_check(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && y, "pz_pool2d_fwd: null tensor");
-	const size_t total = (size_t)d->n * d->c * P * Q;
-	pool_fwd_kernel<<<pz::stream_grid(total, 256), 256, 0, pz::as_stream(stream)>>>(*d, P, Q, x, y, index_ws);
+	const PoolGeom g = pool_geom(d, P, Q, (size_t)P * Q);
+	const unsigned blocks = (g.planes + g.group - 1) / g.group;
+	hipStream_t st = pz::as_stream(stream);
+	if (pool_is_global_avg(d, P, Q)) {
+		pool_global_avg_fwd_kernel<<<(g.planes + 3) / 4, 256, 0, st>>>(x, y, g.planes, d->h * d->w);
+	} else if (d->mode == 0) {
+#define PZ_L(SZ, ST) pool_fwd_kernel<0, SZ, ST><<<blocks, 256, 0, st>>>(*d, g, x, y, index_ws)
+		PZ_POOL_SPECIALISE(PZ_L);
+#undef PZ_L
+	} else if (d->mode == 1) {
+		pool_fwd_kernel<1, 0, 0><<<blocks, 256, 0, st>>>(*d, g, x, y, index_ws);
+	} else {
+		pool_fwd_kernel<2, 0, 0><<<blocks, 256, 0, st>>>(*d, g, x, y, index_ws);
+	}
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
@@ -152,8 +228,23 @@ int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const 
 	(void)y;
 	PZ_REQUIRE(dy && dx, "pz_pool2d_bwd: null tensor");
 	PZ_REQUIRE(d->mode != 0 || index_ws || x, "pz_pool2d_bwd: max pooling needs the index workspace or the input tensor");
-	const size_t total = (size_t)d->n * d->c * d->h * d->w;
-	pool_bwd_kernel<<<pz::stream_grid(total, 256), 256, 0, pz::as_stream(stream)>>>(*d, P, Q, dy, x, index_ws, dx);
+	const PoolGeom g = pool_geom(d, P, Q, (size_t)d->h * d->w);
+	const unsigned blocks = (g.planes + g.group - 1) / g.group;
+	hipStream_t st = pz::as_stream(stream);
+	if (pool_is_global_avg(d, P, Q)) {
+		const size_t total = (size_t)g.planes * d->h * d->w;
+		pool_global_avg_bwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(dy, dx, total, d->h * d->w);
+	} else if (d->mode == 0 && index_ws) {
+#define PZ_L(SZ, ST) pool_bwd_kernel<0, true, SZ, ST><<<blocks, 256, 0, st>>>(*d, g, dy, x, index_ws, dx)
+		PZ_POOL_SPECIALISE(PZ_L);
+#undef PZ_L
+	} else if (d->mode == 0) {
+		pool_bwd_kernel<0, false, 0, 0><<<blocks, 256, 0, st>>>(*d, g, dy, x, index_ws, dx);
+	} else if (d->mode == 1) {
+		pool_bwd_kernel<1, false, 0, 0><<<blocks, 256, 0, st>>>(*d, g, dy, x, index_ws, dx);
+	} else {
+		pool_bwd_kernel<2, false, 0, 0><<<blocks, 256, 0, st>>>(*d, g, dy, x, index_ws, dx);
+	}
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

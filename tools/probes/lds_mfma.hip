@@ -12,9 +12,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // LDS tile of a 32-deep k-step: [group][half][row][PER] floats; lane (row, h) reads the PER floats at [g][h][row] with one
 // ds_read_b32 / b64 / b128 and uses them for PER consecutive k2-steps (PER = 1 is the [k][row] layout of the igemm kernel,
 // PER = 2 the half-cell layout of the backward-filter kernel)
-template <int TM, int TN, int PER, bool BAR, int SB, int MEM = 0>
+template <int TM, int TN, int PER, bool BAR, int SB, int MEM = 0, int BK = 32, int VALU = 0>
 __global__ void __launch_bounds__(256) loop(float *out, int steps, const float *src = nullptr, unsigned plane = 0) {
-	constexpr int BK = 32, ROWS_A = 2 * 32 * TM, ROWS_B = 2 * 32 * TN, G = BK / (2 * PER);
+	constexpr int ROWS_A = 2 * 32 * TM, ROWS_B = 2 * 32 * TN, G = BK / (2 * PER);
 	constexpr int PAD = PER == 1 ? 0 : PER == 2 ? 2 : 1;
 	typedef float vec __attribute__((ext_vector_type(PER)));
 	__shared__ __attribute__((aligned(16))) float As[2][G][2][ROWS_A + PAD][PER];
@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) loop(float *out, int steps, const float *
 	unsigned col = (blockIdx.x / 4) * 8192u + run * 16u;
 	unsigned base = rowbase + col;
 
+	int junk[4] = {lane, lane + 1, lane + 2, lane + 3};
 	for (int s = 0; s < steps; ++s) {
 		const int buf = s & 1;
 		float av[2][TM][PER], bv[2][TN][PER];
@@ -68,6 +69,8 @@ __global__ void __launch_bounds__(256) loop(float *out, int steps, const float *
 				for (int q = g * NLD / G; q < (g + 1) * NLD / G; ++q)
 					ld[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, base, (unsigned)(32 * q) * plane, 0));
 			}
+#pragma unroll
+			for (int q = 0; q < VALU; ++q) asm volatile("v_add_u32 %0, %0, %1" : "+v"(junk[q & 3]) : "v"(lane));      // VALU per group
 			if (SB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int p = 0; p < PER; ++p)
@@ -93,6 +96,7 @@ __global__ void __launch_bounds__(256) loop(float *out, int steps, const float *
 		if (BAR) __syncthreads();
 	}
 	if (MEM & 2) for (int q = 0; q < NLD; ++q) acc[0][0][q % 16] += ld[q][0];
+	if (VALU) acc[0][0][0] += (float)(junk[0] + junk[1] + junk[2] + junk[3]);
 	float sum = 0.f;
 	for (int i = 0; i < TM; ++i)
 		for (int j = 0; j < TN; ++j)
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(256) loop(float *out, int steps, const float *
 	out[blockIdx.x * 256 + tid] = sum;
 }
 
-template <int TM, int TN, int W, bool BAR, int SB, int MEM = 0>
+template <int TM, int TN, int W, bool BAR, int SB, int MEM = 0, int BK = 32, int VALU = 0>
 void run(const char *name, int per_cu) {
 	const int blocks = 256 * per_cu, steps = 4000;
 	float *out, *src = nullptr;
@@ -112,14 +116,14 @@ void run(const char *name, int per_cu) {
 	float best = 1e9;
 	for (int rep = 0; rep < 3; ++rep) {
 		hipEventRecord(e0);
-		loop<TM, TN, W, BAR, SB, MEM><<<blocks, 256>>>(out, steps, src, plane);
+		loop<TM, TN, W, BAR, SB, MEM, BK, VALU><<<blocks, 256>>>(out, steps, src, plane);
 		hipEventRecord(e1);
 		hipEventSynchronize(e1);
 		float ms;
 		hipEventElapsedTime(&ms, e0, e1);
 		best = ms < best ? ms : best;
 	}
-	const double flop = (double)blocks * steps * 2.0 * (64 * TM) * (64 * TN) * 32;
+	const double flop = (double)blocks * steps * 2.0 * (64 * TM) * (64 * TN) * BK;
 	printf("%-44s %d blocks/CU: %7.2f ms  %6.1f TFLOP/s  (%s)\n", name, per_cu, best, flop / best / 1e9, hipGetErrorString(hipGetLastError()));
 	hipFree(out);
 	if (src) hipFree(src);
@@ -138,6 +142,18 @@ int main() {
 	run<2, 4, 2, false, 1>("64x128 wave tile, b64, no barrier", 1);
 	run<2, 4, 4, true, 1>("64x128 wave tile, b128", 1);
 	run<2, 4, 1, true, 1>("64x128 wave tile, b32", 1);
+	run<2, 2, 1, true, 1, 0, 16>("64x64 b32, BK=16 barrier/step", 2);
+	run<2, 2, 1, true, 1, 0, 16>("64x64 b32, BK=16 barrier/step", 4);
+	run<2, 2, 1, true, 1, 0, 32>("64x64 b32, BK=32 barrier/step", 4);
+	run<2, 2, 2, true, 1, 0, 16>("64x64 b64, BK=16 barrier/step", 4);
+	run<2, 2, 1, true, 1, 0, 24>("64x64 b32, BK=24 barrier/step", 3);
+	run<2, 2, 1, true, 1, 0, 16>("64x64 b32, BK=16 barrier/step", 3);
+	run<2, 2, 1, true, 1, 0, 24>("64x64 b32, BK=24 barrier/step", 4);
+	run<2, 2, 1, false, 1, 0, 16>("64x64 b32, BK=16 NO barrier", 4);
+	run<2, 2, 2, true, 1, 0, 32, 4>("64x64 b64 + 4 VALU per 8 MFMA", 2);
+	run<2, 2, 2, true, 1, 0, 32, 8>("64x64 b64 + 8 VALU per 8 MFMA", 2);
+	run<2, 2, 2, true, 1, 0, 32, 16>("64x64 b64 + 16 VALU per 8 MFMA", 2);
+	run<2, 2, 2, true, 1, 0, 32, 32>("64x64 b64 + 32 VALU per 8 MFMA", 2);
 	run<2, 2, 2, true, 1, 1>("64x64 b64 + 16 ds_write_b64 per step", 2);
 	run<2, 2, 2, true, 1, 2>("64x64 b64 + 8 global b128 loads per step", 2);
 	run<2, 2, 2, true, 1, 3>("64x64 b64 + loads + LDS stores", 2);
