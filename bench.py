@@ -156,6 +156,21 @@ def main():
 	dom = max(range(3), key=lambda i: ms[i])
 	achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
 
+	# HBM bytes per launch of the dominant kernel family: memory-side L2 counters of the same command, collected with
+	# rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md prescribes (tools/pmc_bench.sh ->
+	# profiles/r01_hbm_traffic.json). PMC collection cannot run inside the timed process, hence the committed summary.
+	traffic, traffic_note = None, None
+	try:
+		prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+		key = ["igemm_conv_kernel<128, 128", "igemm_conv_kernel<64, 256", "wgrad_conv_kernel<"][dom]
+		rows = [v for k, v in prof["kernels"].items() if key in k]
+		n = sum(v["dispatches"] for v in rows)
+		if n > 0 and args.batch == BATCH:
+			traffic = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in rows) / n
+			traffic_note = "bytes per launch, mean over %d profiled launches; %s" % (n, prof["calibration"]["note"])
+	except (OSError, KeyError, ValueError):
+		pass
+
 	result = {
 		"metric": "images/sec fwd+bwd+Adam ResNet-50 224x224 fp32 b256 per GPU", "value": images_per_sec,
 		"unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +187,7 @@ def main():
 		"final_loss": loss,
 		"roofline": {
 			"kernel": FAMILY[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-			"frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+			"frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
 			"avg_launch_ms": ms[dom] / max(launches[dom], 1), "launches_in_timed_region": int(launches[dom])
 		},
 		"conv_kernel_families": fams,

@@ -27,6 +27,9 @@
 #else
 #define PZ_ABL_NEAR(off) (off)
 #endif
+#ifndef PZ_IG_LOAD_STEPS
+#define PZ_IG_LOAD_STEPS 8        // k2-steps of a k-tile over which the next tile's global loads are spread
+#endif
 #ifndef PZ_WG_LOAD_RUNS
 #define PZ_WG_LOAD_RUNS 8
 #endif
@@ -96,6 +99,9 @@ struct PackArgs {
 	int a_h, a_w, st_h, st_w, Rc, Sc;      // backward-data residue class: taps r = a + st*(Rc-1-r'')
 	int dil_h, dil_w;
 	int in_h, in_w;                         // spatial dims of the tensor the GEMM gathers from
+	// tap-major reduction order (reduction channels % 16 == 0): kred = tap * chans + channel, so the 16 rows of a k-tile
+	// share one filter tap; `tab` then holds one int4 per k-tile {tap byte offset, tap index, first channel's byte offset}
+	int tapmajor, chans;
 };
 
 __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
@@ -111,7 +117,7 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
 
 		float v = 0.f;
 		if (m < a.M && kr < a.kred) {
-			const int ch = kr / RS, rs = kr - ch * RS;
+			const int ch = a.tapmajor ? kr % a.chans : kr / RS, rs = a.tapmajor ? kr / a.chans : kr - ch * RS;
 			const int rr = rs / Sx, ss = rs - rr * Sx;
 
 			if (a.mode == 0) {
@@ -123,7 +129,14 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
 		}
 		a.wp[i] = v;
 
-		if (g == 0 && m == 0) {
+		if (g == 0 && m == 0 && a.tapmajor) {
+			if (kr % 16 == 0) {
+				const int ch = kr % a.chans, rs = kr / a.chans;
+				const int rr = rs / Sx, ss = rs - rr * Sx;
+				reinterpret_cast<int4 *>(a.tab)[kr / 16] =
+				    make_int4((rr * a.dil_h * a.in_w + ss * a.dil_w) * 4, rs, ch * a.in_h * a.in_w * 4, 0);
+			}
+		} else if (g == 0 && m == 0) {
 			int2 e = make_int2(0, kPadTap);
 			if (kr < a.kred) {
 				const int ch = kr / RS, rs = kr - ch * RS;
@@ -170,6 +183,7 @@ struct IgemmArgs {
 	// `tail_splits` k-slices whose partial accumulators go to `slabs` and are summed by igemm_tail_reduce_kernel
 	int full_tiles, tail_splits;
 	float *slabs;
+	int tapmajor;                          // `tab` is the per-k-tile int4 table of the tap-major order
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -213,7 +227,7 @@ __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int
 	}
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TAPMAJOR>
 __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 	constexpr int BK = 16, NT = 256;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -291,11 +305,26 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 	const int l31 = lane & 31, lhi = lane >> 5;
 	int2 e[NB];
 
+	// tap-major order: the NB gathers of a k-tile share the tap (one mask test, one per-lane offset) and differ by a
+	// scalar channel offset, which travels in the buffer load's soffset — VALU instructions serialise with MFMAs
+	// (tools/probes/lds_mfma.hip), so the loop keeps them to a handful per k-tile
+	const unsigned mask_lo = (unsigned)tapmask, mask_hi = (unsigned)(tapmask >> 32);
+	const unsigned hw4 = (unsigned)(a.H * a.W) * 4u;
+	const unsigned row_off = (unsigned)(kb0 * NB) * hw4;      // this wave's first channel inside the k-tile
+	unsigned voff_tile = kOOB, soff_tile = 0;
+
 	// global -> register loads of k-tile `kt`, cut into BK/2 parts so that each part's address arithmetic and its
 	// load issue can sit in the shadow of one k2-step's MFMAs (the matrix pipe is busy 4 x 64 cycles per k2-step)
 	auto load_tab = [&](int kt) {
+		if constexpr (TAPMAJOR) {
+			const int4 t = reinterpret_cast<const int4 *>(a.tab)[kt];
+			const unsigned word = t.y < 32 ? mask_lo : mask_hi;
+			voff_tile = (word >> (t.y & 31)) & 1u ? base_bytes + (unsigned)t.x : kOOB;
+			soff_tile = (unsigned)t.z + row_off;
+		} else {
 #pragma unroll
-		for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];   // contiguous: one wide scalar load
+			for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];   // contiguous: one wide scalar load
+		}
 	};
 
 	auto load_part = [&](int kt, int j) {
@@ -305,8 +334,12 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
 		for (int t = 0; t < PER; ++t) {
 			const int i = j * PER + t;
-			const bool ok = (tapmask >> e[i].y) & 1ull;
-			rb[i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
+			if constexpr (TAPMAJOR) {
+				rb[i] = buf_load_f32(xr, voff_tile, soff_tile + (unsigned)i * hw4);
+			} else {
+				const bool ok = (tapmask >> e[i].y) & 1ull;
+				rb[i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
+			}
 		}
 	};
 
@@ -338,7 +371,10 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
 		for (int j = 0; j < BK / 2; ++j) {
 			if (j + 1 < BK / 2) read_frag(buf, 2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
-			if (has_next) load_part(kt_next, j);
+			if (has_next && j < PZ_IG_LOAD_STEPS) {
+#pragma unroll
+				for (int q = 0; q < (BK / 2) / PZ_IG_LOAD_STEPS; ++q) load_part(kt_next, j * ((BK / 2) / PZ_IG_LOAD_STEPS) + q);
+			}
 			__builtin_amdgcn_sched_barrier(0);        // keep this step's LDS reads / gather ahead of its MFMAs ...
 #if PZ_ABL & 4
 			__builtin_amdgcn_s_setprio(1);
@@ -852,7 +888,10 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
 	static const int lds_pad = getenv("PZ_IGEMM_LDS_PAD") ? atoi(getenv("PZ_IGEMM_LDS_PAD")) : 0;     // experiment: cap co-residency
-	igemm_conv_kernel<BM, BN, WM, WN><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+	if (a.tapmajor)
+		igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+	else
+		igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
 	if (p.tail_splits > 1)
 		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 256, 0, st>>>(a);
 }
@@ -1035,6 +1074,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	pa.Kg = Kg, pa.Cg = Cg, pa.R = d->r, pa.S = d->s, pa.groups = d->groups, pa.mode = 0;
 	pa.M = Kg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
 	pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = d->h, pa.in_w = d->w;
+	pa.tapmajor = Cg % 16 == 0, pa.chans = Cg;
 	const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
 	pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
 	PZ_LAUNCH_CHECK();
@@ -1050,6 +1090,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
 	a.y_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
+	a.tapmajor = pa.tapmajor;
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
@@ -1103,6 +1144,7 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		pa.M = Cg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
 		pa.a_h = c.a_h, pa.a_w = c.a_w, pa.st_h = d->stride_h, pa.st_w = d->stride_w, pa.Rc = c.Rc, pa.Sc = c.Sc;
 		pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = P, pa.in_w = Q;
+		pa.tapmajor = Kg % 16 == 0, pa.chans = Kg;
 		const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
 		pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
 		PZ_LAUNCH_CHECK();
@@ -1119,6 +1161,7 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.y_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
+		a.tapmajor = pa.tapmajor;
 		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
 	}
