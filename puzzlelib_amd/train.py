@@ -410,17 +410,42 @@ class Handler:
 		return post(data[idx * size:(idx + 1) * size])
 
 
+	asyncUpload = True       # stage macro-batches through pinned memory on a copy stream (pipeline.HostStager)
+
+
 	def handleFromHost(self, data, state=None, macroBatchSize=10000, onMacroBatchFinish=None, random=True):
-		"""One synchronous H2D upload per macro-batch, then on-device slicing per batch (Handlers/Handler.py:20-36)."""
-		to_gpu = S().gpuarray.to_gpu
+		"""Handlers/Handler.py:20-36 uploads each macro-batch synchronously before training on it. Same loop, same
+		order and callbacks; with `asyncUpload` the next macro-batch is staged in pinned memory and copied on a side
+		stream while the current one trains (Handler.asyncUpload = False gives the reference's literal behaviour)."""
 		self.totalMacroBatches = (self.dataSize(data) + macroBatchSize - 1) // macroBatchSize
 		order = np.random.permutation(self.totalMacroBatches) if random else np.arange(self.totalMacroBatches)
 
+		if not Handler.asyncUpload:
+			to_gpu = S().gpuarray.to_gpu
+			for i, n in enumerate(order):
+				macrobatch = self.sliceData(data, n, macroBatchSize, to_gpu)
+				self.currMacroBatch = i + 1
+
+				self.handle(macrobatch, state, random=random)
+				if onMacroBatchFinish:
+					onMacroBatchFinish(self)
+			return
+
+		from .pipeline import HostStager
+		S()                                      # the backend (device, pool) must be up before streams are made
+		stager = getattr(self, "stager", None)  # pinned memory is expensive to allocate: one stager per handler
+		if stager is None:
+			stager = self.stager = HostStager()
+		hostSlice = lambda idx: self.sliceData(data, idx, macroBatchSize, lambda dat: dat)
+
+		ticket = stager.submit(hostSlice(order[0])) if len(order) > 0 else None
 		for i, n in enumerate(order):
-			macrobatch = self.sliceData(data, n, macroBatchSize, to_gpu)
+			macrobatch = stager.acquire(ticket)
+			current, ticket = ticket, (stager.submit(hostSlice(order[i + 1])) if i + 1 < len(order) else None)
 			self.currMacroBatch = i + 1
 
 			self.handle(macrobatch, state, random=random)
+			stager.release(current)
 			if onMacroBatchFinish:
 				onMacroBatchFinish(self)
 

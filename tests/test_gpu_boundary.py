@@ -98,3 +98,60 @@ def test_rccl_single_rank_roundtrip(bnd):
 	node.broadcastBuffer("data", g.gpudata)
 	assert np.array_equal(g.get(), host)
 	node.close()
+
+
+def test_host_stager_uploads_match_and_overlap_safely(bnd):
+	"""pipeline.HostStager: more submits than slots, ragged last macro-batch, nested [data, labels] trees — every
+	upload must arrive intact although pinned and device halves of the slots are recycled."""
+	from puzzlelib_amd.pipeline import HostStager
+
+	rng = np.random.RandomState(3)
+	data = rng.randn(1000, 3, 8, 8).astype(np.float32)
+	labels = rng.randint(0, 10, size=(1000, )).astype(np.int32)
+
+	stager = HostStager()
+	tickets, seen = [], []
+	sizes = [(0, 300), (300, 600), (600, 900), (900, 1000), (0, 300)]
+
+	ticket = stager.submit([data[sizes[0][0]:sizes[0][1]], labels[sizes[0][0]:sizes[0][1]]])
+	for i, (lo, hi) in enumerate(sizes):
+		gd, gl = stager.acquire(ticket)
+		current = ticket
+		if i + 1 < len(sizes):
+			nlo, nhi = sizes[i + 1]
+			ticket = stager.submit([data[nlo:nhi], labels[nlo:nhi]])
+
+		# "train": device-side work reading the macro-batch after the next upload was already queued
+		doubled = gd + gd
+		assert np.array_equal(doubled.get(), data[lo:hi] * 2)
+		assert np.array_equal(gl.get(), labels[lo:hi])
+		stager.release(current)
+
+
+def test_train_from_host_async_upload_is_bit_identical(bnd):
+	"""Handlers/Handler.py:20-36 path: trainFromHost over 3 macro-batches with the staged asynchronous upload gives
+	exactly the parameters of the synchronous upload."""
+	from puzzlelib_amd import nets, train
+	from puzzlelib_amd.surface import bound
+
+	bound()
+	rng = np.random.RandomState(5)
+	data = rng.randn(96, 1, 28, 28).astype(np.float32)
+	labels = rng.randint(0, 10, size=(96, )).astype(np.int32)
+
+	results = []
+	for mode in (False, True):
+		train.Handler.asyncUpload = mode
+		try:
+			np.random.seed(11)
+			net = nets.loadLeNet(None, initscheme=None)
+			optimizer = train.MomentumSGD(learnRate=0.05, momRate=0.9)
+			optimizer.setupOn(net, useGlobalState=True)
+			trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=16)
+			trainer.trainFromHost(data, labels, macroBatchSize=40, random=False)
+			results.append({k: v.data.get() for k, v in nets.namedVariables(net).items()})
+		finally:
+			train.Handler.asyncUpload = True
+
+	for name in results[0]:
+		assert np.array_equal(results[0][name], results[1][name]), name
