@@ -729,7 +729,59 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(float *__restrict__ d
 	}
 }
 
-// db[k] = beta*db[k] + alpha * sum_{n,pq} dy[n,k,pq]   (one workgroup per channel)
+// db[k] = beta*db[k] + alpha * sum_{n,pq} dy[n,k,pq], two deterministic stages: workgroup (k, s) sums the images
+// n = s (mod S) of channel k with 16-byte (4-byte aligned) loads, four in flight; the finish kernel adds the S partials
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, float *__restrict__ part, int N, int K,
+                                                                 int PQ, int S) {
+	__shared__ float red[16];
+	const int k = blockIdx.x, s = blockIdx.y;
+	const int n4 = PQ >> 2, rem = PQ & 3;
+	float acc = 0.f;
+
+	// flat index over (image of this split, 4-float group)
+	const int nimg = (N - s + S - 1) / S;
+	const int items = nimg * n4;
+	for (int i0 = threadIdx.x; i0 < items; i0 += 4 * 256) {
+		f4u v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + u * 256;
+			v[u] = f4u{0.f, 0.f, 0.f, 0.f};
+			if (i < items) {
+				const int img = i / n4, g = i - img * n4;
+				v[u] = *reinterpret_cast<const f4u *>(dy + ((size_t)(s + img * S) * K + k) * PQ + 4 * g);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+	}
+	for (int i = threadIdx.x; i < nimg * rem; i += 256) {
+		const int img = i / rem, e = i - img * rem;
+		acc += dy[((size_t)(s + img * S) * K + k) * PQ + 4 * n4 + e];
+	}
+
+	acc = block_sum(acc, red);
+	if (threadIdx.x == 0) part[(size_t)k * S + s] = acc;
+}
+
+__global__ void __launch_bounds__(256) bias_grad_finish_kernel(const float *__restrict__ part, float *__restrict__ db, int K, int S,
+                                                                float alpha, float beta) {
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= K) return;
+	float s = 0.f;
+	for (int i = 0; i < S; ++i) s += part[(size_t)k * S + i];
+	db[k] = (beta == 0.f ? 0.f : beta * db[k]) + alpha * s;
+}
+
+inline int bias_grad_splits(int n, int k) {
+	int s = pz::ceil_div(8 * pz::kNumCU, k);
+	s = s > n ? n : s;
+	return s > 64 ? 64 : (s < 1 ? 1 : s);
+}
+
+// single-stage variant (one workgroup per channel) for callers without workspace
 __global__ void __launch_bounds__(256) bias_grad_kernel(const float *__restrict__ dy, float *__restrict__ db, int N, int K, int PQ,
                                                          float alpha, float beta) {
 	__shared__ float red[16];
@@ -1036,7 +1088,8 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 
 	} else if (which == PZ_CONV_BWD_FILTER) {
 		WgradPlan p = plan_wgrad(d, P, Q);
-		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);
+		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0) +
+		          align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float));       // bias-gradient partials
 
 	} else {
 		PZ_REQUIRE(false, "pz_conv2d_workspace_bytes: unknown pass %d", which);
@@ -1175,12 +1228,25 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	PZ_REQUIRE(x && dy && dw, "pz_conv2d_bwd_filter: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	const bool gemm_path = !(algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q));
+
 	if (db) {
-		bias_grad_kernel<<<d->k, 256, 0, st>>>(dy, db, d->n, d->k, P * Q, alpha, beta);
+		size_t need_all = 0;
+		if (gemm_path) pz_conv2d_workspace_bytes(d, PZ_CONV_BWD_FILTER, algo, &need_all);
+		const int S = bias_grad_splits(d->n, d->k);
+		const size_t part_bytes = align256((size_t)d->k * S * sizeof(float));
+
+		if (gemm_path && workspace && ws_bytes >= need_all && S > 1) {
+			float *part = (float *)((char *)workspace + need_all - part_bytes);      // last block of the workspace
+			bias_grad_partial_kernel<<<dim3(d->k, S), 256, 0, st>>>(dy, part, d->n, d->k, P * Q, S);
+			PZ_LAUNCH_CHECK();
+			bias_grad_finish_kernel<<<pz::ceil_div(d->k, 256), 256, 0, st>>>(part, db, d->k, S, alpha, beta);
+		} else {
+			bias_grad_kernel<<<d->k, 256, 0, st>>>(dy, db, d->n, d->k, P * Q, alpha, beta);
+		}
 		PZ_LAUNCH_CHECK();
 	}
-
-	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
 		direct_bwd_filter_kernel<<<d->k * Cg * d->r * d->s, 256, 0, st>>>(*d, P, Q, x, dy, dw, alpha, beta);
@@ -1189,7 +1255,7 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	}
 
 	WgradPlan p = plan_wgrad(d, P, Q);
-	const size_t need = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);
+	const size_t need = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);   // (+ bias partials, optional)
 	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_filter: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	int2 *tab = (int2 *)workspace;
