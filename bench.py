@@ -74,7 +74,7 @@ def main():
 
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
-	local = int(os.environ.get("LOCAL_RANK", "0"))
+	local = int(os.environ.get("PUZZLE_MI355_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 	assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
 
 	from puzzlelib_amd.settings import Config

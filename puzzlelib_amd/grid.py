@@ -269,6 +269,9 @@ def nodeFromEnv(bucketBytes=25 << 20):
 		return None
 
 	rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+	# PUZZLE_MI355_DEVICE pins every rank to one device: a single-GPU rehearsal of the multi-process path (RCCL itself
+	# refuses two ranks on one device unless it is built/configured to allow it)
+	local = int(os.environ.get("PUZZLE_MI355_DEVICE", local))
 
 	import torch.distributed as dist
 	if not dist.is_initialized():
