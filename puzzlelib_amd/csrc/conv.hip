@@ -184,6 +184,10 @@ struct IgemmArgs {
 	int full_tiles, tail_splits;
 	float *slabs;
 	int tapmajor;                          // `tab` is the per-k-tile int4 table of the tap-major order
+	int contig;                            // output pixel index == position inside the image (stride-1 output grid):
+	                                       // the epilogue goes through LDS and stores 4 pixels (16 B) per lane
+	float4 *stats;                         // optional [strip][OC_total] {shift, sum(v-shift), sum((v-shift)^2), -} per
+	                                       // (32*TN-pixel strip, channel) for a following batch normalisation
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -227,14 +231,109 @@ __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int
 	}
 }
 
+// Epilogue through LDS for outputs whose pixel index is contiguous inside an image (forward, stride-1 backward-data).
+// The MFMA result layout gives a lane one pixel of 16 scattered channel rows: stored directly that is 64 four-byte stores
+// per lane and the texture-address unit, not HBM, bounds short-K layers. Each wave parks a 32x32 sub-tile in its own
+// 4.5 KB of LDS ([row][36]) and reads it back as [8 rows][8 x 4 pixels]: 16 B per lane, 128 contiguous bytes per channel
+// row, 4 stores per sub-tile instead of 16. Groups that straddle two images or the end of the tensor fall back to
+// 4-byte stores. With a.stats the same pass accumulates, per channel row and 32*TN-pixel strip, shifted sums for the
+// batch normalisation that follows (saves its statistics pass over y).
+constexpr int kEpiStride = 36;
+constexpr int kEpiFloatsPerWave = 32 * kEpiStride;
+
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm, int tn, int g, int wm, int wn, int wave, int lane,
+                                                     f32x16 (&acc)[TM][TN], float *smem) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const int rr = lane >> 3, c4 = lane & 7;
+	float *scr = smem + wave * kEpiFloatsPerWave;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+	const int PQ = a.OH * a.OW;
+	const int strip0 = tn * BN + wn * (32 * TN);                  // first pixel of this wave's strip
+
+#pragma unroll
+	for (int i = 0; i < TM; ++i) {
+		const int row_base = tm * BM + wm * (32 * TM) + i * 32;      // first channel row of this sub-tile row
+		float st_shift[4], st_s1[4], st_s2[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) st_shift[k] = 0.f, st_s1[k] = 0.f, st_s2[k] = 0.f;
+
+#pragma unroll
+		for (int j = 0; j < TN; ++j) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lhi) * kEpiStride + l31] = acc[i][j][r];
+
+			const int opix = strip0 + j * 32 + c4 * 4;                // this lane's 4 pixels
+			const int n_img = opix / PQ, pq = opix - n_img * PQ;
+			const int nvalid = min(4, a.npix - opix);                 // <= 0: beyond the tensor
+#ifdef PZ_EPI_FORCE_SCALAR
+			const bool whole = false;
+#else
+			const bool whole = nvalid == 4 && pq + 3 < PQ;
+#endif
+
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int ch = row_base + rr + 8 * k;
+				typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));      // written as scalars, read as vectors
+				f32x4 v = *reinterpret_cast<const f32x4_alias *>(&scr[(rr + 8 * k) * kEpiStride + c4 * 4]);
+				const bool row_ok = ch < a.M;
+				if (a.bias) {
+					const float bv = a.bias[g * a.M + min(ch, a.M - 1)];
+					v[0] += bv, v[1] += bv, v[2] += bv, v[3] += bv;
+				}
+
+				if (a.stats) {
+					if (j == 0) st_shift[k] = __shfl(v[0], lane & ~7);      // first pixel of the strip, same for the row's 8 lanes
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const float dlt = e < nvalid ? v[e] - st_shift[k] : 0.f;
+						st_s1[k] += dlt;
+						st_s2[k] = __builtin_fmaf(dlt, dlt, st_s2[k]);
+					}
+				}
+
+				const unsigned chan_off = (unsigned)(g * a.M + ch) * (unsigned)PQ;
+				if (whole) {
+					const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u : kOOB;
+					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, 0);
+				} else {
+					auto store_one = [&](int e, float val) {
+						const int o = opix + e;
+						const int n2 = o / PQ, pq2 = o - n2 * PQ;
+						const unsigned off = (row_ok && e < nvalid) ? (((unsigned)n2 * a.OC_total) * (unsigned)PQ + chan_off + pq2) * 4u : kOOB;
+						__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yr, off, 0, 0);
+					};
+					store_one(0, v[0]), store_one(1, v[1]), store_one(2, v[2]), store_one(3, v[3]);
+				}
+			}
+		}
+
+		if (a.stats) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				float s1 = st_s1[k], s2 = st_s2[k];
+#pragma unroll
+				for (int d = 1; d < 8; d <<= 1) s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
+				const int ch = row_base + rr + 8 * k;
+				if (c4 == 0 && ch < a.M && strip0 < a.npix)
+					a.stats[(size_t)(strip0 / (32 * TN)) * a.OC_total + g * a.M + ch] = make_float4(st_shift[k], s1, s2, 0.f);
+			}
+		}
+	}
+}
+
 template <int BM, int BN, int WM, int WN, bool TAPMAJOR>
 __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 	constexpr int BK = 16, NT = 256;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
 
-	__shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-	__shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+	// one LDS block: operand tiles during the k loop, per-wave transposition scratch in the epilogue
+	static_assert(2 * BK * (BM + BN) >= 4 * kEpiFloatsPerWave, "epilogue scratch does not fit the operand tiles");
+	__shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+	float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
+	float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,7 +518,16 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 	compute_tile((kt1 - 1 - kt0) & 1, 0, false);
 
 	if (kslice < 0) {
-		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+#if PZ_ABL & 256        // ablation: no epilogue stores except one element per lane (timing only)
+		a.y[(size_t)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15];
+		return;
+#endif
+		if (a.contig) {
+			__syncthreads();          // every wave is done reading the operand tiles
+			igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, smem);
+		} else {
+			igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+		}
 	} else {
 		// partial accumulators of a tail slice: slab[(tail tile, slice)][register][thread] — coalesced 256-B rows
 		float *slab = a.slabs + ((size_t)(blockIdx.x - a.full_tiles) + (size_t)g * (gridDim.x - a.full_tiles)) * (BM * BN);
@@ -463,7 +571,12 @@ __global__ void __launch_bounds__(256) igemm_tail_reduce_kernel(IgemmArgs a) {
 				for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((i * TN + j) * 16 + r) * NT + tid];
 	}
 
-	igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+	if (a.contig) {
+		__shared__ __attribute__((aligned(16))) float smem[4 * kEpiFloatsPerWave];
+		igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, smem);
+	} else {
+		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1144,6 +1257,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.y_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tapmajor = pa.tapmajor;
+	a.contig = 1, a.stats = nullptr;
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
@@ -1215,6 +1329,8 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;
 		a.tapmajor = pa.tapmajor;
+		a.contig = d->stride_h == 1 && d->stride_w == 1 && c.Pv == d->h && c.Qv == d->w && c.oo_h == 0 && c.oo_w == 0;
+		a.stats = nullptr;
 		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
 	}
