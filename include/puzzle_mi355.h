@@ -100,6 +100,15 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 /* y = conv(x, w) (+ bias[k] when bias != NULL) */
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                   int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* Forward convolution that also leaves, for a batch normalisation reading y next (Conv -> BatchNorm pairs of
+ * Models/Nets/ResNet.py:27-30), per-channel shifted sums over strips of PZ_CONV_STATS_STRIP consecutive
+ * output pixels (flattened n*P*Q axis): stats[(strip*K + k)*4 + {0,1,2}] = {shift, sum(y-shift), sum((y-shift)^2)},
+ * shift = the strip's first value of channel k. pz_conv2d_fwd_stats_strips reports the number of strips (0: this
+ * configuration runs on a path that cannot produce them — call pz_conv2d_fwd and let the BN compute its own).  */
+#define PZ_CONV_STATS_STRIP 64
+int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips);
+int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                        float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* dx = conv^T(dy, w); dx has the (n,c,h,w) of the descriptor */
 int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx,
                        int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
@@ -143,6 +152,12 @@ enum pz_bn_act { PZ_BN_ACT_NONE = 0, PZ_BN_ACT_RELU = 1 };
 int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
                         float *run_mean, float *run_var, float *save_mean, float *save_invvar,
                         float epsilon, float factor, int act, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* pz_bn_fwd_train_act with the statistics pass replaced by the producer's strip sums (pz_conv2d_fwd_stats): the
+ * strips are merged per channel in fp64 with the pairwise (count, mean, M2) update, in a fixed order.            */
+int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                        float *run_mean, float *run_var, float *save_mean, float *save_invvar,
+                        float epsilon, float factor, int act, const float *stats, int strips,
+                        void *workspace, size_t ws_bytes, pz_stream_t stream);
 int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, void *workspace, size_t ws_bytes, pz_stream_t stream);

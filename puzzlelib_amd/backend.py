@@ -113,6 +113,14 @@ def pair(v):
 	return (int(v), int(v)) if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
 
 
+class ConvStats:
+	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
+	__slots__ = ["tensor", "stats"]
+
+	def __init__(self, tensor, stats):
+		self.tensor, self.stats = tensor, stats
+
+
 def requireF32(*arrays):
 	for ary in arrays:
 		if ary is None:
@@ -228,7 +236,9 @@ class DnnContext:
 
 
 	def convNd(self, data, W, bias=None, stride=1, pad=0, dilation=1, groups=1, algo=ConvFwdAlgo.auto.value,
-			   out=None, allocator=None):
+			   out=None, allocator=None, withStats=False):
+		"""`withStats` (backend-internal): also return the per-strip channel sums of the output for a BatchNorm that
+		reads it next -> (out, ConvStats | None); see batchNormNd(convStats=)."""
 		assert data.ndim == W.ndim and data.shape[1] == W.shape[1] * groups
 		requireF32(data, W, bias, out)
 
@@ -246,8 +256,21 @@ class DnnContext:
 		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_FWD, algo, byref(size))
 		ws = self.workspace(size.value, allocator)
 
-		lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
-		return out
+		if not withStats:
+			lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
+			return out
+
+		strips = c_int(0)
+		lib.pz_conv2d_fwd_stats_strips(byref(desc), algo, byref(strips))
+		if strips.value == 0:
+			lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
+			return out, None
+
+		stats = GPUArray.empty((strips.value, W.shape[0], 4), dtype=np.float32, allocator=allocator)
+		lib.pz_conv2d_fwd_stats(
+			byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, stats.ptr, algo, ptrOf(ws), size.value, None
+		)
+		return out, ConvStats(out, stats)
 
 
 	def convNdBackwardData(self, grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1,
@@ -446,7 +469,7 @@ class DnnContext:
 
 
 	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,
-					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False):
+					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False, convStats=None):
 		"""`fuseRelu` (backend-internal, train mode only): write relu(bn(data)) — used by Sequential for a BatchNorm
 		followed by an in-place ReLU; the matching backward is batchNormNdBackward(..., bias=, fuseRelu=True)."""
 		assert mean.ndim == 1 and var.ndim == 1 and scale.ndim == 1 and bias.ndim == 1
@@ -466,10 +489,19 @@ class DnnContext:
 		saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
 		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 
-		lib.pz_bn_fwd_train_act(
-			data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
-			epsilon, factor, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE, ws.ptr, nbytes, None
-		)
+		act = lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE
+
+		if convStats is not None and convStats.tensor is data:
+			# the producing convolution already summed this tensor per strip: no statistics pass over `data`
+			lib.pz_bn_fwd_train_pre(
+				data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
+				epsilon, factor, act, convStats.stats.ptr, convStats.stats.shape[0], ws.ptr, nbytes, None
+			)
+		else:
+			lib.pz_bn_fwd_train_act(
+				data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
+				epsilon, factor, act, ws.ptr, nbytes, None
+			)
 		return out, savemean, saveinvvar
 
 

@@ -120,7 +120,49 @@ __device__ __forceinline__ float bn_act(float x, float a, float b) {
 	return RELU ? (y > 0.f ? y : 0.f) : y;
 }
 
-template <bool RELU>
+// ---- statistics from the producing convolution's strip sums: stats[(strip*C + ch)] = {shift, s1, s2, -} over
+// `strip_px` consecutive pixels of the flattened (n, hw) axis. One workgroup per channel merges them with the pairwise
+// (count, mean, M2) update in fp64 — threads own strips t, t+256, ..., then a fixed-order tree — into pre[ch] = {mean, var}.
+__global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__restrict__ stats, int strips, int strip_px, long total_px,
+                                                               int c, float *__restrict__ pre) {
+	__shared__ double sh_n[256], sh_mean[256], sh_m2[256];
+	const int ch = blockIdx.x, t = threadIdx.x;
+
+	double cnt = 0.0, mean = 0.0, m2 = 0.0;
+	auto combine = [](double &na, double &ma, double &qa, double nb, double mb, double qb) {
+		if (nb == 0.0) return;
+		const double tot = na + nb, delta = mb - ma;
+		ma += delta * (nb / tot);
+		qa += qb + delta * delta * (na * nb / tot);
+		na = tot;
+	};
+
+	for (int s = t; s < strips; s += 256) {
+		const float4 e = stats[(size_t)s * c + ch];
+		const long left = total_px - (long)s * strip_px;
+		const double nb = (double)(left < strip_px ? left : strip_px);
+		const double s1 = (double)e.y, s2 = (double)e.z;
+		combine(cnt, mean, m2, nb, (double)e.x + s1 / nb, s2 - s1 * s1 / nb);
+	}
+
+	sh_n[t] = cnt, sh_mean[t] = mean, sh_m2[t] = m2;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if (t < w) {
+			double na = sh_n[t], ma = sh_mean[t], qa = sh_m2[t];
+			combine(na, ma, qa, sh_n[t + w], sh_mean[t + w], sh_m2[t + w]);
+			sh_n[t] = na, sh_mean[t] = ma, sh_m2[t] = qa;
+		}
+		__syncthreads();
+	}
+	if (t == 0) {
+		const double var = sh_m2[0] / sh_n[0];
+		pre[2 * ch + 0] = (float)sh_mean[0];
+		pre[2 * ch + 1] = (float)(var > 0.0 ? var : 0.0);
+	}
+}
+
+template <bool RELU, bool PRE = false>
 __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, float *y, BnGeom g,
                                                               const float *__restrict__ part, const float *__restrict__ shift,
                                                               const float *__restrict__ scale, const float *__restrict__ bias,
@@ -129,13 +171,19 @@ __global__ void __launch_bounds__(256) bn_apply_train_kernel(const float *x, flo
                                                               float eps, float factor) {
 	const int ch = blockIdx.x, s = blockIdx.y;
 
-	double S1, S2;
-	bn_merge(part, g.splits, ch, S1, S2);
 	const double cnt = (double)g.n * g.hw;
-	const double m1 = S1 / cnt;
-	double var = S2 / cnt - m1 * m1;
-	var = var > 0.0 ? var : 0.0;
-	const float mean = (float)((double)shift[ch] + m1);
+	double var;
+	float mean;
+	if (PRE) {                  // `part` holds {mean, var} per channel (bn_merge_strips_kernel)
+		mean = part[2 * ch], var = (double)part[2 * ch + 1];
+	} else {
+		double S1, S2;
+		bn_merge(part, g.splits, ch, S1, S2);
+		const double m1 = S1 / cnt;
+		var = S2 / cnt - m1 * m1;
+		var = var > 0.0 ? var : 0.0;
+		mean = (float)((double)shift[ch] + m1);
+	}
 	const float rstd = (float)(1.0 / sqrt(var + (double)eps));
 
 	if (s == 0 && threadIdx.x == 0) {
@@ -307,6 +355,34 @@ int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const fl
 	else
 		bn_apply_train_kernel<false><<<grid, 256, 0, st>>>(x, y, g, part, shift, scale, bias, run_mean, run_var, save_mean,
 		                                                   save_invvar, epsilon, factor);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+                        float *run_mean, float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor,
+                        int act, const float *stats, int strips, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && y && scale && bias && run_mean && run_var && save_mean && save_invvar && stats, "pz_bn_fwd_train_pre: null tensor");
+	PZ_REQUIRE(act == PZ_BN_ACT_NONE || act == PZ_BN_ACT_RELU, "pz_bn_fwd_train_pre: unknown fused activation %d", act);
+	const long total_px = (long)n * hw;
+	PZ_REQUIRE(strips == (int)((total_px + PZ_CONV_STATS_STRIP - 1) / PZ_CONV_STATS_STRIP),
+	           "pz_bn_fwd_train_pre: %d strips do not cover %ld pixels", strips, total_px);
+	const BnGeom g = bn_geom(n, c, hw);
+	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train_pre: workspace too small");
+
+	float *pre = (float *)workspace;             // 2*c floats <= the statistics workspace
+	hipStream_t st = pz::as_stream(stream);
+	bn_merge_strips_kernel<<<c, 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, PZ_CONV_STATS_STRIP, total_px, c, pre);
+	PZ_LAUNCH_CHECK();
+
+	dim3 grid(c, g.splits);
+	if (act == PZ_BN_ACT_RELU)
+		bn_apply_train_kernel<true, true><<<grid, 256, 0, st>>>(x, y, g, pre, nullptr, scale, bias, run_mean, run_var, save_mean,
+		                                                        save_invvar, epsilon, factor);
+	else
+		bn_apply_train_kernel<false, true><<<grid, 256, 0, st>>>(x, y, g, pre, nullptr, scale, bias, run_mean, run_var, save_mean,
+		                                                         save_invvar, epsilon, factor);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

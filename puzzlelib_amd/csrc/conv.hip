@@ -1210,14 +1210,28 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	return PZ_OK;
 }
 
+int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(strips != nullptr, "pz_conv2d_fwd_stats_strips: null output");
+	*strips = (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) ? 0 : pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
+	return PZ_OK;
+}
+
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, int algo,
                   void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	return pz_conv2d_fwd_stats(d, x, w, bias, y, nullptr, algo, workspace, ws_bytes, stream);
+}
+
+int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, float *stats,
+                        int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && w && y, "pz_conv2d_fwd: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
+		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: this configuration cannot produce strip statistics");
 		const size_t total = (size_t)d->n * d->k * P * Q;
 		direct_fwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(*d, P, Q, x, w, bias, y);
 		PZ_LAUNCH_CHECK();
@@ -1257,7 +1271,8 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
 	a.y_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tapmajor = pa.tapmajor;
-	a.contig = 1, a.stats = nullptr;
+	a.contig = 1, a.stats = reinterpret_cast<float4 *>(stats);
+	static_assert(PZ_CONV_STATS_STRIP == 64, "strip = 32 * TN pixels of both tile configurations");
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;

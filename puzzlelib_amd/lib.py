@@ -93,6 +93,8 @@ _PROTOS = {
 	"pz_conv2d_out_shape": [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)],
 	"pz_conv2d_workspace_bytes": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
 	"pz_conv2d_fwd": [POINTER(ConvDesc), P, P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_fwd_stats_strips": [POINTER(ConvDesc), c_int, POINTER(c_int)],
+	"pz_conv2d_fwd_stats": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_data": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 
@@ -106,6 +108,7 @@ _PROTOS = {
 	"pz_bn_fwd_infer": [P, P, c_int, c_int, c_int, P, P, P, P, c_float, P],
 	"pz_bn_bwd": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P],
 	"pz_bn_fwd_train_act": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
+	"pz_bn_fwd_train_pre": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, c_int, P, c_int, P, c_size_t, P],
 	"pz_bn_bwd_act": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, c_size_t, P],
 
 	"pz_pool2d_out_shape": [POINTER(PoolDesc), POINTER(c_int), POINTER(c_int)],

@@ -305,10 +305,17 @@ class Conv2D(Module):
 
 
 	def updateData(self, data):
-		self.data = S().Dnn.convNd(
+		emit = getattr(self, "emitStats", False)      # set per forward pass by Sequential.planFusion
+		result = S().Dnn.convNd(
 			data, self.W, self.b, stride=self.stride, pad=self.pad, dilation=self.dilation, groups=self.groups,
-			algo=self.fwdAlgo
+			algo=self.fwdAlgo, withStats=emit
 		)
+		self.data, self.outStats = result if emit else (result, None)
+
+
+	def reset(self):
+		super().reset()
+		self.outStats = None
 
 
 	def updateGrad(self, grad):
@@ -454,6 +461,7 @@ class BatchNorm2D(Module):
 		self.scale = self.bias = self.mean = self.var = None
 		self.savemean = self.saveinvvar = self.scalegrad = self.biasgrad = None
 		self.fusedRelu = False       # set per forward pass by Sequential (planFusion): output is relu(bn(x))
+		self.statsFrom = None        # ... and the Conv2D right in front whose epilogue sums this layer's input per channel
 
 		if empty:
 			return
@@ -479,7 +487,8 @@ class BatchNorm2D(Module):
 			factor = max(self.initFactor / self.numOfProps, self.minFactor)
 
 			self.data, self.savemean, self.saveinvvar = dnn.batchNormNd(
-				data, self.scale, self.bias, self.mean, self.var, self.epsilon, factor, False, fuseRelu=self.fusedRelu
+				data, self.scale, self.bias, self.mean, self.var, self.epsilon, factor, False, fuseRelu=self.fusedRelu,
+				convStats=self.statsFrom.outStats if self.statsFrom is not None else None
 			)
 		else:
 			self.data = dnn.batchNormNd(
@@ -1016,6 +1025,7 @@ class Container(Module):
 class Sequential(Container):
 	honourUpdGrad = True
 	fuseInplaceRelu = True       # backend-internal fusion around in-place ReLUs (see planFusion)
+	fuseConvStats = True         # BatchNorm statistics from the preceding convolution's epilogue (see planFusion)
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1029,16 +1039,27 @@ class Sequential(Container):
 		  BatchNorm2D (train) -> ReLU : BN writes relu(bn(x)); its backward gates the incoming grad with (bn(x) > 0)
 		  Add (2 inputs)      -> ReLU : the sum kernel writes relu(a + b)
 		  ReLU -> Replicate(2)        : the fan-in kernel writes (g0 + g1) * (y > 0), y = the ReLU's output
-		The ReLU module itself then only forwards data / grad. Values are bit-identical to the unfused sequence."""
+		The ReLU module itself then only forwards data / grad. Values are bit-identical to the unfused sequence.
+		Independently of ReLUs (Sequential.fuseConvStats): Conv2D -> BatchNorm2D (train): the convolution's epilogue
+		leaves per-strip channel sums of its output and the BN skips its own statistics pass over that tensor (same
+		mean/variance up to fp32 summation order)."""
 		graph, on = self.graph, Sequential.fuseInplaceRelu
 
-		for mod in graph:
+		for i, mod in enumerate(graph):
 			if isinstance(mod, Activation):
 				mod.dataFused = mod.gradFused = False
 			elif isinstance(mod, (BatchNorm2D, Add)):
 				mod.fusedRelu = False
 			elif isinstance(mod, Replicate):
 				mod.gateGrad = False
+
+			if isinstance(mod, Conv2D):
+				mod.emitStats = False
+			if isinstance(mod, BatchNorm2D):
+				prev = graph[i - 1] if i > 0 else None
+				mod.statsFrom = None
+				if Sequential.fuseConvStats and mod.train and isinstance(prev, Conv2D):
+					prev.emitStats, mod.statsFrom = True, prev
 
 		if not on:
 			return

@@ -76,10 +76,10 @@ def bind():
 	)
 
 	# ------------------------------------------------------------------ Dnn (Backend/Dnn.py:124-268)
-	def convNd(data, W, bias, stride, pad, dilation, groups, algo):
+	def convNd(data, W, bias, stride, pad, dilation, groups, algo, withStats=False):
 		return dnn.convNd(
 			data, W, bias.ravel() if bias is not None else None, stride, pad, dilation, groups, algo.value, None,
-			memoryPool
+			memoryPool, withStats=withStats
 		)
 
 	def convNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo):
@@ -99,11 +99,11 @@ def bind():
 		return dnn.poolNdBackward(grad, indata, outdata, workspace, size, stride, pad, mode.value, None, memoryPool)
 
 	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None,
-					fuseRelu=False):
+					fuseRelu=False, convStats=None):
 		shape = scale.shape
 		result = dnn.batchNormNd(
 			data, mean.ravel(), var.ravel(), scale.ravel(), bias.ravel(), epsilon, factor, test, mode.value, out=out,
-			allocator=memoryPool, fuseRelu=fuseRelu
+			allocator=memoryPool, fuseRelu=fuseRelu, convStats=convStats
 		)
 		if test:
 			return result

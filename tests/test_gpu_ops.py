@@ -364,6 +364,69 @@ def test_batchnorm_fused_relu_is_the_unfused_sequence(bnd, shape):
 		bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, smf, sif, 1e-5, fuseRelu=True)      # gate needs the bias
 
 
+@pytest.mark.parametrize("cfg", [
+	dict(n=3, c=5, k=70, hw=(13, 17), r=3, pad=1, stride=1, groups=1, bias=True),        # odd map: strips straddle images
+	dict(n=4, c=16, k=64, hw=(28, 28), r=1, pad=0, stride=1, groups=1, bias=False),      # 64x256 tile configuration, tap-major
+	dict(n=2, c=32, k=160, hw=(15, 15), r=3, pad=1, stride=2, groups=2, bias=False),     # groups, stride, ragged channel tiles
+	dict(n=20, c=64, k=128, hw=(20, 20), r=3, pad=1, stride=1, groups=1, bias=False),    # enough tiles for a k-sliced tail
+])
+def test_conv_epilogue_statistics_feed_batchnorm(bnd, cfg):
+	"""BN statistics from the producing convolution's epilogue (pz_conv2d_fwd_stats -> pz_bn_fwd_train_pre).
+	The strip sums must reproduce the per-channel mean / variance of y, and BN fed by them must equal BN computing its own
+	statistics (fp32 summation-order tolerance) and the oracle."""
+	rng = np.random.RandomState(5)
+	n, c, k, (h, w_), r, groups = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"], cfg["groups"]
+	x = rng.randn(n, c, h, w_).astype(np.float32)
+	wt = (rng.randn(k, c // groups, r, r) / np.sqrt(c // groups * r * r)).astype(np.float32)
+	bias = (3.0 * rng.randn(k)).astype(np.float32) if cfg["bias"] else None          # a large bias: mean >> std per channel
+	okw = dict(stride=(cfg["stride"], ) * 2, pad=(cfg["pad"], ) * 2, dilation=(1, 1), groups=groups)
+
+	gx, gw, gb = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias) if bias is not None else None
+	y_plain = bnd.dnn.convNd(gx, gw, gb, **okw)
+	y, stats = bnd.dnn.convNd(gx, gw, gb, withStats=True, **okw)
+	assert stats is not None and stats.tensor is y
+	assert np.array_equal(y.get(), y_plain.get())
+
+	# strip sums -> exact per-channel moments
+	yh = y.get().astype(np.float64)
+	flat = yh.transpose(1, 0, 2, 3).reshape(k, -1)                       # (k, n*p*q) in the kernel's pixel order? no: (n, pq)
+	flat = yh.transpose(0, 2, 3, 1).reshape(-1, k)                       # pixel-major (n, p, q) x channel
+	st = stats.stats.get().astype(np.float64)
+	strips = st.shape[0]
+	assert strips == -(-flat.shape[0] // 64)
+	for s_ in (0, strips // 2, strips - 1):
+		seg = flat[64 * s_:64 * (s_ + 1)]
+		shift = st[s_, :, 0]
+		assert np.allclose(shift, seg[0], rtol=0, atol=0)
+		assert np.allclose(st[s_, :, 1], (seg - shift).sum(0), rtol=1e-4, atol=1e-4)
+		assert np.allclose(st[s_, :, 2], ((seg - shift) ** 2).sum(0), rtol=1e-4, atol=1e-4)
+
+	scale, bnb = rng.randn(k).astype(np.float32), rng.randn(k).astype(np.float32)
+	rm0, rv0 = rng.randn(k).astype(np.float32), (1 + rng.rand(k)).astype(np.float32)
+	gs, gbb = gpu(bnd, scale), gpu(bnd, bnb)
+
+	rm_a, rv_a = gpu(bnd, rm0), gpu(bnd, rv0)
+	out_a, sm_a, si_a = bnd.dnn.batchNormNd(y, rm_a, rv_a, gs, gbb, 1e-5, 0.3, False)
+	rm_b, rv_b = gpu(bnd, rm0), gpu(bnd, rv0)
+	out_b, sm_b, si_b = bnd.dnn.batchNormNd(y, rm_b, rv_b, gs, gbb, 1e-5, 0.3, False, convStats=stats, fuseRelu=False)
+
+	assert_close(sm_b.get(), sm_a.get(), atol=2e-6, rtol=1e-5, what="mean: strips vs own pass")
+	assert_close(si_b.get(), si_a.get(), atol=1e-6, rtol=2e-5, what="invvar: strips vs own pass")
+	assert_close(out_b.get(), out_a.get(), atol=3e-5, rtol=1e-4, what="y: strips vs own pass")
+	assert_close(rv_b.get(), rv_a.get(), atol=1e-5, rtol=1e-4, what="running var")
+
+	rm, rv = rm0.copy(), rv0.copy()
+	y_ref, sm_ref, si_ref = R.bn_fwd_train(y.get(), scale, bnb, rm, rv, 1e-5, 0.3, acc=np.float64)
+	assert_close(sm_b.get(), sm_ref, atol=1e-5, what="mean vs oracle")
+	assert_close(si_b.get(), si_ref, atol=1e-5, rtol=1e-4, what="invvar vs oracle")
+	assert_close(out_b.get(), y_ref, atol=3e-5, rtol=1e-4, what="y vs oracle")
+
+	# statistics of a different tensor object are ignored (the BN then runs its own pass)
+	y2 = y.copy()
+	out_c, sm_c, _ = bnd.dnn.batchNormNd(y2, gpu(bnd, rm0), gpu(bnd, rv0), gs, gbb, 1e-5, 0.3, False, convStats=stats)
+	assert np.array_equal(sm_c.get(), sm_a.get())
+
+
 @pytest.mark.parametrize("n", [1, 5, 1024, 4 * 3025 + 3])
 def test_fused_residual_kernels(bnd, n):
 	rng = np.random.RandomState(n)
