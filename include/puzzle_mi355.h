@@ -102,7 +102,7 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
                   int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* Forward convolution that also leaves, for a batch normalisation reading y next (Conv -> BatchNorm pairs of
  * Models/Nets/ResNet.py:27-30), per-channel shifted sums over strips of PZ_CONV_STATS_STRIP consecutive
- * output pixels (flattened n*P*Q axis): stats[(strip*K + k)*4 + {0,1,2}] = {shift, sum(y-shift), sum((y-shift)^2)},
+ * output pixels (flattened n*P*Q axis): stats[(k*strips + strip)*4 + {0,1,2}] = {shift, sum(y-shift), sum((y-shift)^2)},
  * shift = the strip's first value of channel k. pz_conv2d_fwd_stats_strips reports the number of strips (0: this
  * configuration runs on a path that cannot produce them — call pz_conv2d_fwd and let the BN compute its own).  */
 #define PZ_CONV_STATS_STRIP 64

@@ -266,7 +266,7 @@ class DnnContext:
 			lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
 			return out, None
 
-		stats = GPUArray.empty((strips.value, W.shape[0], 4), dtype=np.float32, allocator=allocator)
+		stats = GPUArray.empty((W.shape[0], strips.value, 4), dtype=np.float32, allocator=allocator)
 		lib.pz_conv2d_fwd_stats(
 			byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, stats.ptr, algo, ptrOf(ws), size.value, None
 		)
@@ -495,7 +495,7 @@ class DnnContext:
 			# the producing convolution already summed this tensor per strip: no statistics pass over `data`
 			lib.pz_bn_fwd_train_pre(
 				data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
-				epsilon, factor, act, convStats.stats.ptr, convStats.stats.shape[0], ws.ptr, nbytes, None
+				epsilon, factor, act, convStats.stats.ptr, convStats.stats.shape[1], ws.ptr, nbytes, None
 			)
 		else:
 			lib.pz_bn_fwd_train_act(

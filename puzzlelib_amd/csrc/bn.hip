@@ -120,7 +120,7 @@ __device__ __forceinline__ float bn_act(float x, float a, float b) {
 	return RELU ? (y > 0.f ? y : 0.f) : y;
 }
 
-// ---- statistics from the producing convolution's strip sums: stats[(strip*C + ch)] = {shift, s1, s2, -} over
+// ---- statistics from the producing convolution's strip sums: stats[ch*strips + strip] = {shift, s1, s2, -} over
 // `strip_px` consecutive pixels of the flattened (n, hw) axis. One workgroup per channel merges them with the pairwise
 // (count, mean, M2) update in fp64 — threads own strips t, t+256, ..., then a fixed-order tree — into pre[ch] = {mean, var}.
 __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__restrict__ stats, int strips, int strip_px, long total_px,
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__re
 	};
 
 	for (int s = t; s < strips; s += 256) {
-		const float4 e = stats[(size_t)s * c + ch];
+		const float4 e = stats[(size_t)ch * strips + s];
 		const long left = total_px - (long)s * strip_px;
 		const double nb = (double)(left < strip_px ? left : strip_px);
 		const double s1 = (double)e.y, s2 = (double)e.z;

@@ -186,8 +186,8 @@ struct IgemmArgs {
 	int tapmajor;                          // `tab` is the per-k-tile int4 table of the tap-major order
 	int contig;                            // output pixel index == position inside the image (stride-1 output grid):
 	                                       // the epilogue goes through LDS and stores 4 pixels (16 B) per lane
-	float4 *stats;                         // optional [strip][OC_total] {shift, sum(v-shift), sum((v-shift)^2), -} per
-	                                       // (32*TN-pixel strip, channel) for a following batch normalisation
+	float4 *stats;                         // optional [OC_total][stat_strips] {shift, sum(v-shift), sum((v-shift)^2), -} per
+	int stat_strips;                       // (channel, 32*TN-pixel strip) for a following batch normalisation
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -317,7 +317,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 				for (int d = 1; d < 8; d <<= 1) s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
 				const int ch = row_base + rr + 8 * k;
 				if (c4 == 0 && ch < a.M && strip0 < a.npix)
-					a.stats[(size_t)(strip0 / (32 * TN)) * a.OC_total + g * a.M + ch] = make_float4(st_shift[k], s1, s2, 0.f);
+					a.stats[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / (32 * TN)] = make_float4(st_shift[k], s1, s2, 0.f);
 			}
 		}
 	}
@@ -1272,6 +1272,7 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tapmajor = pa.tapmajor;
 	a.contig = 1, a.stats = reinterpret_cast<float4 *>(stats);
+	a.stat_strips = pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	static_assert(PZ_CONV_STATS_STRIP == 64, "strip = 32 * TN pixels of both tile configurations");
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	PZ_LAUNCH_CHECK();

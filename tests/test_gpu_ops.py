@@ -391,7 +391,7 @@ def test_conv_epilogue_statistics_feed_batchnorm(bnd, cfg):
 	yh = y.get().astype(np.float64)
 	flat = yh.transpose(1, 0, 2, 3).reshape(k, -1)                       # (k, n*p*q) in the kernel's pixel order? no: (n, pq)
 	flat = yh.transpose(0, 2, 3, 1).reshape(-1, k)                       # pixel-major (n, p, q) x channel
-	st = stats.stats.get().astype(np.float64)
+	st = stats.stats.get().astype(np.float64).transpose(1, 0, 2)         # (strip, channel, 4)
 	strips = st.shape[0]
 	assert strips == -(-flat.shape[0] // 64)
 	for s_ in (0, strips // 2, strips - 1):
