@@ -138,6 +138,108 @@ __global__ void __launch_bounds__(256) pool_bwd_kernel(pz_pool_desc d, PoolGeom 
 	}
 }
 
+// Max pooling through LDS (3x3/2 on 112x112 -> 55x55 is the ResNet stem): the generic kernels issue one 4-byte load per
+// tap and are bound by the texture-address unit, not by HBM. A workgroup owns a band of rows of one (image, channel)
+// plane — small enough (<= 16 KB) that 8 workgroups share a CU and loads of one overlap the arithmetic of another:
+//   forward : the band's input rows are read once with 16-byte loads into LDS, windows are evaluated out of LDS
+//   backward: the dy rows and arg-max bytes covering the band are staged in LDS, dx is written 16 bytes per lane
+constexpr int kPoolBandFloats = 3584;           // 14 KB
+constexpr int kPoolFwdBand = 8;                 // output rows per workgroup (forward)
+constexpr int kPoolBwdBand = 16;                // input rows per workgroup (backward)
+
+template <int SZ, int ST>
+__global__ void __launch_bounds__(256) maxpool_fwd_lds_kernel(pz_pool_desc d, PoolGeom g, const float *__restrict__ x,
+                                                               float *__restrict__ y, uint8_t *__restrict__ idx) {
+	__shared__ __attribute__((aligned(16))) float rows[kPoolBandFloats];
+	const int HW = d.h * d.w, PQ = g.P * g.Q;
+	const int p0 = blockIdx.y * kPoolFwdBand, p1 = min(p0 + kPoolFwdBand, g.P);
+	const int h_lo = max(p0 * ST - d.pad_h, 0), h_hi = min((p1 - 1) * ST - d.pad_h + SZ, d.h);     // input rows [h_lo, h_hi)
+	const float *img = x + (size_t)blockIdx.x * HW + (size_t)h_lo * d.w;
+	const int count = (h_hi - h_lo) * d.w;
+
+	typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+	typedef float f4a __attribute__((ext_vector_type(4), may_alias));
+	for (int i = threadIdx.x; i < (count >> 2); i += 256) *reinterpret_cast<f4a *>(&rows[4 * i]) = *reinterpret_cast<const f4u *>(img + 4 * i);
+	for (int i = (count & ~3) + threadIdx.x; i < count; i += 256) rows[i] = img[i];
+	__syncthreads();
+
+	for (int i = threadIdx.x; i < (p1 - p0) * g.Q; i += 256) {
+		const int p = p0 + i / g.Q, q = i % g.Q;
+		const int h0 = p * ST - d.pad_h, w0 = q * ST - d.pad_w;
+		float best = -INFINITY;
+		int bi = 0;
+		bool found = false;
+#pragma unroll
+		for (int r = 0; r < SZ; ++r)
+#pragma unroll
+			for (int t = 0; t < SZ; ++t) {
+				const int hh = h0 + r, ww = w0 + t;
+				if ((unsigned)hh >= (unsigned)d.h || (unsigned)ww >= (unsigned)d.w) continue;
+				const float v = rows[(hh - h_lo) * d.w + ww];
+				if (!found || v > best) best = v, bi = r * SZ + t, found = true;
+			}
+		const size_t o = (size_t)blockIdx.x * PQ + (size_t)p * g.Q + q;
+		y[o] = best;
+		if (idx) idx[o] = (uint8_t)bi;
+	}
+}
+
+template <int SZ, int ST>
+__global__ void __launch_bounds__(256) maxpool_bwd_lds_kernel(pz_pool_desc d, PoolGeom g, const float *__restrict__ dy,
+                                                               const uint8_t *__restrict__ idx, float *__restrict__ dx) {
+	__shared__ __attribute__((aligned(16))) float grad[kPoolBandFloats * 4 / 5];
+	__shared__ uint8_t win[kPoolBandFloats * 4 / 5];
+	const int HW = d.h * d.w, PQ = g.P * g.Q;
+	const size_t plane = blockIdx.x;
+	const int h0 = blockIdx.y * kPoolBwdBand, h1 = min(h0 + kPoolBwdBand, d.h);
+
+	// output rows whose windows touch input rows [h0, h1)
+	int pa = h0 + d.pad_h - SZ + 1;
+	pa = pa <= 0 ? 0 : (pa + ST - 1) / ST;
+	const int pb = min((h1 - 1 + d.pad_h) / ST, g.P - 1);
+	const int count = max(pb - pa + 1, 0) * g.Q;
+	for (int i = threadIdx.x; i < count; i += 256) {
+		grad[i] = dy[plane * PQ + (size_t)pa * g.Q + i];
+		win[i] = idx[plane * PQ + (size_t)pa * g.Q + i];
+	}
+	__syncthreads();
+
+	auto pixel = [&](int hh, int ww) {
+		const int hp = hh + d.pad_h, wp = ww + d.pad_w;
+		int p_lo = hp - SZ + 1;
+		p_lo = p_lo <= 0 ? 0 : (p_lo + ST - 1) / ST;
+		const int p_hi = min(hp / ST, g.P - 1);
+		int q_lo = wp - SZ + 1;
+		q_lo = q_lo <= 0 ? 0 : (q_lo + ST - 1) / ST;
+		const int q_hi = min(wp / ST, g.Q - 1);
+		float sum = 0.f;
+		for (int p = p_lo; p <= p_hi; ++p)
+			for (int q = q_lo; q <= q_hi; ++q)
+				if (win[(p - pa) * g.Q + q] == (hp - p * ST) * SZ + (wp - q * ST)) sum += grad[(p - pa) * g.Q + q];
+		return sum;
+	};
+
+	typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+	float *out = dx + plane * HW;
+	const int w4 = d.w >> 2;                                   // 4-pixel groups per row, then the row's remainder
+	for (int i = threadIdx.x; i < (h1 - h0) * w4; i += 256) {
+		const int hh = h0 + i / w4, ww = (i % w4) * 4;
+		*reinterpret_cast<f4u *>(out + hh * d.w + ww) = f4u{pixel(hh, ww), pixel(hh, ww + 1), pixel(hh, ww + 2), pixel(hh, ww + 3)};
+	}
+	const int rem = d.w & 3;
+	for (int i = threadIdx.x; i < (h1 - h0) * rem; i += 256) {
+		const int hh = h0 + i / rem, ww = 4 * w4 + i % rem;
+		out[hh * d.w + ww] = pixel(hh, ww);
+	}
+}
+
+// whether the band of a plane of this geometry fits the LDS arrays above
+inline bool pool_lds_fits(const pz_pool_desc *d, int Q, bool fwd) {
+	const int st = d->stride_h, sz = d->size_h;
+	if (fwd) return (size_t)((kPoolFwdBand - 1) * st + sz) * d->w <= kPoolBandFloats;
+	return (size_t)(kPoolBwdBand / st + sz + 1) * Q <= kPoolBandFloats * 4 / 5;
+}
+
 // average over the whole plane (window = plane, no padding, one output): one wave per plane, coalesced, shuffle-reduced
 __global__ void __launch_bounds__(256) pool_global_avg_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                    unsigned planes, int hw) {
@@ -159,6 +261,12 @@ __global__ void __launch_bounds__(256) pool_global_avg_bwd_kernel(const float *_
 inline bool pool_is_global_avg(const pz_pool_desc *d, int P, int Q) {
 	return d->mode != 0 && P == 1 && Q == 1 && d->pad_h == 0 && d->pad_w == 0 && d->size_h == d->h && d->size_w == d->w &&
 	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32);
+}
+
+// windows the LDS kernels are instantiated for: square 2x2/2, 3x3/2, 3x3/1
+inline bool pool_lds_window(const pz_pool_desc *d) {
+	const bool sq = d->size_h == d->size_w && d->stride_h == d->stride_w;
+	return sq && ((d->size_h == 3 && (d->stride_h == 2 || d->stride_h == 1)) || (d->size_h == 2 && d->stride_h == 2));
 }
 
 // compile-time window variants
@@ -208,6 +316,11 @@ int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *inde
 	hipStream_t st = pz::as_stream(stream);
 	if (pool_is_global_avg(d, P, Q)) {
 		pool_global_avg_fwd_kernel<<<(g.planes + 3) / 4, 256, 0, st>>>(x, y, g.planes, d->h * d->w);
+	} else if (d->mode == 0 && pool_lds_window(d) && pool_lds_fits(d, Q, true) && g.planes < 65536u * 32768u) {
+		const dim3 grid(g.planes, (P + kPoolFwdBand - 1) / kPoolFwdBand);
+		if (d->size_h == 3 && d->stride_h == 2) maxpool_fwd_lds_kernel<3, 2><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws);
+		else if (d->size_h == 2) maxpool_fwd_lds_kernel<2, 2><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws);
+		else maxpool_fwd_lds_kernel<3, 1><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws);
 	} else if (d->mode == 0) {
 #define PZ_L(SZ, ST) pool_fwd_kernel<0, SZ, ST><<<blocks, 256, 0, st>>>(*d, g, x, y, index_ws)
 		PZ_POOL_SPECIALISE(PZ_L);
@@ -234,6 +347,11 @@ int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const 
 	if (pool_is_global_avg(d, P, Q)) {
 		const size_t total = (size_t)g.planes * d->h * d->w;
 		pool_global_avg_bwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(dy, dx, total, d->h * d->w);
+	} else if (d->mode == 0 && index_ws && pool_lds_window(d) && pool_lds_fits(d, Q, false)) {
+		const dim3 grid(g.planes, (d->h + kPoolBwdBand - 1) / kPoolBwdBand);
+		if (d->size_h == 3 && d->stride_h == 2) maxpool_bwd_lds_kernel<3, 2><<<grid, 256, 0, st>>>(*d, g, dy, index_ws, dx);
+		else if (d->size_h == 2) maxpool_bwd_lds_kernel<2, 2><<<grid, 256, 0, st>>>(*d, g, dy, index_ws, dx);
+		else maxpool_bwd_lds_kernel<3, 1><<<grid, 256, 0, st>>>(*d, g, dy, index_ws, dx);
 	} else if (d->mode == 0 && index_ws) {
 #define PZ_L(SZ, ST) pool_bwd_kernel<0, true, SZ, ST><<<blocks, 256, 0, st>>>(*d, g, dy, x, index_ws, dx)
 		PZ_POOL_SPECIALISE(PZ_L);
