@@ -607,7 +607,7 @@ struct WgradArgs {
 // LDS keeps a run as two 8-byte half-cells [run][half][row]{2 pixels}: the MFMA fragment of lane (row, half h) is
 // {pixel 2h, 2h+1} of its row, i.e. the k order inside a run is (0,2 | 1,3) for both operands.
 template <int BM, int BN, int WM, int WN, bool UNIT_W>
-__global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	constexpr int BK = 32, RUNS = BK / 4;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -644,8 +644,12 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-	f32x4 ra[NA], rb[NB];
-	unsigned mb[NB];               // valid-pixel masks of the operand-B runs in flight
+	// two register sets: the gathers of k-step s+2 are issued while step s computes and are parked in LDS at the end of
+	// step s+1, a full step after their issue — with 2 workgroups per CU there is too little other work to hide an
+	// exposed HBM latency behind
+	f32x4 ra[2][NA], rb[2][NB];
+	unsigned mb[2][NB];            // valid-pixel masks of the operand-B runs in flight
+	int x_img_of[2] = {0, 0};      // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
 	const int PQ = a.P * a.Q;
 
 	__syncthreads();   // tabs visible
@@ -687,11 +691,11 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 
 	// one part = one operand-A row pass or one operand-B row pass (each a 16-byte load per thread). Pixels beyond the
 	// row end (nq < 4) are zeroed in operand B only: operand A then holds finite data of the next row, times zero.
-	auto load_part = [&](int j) {
+	auto load_part = [&](int set, int j) {
 		if (j < NA) {
 			const int i = j;
 			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + 32 * i < a.Kg);
-			ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+			ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
 			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(32 * i) * (unsigned)PQ * 4u, 0));
 		} else if (j < NA + NB) {
 			const int i = j - NA;
@@ -707,9 +711,9 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 				// A run that starts left of the tensor's first byte (first row of the first image, left padding) would wrap
 				// the 32-bit offset: such a lane loads nothing here and is flagged (bit 4) for store_step to gather it.
 				const bool far_left = first < 0 && m != 0u;
-				rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+				rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
 				    xr, (m != 0u && first >= 0) ? PZ_ABL_NEAR((unsigned)first * 4u) : kOOB, 0, 0));
-				mb[i] = far_left ? (m | 16u) : m;      // the mask is applied when the run is parked in LDS: no wait on the load here
+				mb[set][i] = far_left ? (m | 16u) : m;      // the mask is applied when the run is parked in LDS: no wait on the load here
 			} else {
 				f32x4 v;
 #pragma unroll
@@ -717,27 +721,28 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 					const bool ok = row_ok && q < nq && (unsigned)(w0 + q * a.st_w) < (unsigned)a.W;
 					v[q] = buf_load_f32(xr, ok ? (unsigned)(first + q * a.st_w) * 4u : kOOB, 0);
 				}
-				rb[i] = v, mb[i] = 0xfu;
+				rb[set][i] = v, mb[set][i] = 0xfu;
 			}
 		}
+		if (j == NA + NB - 1) x_img_of[set] = x_img;
 	};
 
-	auto store_step = [&](int buf) {
+	auto store_step = [&](int set, int buf) {
 #pragma unroll
 		for (int i = 0; i < NA; ++i) {
-			As[buf][run][0][row0 + 32 * i] = f32x2{ra[i][0], ra[i][1]};
-			As[buf][run][1][row0 + 32 * i] = f32x2{ra[i][2], ra[i][3]};
+			As[buf][run][0][row0 + 32 * i] = f32x2{ra[set][i][0], ra[set][i][1]};
+			As[buf][run][1][row0 + 32 * i] = f32x2{ra[set][i][2], ra[set][i][3]};
 		}
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
-			const unsigned m = mb[i];
-			if (UNIT_W && (m & 16u)) {       // rare: run starting left of the tensor base, gathered element-wise (x_img is still this step's)
-				const int first = x_img + tap_off[i];
+			const unsigned m = mb[set][i];
+			if (UNIT_W && (m & 16u)) {       // rare: run starting left of the tensor base, gathered element-wise
+				const int first = x_img_of[set] + tap_off[i];
 #pragma unroll
-				for (int q = 0; q < 4; ++q) rb[i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
+				for (int q = 0; q < 4; ++q) rb[set][i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
 			}
-			Bs[buf][run][0][row0 + 32 * i] = f32x2{m & 1u ? rb[i][0] : 0.f, m & 2u ? rb[i][1] : 0.f};
-			Bs[buf][run][1][row0 + 32 * i] = f32x2{m & 4u ? rb[i][2] : 0.f, m & 8u ? rb[i][3] : 0.f};
+			Bs[buf][run][0][row0 + 32 * i] = f32x2{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f};
+			Bs[buf][run][1][row0 + 32 * i] = f32x2{m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
 		}
 	};
 
@@ -751,7 +756,8 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 			bv[j] = Bs[buf][rn][lhi][wn * (32 * TN) + j * 32 + l31];
 	};
 
-	auto compute_step = [&](int buf, int next, bool has_next) {
+	// MFMAs of the k-step parked in LDS buffer `buf`; when has_next, the gathers of step `next` go into register set `set`
+	auto compute_step = [&](int buf, int set, int next, bool has_next) {
 		f32x2 av[2][TM], bv[2][TN];
 		read_frag(buf, 0, av[0], bv[0]);
 		if (has_next) load_head(next);
@@ -761,7 +767,7 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 			if (rn + 1 < RUNS) read_frag(buf, rn + 1, av[(rn + 1) & 1], bv[(rn + 1) & 1]);
 			if (has_next && rn < PZ_WG_LOAD_RUNS) {       // gathers go out early in the step: half a step of MFMAs covers their latency
 #pragma unroll
-				for (int j = 0; j < RUNS / PZ_WG_LOAD_RUNS; ++j) load_part(rn * (RUNS / PZ_WG_LOAD_RUNS) + j);
+				for (int j = 0; j < RUNS / PZ_WG_LOAD_RUNS; ++j) load_part(set, rn * (RUNS / PZ_WG_LOAD_RUNS) + j);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -779,34 +785,46 @@ __global__ void __launch_bounds__(256) wgrad_conv_kernel(WgradArgs a) {
 	const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
 
 	if (s_begin < s_end) {
+		// prologue: step s_begin -> set 0 -> LDS buffer 0; step s_begin+1 -> set 1 (left in flight)
 		load_head(s_begin);
 #pragma unroll
-		for (int j = 0; j < NA + NB; ++j) load_part(j);
-		store_step(0);
+		for (int j = 0; j < NA + NB; ++j) load_part(0, j);
+		store_step(0, 0);
+		if (s_begin + 1 < s_end) {
+			load_head(s_begin + 1);
+#pragma unroll
+			for (int j = 0; j < NA + NB; ++j) load_part(1, j);
+		}
 		__syncthreads();
 
-		for (int step = s_begin; step + 1 < s_end; ++step) {
-			const int buf = (step - s_begin) & 1;
-#if PZ_ABL & 8          // ablation: no global loads / LDS stores in the loop (wrong results, timing only)
-			compute_step(buf, step + 1, false);
-#elif PZ_ABL & 32       // ablation: global loads, no LDS stores
-			compute_step(buf, step + 1, true);
-#pragma unroll
-			for (int i = 0; i < NA; ++i) asm volatile("" :: "v"(ra[i]));
-#pragma unroll
-			for (int i = 0; i < NB; ++i) asm volatile("" :: "v"(rb[i]));
-#elif PZ_ABL & 64       // ablation: LDS stores, no global loads
-			compute_step(buf, step + 1, false);
-			store_step(buf ^ 1);
-#else
-			compute_step(buf, step + 1, true);
-			store_step(buf ^ 1);
-#endif
-#if !(PZ_ABL & 16)      // ablation: no barrier
+		// invariant at an even position: LDS buffer 0 holds `step`, set 1 holds step+1 in flight, set 0 is free
+		int step = s_begin;
+		for (; step + 3 < s_end; step += 2) {
+			compute_step(0, 0, step + 2, true);
+			store_step(1, 1);
 			__syncthreads();
-#endif
+			compute_step(1, 1, step + 3, true);
+			store_step(0, 0);
+			__syncthreads();
 		}
-		compute_step((s_end - 1 - s_begin) & 1, 0, false);
+
+		const int left = s_end - step;           // 1, 2 or 3 steps remain
+		if (left == 3) {
+			compute_step(0, 0, step + 2, true);
+			store_step(1, 1);
+			__syncthreads();
+			compute_step(1, 1, 0, false);
+			store_step(0, 0);
+			__syncthreads();
+			compute_step(0, 0, 0, false);
+		} else if (left == 2) {
+			compute_step(0, 0, 0, false);
+			store_step(1, 1);
+			__syncthreads();
+			compute_step(1, 1, 0, false);
+		} else {
+			compute_step(0, 0, 0, false);
+		}
 	}
 
 	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
