@@ -1,0 +1,227 @@
+"""
+Full-size and edge-case checks of the hot path on the GPU (⑶ of the task: BASELINE.json's full sizes through
+size-independent properties; the reference's own edge cases).
+
+* Config 2 of BASELINE.json — Conv2D 3x3, 64 -> 128 maps, 56x56, batch 128, fp32 — at full size: linearity of the
+  forward pass, the adjoint identities <dy, conv(x; w)> = <bwd_data(dy; w), x> = <w, bwd_filter(x, dy)> (backward-data and
+  backward-filter ARE the adjoints of forward in x and in w), and an oracle spot check on two images of the batch.
+* ResNet-50 b256 stage shapes: batch-norm output statistics (per-channel mean = bias, variance = scale^2), residual
+  kernels, pooling round trip (max-pool backward puts each gradient where the maximum was).
+* Determinism: the same training step from the same state gives the same bits (no atomics anywhere on the path).
+* Degenerate shapes the reference's tests touch: 1x1 maps, single image / channel, windows covering the whole plane,
+  zero-size element-wise launches, batch-norm of a constant tensor.
+"""
+import numpy as np
+import pytest
+
+import cpu_ref as R
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu(bnd, ary):
+	return bnd.GPUArray.toGpu(np.ascontiguousarray(ary))
+
+
+def dev_randn(bnd, shape, seed):
+	"""Normal tensor generated on the device (full-size tensors would take seconds to create on the host)."""
+	out = bnd.GPUArray.empty(shape, dtype=np.float32)
+	rng = bnd.RandomNumberGenerator(seed=seed) if hasattr(bnd, "RandomNumberGenerator") else bnd.globalRng
+	rng.fillNormal(out, mean=0.0, stddev=1.0)
+	return out
+
+
+def test_config2_conv_full_size_properties(bnd):
+	n, c, k, h, w = 128, 64, 128, 56, 56
+	kw = dict(stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	dot = bnd.blas.dot
+
+	x1, x2 = dev_randn(bnd, (n, c, h, w), 1), dev_randn(bnd, (n, c, h, w), 2)
+	dy = dev_randn(bnd, (n, k, h, w), 3)
+	wt = gpu(bnd, (np.random.RandomState(4).randn(k, c, 3, 3) / np.sqrt(c * 9)).astype(np.float32))
+
+	y1, y2 = bnd.dnn.convNd(x1, wt, None, **kw), bnd.dnn.convNd(x2, wt, None, **kw)
+	assert y1.shape == (n, k, h, w)
+
+	# linearity in x: conv(2 x1 - 3 x2) == 2 conv(x1) - 3 conv(x2)
+	xs = bnd.GPUArray.empty(x1.shape, dtype=np.float32)
+	bnd.addKer(np.float32)(xs, x1, 2.0, x2, -3.0)
+	ys = bnd.dnn.convNd(xs, wt, None, **kw)
+	comb = bnd.GPUArray.empty(y1.shape, dtype=np.float32)
+	bnd.addKer(np.float32)(comb, y1, 2.0, y2, -3.0)
+	diff = bnd.GPUArray.empty(y1.shape, dtype=np.float32)
+	bnd.addKer(np.float32)(diff, ys, 1.0, comb, -1.0)
+	assert float(diff.max().get()) < 2e-4 and float(diff.min().get()) > -2e-4, "forward is not linear in x"
+
+	# adjoint identities (sums of 51 M products of O(1) terms: relative tolerance on the scalar)
+	lhs = dot(dy.ravel(), y1.ravel())
+	dx = bnd.dnn.convNdBackwardData(dy, wt, data=x1, **kw)
+	mid = dot(dx.ravel(), x1.ravel())
+	dw = bnd.dnn.convNdBackwardParams(x1, dy, wt, **kw)
+	rhs = dot(dw.ravel(), wt.ravel())
+	scale = abs(lhs) + np.sqrt(float(dy.size))
+	assert abs(lhs - mid) < 2e-4 * scale, "backward-data is not the adjoint of forward: %r vs %r" % (lhs, mid)
+	assert abs(lhs - rhs) < 2e-4 * scale, "backward-filter is not the adjoint of forward: %r vs %r" % (lhs, rhs)
+
+	# oracle spot check: images 0 and 127 of the batch
+	xh, wh, dyh = x1.get(), wt.get(), dy.get()
+	for img in (0, n - 1):
+		ref = R.conv2d_fwd(xh[img:img + 1], wh, None, acc=np.float64, **kw)
+		assert_close(y1.get()[img:img + 1], ref, atol=1e-4, rtol=1e-4, what="forward, image %d" % img)
+		ref = R.conv2d_bwd_data(dyh[img:img + 1], wh, (1, c, h, w), acc=np.float64, **kw)
+		assert_close(dx.get()[img:img + 1], ref, atol=1e-4, rtol=1e-4, what="backward-data, image %d" % img)
+
+	# backward-filter against float64 sums over a 4-image sub-batch
+	dw4 = bnd.dnn.convNdBackwardParams(gpu(bnd, xh[:4]), gpu(bnd, dyh[:4]), wt, **kw)
+	ref = R.conv2d_bwd_filter(xh[:4], dyh[:4], wh.shape, withbias=False, acc=np.float64, **kw)
+	assert_close(dw4.get(), ref, atol=2e-6 * np.sqrt(4 * h * w) * 30, rtol=1e-4, what="backward-filter, 4 images")
+
+
+@pytest.mark.parametrize("shape", [(256, 64, 55, 55), (256, 512, 28, 28), (256, 2048, 7, 7)])
+def test_resnet_stage_batchnorm_normalises(bnd, shape):
+	c = shape[1]
+	x = dev_randn(bnd, shape, 7)
+	bnd.linearKer(np.float32)(x, x, 3.0, -1.5)                          # mean -1.5, std 3
+	rng = np.random.RandomState(1)
+	scale, bias = (0.5 + rng.rand(c)).astype(np.float32), rng.randn(c).astype(np.float32)
+	mean, var = gpu(bnd, np.zeros(c, np.float32)), gpu(bnd, np.ones(c, np.float32))
+
+	y, sm, si = bnd.dnn.batchNormNd(x, mean, var, gpu(bnd, scale), gpu(bnd, bias), 1e-5, 1.0, False)
+	n_red = shape[0] * shape[2] * shape[3]                              # samples per channel: 6-sigma sampling bounds
+	assert_close(sm.get(), np.full(c, -1.5, np.float32), atol=6 * 3.0 / np.sqrt(n_red), what="batch mean")
+	assert_close(1.0 / si.get() ** 2, np.full(c, 9.0, np.float32), rtol=6 * np.sqrt(2.0 / n_red), what="batch variance")
+
+	# the output of every channel has mean = bias and variance = scale^2 (checked through the layer itself: a second
+	# BN with unit scale / zero bias must report exactly those statistics)
+	_, m2, i2 = bnd.dnn.batchNormNd(
+		y, gpu(bnd, np.zeros(c, np.float32)), gpu(bnd, np.ones(c, np.float32)), gpu(bnd, np.ones(c, np.float32)),
+		gpu(bnd, np.zeros(c, np.float32)), 0.0, 1.0, False
+	)
+	assert_close(m2.get(), bias, atol=2e-5, rtol=1e-4, what="output mean == bias")
+	assert_close(1.0 / i2.get(), scale, atol=1e-5, rtol=1e-3, what="output std == scale")
+	assert_close(mean.get(), sm.get(), atol=1e-6, what="factor 1: running mean == batch mean")
+
+	# backward: gradients of a BN sum to zero over each channel, and dbias = sum(dy)
+	dy = dev_randn(bnd, shape, 8)
+	dx, dscale, dbias = bnd.dnn.batchNormNdBackward(dy, x, gpu(bnd, scale), sm, si, 1e-5)
+	per_channel = bnd.matmod.matsum(dx.reshape(shape[0], c, shape[2] * shape[3]), axis=2)
+	per_channel = bnd.matmod.matsum(per_channel, axis=0).get()
+	assert np.abs(per_channel).max() < 1e-3 * np.sqrt(n_red), "dx does not sum to zero per channel"
+	ref_db = bnd.matmod.matsum(bnd.matmod.matsum(dy.reshape(shape[0], c, shape[2] * shape[3]), axis=2), axis=0).get()
+	assert_close(dbias.get(), ref_db, atol=1e-4 * np.sqrt(n_red), rtol=1e-4, what="dbias == sum(dy)")
+
+
+def test_resnet_stem_maxpool_round_trip(bnd):
+	shape = (256, 64, 112, 112)
+	x = dev_randn(bnd, shape, 11)
+	y, ws = bnd.dnn.poolNd(x, size=(3, 3), stride=(2, 2), pad=(0, 0), mode=bnd.PoolMode.max.value, test=False)
+	assert y.shape == (256, 64, 55, 55)
+
+	# every output is >= the window centre and equals some input; gradient routing: bwd(dy=1) has exactly one credit per
+	# window (sum == number of windows) and x * (bwd > 0) recovers the maxima
+	ones = bnd.GPUArray.empty(y.shape, dtype=np.float32).fill(1.0)
+	dx = bnd.dnn.poolNdBackward(ones, x, y, ws, size=(3, 3), stride=(2, 2), pad=(0, 0), mode=bnd.PoolMode.max.value)
+	assert abs(bnd.blas.l1norm(dx.ravel()) - y.size) < 1e-3 * y.size
+	# <dx, x> = sum of the maxima = sum(y)
+	lhs, rhs = bnd.blas.dot(dx.ravel(), x.ravel()), bnd.blas.dot(ones.ravel(), y.ravel())
+	assert abs(lhs - rhs) < 1e-4 * (abs(rhs) + np.sqrt(y.size)), (lhs, rhs)
+
+	sub = x.get()[:1, :2]
+	ref = R.pool2d_fwd(sub, (3, 3), (2, 2), (0, 0), R.POOL_MAX)
+	assert np.array_equal(y.get()[:1, :2], ref)
+
+
+def test_training_step_is_deterministic(bnd, mini_golden):
+	from puzzlelib_amd import nets, train
+	from puzzlelib_amd.surface import bound
+
+	gpuarray = bound().gpuarray
+	spec = nets.resnet_spec(stages=((8, 1), (16, 2)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	data, labels = gpuarray.to_gpu(mini_golden["data"]), gpuarray.to_gpu(mini_golden["labels"])
+
+	outs = []
+	for _ in range(2):
+		np.random.seed(7)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		for name, var in nets.namedVariables(net).items():
+			var.data.set(mini_golden["init_" + name])
+		optimizer = train.Adam(alpha=1e-3)
+		optimizer.setupOn(net, useGlobalState=True)
+		trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=4)
+		for _ in range(3):
+			trainer.train(data, labels, random=False)
+		outs.append({k: v.data.get() for k, v in nets.namedVariables(net).items()})
+
+	for name in outs[0]:
+		assert np.array_equal(outs[0][name], outs[1][name]), "non-deterministic parameter " + name
+
+
+@pytest.mark.parametrize("cs", [
+	dict(n=1, c=1, h=1, w=1, k=1, r=1, pad=0, stride=1),          # the smallest convolution
+	dict(n=1, c=3, h=5, w=5, k=2, r=5, pad=0, stride=1),          # filter == image: 1x1 output
+	dict(n=2, c=4, h=1, w=9, k=3, r=1, pad=0, stride=1),          # one-row maps
+	dict(n=7, c=16, h=3, w=3, k=16, r=3, pad=1, stride=1),        # tap-major path, tiny maps, ragged pixel tile
+	dict(n=1, c=2, h=8, w=8, k=5, r=3, pad=3, stride=3),          # padding larger than the filter reach
+])
+def test_conv_degenerate_shapes(bnd, cs):
+	rng = np.random.RandomState(0)
+	x = rng.randn(cs["n"], cs["c"], cs["h"], cs["w"]).astype(np.float32)
+	w = rng.randn(cs["k"], cs["c"], cs["r"], cs["r"]).astype(np.float32)
+	kw = dict(stride=(cs["stride"], ) * 2, pad=(cs["pad"], ) * 2, dilation=(1, 1), groups=1)
+	y_ref = R.conv2d_fwd(x, w, None, acc=np.float64, **kw)
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+
+	gx, gw, gdy = gpu(bnd, x), gpu(bnd, w), gpu(bnd, dy)
+	assert_close(bnd.dnn.convNd(gx, gw, None, **kw).get(), y_ref, atol=1e-4, rtol=1e-4, what="fwd")
+	assert_close(bnd.dnn.convNdBackwardData(gdy, gw, data=gx, **kw).get(),
+				 R.conv2d_bwd_data(dy, w, x.shape, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what="bwd data")
+	dw_ref = R.conv2d_bwd_filter(x, dy, w.shape, withbias=False, acc=np.float64, **kw)
+	assert_close(bnd.dnn.convNdBackwardParams(gx, gdy, gw, **kw).get(), dw_ref, atol=1e-4, rtol=1e-4, what="bwd filter")
+
+
+def test_elementwise_and_norm_edge_cases(bnd):
+	# zero-size launches are no-ops
+	empty = bnd.GPUArray.empty((0, ), dtype=np.float32)
+	bnd.reluKer(np.float32)(empty, empty)
+	bnd.add3Ker(empty, empty, empty)
+	assert empty.get().shape == (0, )
+
+	# sizes around the 16-byte vector width, unaligned views
+	for n in (1, 2, 3, 4, 5, 7, 8, 9, 1023):
+		a = np.random.RandomState(n).randn(n + 3).astype(np.float32)
+		ga = gpu(bnd, a)
+		view = ga[1:n + 1]                                        # 4-byte aligned only
+		out = bnd.GPUArray.empty((n, ), dtype=np.float32)
+		bnd.reluKer(np.float32)(out, view)
+		assert np.array_equal(out.get(), R.relu(a[1:n + 1]))
+
+	# batch-norm of a constant tensor: variance 0 -> y = bias, invvar = 1/sqrt(eps)
+	c = 3
+	x = gpu(bnd, np.full((4, c, 5, 5), 2.5, np.float32))
+	y, sm, si = bnd.dnn.batchNormNd(
+		x, gpu(bnd, np.zeros(c, np.float32)), gpu(bnd, np.ones(c, np.float32)), gpu(bnd, np.full(c, 2.0, np.float32)),
+		gpu(bnd, np.full(c, -1.0, np.float32)), 1e-5, 1.0, False
+	)
+	assert_close(sm.get(), np.full(c, 2.5, np.float32), atol=1e-6, what="mean of a constant")
+	assert_close(si.get(), np.full(c, 1.0 / np.sqrt(1e-5), np.float32), rtol=1e-4, what="invvar of a constant")
+	assert_close(y.get(), np.full((4, c, 5, 5), -1.0, np.float32), atol=1e-4, what="y == bias")
+
+	# single-element reductions / N = 1 batch-norm with one pixel
+	x1 = gpu(bnd, np.array([[[[4.0]]]], np.float32))
+	y1, sm1, _ = bnd.dnn.batchNormNd(
+		x1, gpu(bnd, np.zeros(1, np.float32)), gpu(bnd, np.ones(1, np.float32)), gpu(bnd, np.ones(1, np.float32)),
+		gpu(bnd, np.zeros(1, np.float32)), 1e-5, 1.0, False
+	)
+	assert float(sm1.get()[0]) == 4.0 and abs(float(y1.get().ravel()[0])) < 1e-6
+
+	# pooling window == plane (global average / global max), 1x1 window
+	xp = np.random.RandomState(3).randn(2, 3, 7, 7).astype(np.float32)
+	gp = gpu(bnd, xp)
+	avg = bnd.dnn.poolNd(gp, size=(7, 7), stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.avgWithPad.value, test=True)
+	assert_close(avg.get(), xp.mean(axis=(2, 3), keepdims=True), atol=1e-6, what="global average")
+	mx = bnd.dnn.poolNd(gp, size=(7, 7), stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.max.value, test=True)
+	assert np.array_equal(mx.get(), xp.max(axis=(2, 3), keepdims=True))
+	one = bnd.dnn.poolNd(gp, size=(1, 1), stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.max.value, test=True)
+	assert np.array_equal(one.get(), xp)
