@@ -55,10 +55,19 @@ def cpu_baseline(sample_batch=32):
 	N.train_step(net, opt, data, labels)
 	dt = time.perf_counter() - t0
 
+	threads = os.cpu_count()
+	try:                                               # the threads numpy's BLAS actually runs its GEMMs on
+		from threadpoolctl import threadpool_info
+		blas = [p["num_threads"] for p in threadpool_info() if p.get("user_api") == "blas"]
+		threads = max(blas) if blas else threads
+	except Exception:
+		pass
+
 	return {
-		"value": sample_batch / dt, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
-		"sample": "1 training step (fwd+CE+bwd+Adam) of the same ResNet-50 at batch %d, %.1f s wall, numpy %s" % (
-			sample_batch, dt, np.__version__
+		"value": sample_batch / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+		"sample": "1 training step (fwd+CE+bwd+Adam) of the same ResNet-50 at batch %d, %.1f s wall, numpy %s, BLAS threads %d "
+				  "of %d host CPUs (im2col / element-wise parts are single-threaded numpy)" % (
+			sample_batch, dt, np.__version__, threads, os.cpu_count()
 		)
 	}
 

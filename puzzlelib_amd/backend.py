@@ -665,6 +665,94 @@ class CostModule:
 		raise NotImplementedError("SVM cost is outside the implemented operator path")
 
 
+class MemModule:
+	"""transpose / moveaxis / swapaxes / depthConcat / depthSplit — Cuda/Kernels/Memory.py:81-203. The reference
+	instantiates a `transformNd` kernel per rank; here every case is one strided copy (pz_strided_copy, up to 6 axes)
+	between a tensor and a strided VIEW of the other side, so the index arithmetic lives in the view's strides."""
+
+	def __init__(self, backend):
+		self.backend = backend
+
+
+	@staticmethod
+	def viewLike(ary, shape, strides, offsetBytes=0):
+		return GPUArray(shape, ary.dtype, gpudata=ary.gpudata[offsetBytes:], strides=strides)
+
+
+	def transpose(self, tensor, axes=None, out=None, allocator=None):
+		if axes is not None and len(axes) != tensor.ndim:
+			raise ValueError("axes do not match the tensor rank")
+		if tensor.dtype.itemsize != 4:
+			raise NotImplementedError("memmod: 4-byte element types only (this backend computes in float32)")
+
+		axes = tuple(reversed(range(tensor.ndim))) if axes is None else tuple(axes)
+		shape = tuple(tensor.dimAt(axis) for axis in axes)
+
+		if out is None:
+			out = GPUArray.empty(shape, dtype=tensor.dtype, allocator=allocator)
+		elif out.shape != shape:
+			raise ValueError("transpose output has shape %s, expected %s" % (out.shape, shape))
+
+		outstrides = [0] * len(axes)
+		for i, axis in enumerate(axes):
+			outstrides[axis] = out.strideAt(i)
+
+		if tensor.size > 0:
+			self.viewLike(out, tensor.shape, outstrides).stridedCopyFrom(tensor)
+		return out
+
+
+	def moveaxis(self, data, src, dst, out=None, allocator=None):
+		if src < dst:
+			axes = tuple(range(src)) + tuple(range(src + 1, dst + 1)) + (src, ) + tuple(range(dst + 1, data.ndim))
+		else:
+			axes = tuple(range(dst)) + (src, ) + tuple(range(dst, src)) + tuple(range(src + 1, data.ndim))
+		return self.transpose(data, axes, out=out, allocator=allocator)
+
+
+	def swapaxes(self, data, axis1, axis2, out=None, allocator=None):
+		axes = list(range(data.ndim))
+		axes[axis1], axes[axis2] = axes[axis2], axes[axis1]
+		return self.transpose(data, tuple(axes), out=out, allocator=allocator)
+
+
+	@staticmethod
+	def centred(big, small):
+		"""byte offset that centres `small`'s maps inside `big`'s (Memory.py:178,194)"""
+		return (big.dimAt(2) - small.dimAt(2)) // 2 * big.strideAt(2) + (big.dimAt(3) - small.dimAt(3)) // 2 * big.strideAt(3)
+
+
+	def depthConcat(self, tensors, out=None, allocator=None):
+		assert all(tn.ndim == 4 and tn.dtype == tensors[0].dtype for tn in tensors)
+		assert all(tn.dimAt(0) == tensors[0].dimAt(0) for tn in tensors)
+
+		depth = sum(tn.dimAt(1) for tn in tensors)
+		h, w = max(tn.dimAt(2) for tn in tensors), max(tn.dimAt(3) for tn in tensors)
+		shape = (tensors[0].dimAt(0), depth, h, w)
+
+		if out is None:
+			out = GPUArray.zeros(shape, dtype=tensors[0].dtype, allocator=allocator)
+		elif out.shape != shape:
+			raise ValueError("depthConcat output has shape %s, expected %s" % (out.shape, shape))
+
+		offset = 0
+		for tn in tensors:
+			self.viewLike(out, tn.shape, out.strides, offset + self.centred(out, tn)).stridedCopyFrom(tn)
+			offset += out.strideAt(1) * tn.dimAt(1)
+		return out
+
+
+	def depthSplit(self, grad, tensors, allocator=None):
+		assert all(tn.ndim == 4 and tn.dtype == tensors[0].dtype for tn in tensors)
+		ingrads = [GPUArray.empty(tn.shape, dtype=tn.dtype, allocator=allocator) for tn in tensors]
+
+		offset = 0
+		for gr in ingrads:
+			gr.stridedCopyFrom(self.viewLike(grad, gr.shape, grad.strides, offset + self.centred(grad, gr)))
+			offset += grad.strideAt(1) * gr.dimAt(1)
+		return ingrads
+
+
 class StubModule:
 	def __init__(self, name):
 		self.stubName = name
@@ -888,7 +976,8 @@ class Mi355Backend:
 		self.costmod = CostModule(self)
 		self.getAccuracyKernel = self.costmod.getAccuracyKernel
 
-		for name in ("ctcmod", "embedmod", "padmod", "poolmod", "prelumod", "upsamplemod", "memmod"):
+		self.memmod = MemModule(self)
+		for name in ("ctcmod", "embedmod", "padmod", "poolmod", "prelumod", "upsamplemod"):
 			setattr(self, name, StubModule(name))
 
 		K = memoizedKernel

@@ -156,3 +156,33 @@ def test_train_from_host_async_upload_is_bit_identical(bnd):
 
 	for name in results[0]:
 		assert np.array_equal(results[0][name], results[1][name]), name
+
+
+def test_memmod_matches_the_reference_tests(bnd):
+	"""Cuda/Kernels/Memory.py:221-300 (transposeTest / moveAxisTest / swapAxesTest / depthConcatTest) with numpy as the
+	oracle, exactly as the reference tests do; shapes and cases are the reference's."""
+	import itertools
+	rng = np.random.RandomState(0)
+	mem = bnd.memmod
+
+	for shape in [(10, ), (10, 3), (10, 3, 5, 4, 2)]:
+		host = rng.randn(*shape).astype(np.float32)
+		data = bnd.GPUArray.toGpu(host)
+
+		for axes in itertools.permutations(range(len(shape))):
+			assert np.array_equal(mem.transpose(data, axes=axes).get(), np.transpose(host, axes=axes))
+		for src, dst in itertools.product(range(len(shape)), repeat=2):
+			assert np.array_equal(mem.moveaxis(data, src=src, dst=dst).get(), np.moveaxis(host, src, dst))
+			assert np.array_equal(mem.swapaxes(data, axis1=src, axis2=dst).get(), np.swapaxes(host, src, dst))
+		assert np.array_equal(mem.transpose(data).get(), host.T)
+
+	hosts = [rng.randn(3, 4, 3, 3).astype(np.float32), rng.randn(3, 2, 6, 6).astype(np.float32), rng.randn(3, 5, 4, 4).astype(np.float32)]
+	tensors = [bnd.GPUArray.toGpu(h) for h in hosts]
+	ref = np.zeros((3, 11, 6, 6), np.float32)
+	ref[:, :4, 1:4, 1:4], ref[:, 4:6], ref[:, 6:, 1:5, 1:5] = hosts
+	assert np.array_equal(mem.depthConcat(tensors).get(), ref)
+
+	grad = rng.randn(*ref.shape).astype(np.float32)
+	parts = mem.depthSplit(bnd.GPUArray.toGpu(grad), tensors)
+	for part, want in zip(parts, [grad[:, :4, 1:4, 1:4], grad[:, 4:6], grad[:, 6:, 1:5, 1:5]]):
+		assert np.array_equal(part.get(), want)
