@@ -158,6 +158,16 @@ int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const fl
                         float *run_mean, float *run_var, float *save_mean, float *save_invvar,
                         float epsilon, float factor, int act, const float *stats, int strips,
                         void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
+ * projection shortcut of Models/Nets/ResNet.py:36-58) the normalised tensor is never written. pz_bn_fwd_train_defer does
+ * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;
+ * pz_bn_apply_add computes out = act((a1*x1 + b1) + (coef2 ? a2*x2 + b2 : x2)) — or out = a1*x1 + b1 when x2 == NULL —
+ * with the same fma and summation order as the unfused kernels (bit-identical), saving 8 B/elem per deferred BN. */
+int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float *bias, float *run_mean, float *run_var,
+                          float *save_mean, float *save_invvar, float epsilon, float factor, const float *stats,
+                          int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_bn_apply_add(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
+                    int n, int c, int hw, int relu, pz_stream_t stream);
 int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, void *workspace, size_t ws_bytes, pz_stream_t stream);

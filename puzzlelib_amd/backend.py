@@ -113,6 +113,26 @@ def pair(v):
 	return (int(v), int(v)) if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
 
 
+class DeferredBN:
+	"""A batch-normalised tensor that was not written: the un-normalised input plus per-channel {a, b} of y = a*x + b
+	(pz_bn_fwd_train_defer). Only DnnContext.bnApplyAdd consumes it; `materialize()` writes it out for anyone else."""
+	__slots__ = ["tensor", "coef", "dnn"]
+
+	def __init__(self, tensor, coef, dnn):
+		self.tensor, self.coef, self.dnn = tensor, coef, dnn
+
+	@property
+	def shape(self):
+		return self.tensor.shape
+
+	@property
+	def dtype(self):
+		return self.tensor.dtype
+
+	def materialize(self, allocator=None):
+		return self.dnn.bnApplyAdd(self, None, relu=False, allocator=allocator)
+
+
 class ConvStats:
 	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
 	__slots__ = ["tensor", "stats"]
@@ -468,8 +488,27 @@ class DnnContext:
 		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
 
 
+	def bnApplyAdd(self, first, second, relu=False, allocator=None):
+		"""out = act(bn(first) + second') for a DeferredBN `first` and `second` = DeferredBN | GPUArray | None
+		(None: out = bn(first), no activation). Backend-internal (see Sequential.planFusion)."""
+		x1 = first.tensor
+		n, c, hw = x1.shape[0], x1.shape[1], prod(x1.shape[2:])
+		if isinstance(second, DeferredBN):
+			x2, coef2 = second.tensor, second.coef
+		else:
+			x2, coef2 = second, None
+		if x2 is not None and x2.shape != x1.shape:
+			raise ValueError("bnApplyAdd: operand shapes %s and %s differ" % (x1.shape, x2.shape))
+		requireF32(x1, x2)
+
+		out = GPUArray.empty(x1.shape, dtype=x1.dtype, allocator=allocator)
+		lib.pz_bn_apply_add(x1.ptr, first.coef.ptr, ptrOf(x2), ptrOf(coef2), out.ptr, n, c, hw, int(bool(relu)), None)
+		return out
+
+
 	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,
-					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False, convStats=None):
+					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False, convStats=None,
+					defer=False):
 		"""`fuseRelu` (backend-internal, train mode only): write relu(bn(data)) — used by Sequential for a BatchNorm
 		followed by an in-place ReLU; the matching backward is batchNormNdBackward(..., bias=, fuseRelu=True)."""
 		assert mean.ndim == 1 and var.ndim == 1 and scale.ndim == 1 and bias.ndim == 1
@@ -478,8 +517,21 @@ class DnnContext:
 		if mode != BatchNormMode.spatial.value:
 			raise NotImplementedError("per-activation batch normalisation is not implemented on this backend")
 
-		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
 		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
+
+		if defer and not test and not fuseRelu and out is None and convStats is not None and convStats.tensor is data:
+			# statistics from the convolution's strip sums, normalisation left to the consumer (bnApplyAdd)
+			savemean = GPUArray.empty(mean.shape, dtype=data.dtype, allocator=allocator)
+			saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
+			coef = GPUArray.empty((c, 2), dtype=data.dtype, allocator=allocator)
+			ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+			lib.pz_bn_fwd_train_defer(
+				n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr, epsilon, factor,
+				convStats.stats.ptr, convStats.stats.shape[1], coef.ptr, ws.ptr, nbytes, None
+			)
+			return DeferredBN(data, coef, self), savemean, saveinvvar
+
+		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
 
 		if test:
 			lib.pz_bn_fwd_infer(data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, epsilon, None)

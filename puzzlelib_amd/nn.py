@@ -462,6 +462,7 @@ class BatchNorm2D(Module):
 		self.savemean = self.saveinvvar = self.scalegrad = self.biasgrad = None
 		self.fusedRelu = False       # set per forward pass by Sequential (planFusion): output is relu(bn(x))
 		self.statsFrom = None        # ... and the Conv2D right in front whose epilogue sums this layer's input per channel
+		self.deferApply = False      # ... the only consumer is a residual Add that normalises on the fly (DeferredBN output)
 
 		if empty:
 			return
@@ -488,7 +489,8 @@ class BatchNorm2D(Module):
 
 			self.data, self.savemean, self.saveinvvar = dnn.batchNormNd(
 				data, self.scale, self.bias, self.mean, self.var, self.epsilon, factor, False, fuseRelu=self.fusedRelu,
-				convStats=self.statsFrom.outStats if self.statsFrom is not None else None
+				convStats=self.statsFrom.outStats if self.statsFrom is not None else None,
+				defer=self.deferApply and not self.fusedRelu
 			)
 		else:
 			self.data = dnn.batchNormNd(
@@ -688,6 +690,10 @@ class AvgPool2D(Pool2D):
 		self.mode = PoolMode.avgWithPad if includePad else PoolMode.avgNoPad
 
 
+def isDeferred(obj):
+	return type(obj).__name__ == "DeferredBN"
+
+
 def sumTensors(tensors, relu=False, gate=None):
 	"""memset + one axpy per input in the reference (Modules/Add.py:15-22, Replicate.py:22-29: 28 B/elem for two
 	inputs); here the first two inputs are summed by one 3-operand kernel (12 B/elem), further ones by axpy.
@@ -724,6 +730,14 @@ class Add(Module):
 
 
 	def updateData(self, data):
+		lazy = [isDeferred(d) for d in data]
+		if any(lazy):
+			if len(data) == 2:            # normalise the deferred BatchNorm outputs while summing them
+				first, second = (data[0], data[1]) if lazy[0] else (data[1], data[0])
+				self.data = S().Dnn.bnApplyAdd(first, second, relu=self.fusedRelu)
+				return
+			data = [d.materialize() if isDeferred(d) else d for d in data]
+
 		if self.fusedRelu and len(data) != 2:
 			self.data = sumTensors(data)
 			S().ElementWise.reluKer(self.data.dtype)(self.data, self.data)
@@ -1026,6 +1040,7 @@ class Sequential(Container):
 	honourUpdGrad = True
 	fuseInplaceRelu = True       # backend-internal fusion around in-place ReLUs (see planFusion)
 	fuseConvStats = True         # BatchNorm statistics from the preceding convolution's epilogue (see planFusion)
+	fuseBnAdd = True             # residual Add normalises its BatchNorm inputs on the fly (see planFusion)
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1040,6 +1055,9 @@ class Sequential(Container):
 		  Add (2 inputs)      -> ReLU : the sum kernel writes relu(a + b)
 		  ReLU -> Replicate(2)        : the fan-in kernel writes (g0 + g1) * (y > 0), y = the ReLU's output
 		The ReLU module itself then only forwards data / grad. Values are bit-identical to the unfused sequence.
+		Sequential.fuseBnAdd: Parallel(… Conv2D -> BatchNorm2D, …) -> Add: those BatchNorms only compute their
+		statistics / coefficients; the Add kernel reads the convolution outputs and normalises while summing
+		(bit-identical; the BN output tensor is never written).
 		Independently of ReLUs (Sequential.fuseConvStats): Conv2D -> BatchNorm2D (train): the convolution's epilogue
 		leaves per-strip channel sums of its output and the BN skips its own statistics pass over that tensor (same
 		mean/variance up to fp32 summation order)."""
@@ -1055,6 +1073,18 @@ class Sequential(Container):
 
 			if isinstance(mod, Conv2D):
 				mod.emitStats = False
+
+			# Parallel -> Add: a branch ending in Conv2D -> BatchNorm2D hands the Add an un-normalised tensor plus
+			# per-channel coefficients (the BN's output has no other reader), see BatchNorm2D.deferApply
+			if isinstance(mod, Parallel):
+				nxt = graph[i + 1] if i + 1 < len(graph) else None
+				for branch in mod.graph:
+					tail = branch.graph[-2:] if isinstance(branch, Sequential) else []
+					if len(tail) == 2 and isinstance(tail[1], BatchNorm2D) and isinstance(tail[0], Conv2D):
+						tail[1].deferApply = (
+							Sequential.fuseBnAdd and Sequential.fuseConvStats and tail[1].train and isinstance(nxt, Add) and
+							len(mod.graph) == 2
+						)
 			if isinstance(mod, BatchNorm2D):
 				prev = graph[i - 1] if i > 0 else None
 				mod.statsFrom = None

@@ -99,11 +99,11 @@ def bind():
 		return dnn.poolNdBackward(grad, indata, outdata, workspace, size, stride, pad, mode.value, None, memoryPool)
 
 	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None,
-					fuseRelu=False, convStats=None):
+					fuseRelu=False, convStats=None, defer=False):
 		shape = scale.shape
 		result = dnn.batchNormNd(
 			data, mean.ravel(), var.ravel(), scale.ravel(), bias.ravel(), epsilon, factor, test, mode.value, out=out,
-			allocator=memoryPool, fuseRelu=fuseRelu, convStats=convStats
+			allocator=memoryPool, fuseRelu=fuseRelu, convStats=convStats, defer=defer
 		)
 		if test:
 			return result
@@ -131,7 +131,11 @@ def bind():
 		fwd, bwdData, bwdParam = bnd.convNdbenchmark(datashape, Wshape, np.float32, stride, pad, dilation, groups)
 		return fwd, bwdParam, bwdData
 
+	def bnApplyAdd(first, second, relu=False):
+		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool)
+
 	Dnn = SimpleNamespace(
+		bnApplyAdd=bnApplyAdd,
 		ConvFwdAlgo=bnd.ConvFwdAlgo, ConvBwdDataAlgo=bnd.ConvBwdDataAlgo, ConvBwdFilterAlgo=bnd.ConvBwdFilterAlgo,
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,

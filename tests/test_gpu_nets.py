@@ -140,8 +140,9 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 	data, labels = mini_golden["data"], mini_golden["labels"]
 
 	results = {}
-	for fused in (False, True):
-		nn.Sequential.fuseInplaceRelu = fused
+	for fused in (False, True, "no-bn-add"):
+		nn.Sequential.fuseInplaceRelu = bool(fused)
+		nn.Sequential.fuseBnAdd = fused is True        # False / "no-bn-add": the residual Add reads materialised BN outputs
 		try:
 			np.random.seed(7)
 			net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
@@ -162,6 +163,9 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 			optimizer.update()
 			params = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
 
+			if fused is True:
+				bns = [m for m in allModules(net) if isinstance(m, nn.BatchNorm2D)]
+				assert sum(m.deferApply for m in bns) == 5, "3 blocks' branch-tail BNs + 2 projection-shortcut BNs feed an Add"
 			if fused:
 				acts = [m for m in allModules(net) if isinstance(m, nn.Activation)]
 				assert acts and all(m.dataFused and m.gradFused for m in acts[:-1]), "every inner ReLU must have been absorbed"
@@ -169,13 +173,15 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 
 			results[fused] = (logits, float(cost.devErr.get()), grads, params)
 		finally:
-			nn.Sequential.fuseInplaceRelu = True
+			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = True
 
-	(l0, e0, g0, p0), (l1, e1, g1, p1) = results[False], results[True]
-	assert np.array_equal(l0, l1) and e0 == e1
-	for name in g0:
-		assert np.array_equal(g0[name], g1[name]), "grad " + name
-		assert np.array_equal(p0[name], p1[name]), "param " + name
+	(l1, e1, g1, p1) = results[True]
+	for other in (False, "no-bn-add"):
+		l0, e0, g0, p0 = results[other]
+		assert np.array_equal(l0, l1) and e0 == e1
+		for name in g0:
+			assert np.array_equal(g0[name], g1[name]), "grad %s (%s)" % (name, other)
+			assert np.array_equal(p0[name], p1[name]), "param %s (%s)" % (name, other)
 
 	assert_close(l1, mini_golden["orc_logits"], atol=2e-4, rtol=1e-3, what="logits")
 	assert np.isclose(e1, mini_golden["orc_err"][0], rtol=1e-4)

@@ -427,6 +427,43 @@ def test_conv_epilogue_statistics_feed_batchnorm(bnd, cfg):
 	assert np.array_equal(sm_c.get(), sm_a.get())
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 13, 17), (4, 64, 28, 28), (2, 130, 7, 7)])
+def test_deferred_batchnorm_into_residual_add(bnd, shape):
+	"""pz_bn_fwd_train_defer + pz_bn_apply_add == batchNormNd + add3(/Relu) bit for bit (projection and identity shortcuts,
+	with and without the fused ReLU), and materialize() == the BN output."""
+	rng = np.random.RandomState(2)
+	n, k = shape[0], shape[1]
+	kw = dict(stride=(1, 1), pad=(0, 0), dilation=(1, 1), groups=1)
+
+	def conv_bn(seed, defer):
+		r = np.random.RandomState(seed)
+		x = gpu(bnd, r.randn(n, 8, *shape[2:]).astype(np.float32))
+		w = gpu(bnd, r.randn(k, 8, 1, 1).astype(np.float32))
+		scale, bias = gpu(bnd, r.randn(k).astype(np.float32)), gpu(bnd, r.randn(k).astype(np.float32))
+		mean, var = gpu(bnd, np.zeros(k, np.float32)), gpu(bnd, np.ones(k, np.float32))
+		y, stats = bnd.dnn.convNd(x, w, None, withStats=True, **kw)
+		assert stats is not None
+		out, sm, si = bnd.dnn.batchNormNd(y, mean, var, scale, bias, 1e-5, 0.5, False, convStats=stats, defer=defer)
+		return out, sm, si, mean, var
+
+	a_l, sm_l, si_l, rm_l, rv_l = conv_bn(1, True)
+	a_m, sm_m, si_m, rm_m, rv_m = conv_bn(1, False)
+	b_l, *_ = conv_bn(2, True)
+	b_m, *_ = conv_bn(2, False)
+	assert type(a_l).__name__ == "DeferredBN" and a_l.shape == a_m.shape
+	for got, want in ((sm_l, sm_m), (si_l, si_m), (rm_l, rm_m), (rv_l, rv_m)):
+		assert np.array_equal(got.get(), want.get())
+	assert np.array_equal(a_l.materialize().get(), a_m.get())
+
+	plain = gpu(bnd, rng.randn(*a_m.shape).astype(np.float32))             # identity shortcut
+	out = bnd.GPUArray.empty(a_m.shape, dtype=np.float32)
+	for second_l, second_m in ((b_l, b_m), (plain, plain)):
+		bnd.add3Ker(out, a_m, second_m)
+		assert np.array_equal(bnd.dnn.bnApplyAdd(a_l, second_l, relu=False).get(), out.get())
+		bnd.add3ReluKer(out, a_m, second_m)
+		assert np.array_equal(bnd.dnn.bnApplyAdd(a_l, second_l, relu=True).get(), out.get())
+
+
 @pytest.mark.parametrize("n", [1, 5, 1024, 4 * 3025 + 3])
 def test_fused_residual_kernels(bnd, n):
 	rng = np.random.RandomState(n)
