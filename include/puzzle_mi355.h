@@ -158,6 +158,13 @@ int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const fl
                         float *run_mean, float *run_var, float *save_mean, float *save_invvar,
                         float epsilon, float factor, int act, const float *stats, int strips,
                         void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* pz_bn_bwd_act that also accumulates the parameter gradients where the optimiser reads them:
+ * dscale_acc <- alpha*dscale + beta*dscale_acc (same for dbias_acc; either may be NULL) — BatchNormND.accGradParams
+ * (Modules/BatchNormND.py:74-83, Blas.addVectorToVector with alpha = scale, beta = momentum) without its two launches. */
+int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                  const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                  int act, float *dscale_acc, float *dbias_acc, float alpha, float beta,
+                  void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
  * projection shortcut of Models/Nets/ResNet.py:36-58) the normalised tensor is never written. pz_bn_fwd_train_defer does
  * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;

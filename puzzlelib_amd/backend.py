@@ -558,7 +558,10 @@ class DnnContext:
 
 
 	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
-							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False):
+							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False,
+							accumulate=None):
+		"""`accumulate` (backend-internal) = (scalegradDst, biasgradDst, alpha, beta): additionally
+		dst = alpha*fresh + beta*dst for both parameter gradients inside the same launch."""
 		assert data.ndim == grad.ndim
 		requireF32(grad, data, scale, savemean, saveinvvar, out, bias)
 		if fuseRelu and bias is None:
@@ -573,9 +576,12 @@ class DnnContext:
 		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
 		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 
-		lib.pz_bn_bwd_act(
+		sdst, bdst, alpha, beta = accumulate if accumulate is not None else (None, None, 1.0, 0.0)
+		requireF32(sdst, bdst)
+		lib.pz_bn_bwd_acc(
 			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr if fuseRelu else None, savemean.ptr,
-			saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE, ws.ptr, nbytes, None
+			saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE,
+			ptrOf(sdst), ptrOf(bdst), alpha, beta, ws.ptr, nbytes, None
 		)
 		return out, scalegrad, bgrad
 

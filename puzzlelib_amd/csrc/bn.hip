@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
                                                             const float *__restrict__ scale, const float *__restrict__ bias,
                                                             const float *__restrict__ save_mean,
                                                             const float *__restrict__ save_invvar, float *__restrict__ dscale,
-                                                            float *__restrict__ dbias) {
+                                                            float *__restrict__ dbias, float *__restrict__ dscale_acc,
+                                                            float *__restrict__ dbias_acc, float alpha, float beta) {
 	const int ch = blockIdx.x, s = blockIdx.y;
 
 	double S1, S2;
@@ -350,6 +351,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 	if (s == 0 && threadIdx.x == 0) {
 		dscale[ch] = ds;
 		dbias[ch] = db;
+		// optional parameter-gradient accumulate (BatchNormND.accGradParams: grad = scale*fresh + momentum*grad) — saves the
+		// two 5 us vector kernels per layer
+		if (dscale_acc) dscale_acc[ch] = alpha * ds + (beta == 0.f ? 0.f : beta * dscale_acc[ch]);
+		if (dbias_acc) dbias_acc[ch] = alpha * db + (beta == 0.f ? 0.f : beta * dbias_acc[ch]);
 	}
 
 	// dx = sc*rstd*(dy - db/m - xhat*ds/m),  xhat = (x-mu)*rstd
@@ -503,6 +508,13 @@ int pz_bn_fwd_infer(const float *x, float *y, int n, int c, int hw, const float 
 int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *bias,
                   const float *save_mean, const float *save_invvar, float *dscale, float *dbias, int act, void *workspace,
                   size_t ws_bytes, pz_stream_t stream) {
+	return pz_bn_bwd_acc(x, dy, dx, n, c, hw, scale, bias, save_mean, save_invvar, dscale, dbias, act, nullptr, nullptr, 1.f, 0.f,
+	                     workspace, ws_bytes, stream);
+}
+
+int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *bias,
+                  const float *save_mean, const float *save_invvar, float *dscale, float *dbias, int act, float *dscale_acc,
+                  float *dbias_acc, float alpha, float beta, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias, "pz_bn_bwd: null tensor");
 	PZ_REQUIRE(act == PZ_BN_ACT_NONE || (act == PZ_BN_ACT_RELU && bias), "pz_bn_bwd: fused activation %d needs the bias", act);
@@ -516,11 +528,13 @@ int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int 
 	if (act == PZ_BN_ACT_RELU) {
 		bn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(x, dy, g, save_mean, save_invvar, scale, bias, part);
 		PZ_LAUNCH_CHECK();
-		bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias);
+		bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias,
+		                                                dscale_acc, dbias_acc, alpha, beta);
 	} else {
 		bn_bwd_stats_kernel<false><<<grid, 256, 0, st>>>(x, dy, g, save_mean, save_invvar, scale, bias, part);
 		PZ_LAUNCH_CHECK();
-		bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias);
+		bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias,
+		                                                 dscale_acc, dbias_acc, alpha, beta);
 	}
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;

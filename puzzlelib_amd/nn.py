@@ -499,10 +499,23 @@ class BatchNorm2D(Module):
 			)
 
 
+	def backward(self, grad, updParamGrads=True, updGrad=True, scale=1.0, momentum=0.0):
+		"""Module.backward (Modules/Module.py) runs updateGrad then accGradParams; when both are wanted the parameter
+		gradients are accumulated by the backward kernel itself (pz_bn_bwd_acc) instead of two extra vector kernels."""
+		self.accumulate = None
+		if updGrad and updParamGrads and self.train and self.affine:
+			self.accumulate = (self.vars["scale"].grad, self.vars["bias"].grad, scale, momentum)
+		try:
+			super().backward(grad, updParamGrads=updParamGrads, updGrad=updGrad, scale=scale, momentum=momentum)
+		finally:
+			self.accumulate = None
+
+
 	def updateGrad(self, grad):
 		tup = S().Dnn.batchNormNdBackward(
 			self.inData, grad, self.scale, self.savemean, self.saveinvvar, self.epsilon,
-			bias=self.bias if self.fusedRelu else None, fuseRelu=self.fusedRelu
+			bias=self.bias if self.fusedRelu else None, fuseRelu=self.fusedRelu,
+			accumulate=getattr(self, "accumulate", None)
 		)
 		if self.affine:
 			self.grad, self.scalegrad, self.biasgrad = tup
@@ -511,7 +524,7 @@ class BatchNorm2D(Module):
 
 
 	def accGradParams(self, grad, scale=1.0, momentum=0.0):
-		if not self.affine:
+		if not self.affine or getattr(self, "accumulate", None) is not None:     # already done inside updateGrad
 			return
 
 		Blas = S().Blas
