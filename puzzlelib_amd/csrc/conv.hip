@@ -30,8 +30,8 @@
 #ifndef PZ_IG_LOAD_STEPS
 #define PZ_IG_LOAD_STEPS 8        // k2-steps of a k-tile over which the next tile's global loads are spread
 #endif
-#ifndef PZ_WG_LOAD_RUNS
-#define PZ_WG_LOAD_RUNS 8
+#ifndef PZ_WG_RUNS
+#define PZ_WG_RUNS 8              // 4-pixel runs per backward-filter k-step: 8 (32 pixels, 2 workgroups/CU) or 4 (16 pixels, 4/CU)
 #endif
 #ifndef PZ_LB
 #define PZ_LB 4
@@ -606,17 +606,18 @@ struct WgradArgs {
 // both operands arrive as 16-byte loads (4-byte aligned is enough on gfx950). A k-step is 8 runs = 32 (padded) pixels.
 // LDS keeps a run as two 8-byte half-cells [run][half][row]{2 pixels}: the MFMA fragment of lane (row, half h) is
 // {pixel 2h, 2h+1} of its row, i.e. the k order inside a run is (0,2 | 1,3) for both operands.
-template <int BM, int BN, int WM, int WN, bool UNIT_W>
-__global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
-	constexpr int BK = 32, RUNS = BK / 4;
+template <int BM, int BN, int WM, int WN, bool UNIT_W, int RUNS>
+__global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(WgradArgs a) {
+	constexpr int RP = 256 / RUNS;               // tile rows loaded per pass (one 16-byte run per thread)
+	constexpr int PADC = RUNS == 8 ? 2 : 4;      // row padding (cells) that spreads the (run, row) write pattern over all banks
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4, "4 waves per workgroup");
 
 	typedef float f32x2 __attribute__((ext_vector_type(2)));
 	// double buffered (one barrier per k-step); row stride BM + 2 makes the 8-runs x 4-rows write pattern of half a wave
 	// and the 32-consecutive-rows read pattern both bank-conflict free
-	__shared__ __attribute__((aligned(16))) f32x2 As[2][RUNS][2][BM + 2];
-	__shared__ __attribute__((aligned(16))) f32x2 Bs[2][RUNS][2][BN + 2];
+	__shared__ __attribute__((aligned(16))) f32x2 As[2][RUNS][2][BM + PADC];
+	__shared__ __attribute__((aligned(16))) f32x2 Bs[2][RUNS][2][BN + PADC];
 	__shared__ int2 tabs[BN];
 
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -634,7 +635,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	if (tid < BN) tabs[tid] = a.tab[tn * BN + tid];
 
 	const int run = tid % RUNS, row0 = tid / RUNS;    // this thread's run of the k-step, first tile row it loads (32 rows per pass)
-	constexpr int NA = BM / 32, NB = BN / 32;
+	constexpr int NA = BM / RP, NB = BN / RP;
+	static_assert(NA >= 1 && NB >= 1, "tile narrower than one load pass");
 
 	f32x16 acc[TM][TN];
 #pragma unroll
@@ -647,9 +649,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	// two register sets: the gathers of k-step s+2 are issued while step s computes and are parked in LDS at the end of
 	// step s+1, a full step after their issue — with 2 workgroups per CU there is too little other work to hide an
 	// exposed HBM latency behind
-	f32x4 ra[2][NA], rb[2][NB];
-	unsigned mb[2][NB];            // valid-pixel masks of the operand-B runs in flight
-	int x_img_of[2] = {0, 0};      // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
+	constexpr int SETS = RUNS == 8 ? 2 : 1;       // the short k-step variant runs 4 workgroups per CU and hides latency with those
+	f32x4 ra[SETS][NA], rb[SETS][NB];
+	unsigned mb[SETS][NB];         // valid-pixel masks of the operand-B runs in flight
+	int x_img_of[SETS] = {};       // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
 	const int PQ = a.P * a.Q;
 
 	__syncthreads();   // tabs visible
@@ -659,7 +662,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	int tap_h[NB], tap_w[NB], tap_off[NB];
 #pragma unroll
 	for (int i = 0; i < NB; ++i) {
-		const int2 e = tabs[row0 + 32 * i];
+		const int2 e = tabs[row0 + RP * i];
 		tap_h[i] = (e.y >> 8) * a.dil_h, tap_w[i] = (e.y & 0xff) * a.dil_w, tap_off[i] = e.x >> 2;
 	}
 
@@ -694,9 +697,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	auto load_part = [&](int set, int j) {
 		if (j < NA) {
 			const int i = j;
-			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + 32 * i < a.Kg);
+			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + RP * i < a.Kg);
 			ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(32 * i) * (unsigned)PQ * 4u, 0));
+			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
 		} else if (j < NA + NB) {
 			const int i = j - NA;
 			const int w0 = wb + tap_w[i];
@@ -730,8 +733,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	auto store_step = [&](int set, int buf) {
 #pragma unroll
 		for (int i = 0; i < NA; ++i) {
-			As[buf][run][0][row0 + 32 * i] = f32x2{ra[set][i][0], ra[set][i][1]};
-			As[buf][run][1][row0 + 32 * i] = f32x2{ra[set][i][2], ra[set][i][3]};
+			As[buf][run][0][row0 + RP * i] = f32x2{ra[set][i][0], ra[set][i][1]};
+			As[buf][run][1][row0 + RP * i] = f32x2{ra[set][i][2], ra[set][i][3]};
 		}
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
@@ -741,8 +744,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 #pragma unroll
 				for (int q = 0; q < 4; ++q) rb[set][i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
 			}
-			Bs[buf][run][0][row0 + 32 * i] = f32x2{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f};
-			Bs[buf][run][1][row0 + 32 * i] = f32x2{m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
+			Bs[buf][run][0][row0 + RP * i] = f32x2{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f};
+			Bs[buf][run][1][row0 + RP * i] = f32x2{m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
 		}
 	};
 
@@ -765,9 +768,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 #pragma unroll
 		for (int rn = 0; rn < RUNS; ++rn) {
 			if (rn + 1 < RUNS) read_frag(buf, rn + 1, av[(rn + 1) & 1], bv[(rn + 1) & 1]);
-			if (has_next && rn < PZ_WG_LOAD_RUNS) {       // gathers go out early in the step: half a step of MFMAs covers their latency
+			if (has_next) {                               // the next-but-one step's gathers, spread over this step's runs
+				constexpr int PER = (NA + NB + RUNS - 1) / RUNS;
 #pragma unroll
-				for (int j = 0; j < RUNS / PZ_WG_LOAD_RUNS; ++j) load_part(set, rn * (RUNS / PZ_WG_LOAD_RUNS) + j);
+				for (int j = 0; j < PER; ++j) load_part(set, rn * PER + j);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -784,8 +788,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 	const int s_begin = split * a.steps_per_split;
 	const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
 
-	if (s_begin < s_end) {
+	if (s_begin < s_end && SETS == 2) {
 		// prologue: step s_begin -> set 0 -> LDS buffer 0; step s_begin+1 -> set 1 (left in flight)
+		constexpr int S1 = SETS - 1;
 		load_head(s_begin);
 #pragma unroll
 		for (int j = 0; j < NA + NB; ++j) load_part(0, j);
@@ -793,7 +798,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 		if (s_begin + 1 < s_end) {
 			load_head(s_begin + 1);
 #pragma unroll
-			for (int j = 0; j < NA + NB; ++j) load_part(1, j);
+			for (int j = 0; j < NA + NB; ++j) load_part(S1, j);
 		}
 		__syncthreads();
 
@@ -801,9 +806,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 		int step = s_begin;
 		for (; step + 3 < s_end; step += 2) {
 			compute_step(0, 0, step + 2, true);
-			store_step(1, 1);
+			store_step(S1, 1);
 			__syncthreads();
-			compute_step(1, 1, step + 3, true);
+			compute_step(1, S1, step + 3, true);
 			store_step(0, 0);
 			__syncthreads();
 		}
@@ -811,20 +816,35 @@ __global__ void __launch_bounds__(256, 2) wgrad_conv_kernel(WgradArgs a) {
 		const int left = s_end - step;           // 1, 2 or 3 steps remain
 		if (left == 3) {
 			compute_step(0, 0, step + 2, true);
-			store_step(1, 1);
+			store_step(S1, 1);
 			__syncthreads();
-			compute_step(1, 1, 0, false);
+			compute_step(1, S1, 0, false);
 			store_step(0, 0);
 			__syncthreads();
 			compute_step(0, 0, 0, false);
 		} else if (left == 2) {
 			compute_step(0, 0, 0, false);
-			store_step(1, 1);
+			store_step(S1, 1);
 			__syncthreads();
-			compute_step(1, 1, 0, false);
+			compute_step(1, S1, 0, false);
 		} else {
 			compute_step(0, 0, 0, false);
 		}
+	} else if (s_begin < s_end) {
+		// one register set: the gathers of step s+1 are issued during step s and parked at its end
+		load_head(s_begin);
+#pragma unroll
+		for (int j = 0; j < NA + NB; ++j) load_part(0, j);
+		store_step(0, 0);
+		__syncthreads();
+
+		for (int step = s_begin; step + 1 < s_end; ++step) {
+			const int buf = (step - s_begin) & 1;
+			compute_step(buf, 0, step + 1, true);
+			store_step(0, buf ^ 1);
+			__syncthreads();
+		}
+		compute_step((s_end - 1 - s_begin) & 1, 0, 0, false);
 	}
 
 	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
@@ -1150,10 +1170,10 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
 	p.ncrs_pad = p.tiles_n * p.bn;
 	const long nruns = (long)d->n * P * ((Q + 3) / 4);         // reduction axis in runs of 4 pixels (rows padded to 4)
-	p.steps_total = pz::ceil_div(nruns, 8);
+	p.steps_total = pz::ceil_div(nruns, PZ_WG_RUNS);
 
 	const int tiles = p.tiles_m * p.tiles_n * d->groups;
-	int splits = 2 * pz::kNumCU / tiles;                        // 2 workgroups fit a CU (LDS): one balanced round
+	int splits = (PZ_WG_RUNS == 8 ? 2 : 4) * pz::kNumCU / tiles;       // workgroups that fit a CU (LDS): one balanced round
 	const int max_by_work = p.steps_total / 8 > 0 ? p.steps_total / 8 : 1;   // >= 8 k-steps (256 pixels) per split
 	if (splits > max_by_work) splits = max_by_work;
 	if (splits < 1) splits = 1;
@@ -1438,7 +1458,8 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	const bool unit_w = d->stride_w == 1;
 #define PZ_WGRAD_LAUNCH(BM_, BN_) \
-	(unit_w ? wgrad_conv_kernel<BM_, BN_, 2, 2, true><<<grid, 256, 0, st>>>(a) : wgrad_conv_kernel<BM_, BN_, 2, 2, false><<<grid, 256, 0, st>>>(a))
+	(unit_w ? wgrad_conv_kernel<BM_, BN_, 2, 2, true, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
+	        : wgrad_conv_kernel<BM_, BN_, 2, 2, false, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a))
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128);
 	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64);
 	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128);
