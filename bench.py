@@ -189,7 +189,10 @@ def main():
 			"workload": "ResNet-50 (PuzzleLib variant, 55x55 stage 2) synthetic ImageNet 224x224 fp32, batch %d per GPU, "
 						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True)" % args.batch,
 			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
-			"grad_allreduce": "none" if world == 1 else "RCCL sum + 1/N, 25 MB buckets overlapped with backward"
+			"grad_allreduce": "none" if world == 1 else (
+				"RCCL sum + 1/N, 25 MB buckets overlapped with backward" if nodeinfo.transport == "rccl" else
+				"FALLBACK: host-staged gloo all-reduce (RCCL communicator could not be created)"
+			)
 		},
 		"model_tflops_per_gpu": images_per_sec / world * FLOP_PER_IMAGE / 1e12,
 		"pct_of_f32_mfma_peak": images_per_sec / world * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,

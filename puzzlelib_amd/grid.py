@@ -133,18 +133,44 @@ class RcclNodeInfo(NodeInfo):
 
 
 	# ---- lazy device side (the backend must be bound to Config.deviceIdx == self.device first)
+	transport = "rccl"
+
+	def allRanksOk(self, ok):
+		"""True iff every rank reports success (host all-reduce over the bootstrap group)."""
+		import torch, torch.distributed as dist
+		flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+		dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.hostGroup)
+		return bool(flag.item())
+
+
 	def ensureComm(self):
-		if self.comm is not None:
+		if self.comm is not None or self.transport != "rccl":
 			return
 
-		import ctypes
+		import ctypes, sys
 		from puzzlelib_amd import lib, driver
 
-		handle = ctypes.c_void_p()
-		lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+		handle, error = ctypes.c_void_p(), None
+		try:
+			if self.uniqueId is None:
+				raise lib.CommError("no RCCL unique id (librccl could not be loaded on some rank)")
+			lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+		except lib.HipError as e:
+			error = e
 
-		self.comm = handle.value
-		self.commStream = driver.Stream()
+		if self.allRanksOk(error is None):
+			self.comm = handle.value
+			self.commStream = driver.Stream()
+			return
+
+		# RCCL is the design; if it cannot be brought up on every rank the run continues on a host-staged gloo exchange
+		# (correct, not overlapped, slow) and says so loudly — bench.py reports the transport in its config
+		if error is None and handle.value:
+			lib.pz_comm_destroy(handle.value)
+		self.transport = "gloo-host-staged"
+		print("[puzzlelib_amd.grid] rank %d: RCCL communicator unavailable (%s) — falling back to a host-staged gloo "
+			  "all-reduce; expect poor scaling" % (self.index, error if error is not None else "failed on another rank"),
+			  file=sys.stderr, flush=True)
 
 
 	def close(self):
@@ -167,14 +193,25 @@ class RcclNodeInfo(NodeInfo):
 	def broadcastBuffer(self, name, buffer):
 		from puzzlelib_amd import lib
 		self.ensureComm()
-		lib.pz_comm_broadcast(self.comm, buffer.ptr, buffer.size, 0, None)
+		if self.transport == "rccl":
+			lib.pz_comm_broadcast(self.comm, buffer.ptr, buffer.size, 0, None)
+			return
+
+		import torch, torch.distributed as dist
+		host = np.empty(buffer.size, dtype=np.uint8)
+		lib.pz_memcpy_d2h(host.ctypes.data, buffer.ptr, buffer.size, None)
+		lib.pz_stream_sync(None)
+		dist.broadcast(torch.from_numpy(host), src=0, group=self.hostGroup)
+		lib.pz_memcpy_h2d(buffer.ptr, host.ctypes.data, buffer.size, None)
+		lib.pz_stream_sync(None)
 
 
 	# ---- gradient exchange
 	def attach(self, name, tensor, blocks):
 		"""Registers the flat arena `tensor` (1-d fp32 GPUArray) with its variable blocks for overlapped reduction."""
 		self.ensureComm()
-		self.reducers[name] = GradReducer(blocks, HipReduceOps(self, tensor), self.gridsize, self.bucketBytes)
+		ops = HipReduceOps(self, tensor) if self.transport == "rccl" else HostStagedReduceOps(self, tensor)
+		self.reducers[name] = GradReducer(blocks, ops, self.gridsize, self.bucketBytes)
 		return self.reducers[name]
 
 
@@ -186,7 +223,10 @@ class RcclNodeInfo(NodeInfo):
 			from puzzlelib_amd import lib
 			from puzzlelib_amd.gpuarray import eltwise
 			self.ensureComm()
-			lib.pz_comm_allreduce_sum_f32(self.comm, tensor.ptr, tensor.ptr, tensor.size, None)
+			if self.transport == "rccl":
+				lib.pz_comm_allreduce_sum_f32(self.comm, tensor.ptr, tensor.ptr, tensor.size, None)
+			else:
+				HostStagedReduceOps(self, tensor).allreduce(0, tensor.nbytes, None)
 			eltwise(lib.OP_LINEAR, tensor.size, (tensor, tensor), np.array([1.0 / self.gridsize, 0.0], dtype=np.float32))
 			return
 
@@ -228,6 +268,41 @@ class HipReduceOps:
 			lib.pz_stream_wait_event(None, done.handle)
 		self.events = []
 
+		eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
+
+
+class HostStagedReduceOps:
+	"""Fallback transport when RCCL cannot be initialised: device -> host -> gloo all-reduce -> device, synchronous.
+	Same call protocol as HipReduceOps (GradReducer drives both)."""
+
+	def __init__(self, node, tensor):
+		self.node, self.tensor = node, tensor
+
+
+	def markReady(self):
+		from puzzlelib_amd import driver
+		event = driver.Event()
+		event.record(None)
+		return event
+
+
+	def allreduce(self, start, stop, token):
+		import torch, torch.distributed as dist
+		from puzzlelib_amd import lib
+
+		if token is not None:
+			token.synchronize()
+		host = np.empty((stop - start) // 4, dtype=np.float32)
+		lib.pz_memcpy_d2h(host.ctypes.data, self.tensor.ptr + start, stop - start, None)
+		lib.pz_stream_sync(None)
+		dist.all_reduce(torch.from_numpy(host), group=self.node.hostGroup)
+		lib.pz_memcpy_h2d(self.tensor.ptr + start, host.ctypes.data, stop - start, None)
+		lib.pz_stream_sync(None)
+
+
+	def finish(self, scale):
+		from puzzlelib_amd import lib
+		from puzzlelib_amd.gpuarray import eltwise
 		eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
 
 
@@ -286,9 +361,12 @@ def nodeFromEnv(bucketBytes=25 << 20):
 
 	ids = [None]
 	if rank == 0:
-		buf = ctypes.create_string_buffer(lib.COMM_ID_BYTES)
-		lib.pz_comm_unique_id(buf)
-		ids = [buf.raw]
+		try:
+			buf = ctypes.create_string_buffer(lib.COMM_ID_BYTES)
+			lib.pz_comm_unique_id(buf)
+			ids = [buf.raw]
+		except lib.HipError:
+			ids = [None]            # RcclNodeInfo.ensureComm falls back (on every rank) to the host-staged exchange
 
 	dist.broadcast_object_list(ids, src=0)
 	return RcclNodeInfo(rank, world, local, ids[0], bucketBytes=bucketBytes)
