@@ -9,9 +9,12 @@
 //
 // Tiling (64-lane waves): a workgroup is 4 waves; each wave owns a (32*TM)x(32*TN) accumulator made of
 // 32x32 MFMA tiles. Operands are staged through LDS in layouts whose MFMA fragment reads (lane l reads
-// row/col l&31 at k = l>>5) hit 32 distinct banks: [k][m] for m-contiguous sources, [m][BK+1] for
-// k-contiguous ones. im2col never exists in memory: each lane owns one pixel column of the B tile, the
-// (c,r,s) -> address/offset decode is a per-k table read through the scalar cache.
+// row/col l&31 at k = l>>5) are bank-conflict free: [k][m] (forward / backward-data, 4-byte reads) and
+// [run][half][row]{2 pixels} (backward-filter, 8-byte reads = two k2-steps). im2col never exists in memory:
+// in forward / backward-data each lane owns one pixel column of the B tile and the reduction runs tap-major
+// (k = tap*C + c: one mask test and one per-lane offset per k-tile, the channel offset travels as a scalar);
+// backward-filter gathers 16-byte runs of 4 output pixels for both operands. Epilogues of contiguous outputs
+// go through LDS to store 16 bytes per lane and can leave per-channel strip sums for a following BatchNorm.
 //
 // Replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams — Hip/Wrappers/MIOpen.py:333-462.
 #include "common.h"
