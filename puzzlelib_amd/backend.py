@@ -132,6 +132,10 @@ class DeferredBN:
 	def materialize(self, allocator=None):
 		return self.dnn.bnApplyAdd(self, None, relu=False, allocator=allocator)
 
+	def get(self, stream=None):
+		"""the normalised values on the host (what BatchNorm2D.data.get() gives when nothing is deferred)"""
+		return self.materialize().get(stream)
+
 
 class ConvStats:
 	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
