@@ -29,7 +29,11 @@ def main():
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--only", type=int, default=-1)
 	ap.add_argument("--passes", default="fwd,dgrad,wgrad")
+	ap.add_argument("--config2", action="store_true", help="BASELINE.json config 2: Conv2D 3x3, 64 -> 128, 56x56, batch 128")
 	args = ap.parse_args()
+	if args.config2:
+		global CENSUS
+		CENSUS, args.batch = [((64, 56, 56), (128, 3, 1, 1), 1)], 128
 
 	from puzzlelib_amd import backend, lib
 	bnd = backend.getBackend(0, initmode=2)
