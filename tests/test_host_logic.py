@@ -187,3 +187,27 @@ def test_product_never_imports_the_oracle():
 			if f.endswith(".py"):
 				text = open(os.path.join(dirpath, f)).read()
 				assert not re.search(r"^\s*(from|import)\s+(oracle|cpu_ref|cpu_net)\b", text, re.M), f
+
+
+def test_header_and_ctypes_binding_agree():
+	"""ABI drift guard: every prototype of include/puzzle_mi355.h has as many parameters as its ctypes binding, and the
+	element-wise op enum is in the order puzzlelib_amd.lib numbers it."""
+	from puzzlelib_amd import lib
+
+	header = open(os.path.join(ROOT, "include", "puzzle_mi355.h")).read()
+	header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+	protos = dict(re.findall(r"\bint\s+(pz_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+	assert len(protos) >= 70
+	for name, params in protos.items():
+		if name == "pz_version":                  # int pz_version(void): bound by hand in lib.py
+			continue
+		params = params.strip()
+		count = 0 if params in ("", "void") else len(params.split(","))
+		assert name in lib._PROTOS, name
+		assert count == len(lib._PROTOS[name]), "%s: header has %d parameters, binding %d" % (name, count, len(lib._PROTOS[name]))
+
+	enum = re.search(r"enum\s+pz_eltwise_op\s*\{(.*?)\}", header, flags=re.S).group(1)
+	names = [m for m in re.findall(r"\b(PZ_OP_[A-Z0-9_]+)\b", enum)]
+	for index, name in enumerate(names):
+		assert getattr(lib, name[3:]) == index, "%s is %d in the header, %s in lib.py" % (name, index, getattr(lib, name[3:]))
