@@ -137,7 +137,12 @@ class RcclNodeInfo(NodeInfo):
 
 	def allRanksOk(self, ok):
 		"""True iff every rank reports success (host all-reduce over the bootstrap group)."""
+		if self.gridsize == 1:
+			return ok
+
 		import torch, torch.distributed as dist
+		if not (dist.is_available() and dist.is_initialized()):
+			return ok
 		flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
 		dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.hostGroup)
 		return bool(flag.item())
@@ -162,6 +167,9 @@ class RcclNodeInfo(NodeInfo):
 			self.comm = handle.value
 			self.commStream = driver.Stream()
 			return
+
+		if self.gridsize == 1 and error is not None:
+			raise error
 
 		# RCCL is the design; if it cannot be brought up on every rank the run continues on a host-staged gloo exchange
 		# (correct, not overlapped, slow) and says so loudly — bench.py reports the transport in its config
