@@ -33,6 +33,9 @@
 #ifndef PZ_IG_LOAD_STEPS
 #define PZ_IG_LOAD_STEPS 8        // k2-steps of a k-tile over which the next tile's global loads are spread
 #endif
+#ifndef PZ_WG_SETS
+#define PZ_WG_SETS 1              // 2 = gathers issued two k-steps ahead (needs ~32 more registers; +1 % before the 16-byte LDS cells)
+#endif
 #ifndef PZ_WG_RUNS
 #define PZ_WG_RUNS 8              // 4-pixel runs per backward-filter k-step: 8 (32 pixels, 2 workgroups/CU) or 4 (16 pixels, 4/CU)
 #endif
@@ -612,15 +615,15 @@ struct WgradArgs {
 template <int BM, int BN, int WM, int WN, bool UNIT_W, int RUNS>
 __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(WgradArgs a) {
 	constexpr int RP = 256 / RUNS;               // tile rows loaded per pass (one 16-byte run per thread)
-	constexpr int PADC = RUNS == 8 ? 2 : 4;      // row padding (cells) that spreads the (run, row) write pattern over all banks
+	static_assert(RUNS % 2 == 0, "runs are consumed in pairs (one per lane half)");
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4, "4 waves per workgroup");
 
-	typedef float f32x2 __attribute__((ext_vector_type(2)));
-	// double buffered (one barrier per k-step); row stride BM + 2 makes the 8-runs x 4-rows write pattern of half a wave
-	// and the 32-consecutive-rows read pattern both bank-conflict free
-	__shared__ __attribute__((aligned(16))) f32x2 As[2][RUNS][2][BM + PADC];
-	__shared__ __attribute__((aligned(16))) f32x2 Bs[2][RUNS][2][BN + PADC];
+	// double buffered (one barrier per k-step). A run is one 16-byte cell [run pair][run of the pair][row]: parked with one
+	// ds_write_b128, and the fragment of lane (row, half h) is the whole cell of run 2g+h = four k2-steps per ds_read_b128.
+	// The odd row stride (BM + 1 cells) spreads the 8 runs a group of 8 lanes writes over all banks.
+	__shared__ __attribute__((aligned(16))) f32x4 As[2][RUNS / 2][2][BM + 1];
+	__shared__ __attribute__((aligned(16))) f32x4 Bs[2][RUNS / 2][2][BN + 1];
 	__shared__ int2 tabs[BN];
 
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 	// two register sets: the gathers of k-step s+2 are issued while step s computes and are parked in LDS at the end of
 	// step s+1, a full step after their issue — with 2 workgroups per CU there is too little other work to hide an
 	// exposed HBM latency behind
-	constexpr int SETS = RUNS == 8 ? 2 : 1;       // the short k-step variant runs 4 workgroups per CU and hides latency with those
+	constexpr int SETS = PZ_WG_SETS;              // register sets of gathers in flight (2: issued two k-steps ahead)
 	f32x4 ra[SETS][NA], rb[SETS][NB];
 	unsigned mb[SETS][NB];         // valid-pixel masks of the operand-B runs in flight
 	int x_img_of[SETS] = {};       // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
@@ -735,10 +738,7 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 
 	auto store_step = [&](int set, int buf) {
 #pragma unroll
-		for (int i = 0; i < NA; ++i) {
-			As[buf][run][0][row0 + RP * i] = f32x2{ra[set][i][0], ra[set][i][1]};
-			As[buf][run][1][row0 + RP * i] = f32x2{ra[set][i][2], ra[set][i][3]};
-		}
+		for (int i = 0; i < NA; ++i) As[buf][run >> 1][run & 1][row0 + RP * i] = ra[set][i];
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const unsigned m = mb[set][i];
@@ -747,44 +747,52 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 #pragma unroll
 				for (int q = 0; q < 4; ++q) rb[set][i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
 			}
-			Bs[buf][run][0][row0 + RP * i] = f32x2{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f};
-			Bs[buf][run][1][row0 + RP * i] = f32x2{m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
+			Bs[buf][run >> 1][run & 1][row0 + RP * i] = f32x4{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f,
+			                                                m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
 		}
 	};
 
-	// fragments of one run (2 k2-steps): lane (row, h) takes pixels {2h, 2h+1} of its row's cell
-	auto read_frag = [&](int buf, int rn, f32x2 (&av)[TM], f32x2 (&bv)[TN]) {
+	// fragments of one run pair (4 k2-steps): lane (row, h) takes the 4 pixels of run 2g+h of its row
+	auto read_frag = [&](int buf, int g2, f32x4 (&av)[TM], f32x4 (&bv)[TN]) {
 #pragma unroll
 		for (int i = 0; i < TM; ++i)
-			av[i] = As[buf][rn][lhi][wm * (32 * TM) + i * 32 + l31];
+			av[i] = As[buf][g2][lhi][wm * (32 * TM) + i * 32 + l31];
 #pragma unroll
 		for (int j = 0; j < TN; ++j)
-			bv[j] = Bs[buf][rn][lhi][wn * (32 * TN) + j * 32 + l31];
+			bv[j] = Bs[buf][g2][lhi][wn * (32 * TN) + j * 32 + l31];
 	};
 
 	// MFMAs of the k-step parked in LDS buffer `buf`; when has_next, the gathers of step `next` go into register set `set`
 	auto compute_step = [&](int buf, int set, int next, bool has_next) {
-		f32x2 av[2][TM], bv[2][TN];
+		constexpr int G2 = RUNS / 2;
+		f32x4 av[2][TM], bv[2][TN];
 		read_frag(buf, 0, av[0], bv[0]);
 		if (has_next) load_head(next);
 
 #pragma unroll
-		for (int rn = 0; rn < RUNS; ++rn) {
-			if (rn + 1 < RUNS) read_frag(buf, rn + 1, av[(rn + 1) & 1], bv[(rn + 1) & 1]);
-			if (has_next) {                               // the next-but-one step's gathers, spread over this step's runs
-				constexpr int PER = (NA + NB + RUNS - 1) / RUNS;
+		for (int g2 = 0; g2 < G2; ++g2) {
+			if (g2 + 1 < G2) read_frag(buf, g2 + 1, av[(g2 + 1) & 1], bv[(g2 + 1) & 1]);
 #pragma unroll
-				for (int j = 0; j < PER; ++j) load_part(set, rn * PER + j);
-			}
-			__builtin_amdgcn_sched_barrier(0);
+			for (int sub = 0; sub < 4; ++sub) {
+				{                                         // the next step's gathers, spread evenly over this step's k2-steps
+					constexpr int SLOTS = G2 * 4, PARTS = NA + NB;
+					constexpr int STRIDE = SLOTS >= PARTS ? SLOTS / PARTS : 1;
+					constexpr int PER = SLOTS >= PARTS ? 1 : (PARTS + SLOTS - 1) / SLOTS;
+					const int slot = g2 * 4 + sub;
+					if (has_next && slot % STRIDE == 0) {
 #pragma unroll
-			for (int sub = 0; sub < 2; ++sub)
+						for (int j = 0; j < PER; ++j)
+							if ((slot / STRIDE) * PER + j < PARTS) load_part(set, (slot / STRIDE) * PER + j);
+					}
+				}
+				__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 				for (int i = 0; i < TM; ++i)
 #pragma unroll
 					for (int jj = 0; jj < TN; ++jj)
-						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rn & 1][i][sub], bv[rn & 1][jj][sub], acc[i][jj], 0, 0, 0);
-			__builtin_amdgcn_sched_barrier(0);
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g2 & 1][i][sub], bv[g2 & 1][jj][sub], acc[i][jj], 0, 0, 0);
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 	};
 
