@@ -612,8 +612,12 @@ struct WgradArgs {
 // both operands arrive as 16-byte loads (4-byte aligned is enough on gfx950). A k-step is 8 runs = 32 (padded) pixels.
 // LDS keeps a run as two 8-byte half-cells [run][half][row]{2 pixels}: the MFMA fragment of lane (row, half h) is
 // {pixel 2h, 2h+1} of its row, i.e. the k order inside a run is (0,2 | 1,3) for both operands.
-template <int BM, int BN, int WM, int WN, bool UNIT_W, int RUNS>
+// GATHER: 0 = any stride (element-wise x gathers), 1 = unit stride along w (16-byte x runs with edge masks),
+//         2 = pointwise 1x1 / stride 1 / pad 0 (16-byte runs, only the row tail is masked: no per-tap address or
+//             mask arithmetic — VALU instructions serialise with the MFMAs, see tools/probes/lds_mfma.hip)
+template <int BM, int BN, int WM, int WN, int GATHER, int RUNS>
 __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(WgradArgs a) {
+	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
 	constexpr int RP = 256 / RUNS;               // tile rows loaded per pass (one 16-byte run per thread)
 	static_assert(RUNS % 2 == 0, "runs are consumed in pairs (one per lane half)");
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -712,10 +716,15 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 			const bool row_ok = nq > 0 && (unsigned)(hb + tap_h[i]) < (unsigned)a.H;
 			const int first = x_img + tap_off[i];        // element offset of the run's first input column inside the tensor
 
-			if constexpr (UNIT_W) {
+			if constexpr (POINTWISE) {
+				const unsigned m = (1u << nq) - 1u;          // nq = 0 for runs beyond the tensor
+				rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+				    xr, m != 0u ? PZ_ABL_NEAR((unsigned)first * 4u) : kOOB, 0, 0));
+				mb[set][i] = m;
+			} else if constexpr (UNIT_W) {
 				// valid pixels of the run: q in [lo, hi)
-				const int lo = max(0, -w0), hi = row_ok ? min(nq, a.W - w0) : 0;
-				const unsigned m = hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+				const int lo = max(0, -w0), cnt = row_ok ? min(nq, a.W - w0) - lo : 0;
+				const unsigned m = cnt > 0 ? ((1u << cnt) - 1u) << lo : 0u;          // v_bfm_b32
 
 				// A run that starts left of the tensor's first byte (first row of the first image, left padding) would wrap
 				// the 32-bit offset: such a lane loads nothing here and is flagged (bit 4) for store_step to gather it.
@@ -742,13 +751,17 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const unsigned m = mb[set][i];
-			if (UNIT_W && (m & 16u)) {       // rare: run starting left of the tensor base, gathered element-wise
+			if (GATHER == 1 && (m & 16u)) {  // rare: run starting left of the tensor base, gathered element-wise
 				const int first = x_img_of[set] + tap_off[i];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) rb[set][i][q] = buf_load_f32(xr, (m >> q) & 1u ? (unsigned)(first + q) * 4u : kOOB, 0);
 			}
-			Bs[buf][run >> 1][run & 1][row0 + RP * i] = f32x4{m & 1u ? rb[set][i][0] : 0.f, m & 2u ? rb[set][i][1] : 0.f,
-			                                                m & 4u ? rb[set][i][2] : 0.f, m & 8u ? rb[set][i][3] : 0.f};
+			// bit q of m -> all-ones / zero word (v_bfe_i32), then one AND per element: 2 VALU instead of test + compare + select
+			f32x4 v;
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				v[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)rb[set][i][q]) & __builtin_amdgcn_sbfe((int)m, q, 1));
+			Bs[buf][run >> 1][run & 1][row0 + RP * i] = v;
 		}
 	};
 
@@ -1468,9 +1481,11 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	{
 	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	const bool unit_w = d->stride_w == 1;
+	const bool pointwise = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && unit_w;
 #define PZ_WGRAD_LAUNCH(BM_, BN_) \
-	(unit_w ? wgrad_conv_kernel<BM_, BN_, 2, 2, true, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
-	        : wgrad_conv_kernel<BM_, BN_, 2, 2, false, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a))
+	(pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
+	 : unit_w  ? wgrad_conv_kernel<BM_, BN_, 2, 2, 1, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
+	           : wgrad_conv_kernel<BM_, BN_, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a))
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128);
 	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64);
 	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128);
