@@ -1061,8 +1061,10 @@ struct FwdPlan {
 
 FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
 	FwdPlan p;
-	p.bm = M <= 64 ? 64 : 128;
-	p.bn = M <= 64 ? 256 : 128;
+	// 64 x 256 tiles when 64-row tiles pad the channel axis less than 128-row ones (M <= 64, 160, 192, 320, ...)
+	const bool narrow = M <= 64 || pz::ceil_div(M, 64) * 64 < pz::ceil_div(M, 128) * 128;
+	p.bm = narrow ? 64 : 128;
+	p.bn = narrow ? 256 : 128;
 	p.tiles_m = pz::ceil_div(M, p.bm);
 	p.tiles_n = pz::ceil_div(npix, p.bn);
 	p.mpad = p.tiles_m * p.bm;
@@ -1188,8 +1190,9 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	WgradPlan p;
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 	p.ncrs = Cg * d->r * d->s;
-	p.bm = Kg <= 64 ? 64 : 128;
-	p.bn = p.ncrs <= 64 ? 64 : 128;
+	p.bm = (Kg <= 64 || pz::ceil_div(Kg, 64) * 64 < pz::ceil_div(Kg, 128) * 128) ? 64 : 128;
+	// the narrower column tile when it pads less (conv1: 147 columns = 3 x 64 rather than 2 x 128)
+	p.bn = (p.ncrs <= 64 || pz::ceil_div(p.ncrs, 64) * 64 < pz::ceil_div(p.ncrs, 128) * 128) ? 64 : 128;
 	p.tiles_m = pz::ceil_div(Kg, p.bm);
 	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
 	p.ncrs_pad = p.tiles_n * p.bn;
