@@ -186,3 +186,33 @@ def test_memmod_matches_the_reference_tests(bnd):
 	parts = mem.depthSplit(bnd.GPUArray.toGpu(grad), tensors)
 	for part, want in zip(parts, [grad[:, :4, 1:4, 1:4], grad[:, 4:6], grad[:, 6:, 1:5, 1:5]]):
 		assert np.array_equal(part.get(), want)
+
+
+def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
+	"""tools/dp_rehearsal.py: two ranks on one device, identical shards, full data-parallel path (broadcast of rank 0's
+	parameters, hook-driven bucketed exchange overlapped with backward, 1/N scaling) — rank 0 must end with exactly the
+	single-process parameters."""
+	import subprocess, sys, socket
+	from conftest import ROOT
+
+	script = os.path.join(ROOT, "tools", "dp_rehearsal.py")
+	single, dual = str(tmp_path / "single.npz"), str(tmp_path / "dual.npz")
+
+	env = dict(os.environ, PUZZLE_MI355_DEVICE="0")
+	for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+		env.pop(key, None)
+	subprocess.run([sys.executable, script, single], check=True, env=env, timeout=600)
+
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+	subprocess.run(
+		[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+		 "--master-port", str(port), script, dual], check=True, env=env, timeout=900
+	)
+
+	a, b = np.load(single), np.load(dual)
+	assert str(b["transport"]) in ("rccl", "gloo-host-staged")
+	for name in a.files:
+		if name != "transport":
+			assert np.array_equal(a[name], b[name]), "parameter %s differs between 1 and 2 ranks" % name
