@@ -165,6 +165,19 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, float *dscale_acc, float *dbias_acc, float alpha, float beta,
                   void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* Residual fan-in fused with the statistics pass of the BatchNorm backward(s) it feeds (Replicate.updateGrad + reluDer +
+ * the first half of batchNormNdBackward for bn*_branch2c and the projection-shortcut BN of Models/Nets/ResNet.py:36-58):
+ * gout = (g0 + g1) * (y > 0); part_a[(k*splits + s)*2 + {0,1}] = {sum gout, sum gout*(xa - mean_a[k])} in the layout and
+ * accumulation order pz_bn_bwd uses internally (bit-identical), likewise part_b for the optional second BN (xb == NULL:
+ * none). Each part needs pz_bn_workspace_bytes. pz_bn_bwd_from_partials is then pz_bn_bwd_acc without its statistics
+ * pass.                                                                                                          */
+int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw,
+                     const float *xa, const float *mean_a, float *part_a,
+                     const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
+int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                            const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                            float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
+                            pz_stream_t stream);
 /* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
  * projection shortcut of Models/Nets/ResNet.py:36-58) the normalised tensor is never written. pz_bn_fwd_train_defer does
  * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;

@@ -492,6 +492,28 @@ class DnnContext:
 		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
 
 
+	def bnGateStats(self, grad0, grad1, outdata, targets, allocator=None):
+		"""Backend-internal (Sequential.planFusion): g = (grad0 + grad1) * (outdata > 0) plus, for each of the one or two
+		`targets` = (bnInput, savemean), the partial sums a following batchNormNdBackward(g, bnInput, ..., partials=)
+		would otherwise recompute. Returns (g, [partials...])."""
+		requireF32(grad0, grad1, outdata)
+		assert 1 <= len(targets) <= 2 and grad0.shape == grad1.shape == outdata.shape
+		n, c, hw = grad0.shape[0], grad0.shape[1], prod(grad0.shape[2:])
+
+		out = GPUArray.empty(grad0.shape, dtype=grad0.dtype, allocator=allocator)
+		size = c_size_t(0)
+		lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
+		parts = [GPUArray.empty((size.value // 4, ), dtype=np.float32, allocator=allocator) for _ in targets]
+
+		(xa, ma), (xb, mb) = targets[0], (targets[1] if len(targets) == 2 else (None, None))
+		assert xa.shape == grad0.shape and (xb is None or xb.shape == grad0.shape)
+		lib.pz_bn_gate_stats(
+			grad0.ptr, grad1.ptr, outdata.ptr, out.ptr, n, c, hw, xa.ptr, ma.ptr, parts[0].ptr,
+			ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
+		)
+		return out, parts
+
+
 	def bnApplyAdd(self, first, second, relu=False, allocator=None):
 		"""out = act(bn(first) + second') for a DeferredBN `first` and `second` = DeferredBN | GPUArray | None
 		(None: out = bn(first), no activation). Backend-internal (see Sequential.planFusion)."""
@@ -563,7 +585,7 @@ class DnnContext:
 
 	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
 							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False,
-							accumulate=None):
+							accumulate=None, partials=None):
 		"""`accumulate` (backend-internal) = (scalegradDst, biasgradDst, alpha, beta): additionally
 		dst = alpha*fresh + beta*dst for both parameter gradients inside the same launch."""
 		assert data.ndim == grad.ndim
@@ -582,6 +604,13 @@ class DnnContext:
 
 		sdst, bdst, alpha, beta = accumulate if accumulate is not None else (None, None, 1.0, 0.0)
 		requireF32(sdst, bdst)
+
+		if partials is not None and not fuseRelu:           # statistics already summed by bnGateStats: apply pass only
+			lib.pz_bn_bwd_from_partials(
+				data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
+				ptrOf(sdst), ptrOf(bdst), alpha, beta, partials.ptr, None
+			)
+			return out, scalegrad, bgrad
 		lib.pz_bn_bwd_acc(
 			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr if fuseRelu else None, savemean.ptr,
 			saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE,

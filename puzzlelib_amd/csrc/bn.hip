@@ -380,6 +380,68 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 	    [&](size_t off) { dx[off] = k0 * (bn_gate<RELU>(dy[off], x[off], a, b) - k1 - (x[off] - mu) * k2); });
 }
 
+// Gradient fan-in of a residual block fused with the statistics pass of the batch-norm backward(s) that consume it:
+//   g = (g0 + g1) * (y > 0)                       (OpAdd3Gate: Replicate fan-in + reluDer of the block's output ReLU)
+//   partA[ch][s] = {sum g, sum g*(xa - mean_a)}    (what bn_bwd_stats_kernel<false> computes for the main branch's last BN)
+//   partB likewise for the projection-shortcut BN when the block has one
+// One pass writes g and leaves both BNs only their apply pass: same loop structure and accumulation order as
+// bn_bwd_stats_kernel, hence bit-identical partial sums.
+template <bool TWO>
+__global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restrict__ g0, const float *__restrict__ g1,
+                                                             const float *__restrict__ y, float *__restrict__ gout, BnGeom g,
+                                                             const float *__restrict__ xa, const float *__restrict__ mean_a,
+                                                             float *__restrict__ part_a, const float *__restrict__ xb,
+                                                             const float *__restrict__ mean_b, float *__restrict__ part_b) {
+	__shared__ float red[16];
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const float mua = mean_a[ch], mub = TWO ? mean_b[ch] : 0.f;
+	float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+	f4u v0[2], v1[2], vy[2], va[2], vb[2];
+
+	channel_foreach<2>(
+	    g, ch, s,
+	    [&](int u, size_t off) {
+		    v0[u] = *reinterpret_cast<const f4u *>(g0 + off);
+		    v1[u] = *reinterpret_cast<const f4u *>(g1 + off);
+		    vy[u] = *reinterpret_cast<const f4u *>(y + off);
+		    va[u] = *reinterpret_cast<const f4u *>(xa + off);
+		    if (TWO) vb[u] = *reinterpret_cast<const f4u *>(xb + off);
+	    },
+	    [&](int u, size_t off) {
+		    f4u q;
+#pragma unroll
+		    for (int e = 0; e < 4; ++e) q[e] = (v0[u][e] + v1[u][e]) * (vy[u][e] > 0.f ? 1.f : 0.f);
+		    *reinterpret_cast<f4u *>(gout + off) = q;
+		    const f4u x = va[u];
+		    a1 += (q[0] + q[1]) + (q[2] + q[3]);
+		    a2 += (q[0] * (x[0] - mua) + q[1] * (x[1] - mua)) + (q[2] * (x[2] - mua) + q[3] * (x[3] - mua));
+		    if (TWO) {
+			    const f4u z = vb[u];
+			    b1 += (q[0] + q[1]) + (q[2] + q[3]);
+			    b2 += (q[0] * (z[0] - mub) + q[1] * (z[1] - mub)) + (q[2] * (z[2] - mub) + q[3] * (z[3] - mub));
+		    }
+	    },
+	    [&](size_t off) {
+		    const float q = (g0[off] + g1[off]) * (y[off] > 0.f ? 1.f : 0.f);
+		    gout[off] = q;
+		    a1 += q;
+		    a2 += q * (xa[off] - mua);
+		    if (TWO) b1 += q, b2 += q * (xb[off] - mub);
+	    });
+
+	a1 = block_sum(a1, red);
+	a2 = block_sum(a2, red);
+	if (TWO) b1 = block_sum(b1, red), b2 = block_sum(b2, red);
+	if (threadIdx.x == 0) {
+		part_a[((size_t)ch * g.splits + s) * 2 + 0] = a1;
+		part_a[((size_t)ch * g.splits + s) * 2 + 1] = a2;
+		if (TWO) {
+			part_b[((size_t)ch * g.splits + s) * 2 + 0] = b1;
+			part_b[((size_t)ch * g.splits + s) * 2 + 1] = b2;
+		}
+	}
+}
+
 inline size_t bn_ws_bytes(const BnGeom &g) { return ((size_t)g.c * g.splits * 2 + g.c) * sizeof(float); }
 
 int bn_check(int n, int c, int hw) {
@@ -536,6 +598,35 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
 		bn_bwd_apply_kernel<false><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, bias, save_mean, save_invvar, dscale, dbias,
 		                                                 dscale_acc, dbias_acc, alpha, beta);
 	}
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw, const float *xa,
+                     const float *mean_a, float *part_a, const float *xb, const float *mean_b, float *part_b,
+                     pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(g0 && g1 && y && gout && xa && mean_a && part_a, "pz_bn_gate_stats: null tensor");
+	PZ_REQUIRE((xb == nullptr) == (mean_b == nullptr) && (xb == nullptr) == (part_b == nullptr),
+	           "pz_bn_gate_stats: the second batch-norm needs all of x, mean and partials");
+	const BnGeom g = bn_geom(n, c, hw);
+	const dim3 grid(c, g.splits);
+	hipStream_t st = pz::as_stream(stream);
+	if (xb) bn_gate_stats_kernel<true><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b);
+	else bn_gate_stats_kernel<false><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                            const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                            float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
+                            pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias && partials, "pz_bn_bwd_from_partials: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	bn_bwd_apply_kernel<false><<<dim3(c, g.splits), 256, 0, pz::as_stream(stream)>>>(
+	    x, dy, dx, g, partials, scale, nullptr, save_mean, save_invvar, dscale, dbias, dscale_acc, dbias_acc, alpha, beta);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

@@ -463,6 +463,7 @@ class BatchNorm2D(Module):
 		self.fusedRelu = False       # set per forward pass by Sequential (planFusion): output is relu(bn(x))
 		self.statsFrom = None        # ... and the Conv2D right in front whose epilogue sums this layer's input per channel
 		self.deferApply = False      # ... the only consumer is a residual Add that normalises on the fly (DeferredBN output)
+		self.bwdPartials = None      # (grad tensor, partial sums) left by the Replicate fan-in that produced this layer's grad
 
 		if empty:
 			return
@@ -512,10 +513,12 @@ class BatchNorm2D(Module):
 
 
 	def updateGrad(self, grad):
+		partials, self.bwdPartials = self.bwdPartials, None
 		tup = S().Dnn.batchNormNdBackward(
 			self.inData, grad, self.scale, self.savemean, self.saveinvvar, self.epsilon,
 			bias=self.bias if self.fusedRelu else None, fuseRelu=self.fusedRelu,
-			accumulate=getattr(self, "accumulate", None)
+			accumulate=getattr(self, "accumulate", None),
+			partials=partials[1] if partials is not None and partials[0] is grad and not self.fusedRelu else None
 		)
 		if self.affine:
 			self.grad, self.scalegrad, self.biasgrad = tup
@@ -782,6 +785,7 @@ class Replicate(Module):
 		self.movesData = True
 		self.times = times
 		self.gateGrad = False        # set per forward pass by Sequential (planFusion): input is an in-place ReLU's output
+		self.statsFor = []           # ... and BatchNorms of the block in front whose backward statistics the fan-in also sums
 
 
 	def updateData(self, data):
@@ -789,7 +793,16 @@ class Replicate(Module):
 
 
 	def updateGrad(self, grad):
-		self.grad = sumTensors(grad, gate=self.inData if self.gateGrad else None)
+		targets = [bn for bn in self.statsFor if bn.train and bn.savemean is not None and not bn.fusedRelu and
+				   bn.inData is not None and bn.inData.shape == self.inData.shape]
+
+		if self.gateGrad and len(grad) == 2 and targets:
+			# fan-in + ReLU derivative + the statistics pass of the BatchNorm backward(s) this gradient goes to next
+			self.grad, parts = S().Dnn.bnGateStats(grad[0], grad[1], self.inData, [(bn.inData, bn.savemean) for bn in targets])
+			for bn, part in zip(targets, parts):
+				bn.bwdPartials = (self.grad, part)
+		else:
+			self.grad = sumTensors(grad, gate=self.inData if self.gateGrad else None)
 
 
 	def dataShapeFrom(self, shape):
@@ -1054,6 +1067,7 @@ class Sequential(Container):
 	fuseInplaceRelu = True       # backend-internal fusion around in-place ReLUs (see planFusion)
 	fuseConvStats = True         # BatchNorm statistics from the preceding convolution's epilogue (see planFusion)
 	fuseBnAdd = True             # residual Add normalises its BatchNorm inputs on the fly (see planFusion)
+	fuseGateStats = True         # gradient fan-in also sums the next BatchNorm backward's statistics (see planFusion)
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1082,7 +1096,7 @@ class Sequential(Container):
 			elif isinstance(mod, (BatchNorm2D, Add)):
 				mod.fusedRelu = False
 			elif isinstance(mod, Replicate):
-				mod.gateGrad = False
+				mod.gateGrad, mod.statsFor = False, []
 
 			if isinstance(mod, Conv2D):
 				mod.emitStats = False
@@ -1122,6 +1136,14 @@ class Sequential(Container):
 
 			if not mod.gradFused and isinstance(nxt, Replicate) and nxt.times == 2:
 				nxt.gateGrad = mod.gradFused = True
+
+				# [Parallel, Add, ReLU, Replicate]: the fan-in's output is the gradient of the Parallel's branch-tail
+				# BatchNorms (Add passes it through unchanged) -> it also sums their backward statistics
+				if Sequential.fuseGateStats and i >= 2 and isinstance(prev, Add) and isinstance(graph[i - 2], Parallel):
+					nxt.statsFor = [
+						branch.graph[-1] for branch in graph[i - 2].graph
+						if isinstance(branch, Sequential) and branch.graph and isinstance(branch.graph[-1], BatchNorm2D)
+					][:2]
 
 
 	def append(self, mod, acquire=True):

@@ -112,13 +112,13 @@ def bind():
 		return outdata, savemean.reshape(shape), saveinvvar.reshape(shape)
 
 	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial,
-							bias=None, fuseRelu=False, accumulate=None):
+							bias=None, fuseRelu=False, accumulate=None, partials=None):
 		shape = scale.shape
 		if accumulate is not None:
 			accumulate = (accumulate[0].ravel(), accumulate[1].ravel(), accumulate[2], accumulate[3])
 		ingrad, scalegrad, bgrad = dnn.batchNormNdBackward(
 			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool,
-			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu, accumulate=accumulate
+			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu, accumulate=accumulate, partials=partials
 		)
 		return ingrad, scalegrad.reshape(shape), bgrad.reshape(shape)
 
@@ -133,11 +133,14 @@ def bind():
 		fwd, bwdData, bwdParam = bnd.convNdbenchmark(datashape, Wshape, np.float32, stride, pad, dilation, groups)
 		return fwd, bwdParam, bwdData
 
+	def bnGateStats(grad0, grad1, outdata, targets):
+		return dnn.bnGateStats(grad0, grad1, outdata, [(x, m.ravel()) for x, m in targets], allocator=memoryPool)
+
 	def bnApplyAdd(first, second, relu=False):
 		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool)
 
 	Dnn = SimpleNamespace(
-		bnApplyAdd=bnApplyAdd,
+		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats,
 		ConvFwdAlgo=bnd.ConvFwdAlgo, ConvBwdDataAlgo=bnd.ConvBwdDataAlgo, ConvBwdFilterAlgo=bnd.ConvBwdFilterAlgo,
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,

@@ -140,9 +140,10 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 	data, labels = mini_golden["data"], mini_golden["labels"]
 
 	results = {}
-	for fused in (False, True, "no-bn-add"):
+	for fused in (False, True, "no-bn-add", "no-gate-stats"):
 		nn.Sequential.fuseInplaceRelu = bool(fused)
-		nn.Sequential.fuseBnAdd = fused is True        # False / "no-bn-add": the residual Add reads materialised BN outputs
+		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats")      # else the residual Add reads materialised BN outputs
+		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add")      # else BN backward sums its own statistics
 		try:
 			np.random.seed(7)
 			net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
@@ -164,6 +165,8 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 			params = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
 
 			if fused is True:
+				reps = [m for m in allModules(net) if isinstance(m, nn.Replicate)]
+				assert sum(len(m.statsFor) for m in reps) == 4, "blocks 1 and 2 (each with a projection BN) hand their BN statistics to the next fan-in"
 				bns = [m for m in allModules(net) if isinstance(m, nn.BatchNorm2D)]
 				assert sum(m.deferApply for m in bns) == 5, "3 blocks' branch-tail BNs + 2 projection-shortcut BNs feed an Add"
 			if fused:
@@ -173,10 +176,10 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 
 			results[fused] = (logits, float(cost.devErr.get()), grads, params)
 		finally:
-			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = True
+			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = nn.Sequential.fuseGateStats = True
 
 	(l1, e1, g1, p1) = results[True]
-	for other in (False, "no-bn-add"):
+	for other in (False, "no-bn-add", "no-gate-stats"):
 		l0, e0, g0, p0 = results[other]
 		assert np.array_equal(l0, l1) and e0 == e1
 		for name in g0:
