@@ -291,6 +291,22 @@ __device__ __forceinline__ float bn_gate(float dy, float x, float a, float b) {
 	return RELU ? (__builtin_fmaf(x, a, b) > 0.f ? dy : 0.f) : dy;
 }
 
+// The two running sums of the backward statistics, written with explicit fma so that every kernel that produces them
+// (bn_bwd_stats_kernel, bn_gate_stats_kernel) rounds identically — the fused and unfused paths stay bit-identical.
+__device__ __forceinline__ void bn_bwd_acc4(const f4u &q, const f4u &x, float mu, float &s1, float &s2) {
+#pragma clang fp contract(off)
+	s1 += (q[0] + q[1]) + (q[2] + q[3]);
+	const float d0 = x[0] - mu, d1 = x[1] - mu, d2 = x[2] - mu, d3 = x[3] - mu;
+	const float p01 = __builtin_fmaf(q[0], d0, q[1] * d1), p23 = __builtin_fmaf(q[2], d2, q[3] * d3);
+	s2 += p01 + p23;
+}
+
+__device__ __forceinline__ void bn_bwd_acc1(float q, float x, float mu, float &s1, float &s2) {
+#pragma clang fp contract(off)
+	s1 += q;
+	s2 = __builtin_fmaf(q, x - mu, s2);
+}
+
 template <bool RELU>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ dy, BnGeom g,
                                                             const float *__restrict__ save_mean,
@@ -316,14 +332,9 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restri
 		    f4u q = gv[u];
 #pragma unroll
 		    for (int e = 0; e < 4; ++e) q[e] = bn_gate<RELU>(q[e], v[e], a, b);
-		    s1 += (q[0] + q[1]) + (q[2] + q[3]);
-		    s2 += (q[0] * (v[0] - mu) + q[1] * (v[1] - mu)) + (q[2] * (v[2] - mu) + q[3] * (v[3] - mu));
+		    bn_bwd_acc4(q, v, mu, s1, s2);
 	    },
-	    [&](size_t off) {
-		    const float gj = bn_gate<RELU>(dy[off], x[off], a, b);
-		    s1 += gj;
-		    s2 += gj * (x[off] - mu);
-	    });
+	    [&](size_t off) { bn_bwd_acc1(bn_gate<RELU>(dy[off], x[off], a, b), x[off], mu, s1, s2); });
 
 	s1 = block_sum(s1, red);
 	s2 = block_sum(s2, red);
@@ -412,21 +423,14 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
 #pragma unroll
 		    for (int e = 0; e < 4; ++e) q[e] = (v0[u][e] + v1[u][e]) * (vy[u][e] > 0.f ? 1.f : 0.f);
 		    *reinterpret_cast<f4u *>(gout + off) = q;
-		    const f4u x = va[u];
-		    a1 += (q[0] + q[1]) + (q[2] + q[3]);
-		    a2 += (q[0] * (x[0] - mua) + q[1] * (x[1] - mua)) + (q[2] * (x[2] - mua) + q[3] * (x[3] - mua));
-		    if (TWO) {
-			    const f4u z = vb[u];
-			    b1 += (q[0] + q[1]) + (q[2] + q[3]);
-			    b2 += (q[0] * (z[0] - mub) + q[1] * (z[1] - mub)) + (q[2] * (z[2] - mub) + q[3] * (z[3] - mub));
-		    }
+		    bn_bwd_acc4(q, va[u], mua, a1, a2);
+		    if (TWO) bn_bwd_acc4(q, vb[u], mub, b1, b2);
 	    },
 	    [&](size_t off) {
 		    const float q = (g0[off] + g1[off]) * (y[off] > 0.f ? 1.f : 0.f);
 		    gout[off] = q;
-		    a1 += q;
-		    a2 += q * (xa[off] - mua);
-		    if (TWO) b1 += q, b2 += q * (xb[off] - mub);
+		    bn_bwd_acc1(q, xa[off], mua, a1, a2);
+		    if (TWO) bn_bwd_acc1(q, xb[off], mub, b1, b2);
 	    });
 
 	a1 = block_sum(a1, red);
