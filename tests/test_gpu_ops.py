@@ -142,6 +142,11 @@ FRESH = [
 	dict(n=2, c=8, h=12, w=12, k=8, r=3, s=2, stride=(2, 1), pad=(1, 0), dil=1, groups=4),
 	dict(n=1, c=4, h=9, w=9, k=6, r=3, s=3, stride=2, pad=1, dil=2, groups=1),       # strided+dilated: direct dgrad path
 	dict(n=5, c=130, h=7, w=7, k=200, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
+	# 1x1 / stride 2 / pad 0 (ResNet stage transitions): backward-data writes whole 2x2 cells, odd and even maps
+	dict(n=3, c=32, h=55, w=55, k=16, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	dict(n=2, c=16, h=28, w=28, k=40, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	dict(n=4, c=16, h=7, w=9, k=24, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	dict(n=2, c=150, h=14, w=13, k=16, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
 ]
 
 
