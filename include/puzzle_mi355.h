@@ -178,6 +178,21 @@ int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, i
                             const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                             float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
                             pz_stream_t stream);
+/* BatchNorm backward folded into the gathers of the convolution in front of it (Conv2D -> BatchNorm2D, both backward):
+ * pz_bn_bwd_coef turns the partial sums (pz_bn_gate_stats) into the parameter gradients and coef[4k..4k+2] = {A, B, C}
+ * with dx_bn = A*dy + B*x + C per channel; pz_conv2d_bwd_data_bn / pz_conv2d_bwd_filter_bn are pz_conv2d_bwd_data /
+ * pz_conv2d_bwd_filter whose `dy` operand is that expression evaluated on the fly from dy (the BN's incoming gradient)
+ * and bnx (the BN's input = this convolution's forward output). The BN's 12 B/elem apply pass and its output tensor
+ * disappear. Only for convolutions pz_conv2d_bn_fold_supported accepts (1x1, no padding, ungrouped, MFMA path).   */
+int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_mean, const float *save_invvar,
+                   float *dscale, float *dbias, float *dscale_acc, float *dbias_acc, float alpha, float beta,
+                   const float *partials, float *coef, pz_stream_t stream);
+int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported);
+int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef,
+                          const float *w, float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx,
+                            const float *bncoef, float *dw, float alpha, float beta, int algo,
+                            void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
  * projection shortcut of Models/Nets/ResNet.py:36-58) the normalised tensor is never written. pz_bn_fwd_train_defer does
  * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;

@@ -137,6 +137,32 @@ class DeferredBN:
 		return self.materialize().get(stream)
 
 
+class DeferredBNGrad:
+	"""The input gradient of a BatchNorm that was not written: dx = A*grad + B*data + C per channel (pz_bn_bwd_coef).
+	DnnContext.convNdBackwardData / convNdBackwardParams of the convolution in front evaluate it while gathering;
+	`materialize()` runs the apply pass for anyone else."""
+	__slots__ = ["grad", "data", "coef", "apply", "dense"]
+
+	def __init__(self, grad, data, coef, apply):
+		self.grad, self.data, self.coef, self.apply, self.dense = grad, data, coef, apply, None
+
+	@property
+	def shape(self):
+		return self.grad.shape
+
+	@property
+	def dtype(self):
+		return self.grad.dtype
+
+	def materialize(self):
+		if self.dense is None:
+			self.dense = self.apply()
+		return self.dense
+
+	def get(self, stream=None):
+		return self.materialize().get(stream)
+
+
 class ConvStats:
 	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
 	__slots__ = ["tensor", "stats"]
@@ -297,8 +323,17 @@ class DnnContext:
 		return out, ConvStats(out, stats)
 
 
+	def bnFoldSupported(self, desc, algo):
+		flag = c_int(0)
+		lib.pz_conv2d_bn_fold_supported(byref(desc), algo, byref(flag))
+		return bool(flag.value)
+
+
 	def convNdBackwardData(self, grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1,
 						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None):
+		lazy = grad if isinstance(grad, DeferredBNGrad) else None      # backend-internal: BN backward folded into the gather
+		if lazy is not None:
+			grad = lazy.grad
 		assert grad.ndim == W.ndim and grad.shape[1] == W.shape[0]
 		requireF32(grad, W, bias, out)
 
@@ -328,7 +363,14 @@ class DnnContext:
 		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_DATA, algo, byref(size))
 		ws = self.workspace(size.value, allocator)
 
-		lib.pz_conv2d_bwd_data(byref(desc), grad.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None)
+		if lazy is not None and self.bnFoldSupported(desc, algo):
+			lib.pz_conv2d_bwd_data_bn(
+				byref(desc), grad.ptr, lazy.data.ptr, lazy.coef.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None
+			)
+		else:
+			if lazy is not None:
+				grad = lazy.materialize()
+			lib.pz_conv2d_bwd_data(byref(desc), grad.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None)
 
 		if bias is not None:           # deconvolution forward: bias over the produced maps
 			self.backend.matmod.addVecToMat(
@@ -343,6 +385,9 @@ class DnnContext:
 	def convNdBackwardParams(self, data, grad, W, stride=1, pad=0, dilation=1, groups=1, withbias=False, deconv=False,
 							 wgrad=None, bgrad=None, scale=1.0, momentum=0.0, algo=ConvBwdFilterAlgo.auto.value,
 							 allocator=None):
+		lazy = grad if isinstance(grad, DeferredBNGrad) else None
+		if lazy is not None:
+			grad = lazy.grad
 		assert data.ndim == grad.ndim and grad.shape[1] == W.shape[0] and data.shape[1] == W.shape[1] * groups
 		requireF32(data, grad, wgrad, bgrad)
 		if deconv:
@@ -366,6 +411,15 @@ class DnnContext:
 		bg = None
 		if withbias:
 			bg = GPUArray.empty((grad.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
+
+		if lazy is not None and not withbias and self.bnFoldSupported(desc, algo):
+			lib.pz_conv2d_bwd_filter_bn(
+				byref(desc), data.ptr, grad.ptr, lazy.data.ptr, lazy.coef.ptr, wgrad.ptr, wcoef[0], wcoef[1], algo,
+				ptrOf(ws), size.value, None
+			)
+			return wgrad
+		if lazy is not None:
+			grad = lazy.materialize()
 
 		fused = withbias and bcoef == wcoef       # one library call reduces dw and db with the same (alpha, beta)
 		lib.pz_conv2d_bwd_filter(
@@ -585,7 +639,7 @@ class DnnContext:
 
 	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
 							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False,
-							accumulate=None, partials=None):
+							accumulate=None, partials=None, lazyGrad=False):
 		"""`accumulate` (backend-internal) = (scalegradDst, biasgradDst, alpha, beta): additionally
 		dst = alpha*fresh + beta*dst for both parameter gradients inside the same launch."""
 		assert data.ndim == grad.ndim
@@ -604,6 +658,23 @@ class DnnContext:
 
 		sdst, bdst, alpha, beta = accumulate if accumulate is not None else (None, None, 1.0, 0.0)
 		requireF32(sdst, bdst)
+
+		if partials is not None and not fuseRelu and lazyGrad:
+			# statistics already summed (bnGateStats) and the consumer folds the apply pass into its gathers
+			coef = GPUArray.empty((c, 4), dtype=np.float32, allocator=allocator)
+			lib.pz_bn_bwd_coef(
+				n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, ptrOf(sdst), ptrOf(bdst), alpha, beta,
+				partials.ptr, coef.ptr, None
+			)
+
+			def apply():
+				lib.pz_bn_bwd_from_partials(
+					data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
+					None, None, 1.0, 0.0, partials.ptr, None
+				)
+				return out
+
+			return DeferredBNGrad(grad, data, coef, apply), scalegrad, bgrad
 
 		if partials is not None and not fuseRelu:           # statistics already summed by bnGateStats: apply pass only
 			lib.pz_bn_bwd_from_partials(

@@ -606,6 +606,44 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
 	return PZ_OK;
 }
 
+// Backward coefficients: dx = A*dy + B*x + C per channel (A = gamma*rstd, B = -A*k2, C = A*(mean*k2 - k1) with
+// k1 = dbias/m, k2 = dgamma*rstd/m) plus the parameter gradients, from the partial sums — for consumers that apply the
+// BatchNorm backward while they gather dy (pz_conv2d_bwd_data_bn / pz_conv2d_bwd_filter_bn): the 12 B/elem apply pass
+// over the tensor disappears.
+__global__ void __launch_bounds__(256) bn_bwd_coef_kernel(const float *__restrict__ part, int splits, int c, float inv_m,
+                                                           const float *__restrict__ scale, const float *__restrict__ save_mean,
+                                                           const float *__restrict__ save_invvar, float *__restrict__ dscale,
+                                                           float *__restrict__ dbias, float *__restrict__ dscale_acc,
+                                                           float *__restrict__ dbias_acc, float alpha, float beta,
+                                                           float4 *__restrict__ coef) {
+	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ch >= c) return;
+	double S1, S2;
+	bn_merge(part, splits, ch, S1, S2);
+	const float mu = save_mean[ch], rstd = save_invvar[ch], sc = scale[ch];
+	const float db = (float)S1, ds = (float)(S2 * (double)rstd);
+	dscale[ch] = ds;
+	dbias[ch] = db;
+	if (dscale_acc) dscale_acc[ch] = alpha * ds + (beta == 0.f ? 0.f : beta * dscale_acc[ch]);
+	if (dbias_acc) dbias_acc[ch] = alpha * db + (beta == 0.f ? 0.f : beta * dbias_acc[ch]);
+
+	const float k0 = sc * rstd, k1 = db * inv_m, k2 = ds * inv_m * rstd;
+	coef[ch] = make_float4(k0, -k0 * k2, k0 * (mu * k2 - k1), 0.f);
+}
+
+int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_mean, const float *save_invvar, float *dscale,
+                   float *dbias, float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
+                   float *coef, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(scale && save_mean && save_invvar && dscale && dbias && partials && coef, "pz_bn_bwd_coef: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	bn_bwd_coef_kernel<<<(c + 255) / 256, 256, 0, pz::as_stream(stream)>>>(
+	    partials, g.splits, c, 1.f / ((float)n * (float)hw), scale, save_mean, save_invvar, dscale, dbias, dscale_acc, dbias_acc,
+	    alpha, beta, reinterpret_cast<float4 *>(coef));
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw, const float *xa,
                      const float *mean_a, float *part_a, const float *xb, const float *mean_b, float *part_b,
                      pz_stream_t stream) {

@@ -192,6 +192,10 @@ struct IgemmArgs {
 	int tapmajor;                          // `tab` is the per-k-tile int4 table of the tap-major order
 	int contig;                            // output pixel index == position inside the image (stride-1 output grid):
 	                                       // the epilogue goes through LDS and stores 4 pixels (16 B) per lane
+	// BNX kernels: the gathered tensor is not materialised — element (n, c, ...) is xcoef[c].x * x + xcoef[c].y * x2 +
+	// xcoef[c].z (a BatchNorm backward applied while gathering its incoming gradient x, with x2 = the BN's input)
+	const float *x2;
+	const float4 *xcoef;
 	float4 *stats;                         // optional [OC_total][stat_strips] {shift, sum(v-shift), sum((v-shift)^2), -} per
 	int stat_strips;                       // (channel, 32*TN-pixel strip) for a following batch normalisation
 };
@@ -329,8 +333,9 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 	}
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPMAJOR>
-__global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
+template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false>
+__global__ void __launch_bounds__(256, BNX ? 3 : PZ_LB) igemm_conv_kernel(IgemmArgs a) {
+	static_assert(!BNX || TAPMAJOR, "the BatchNorm-backward gather rides on the tap-major order");
 	constexpr int BK = 16, NT = 256;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
@@ -406,6 +411,9 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 
 	f32x4 ra[NA];
 	float rb[NB];
+	float rb2[BNX ? NB : 1];                  // BNX: the BatchNorm input elements that go with the gradient elements
+	float4 bnc[BNX ? NB : 1];                 // ... and the coefficients of their channels (scalar loads)
+	const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
 
 	const int l31 = lane & 31, lhi = lane >> 5;
 	int2 e[NB];
@@ -426,6 +434,11 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 			const unsigned word = t.y < 32 ? mask_lo : mask_hi;
 			voff_tile = (word >> (t.y & 31)) & 1u ? base_bytes + (unsigned)t.x : kOOB;
 			soff_tile = (unsigned)t.z + row_off;
+			if constexpr (BNX) {                  // channels of this k-tile: (16 kt) mod C onwards (C = reduction channels, % 16 == 0)
+				const int ch0 = g * a.Cg + (kt * BK) % a.Cg + kb0 * NB;
+#pragma unroll
+				for (int i = 0; i < NB; ++i) bnc[i] = a.xcoef[ch0 + i];
+			}
 		} else {
 #pragma unroll
 			for (int i = 0; i < NB; ++i) e[i] = a.tab[kt * BK + kb0 * NB + i];   // contiguous: one wide scalar load
@@ -441,6 +454,7 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 			const int i = j * PER + t;
 			if constexpr (TAPMAJOR) {
 				rb[i] = buf_load_f32(xr, voff_tile, soff_tile + (unsigned)i * hw4);
+				if constexpr (BNX) rb2[i] = buf_load_f32(x2r, voff_tile, soff_tile + (unsigned)i * hw4);
 			} else {
 				const bool ok = (tapmask >> e[i].y) & 1ull;
 				rb[i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
@@ -456,7 +470,11 @@ __global__ void __launch_bounds__(256, PZ_LB) igemm_conv_kernel(IgemmArgs a) {
 			*reinterpret_cast<f32x4 *>(&As[buf][kk][m4]) = ra[i];
 		}
 #pragma unroll
-		for (int i = 0; i < NB; ++i) Bs[buf][kb0 * NB + i][jb] = rb[i];
+		for (int i = 0; i < NB; ++i) {
+			float v = rb[i];
+			if constexpr (BNX) v = __builtin_fmaf(bnc[i].x, rb[i], __builtin_fmaf(bnc[i].y, rb2[i], bnc[i].z));
+			Bs[buf][kb0 * NB + i][jb] = v;
+		}
 	};
 
 	auto read_frag = [&](int buf, int ks, float (&av)[TM], float (&bv)[TN]) {
@@ -605,6 +623,11 @@ struct WgradArgs {
 	float alpha, beta;
 	int direct;           // 1: out = beta*out + alpha*acc ; 0: out[split] = acc
 	size_t slab;          // groups*Kg*ncrs
+	// BNX kernels: dy is not materialised — it is coef[k].x * dy + coef[k].y * bnx + coef[k].z per output channel k, i.e.
+	// the backward of the BatchNorm that follows this convolution applied while gathering (dy = the BN's incoming
+	// gradient, bnx = this convolution's output / the BN's input, same shape)
+	const float *bnx;
+	const float4 *bncoef;
 };
 
 // The reduction axis is enumerated in RUNS of 4 consecutive output pixels of one output row (rows padded to a multiple
@@ -615,7 +638,7 @@ struct WgradArgs {
 // GATHER: 0 = any stride (element-wise x gathers), 1 = unit stride along w (16-byte x runs with edge masks),
 //         2 = pointwise 1x1 / stride 1 / pad 0 (16-byte runs, only the row tail is masked: no per-tap address or
 //             mask arithmetic — VALU instructions serialise with the MFMAs, see tools/probes/lds_mfma.hip)
-template <int BM, int BN, int WM, int WN, int GATHER, int RUNS>
+template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false>
 __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(WgradArgs a) {
 	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
 	constexpr int RP = 256 / RUNS;               // tile rows loaded per pass (one 16-byte run per thread)
@@ -661,6 +684,7 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 	// exposed HBM latency behind
 	constexpr int SETS = PZ_WG_SETS;              // register sets of gathers in flight (2: issued two k-steps ahead)
 	f32x4 ra[SETS][NA], rb[SETS][NB];
+	f32x4 ra2[SETS][BNX ? NA : 1];           // BNX: the BatchNorm input runs that go with the dy runs
 	unsigned mb[SETS][NB];         // valid-pixel masks of the operand-B runs in flight
 	int x_img_of[SETS] = {};       // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
 	const int PQ = a.P * a.Q;
@@ -680,6 +704,13 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 
 	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.bnx : a.dy), 0, a.dy_bytes, 0x00020000);
+
+	float4 bnc[BNX ? NA : 1];                // this thread's operand-A rows are the same output channels in every k-step
+	if constexpr (BNX) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) bnc[i] = a.bncoef[g * a.Kg + min(tm * BM + row0 + RP * i, a.Kg - 1)];
+	}
 	const bool full_m = tm * BM + BM <= a.Kg;
 
 	// ---- per-step state of this thread's run: image / row / first column, number of real pixels in the run
@@ -710,6 +741,9 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + RP * i < a.Kg);
 			ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
 			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
+			if constexpr (BNX)
+				ra2[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+				    bnr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
 		} else if (j < NA + NB) {
 			const int i = j - NA;
 			const int w0 = wb + tap_w[i];
@@ -747,7 +781,15 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 
 	auto store_step = [&](int set, int buf) {
 #pragma unroll
-		for (int i = 0; i < NA; ++i) As[buf][run >> 1][run & 1][row0 + RP * i] = ra[set][i];
+		for (int i = 0; i < NA; ++i) {
+			f32x4 v = ra[set][i];
+			if constexpr (BNX) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+					v[q] = __builtin_fmaf(bnc[i].x, (float)ra[set][i][q], __builtin_fmaf(bnc[i].y, (float)ra2[set][i][q], bnc[i].z));
+			}
+			As[buf][run >> 1][run & 1][row0 + RP * i] = v;
+		}
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const unsigned m = mb[set][i];
@@ -1117,7 +1159,9 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
 	constexpr int lds_pad = 0;
-	if (a.tapmajor)
+	if (a.x2)
+		igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+	else if (a.tapmajor)
 		igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
 	else
 		igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
@@ -1344,8 +1388,41 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	return PZ_OK;
 }
 
+// convolutions whose gathers can apply a following BatchNorm's backward on the fly (pz_conv2d_bwd_*_bn): pointwise
+// filter without padding (no padded tap would turn the affine constant into a contribution), ungrouped, MFMA path,
+// reduction channels in whole k-tiles
+bool bn_fold_eligible(const pz_conv_desc *d, int P, int Q, int algo) {
+	return d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->groups == 1 && d->k % 16 == 0 &&
+	       algo != PZ_CONV_ALGO_DIRECT && igemm_eligible(d, P, Q) && dgrad_uses_igemm(d);
+}
+
+int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(supported != nullptr, "pz_conv2d_bn_fold_supported: null output");
+	*supported = bn_fold_eligible(d, P, Q, algo) ? 1 : 0;
+	return PZ_OK;
+}
+
+static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
 int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx, int algo, void *workspace,
                        size_t ws_bytes, pz_stream_t stream) {
+	return conv2d_bwd_data_impl(d, dy, nullptr, nullptr, w, dx, algo, workspace, ws_bytes, stream);
+}
+
+int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
+                          float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(bnx && bncoef, "pz_conv2d_bwd_data_bn: null BatchNorm operand");
+	PZ_REQUIRE(bn_fold_eligible(d, P, Q, algo), "pz_conv2d_bwd_data_bn: this convolution cannot fold a BatchNorm backward");
+	return conv2d_bwd_data_impl(d, dy, bnx, bncoef, w, dx, algo, workspace, ws_bytes, stream);
+}
+
+static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(dy && w && dx, "pz_conv2d_bwd_data: null tensor");
@@ -1412,14 +1489,34 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
 		a.tapmajor = pa.tapmajor;
 		a.contig = d->stride_h == 1 && d->stride_w == 1 && c.Pv == d->h && c.Qv == d->w && c.oo_h == 0 && c.oo_w == 0;
 		a.stats = nullptr;
+		a.x2 = bnx, a.xcoef = reinterpret_cast<const float4 *>(bncoef);
 		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;
 }
 
+static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx, const float *bncoef,
+                                  float *dw, float *db, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
+                                  pz_stream_t stream);
+
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db, float alpha,
                          float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	return conv2d_bwd_filter_impl(d, x, dy, nullptr, nullptr, dw, db, alpha, beta, algo, workspace, ws_bytes, stream);
+}
+
+int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx, const float *bncoef,
+                            float *dw, float alpha, float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(bnx && bncoef, "pz_conv2d_bwd_filter_bn: null BatchNorm operand");
+	PZ_REQUIRE(bn_fold_eligible(d, P, Q, algo), "pz_conv2d_bwd_filter_bn: this convolution cannot fold a BatchNorm backward");
+	return conv2d_bwd_filter_impl(d, x, dy, bnx, bncoef, dw, nullptr, alpha, beta, algo, workspace, ws_bytes, stream);
+}
+
+static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx, const float *bncoef,
+                                  float *dw, float *db, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
+                                  pz_stream_t stream) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && dy && dw, "pz_conv2d_bwd_filter: null tensor");
@@ -1479,6 +1576,7 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	a.direct = p.splits == 1;
 	a.out = a.direct ? dw : slabs;
 	a.slab = p.slab_elems;
+	a.bnx = bnx, a.bncoef = reinterpret_cast<const float4 *>(bncoef);
 
 	dim3 grid(p.tiles_m * p.tiles_n * p.splits, 1, d->groups);
 	{
@@ -1486,7 +1584,9 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 	const bool unit_w = d->stride_w == 1;
 	const bool pointwise = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && unit_w;
 #define PZ_WGRAD_LAUNCH(BM_, BN_) \
-	(pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
+	(a.bnx     ? (pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS, true><<<grid, 256, 0, st>>>(a) \
+	                        : wgrad_conv_kernel<BM_, BN_, 2, 2, 0, PZ_WG_RUNS, true><<<grid, 256, 0, st>>>(a)) \
+	 : pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
 	 : unit_w  ? wgrad_conv_kernel<BM_, BN_, 2, 2, 1, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
 	           : wgrad_conv_kernel<BM_, BN_, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a))
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128);

@@ -464,6 +464,7 @@ class BatchNorm2D(Module):
 		self.statsFrom = None        # ... and the Conv2D right in front whose epilogue sums this layer's input per channel
 		self.deferApply = False      # ... the only consumer is a residual Add that normalises on the fly (DeferredBN output)
 		self.bwdPartials = None      # (grad tensor, partial sums) left by the Replicate fan-in that produced this layer's grad
+		self.foldBackwardInto = None # the Conv2D in front that applies this layer's backward while gathering its gradient
 
 		if empty:
 			return
@@ -518,7 +519,8 @@ class BatchNorm2D(Module):
 			self.inData, grad, self.scale, self.savemean, self.saveinvvar, self.epsilon,
 			bias=self.bias if self.fusedRelu else None, fuseRelu=self.fusedRelu,
 			accumulate=getattr(self, "accumulate", None),
-			partials=partials[1] if partials is not None and partials[0] is grad and not self.fusedRelu else None
+			partials=partials[1] if partials is not None and partials[0] is grad and not self.fusedRelu else None,
+			lazyGrad=self.foldBackwardInto is not None
 		)
 		if self.affine:
 			self.grad, self.scalegrad, self.biasgrad = tup
@@ -1068,6 +1070,7 @@ class Sequential(Container):
 	fuseConvStats = True         # BatchNorm statistics from the preceding convolution's epilogue (see planFusion)
 	fuseBnAdd = True             # residual Add normalises its BatchNorm inputs on the fly (see planFusion)
 	fuseGateStats = True         # gradient fan-in also sums the next BatchNorm backward's statistics (see planFusion)
+	fuseBnBackward = True        # ... and the BatchNorm's apply pass is folded into the backward of the Conv2D in front
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1117,6 +1120,11 @@ class Sequential(Container):
 				mod.statsFrom = None
 				if Sequential.fuseConvStats and mod.train and isinstance(prev, Conv2D):
 					prev.emitStats, mod.statsFrom = True, prev
+				# Conv2D -> BatchNorm2D: the convolution's backward kernels can evaluate the BN backward while gathering its
+				# gradient (only taken when the BN's statistics were summed by the fan-in and the conv is eligible)
+				mod.foldBackwardInto = prev if (
+					Sequential.fuseBnBackward and mod.train and isinstance(prev, Conv2D) and prev.b is None
+				) else None
 
 		if not on:
 			return

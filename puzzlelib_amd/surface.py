@@ -112,13 +112,14 @@ def bind():
 		return outdata, savemean.reshape(shape), saveinvvar.reshape(shape)
 
 	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial,
-							bias=None, fuseRelu=False, accumulate=None, partials=None):
+							bias=None, fuseRelu=False, accumulate=None, partials=None, lazyGrad=False):
 		shape = scale.shape
 		if accumulate is not None:
 			accumulate = (accumulate[0].ravel(), accumulate[1].ravel(), accumulate[2], accumulate[3])
 		ingrad, scalegrad, bgrad = dnn.batchNormNdBackward(
 			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool,
-			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu, accumulate=accumulate, partials=partials
+			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu, accumulate=accumulate, partials=partials,
+			lazyGrad=lazyGrad
 		)
 		return ingrad, scalegrad.reshape(shape), bgrad.reshape(shape)
 

@@ -141,6 +141,7 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 
 	results = {}
 	for fused in (False, True, "no-bn-add", "no-gate-stats"):
+		nn.Sequential.fuseBnBackward = False           # covered by its own test below (same values up to fp32 rounding, not bit-identical)
 		nn.Sequential.fuseInplaceRelu = bool(fused)
 		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats")      # else the residual Add reads materialised BN outputs
 		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add")      # else BN backward sums its own statistics
@@ -177,6 +178,7 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 			results[fused] = (logits, float(cost.devErr.get()), grads, params)
 		finally:
 			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = nn.Sequential.fuseGateStats = True
+			nn.Sequential.fuseBnBackward = True
 
 	(l1, e1, g1, p1) = results[True]
 	for other in (False, "no-bn-add", "no-gate-stats"):
@@ -190,6 +192,71 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 	assert np.isclose(e1, mini_golden["orc_err"][0], rtol=1e-4)
 	for name in p1:
 		assert_close(p1[name], mini_golden["orc_after_" + name], atol=3e-4, rtol=1e-4, what="param " + name)
+
+
+def test_batchnorm_backward_folded_into_the_convolution(bnd, mini_golden):
+	"""Conv2D -> BatchNorm2D backward with the BN's apply pass evaluated inside the convolution's backward-data /
+	backward-filter gathers (pz_conv2d_bwd_*_bn): gradients equal the unfolded path to fp32 rounding and the oracle to the
+	usual tolerances; the folded kernels must actually have been taken."""
+	from puzzlelib_amd import nets, train, nn, backend
+	from puzzlelib_amd.surface import bound
+
+	gpuarray = bound().gpuarray
+	spec = nets.resnet_spec(stages=((16, 1), (32, 2)), classes=10, stem=16, softmax=False)     # 16-multiples: eligible 1x1 convs
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	rng = np.random.RandomState(3)
+	data = rng.randn(4, 3, 64, 64).astype(np.float32)
+	labels = rng.randint(0, 10, size=(4, )).astype(np.int32)
+
+	taken = []
+	original = backend.DnnContext.convNdBackwardData
+
+	def spy(self, grad, *args, **kwargs):
+		taken.append(isinstance(grad, backend.DeferredBNGrad))
+		return original(self, grad, *args, **kwargs)
+
+	results = {}
+	for fold in (False, True):
+		nn.Sequential.fuseBnBackward = fold
+		backend.DnnContext.convNdBackwardData = spy
+		taken.clear()
+		try:
+			np.random.seed(7)
+			net = nets.build(spec, name="mini16", initscheme="he", actInplace=True)
+			init = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
+			optimizer = train.Adam(alpha=1e-3)
+			optimizer.setupOn(net, useGlobalState=True)
+			cost = train.CrossEntropy()
+			net.trainMode()
+			pred = net(gpuarray.to_gpu(data))
+			grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
+			optimizer.zeroGradParams()
+			net.backward(grad, updGrad=False)
+			results[fold] = ({name: var.grad.get() for name, var in nets.namedVariables(net).items()}, init, sum(taken))
+		finally:
+			backend.DnnContext.convNdBackwardData = original
+			nn.Sequential.fuseBnBackward = True
+
+	(g0, init0, n0), (g1, init1, n1) = results[False], results[True]
+	assert n0 == 0 and n1 >= 3, "the folded backward was taken %d times" % n1
+	for name in g0:
+		scale = np.abs(g0[name]).max() + 1e-12
+		assert_close(g1[name], g0[name], atol=2e-5 * scale, rtol=2e-4, what="grad " + name)
+
+	# oracle
+	params = init1
+	_, ashapes = nets.spec_param_shapes(spec)
+	attrs = {k: (np.zeros(s, np.float32) if k.endswith(".mean") else np.ones(s, np.float32)) for k, s in ashapes.items()}
+	cnet = N.CpuNet(spec, params, attrs)
+	cnet.train = True
+	pred_ref = cnet.forward(data)
+	_, grad_ref = R.cross_entropy(pred_ref, labels)
+	cnet.zero_grads()
+	cnet.backward(grad_ref)
+	for name in g1:
+		ref = cnet.grads[name]
+		scale = np.abs(ref).max() + 1e-6
+		assert_close(g1[name], ref, atol=2e-3 * scale, rtol=2e-3, what="grad vs oracle " + name)
 
 
 def allModules(container):
