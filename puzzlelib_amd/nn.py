@@ -1078,19 +1078,25 @@ class Sequential(Container):
 
 
 	def planFusion(self):
-		"""Marks, for the coming forward/backward pass, the neighbours that absorb an in-place ReLU
-		(Activation(relu, inplace=True), e.g. Models/Nets/ResNet.py:33,58 with actInplace=True). With the in-place flag
-		the pre-activation values are overwritten in the reference as well, so no observable buffer changes:
+		"""Marks, for the coming forward/backward pass, which neighbouring modules share a kernel (fusion
+		inside the backend, module API untouched). Every pattern has its switch on Sequential and is checked against the
+		unfused sequence in tests/test_gpu_nets.py.
+
+		fuseInplaceRelu — around Activation(relu, inplace=True) (Models/Nets/ResNet.py:33,58 with actInplace=True; with
+		the in-place flag the pre-activation values are overwritten in the reference too, so no observable buffer changes):
 		  BatchNorm2D (train) -> ReLU : BN writes relu(bn(x)); its backward gates the incoming grad with (bn(x) > 0)
 		  Add (2 inputs)      -> ReLU : the sum kernel writes relu(a + b)
 		  ReLU -> Replicate(2)        : the fan-in kernel writes (g0 + g1) * (y > 0), y = the ReLU's output
-		The ReLU module itself then only forwards data / grad. Values are bit-identical to the unfused sequence.
-		Sequential.fuseBnAdd: Parallel(… Conv2D -> BatchNorm2D, …) -> Add: those BatchNorms only compute their
-		statistics / coefficients; the Add kernel reads the convolution outputs and normalises while summing
-		(bit-identical; the BN output tensor is never written).
-		Independently of ReLUs (Sequential.fuseConvStats): Conv2D -> BatchNorm2D (train): the convolution's epilogue
-		leaves per-strip channel sums of its output and the BN skips its own statistics pass over that tensor (same
-		mean/variance up to fp32 summation order)."""
+		  the ReLU module itself then only forwards data / grad; bit-identical.
+		fuseConvStats  — Conv2D -> BatchNorm2D (train): the convolution's epilogue leaves per-strip channel sums, the BN
+		                 skips its statistics pass (same mean/variance up to fp32 summation order).
+		fuseBnAdd      — Parallel(... Conv2D -> BatchNorm2D, ...) -> Add: those BatchNorms only produce per-channel
+		                 coefficients (DeferredBN); the Add kernel normalises while summing; bit-identical.
+		fuseGateStats  — [Parallel, Add, ReLU, Replicate]: the fan-in also sums the backward statistics of the Parallel's
+		                 branch-tail BatchNorms, which then run their apply pass only; bit-identical.
+		fuseBnBackward — Conv2D (no bias) -> BatchNorm2D whose statistics came from the fan-in: the BN hands the
+		                 convolution a DeferredBNGrad and the 1x1 convolution's backward kernels evaluate the BN backward
+		                 while gathering (equal to the separate pass up to fp32 rounding)."""
 		graph, on = self.graph, Sequential.fuseInplaceRelu
 
 		for i, mod in enumerate(graph):
