@@ -936,10 +936,29 @@ __global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(Wgra
 	}
 }
 
-// dw = beta*dw + alpha * sum_s slab[s]   (fixed summation order -> deterministic)
+// dw = beta*dw + alpha * sum_s slab[s]   (fixed summation order -> deterministic). 16 bytes per lane and four slabs in
+// flight per step: the launch is latency-, not bandwidth-bound (tens of MB), so independent wide loads are what counts.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
                                                             int splits, float alpha, float beta) {
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+	typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+	const size_t n4 = n >> 2;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+		f4 s = {0.f, 0.f, 0.f, 0.f};
+		int k = 0;
+		for (; k + 4 <= splits; k += 4) {
+			const f4 a = *reinterpret_cast<const f4 *>(slabs + (size_t)k * n + 4 * i);
+			const f4 b = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 1) * n + 4 * i);
+			const f4 c = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 2) * n + 4 * i);
+			const f4 d = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 3) * n + 4 * i);
+			s = (((s + a) + b) + c) + d;              // same order as the scalar loop
+		}
+		for (; k < splits; ++k) s += *reinterpret_cast<const f4 *>(slabs + (size_t)k * n + 4 * i);
+		f4 *o = reinterpret_cast<f4 *>(dw + 4 * i);
+		const f4 old = beta == 0.f ? f4{0.f, 0.f, 0.f, 0.f} : *o;
+		*o = (beta == 0.f ? f4{0.f, 0.f, 0.f, 0.f} : beta * old) + alpha * s;
+	}
+	// the n % 4 trailing elements
+	for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
 		float s = 0.f;
 		for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
 		dw[i] = (beta == 0.f ? 0.f : beta * dw[i]) + alpha * s;
@@ -1598,7 +1617,7 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	PZ_LAUNCH_CHECK();
 
 	if (!a.direct) {
-		wgrad_reduce_kernel<<<pz::stream_grid(p.slab_elems, 256), 256, 0, st>>>(dw, slabs, p.slab_elems, p.splits, alpha, beta);
+		wgrad_reduce_kernel<<<pz::stream_grid((p.slab_elems >> 2) + 1, 256), 256, 0, st>>>(dw, slabs, p.slab_elems, p.splits, alpha, beta);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;
