@@ -121,45 +121,76 @@ __device__ __forceinline__ float bn_act(float x, float a, float b) {
 }
 
 // ---- statistics from the producing convolution's strip sums: stats[ch*strips + strip] = {shift, s1, s2, -} over
-// `strip_px` consecutive pixels of the flattened (n, hw) axis. One workgroup per channel merges them with the pairwise
-// (count, mean, M2) update in fp64 — threads own strips t, t+256, ..., then a fixed-order tree — into pre[ch] = {mean, var}.
+// `strip_px` consecutive pixels of the flattened (n, hw) axis. One workgroup per channel folds them, in fp64 and about the
+// common reference R = the channel's first shift, into S = sum(v - R) and Q = sum((v - R)^2):
+//   sum_strip (v - R)   = s1 + n_s*(shift - R)          sum_strip (v - R)^2 = s2 + 2*(shift - R)*s1 + n_s*(shift - R)^2
+// (no divisions in the loop; R is a typical value of the channel, so mean - R is small and Q/N - ((S/N))^2 is benign),
+// threads own strips t, t+256, ..., then a fixed-order tree -> pre[ch] = {mean, var}.
+// With few channels one workgroup per channel leaves most of the chip idle (64 channels x 50 176 strips after the
+// stem): the strips of a channel are then cut into `parts` segments (blockIdx.y) whose {S, Q} go to `partial`, and
+// bn_merge_finish_kernel adds them in order.
 __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__restrict__ stats, int strips, int strip_px, long total_px,
-                                                               int c, float *__restrict__ pre) {
-	__shared__ double sh_n[256], sh_mean[256], sh_m2[256];
+                                                               int c, float *__restrict__ pre, int parts, double *__restrict__ partial) {
+	__shared__ double sh_s[256], sh_q[256];
 	const int ch = blockIdx.x, t = threadIdx.x;
+	const float4 *mine = stats + (size_t)ch * strips;
+	const double R = (double)mine[0].x;
+	const int per = (strips + parts - 1) / parts, s_lo = blockIdx.y * per, s_hi = min(s_lo + per, strips);
 
-	double cnt = 0.0, mean = 0.0, m2 = 0.0;
-	auto combine = [](double &na, double &ma, double &qa, double nb, double mb, double qb) {
-		if (nb == 0.0) return;
-		const double tot = na + nb, delta = mb - ma;
-		ma += delta * (nb / tot);
-		qa += qb + delta * delta * (na * nb / tot);
-		na = tot;
-	};
-
-	for (int s = t; s < strips; s += 256) {
-		const float4 e = stats[(size_t)ch * strips + s];
+	double S = 0.0, Q = 0.0;
+	for (int s = s_lo + t; s < s_hi; s += 256) {
+		const float4 e = mine[s];
 		const long left = total_px - (long)s * strip_px;
-		const double nb = (double)(left < strip_px ? left : strip_px);
-		const double s1 = (double)e.y, s2 = (double)e.z;
-		combine(cnt, mean, m2, nb, (double)e.x + s1 / nb, s2 - s1 * s1 / nb);
+		const double nb = (double)(left < strip_px ? left : strip_px), d = (double)e.x - R;
+		S += (double)e.y + nb * d;
+		Q += (double)e.z + d * (2.0 * (double)e.y + nb * d);
 	}
 
-	sh_n[t] = cnt, sh_mean[t] = mean, sh_m2[t] = m2;
+	sh_s[t] = S, sh_q[t] = Q;
 	__syncthreads();
 	for (int w = 128; w > 0; w >>= 1) {
-		if (t < w) {
-			double na = sh_n[t], ma = sh_mean[t], qa = sh_m2[t];
-			combine(na, ma, qa, sh_n[t + w], sh_mean[t + w], sh_m2[t + w]);
-			sh_n[t] = na, sh_mean[t] = ma, sh_m2[t] = qa;
-		}
+		if (t < w) sh_s[t] += sh_s[t + w], sh_q[t] += sh_q[t + w];
 		__syncthreads();
 	}
 	if (t == 0) {
-		const double var = sh_m2[0] / sh_n[0];
-		pre[2 * ch + 0] = (float)sh_mean[0];
+		if (parts > 1) {
+			partial[((size_t)ch * parts + blockIdx.y) * 2 + 0] = sh_s[0];
+			partial[((size_t)ch * parts + blockIdx.y) * 2 + 1] = sh_q[0];
+			return;
+		}
+		const double n = (double)total_px, m = sh_s[0] / n;
+		const double var = sh_q[0] / n - m * m;
+		pre[2 * ch + 0] = (float)(R + m);
 		pre[2 * ch + 1] = (float)(var > 0.0 ? var : 0.0);
 	}
+}
+
+__global__ void __launch_bounds__(256) bn_merge_finish_kernel(const float4 *__restrict__ stats, int strips, long total_px, int c,
+                                                               float *__restrict__ pre, int parts, const double *__restrict__ partial) {
+	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ch >= c) return;
+	double S = 0.0, Q = 0.0;
+	for (int p = 0; p < parts; ++p) S += partial[((size_t)ch * parts + p) * 2 + 0], Q += partial[((size_t)ch * parts + p) * 2 + 1];
+	const double R = (double)stats[(size_t)ch * strips].x, n = (double)total_px, m = S / n;
+	const double var = Q / n - m * m;
+	pre[2 * ch + 0] = (float)(R + m);
+	pre[2 * ch + 1] = (float)(var > 0.0 ? var : 0.0);
+}
+
+// launches the strip merge; `scratch` (after the 2*c floats of `pre`) must hold c * parts * 2 doubles
+inline int bn_merge_parts(int c) {
+	int parts = (2 * pz::kNumCU + c - 1) / c;
+	return parts < 1 ? 1 : (parts > 16 ? 16 : parts);
+}
+
+inline void bn_merge_strips(const float *stats, int strips, long total_px, int c, float *pre, double *scratch, hipStream_t st) {
+	int parts = bn_merge_parts(c);
+	if (strips < 4 * 256 * parts) parts = 1;          // not worth a second launch
+	bn_merge_strips_kernel<<<dim3(c, parts), 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, PZ_CONV_STATS_STRIP,
+	                                                       total_px, c, pre, parts, scratch);
+	if (parts > 1)
+		bn_merge_finish_kernel<<<(c + 255) / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, total_px, c, pre,
+		                                                        parts, scratch);
 }
 
 // Deferred apply: per channel, what bn_apply_train_kernel<.., PRE> derives from {mean, var} — saved statistics, running
@@ -446,7 +477,13 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
 	}
 }
 
-inline size_t bn_ws_bytes(const BnGeom &g) { return ((size_t)g.c * g.splits * 2 + g.c) * sizeof(float); }
+// {mean, var} per channel + the strip-merge scratch (c * parts * 2 doubles, 8-byte aligned after 2*c floats)
+inline size_t bn_pre_ws_bytes(int c) { return ((size_t)2 * c + 2) * sizeof(float) + (size_t)c * 16 * 2 * sizeof(double); }
+
+inline size_t bn_ws_bytes(const BnGeom &g) {
+	const size_t stats = ((size_t)g.c * g.splits * 2 + g.c) * sizeof(float), pre = bn_pre_ws_bytes(g.c);
+	return stats > pre ? stats : pre;
+}
 
 int bn_check(int n, int c, int hw) {
 	PZ_REQUIRE(n > 0 && c > 0 && hw > 0, "batchnorm: non-positive dimension (%d, %d, %d)", n, c, hw);
@@ -501,9 +538,10 @@ int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const fl
 	const BnGeom g = bn_geom(n, c, hw);
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train_pre: workspace too small");
 
-	float *pre = (float *)workspace;             // 2*c floats <= the statistics workspace
+	float *pre = (float *)workspace;             // 2*c floats, then the merge scratch
+	PZ_REQUIRE(ws_bytes >= bn_pre_ws_bytes(c), "pz_bn_fwd_train_pre: workspace too small for the strip merge");
 	hipStream_t st = pz::as_stream(stream);
-	bn_merge_strips_kernel<<<c, 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, PZ_CONV_STATS_STRIP, total_px, c, pre);
+	bn_merge_strips(stats, strips, total_px, c, pre, reinterpret_cast<double *>(pre + 2 * c + (2 * c) % 2), st);
 	PZ_LAUNCH_CHECK();
 
 	dim3 grid(c, g.splits);
@@ -525,11 +563,11 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
 	const long total_px = (long)n * hw;
 	PZ_REQUIRE(strips == (int)((total_px + PZ_CONV_STATS_STRIP - 1) / PZ_CONV_STATS_STRIP),
 	           "pz_bn_fwd_train_defer: %d strips do not cover %ld pixels", strips, total_px);
-	PZ_REQUIRE(workspace && ws_bytes >= (size_t)2 * c * sizeof(float), "pz_bn_fwd_train_defer: workspace too small");
+	PZ_REQUIRE(workspace && ws_bytes >= bn_pre_ws_bytes(c), "pz_bn_fwd_train_defer: workspace too small");
 
 	float *pre = (float *)workspace;
 	hipStream_t st = pz::as_stream(stream);
-	bn_merge_strips_kernel<<<c, 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, PZ_CONV_STATS_STRIP, total_px, c, pre);
+	bn_merge_strips(stats, strips, total_px, c, pre, reinterpret_cast<double *>(pre + 2 * c + (2 * c) % 2), st);
 	PZ_LAUNCH_CHECK();
 	bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(pre, c, (double)total_px, scale, bias, run_mean, run_var, save_mean,
 	                                                    save_invvar, epsilon, factor, coef);
