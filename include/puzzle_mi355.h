@@ -237,6 +237,8 @@ int pz_reduce_sum_rows(const float *t, int rows, int cols, float *out, float alp
 int pz_reduce_sum_cols(const float *t, int z, int h, int w, float *out, float alpha, float beta, pz_stream_t stream);
 int pz_argmax_rows(const float *t, int rows, int cols, int32_t *out, pz_stream_t stream);
 int pz_argmax_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_t stream);
+/* out[b] = mat[b] + vec[b] broadcast: axis 0 -> row i gets vec[i % veclen] (veclen | n: a (batch*maps, pixels) view
+ * takes one value per map), axis 1 -> column j gets vec[j % veclen] (veclen | m). z matrices, z vectors of veclen. */
 int pz_bias_add(float *out, const float *mat, const float *vec, int z, int n, int m, int veclen, int axis,
                 pz_stream_t stream);
 int pz_count_neq_i32(const int32_t *x, const int32_t *y, size_t count, float *out, pz_stream_t stream);

@@ -372,11 +372,10 @@ class DnnContext:
 				grad = lazy.materialize()
 			lib.pz_conv2d_bwd_data(byref(desc), grad.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None)
 
-		if bias is not None:           # deconvolution forward: bias over the produced maps
-			self.backend.matmod.addVecToMat(
-				bias, out.reshape(out.shape[0], out.shape[1], prod(out.shape[2:])), axis=0, out=out.reshape(
-					out.shape[0], out.shape[1], prod(out.shape[2:])
-				), tiled=True
+		if bias is not None:           # deconvolution forward: bias over the produced maps, rows of the (n*maps, pixels) view
+			assert bias.size == out.shape[1]
+			lib.pz_bias_add(
+				out.ptr, out.ptr, bias.ptr, 1, out.shape[0] * out.shape[1], prod(out.shape[2:]), out.shape[1], 0, None
 			)
 
 		return out
@@ -390,8 +389,10 @@ class DnnContext:
 			grad = lazy.grad
 		assert data.ndim == grad.ndim and grad.shape[1] == W.shape[0] and data.shape[1] == W.shape[1] * groups
 		requireF32(data, grad, wgrad, bgrad)
-		if deconv:
-			raise NotImplementedError("deconvolution parameter gradients are outside the implemented operator path")
+		# deconv=True (Backend/Dnn.py wrapDeconvNdBackwardParams passes the deconvolution's output gradient as `data` and its
+		# input as `grad`): the filter gradient is the same contraction; only the bias gradient sums over `data`'s maps
+		# instead of `grad`'s (Hip/Wrappers/MIOpen.py:435-436)
+		biasof = data if deconv else grad
 
 		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
 
@@ -410,7 +411,7 @@ class DnnContext:
 
 		bg = None
 		if withbias:
-			bg = GPUArray.empty((grad.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
+			bg = GPUArray.empty((biasof.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
 
 		if lazy is not None and not withbias and self.bnFoldSupported(desc, algo):
 			lib.pz_conv2d_bwd_filter_bn(
@@ -421,15 +422,15 @@ class DnnContext:
 		if lazy is not None:
 			grad = lazy.materialize()
 
-		fused = withbias and bcoef == wcoef       # one library call reduces dw and db with the same (alpha, beta)
+		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
 		lib.pz_conv2d_bwd_filter(
 			byref(desc), data.ptr, grad.ptr, wgrad.ptr, ptrOf(bg) if fused else None, wcoef[0], wcoef[1], algo,
 			ptrOf(ws), size.value, None
 		)
 
 		if withbias and not fused:
-			n, k = grad.shape[:2]
-			persample = self.backend.matmod.matsum(grad.reshape(n * k, prod(grad.shape[2:])), axis=1, allocator=allocator)
+			n, k = biasof.shape[:2]
+			persample = self.backend.matmod.matsum(biasof.reshape(n * k, prod(biasof.shape[2:])), axis=1, allocator=allocator)
 			self.backend.matmod.matsum(persample.reshape(n, k), axis=0, out=bg, alpha=bcoef[0], beta=bcoef[1])
 
 		return (wgrad, bg) if withbias else wgrad

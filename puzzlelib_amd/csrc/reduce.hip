@@ -85,10 +85,10 @@ __global__ void __launch_bounds__(256) bias_add_kernel(float *out, const float *
 	const size_t total = (size_t)n * m;
 	const float *mz = mat + (size_t)z * total;
 	float *oz = out + (size_t)z * total;
-	const float *vz = vec + (size_t)z * (axis == 1 ? veclen : n);
+	const float *vz = vec + (size_t)z * veclen;
 	for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
 		const int i = (int)(e / m), j = (int)(e - (size_t)i * m);
-		oz[e] = mz[e] + (axis == 1 ? vz[j % veclen] : vz[i]);
+		oz[e] = mz[e] + (axis == 1 ? vz[j % veclen] : vz[i % veclen]);
 	}
 }
 
@@ -218,7 +218,8 @@ int pz_argmax_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_
 
 int pz_bias_add(float *out, const float *mat, const float *vec, int z, int n, int m, int veclen, int axis, pz_stream_t stream) {
 	PZ_REQUIRE(out && mat && vec && z > 0 && n > 0 && m > 0 && z <= 65535, "pz_bias_add: bad arguments");
-	PZ_REQUIRE(axis == 0 || (axis == 1 && veclen > 0 && m % veclen == 0), "pz_bias_add: vector length %d does not tile width %d", veclen, m);
+	PZ_REQUIRE(veclen > 0 && ((axis == 0 && n % veclen == 0) || (axis == 1 && m % veclen == 0)),
+	           "pz_bias_add: vector length %d does not tile the %d x %d matrix along axis %d", veclen, n, m, axis);
 	bias_add_kernel<<<dim3(pz::stream_grid((size_t)n * m, 256), 1, z), 256, 0, pz::as_stream(stream)>>>(out, mat, vec, n, m, veclen, axis);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;

@@ -66,7 +66,7 @@ class Variable:
 			self.grad.set(variable.grad)
 
 
-def initTensor(scheme, shape, wscale, factorShape=None, dtype=np.float32):
+def initTensor(scheme, shape, wscale, factorShape=None, dtype=np.float32, factorTranspose=False):
 	"""Parameter initialisation with the reference's RNG call sequence (Modules/Module.py:406-476), so that the same
 	numpy seed yields the same initial parameters."""
 	factorType = "in"
@@ -81,6 +81,9 @@ def initTensor(scheme, shape, wscale, factorShape=None, dtype=np.float32):
 	else:
 		rf = int(np.prod(fshape[2:]))
 		outs, ins = fshape[0] * rf, fshape[1] * rf
+
+	if factorTranspose:        # deconvolution filters are stored (inmaps, outmaps, ...): Modules/Module.py:471
+		outs, ins = ins, outs
 
 	factor = {"in": ins, "out": outs, "avg": (outs + ins) / 2}[factorType]
 
@@ -385,6 +388,111 @@ class Conv2D(Module):
 		inh = (outh - 1) * self.stride[0] + self.dilation[0] * (fh - 1) - 2 * self.pad[0] + 1
 		inw = (outw - 1) * self.stride[1] + self.dilation[1] * (fw - 1) - 2 * self.pad[1] + 1
 		return n, inmaps * self.groups, inh, inw
+
+
+class Deconv2D(Module):
+	"""Transposed convolution (Modules/DeconvND.py + Modules/Deconv2D.py): forward is the convolution's backward-data pass
+	plus a bias over the produced maps, backward-data is the convolution's forward, and the parameter gradient is the
+	convolution's filter gradient with the tensor roles swapped. W is (inmaps, outmaps / groups, fh, fw)."""
+
+	def __init__(self, inmaps, outmaps, size, stride=1, pad=0, dilation=1, postpad=0, wscale=1.0, useBias=True,
+				 name=None, initscheme=None, empty=False, groups=1):
+		super().__init__(name)
+
+		self.stride, self.pad, self.dilation = repeat(stride, 2), repeat(pad, 2), repeat(dilation, 2)
+		self.postpad = repeat(postpad, 2)
+		if any(p >= max(s, d) for p, s, d in zip(self.postpad, self.stride, self.dilation)):
+			raise ModuleError("Postpad must be smaller than stride and dilation")
+
+		self.useBias, self.groups = useBias, groups
+
+		dnn = S().Dnn
+		self.fwdAlgo, self.bwdFilterAlgo, self.bwdDataAlgo = \
+			dnn.ConvFwdAlgo.auto, dnn.ConvBwdFilterAlgo.auto, dnn.ConvBwdDataAlgo.auto
+
+		if inmaps % groups != 0 or outmaps % groups != 0:
+			raise ModuleError(
+				"Number of input and output maps must be divisible by number of groups "
+				"(%d inmaps, %d outmaps, %d groups)" % (inmaps, outmaps, groups)
+			)
+
+		self.W = self.b = None
+		if empty:
+			return
+
+		gpuarray = S().gpuarray
+		Wshape = (inmaps, outmaps // groups, *repeat(size, 2))
+		W = initTensor(initscheme, Wshape, wscale, factorTranspose=True)
+		self.setVar("W", Variable(gpuarray.empty(Wshape, dtype=self.calctype) if W is None else gpuarray.to_gpu(W)))
+
+		if useBias:
+			# the reference sizes the bias (1, outmaps / groups, 1, 1) (Modules/DeconvND.py:51), which only fits the produced
+			# maps for groups == 1; the bias here always covers every produced map
+			self.setVar("b", Variable(gpuarray.zeros((1, outmaps, 1, 1), dtype=self.calctype)))
+
+
+	def updateData(self, data):
+		self.data = S().Dnn.deconvNd(
+			data, self.W, self.b, stride=self.stride, pad=self.pad, dilation=self.dilation, postpad=self.postpad,
+			groups=self.groups, algo=self.bwdDataAlgo
+		)
+
+
+	def updateGrad(self, grad):
+		self.grad = S().Dnn.deconvNdBackwardData(
+			grad, self.W, data=self.inData, stride=self.stride, pad=self.pad, dilation=self.dilation,
+			groups=self.groups, algo=self.fwdAlgo
+		)
+
+
+	def accGradParams(self, grad, scale=1.0, momentum=0.0):
+		S().Dnn.deconvNdBackwardParams(
+			self.inData, grad, self.W, self.b, stride=self.stride, pad=self.pad, dilation=self.dilation,
+			groups=self.groups, wgrad=self.vars["W"].grad, bgrad=self.vars["b"].grad if self.b is not None else None,
+			scale=scale, momentum=momentum, algo=self.bwdFilterAlgo
+		)
+
+
+	def checkDataShape(self, shape):
+		if len(shape) != 4:
+			raise ModuleError("Data must be 4d tensor")
+		if shape[1] != self.W.shape[0]:
+			raise ModuleError("Data has %d maps (expected: %d)" % (shape[1], self.W.shape[0]))
+
+
+	def checkGradShape(self, shape):
+		if len(shape) != 4:
+			raise ModuleError("Grad must be 4d tensor")
+
+		_, outmaps, outh, outw = shape
+		_, _, fh, fw = self.W.shape
+
+		if outmaps != self.W.shape[1] * self.groups:
+			raise ModuleError("Grad has %d maps (expected: %d)" % (outmaps, self.W.shape[1] * self.groups))
+		if outh + 2 * self.pad[0] < self.dilation[0] * (fh - 1) + 1:
+			raise ModuleError("Grad maps height is too small (got %d, expected at least %d)" % (
+				outh + 2 * self.pad[0], self.dilation[0] * (fh - 1) + 1
+			))
+		if outw + 2 * self.pad[1] < self.dilation[1] * (fw - 1) + 1:
+			raise ModuleError("Grad maps width is too small (got %d, expected at least %d)" % (
+				outw + 2 * self.pad[1], self.dilation[1] * (fw - 1) + 1
+			))
+
+
+	def dataShapeFrom(self, shape):
+		n, _, inh, inw = shape
+		_, outmaps, fh, fw = self.W.shape
+		outh = (inh - 1) * self.stride[0] + self.dilation[0] * (fh - 1) - 2 * self.pad[0] + 1 + self.postpad[0]
+		outw = (inw - 1) * self.stride[1] + self.dilation[1] * (fw - 1) - 2 * self.pad[1] + 1 + self.postpad[1]
+		return n, outmaps * self.groups, outh, outw
+
+
+	def gradShapeFrom(self, shape):
+		n, _, outh, outw = shape
+		inmaps, _, fh, fw = self.W.shape
+		inh = (outh + 2 * self.pad[0] - self.dilation[0] * (fh - 1) - 1) // self.stride[0] + 1
+		inw = (outw + 2 * self.pad[1] - self.dilation[1] * (fw - 1) - 1) // self.stride[1] + 1
+		return n, inmaps, inh, inw
 
 
 class Linear(Module):

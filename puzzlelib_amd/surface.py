@@ -91,6 +91,23 @@ def bind():
 			bgrad.ravel() if bgrad is not None else None, scale, momentum, algo.value, memoryPool
 		)
 
+	# deconvolution = the convolution's passes with their roles swapped (Backend/Dnn.py:211-231)
+	def deconvNd(data, W, bias, stride, pad, dilation, postpad, groups, algo):
+		return dnn.convNdBackwardData(
+			data, W, bias.ravel() if bias is not None else None, None, stride, pad, dilation, postpad, groups, algo.value, None,
+			memoryPool
+		)
+
+	def deconvNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo):
+		assert data is not None
+		return dnn.convNd(grad, W, None, stride, pad, dilation, groups, algo.value, None, memoryPool)
+
+	def deconvNdBackwardParams(data, grad, W, bias, stride, pad, dilation, groups, wgrad, bgrad, scale, momentum, algo):
+		return dnn.convNdBackwardParams(
+			grad, data, W, stride, pad, dilation, groups, bias is not None, True, wgrad,
+			bgrad.ravel() if bgrad is not None else None, scale, momentum, algo.value, memoryPool
+		)
+
 	def poolNd(data, size, stride, pad, mode, test):
 		result = dnn.poolNd(data, size, stride, pad, mode.value, test, None, memoryPool)
 		return result if not test else (result, None)
@@ -146,6 +163,7 @@ def bind():
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,
 		convNd=convNd, convNdBackwardData=convNdBackwardData, convNdBackwardParams=convNdBackwardParams,
+		deconvNd=deconvNd, deconvNdBackwardData=deconvNdBackwardData, deconvNdBackwardParams=deconvNdBackwardParams,
 		convNdbenchmark=convNdbenchmark, poolNd=poolNd, poolNdBackward=poolNdBackward,
 		batchNormNd=batchNormNd, batchNormNdBackward=batchNormNdBackward,
 		softmaxNd=softmaxNd, softmaxNdBackward=softmaxNdBackward,

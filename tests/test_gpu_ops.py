@@ -665,3 +665,89 @@ def test_timekernel_and_pool_stats(bnd):
 	del x
 	bnd.memoryPool.freeHeld()
 	assert bnd.memoryPool.getStats()["heldBytes"] == 0
+
+
+@pytest.mark.parametrize("cfg", [
+	dict(n=2, c=6, k=8, h=7, w=9, r=3, stride=2, pad=1, postpad=1),        # the usual "upsample by 2" deconvolution
+	dict(n=3, c=16, k=4, h=5, w=5, r=2, stride=2, pad=0, postpad=0),
+	dict(n=2, c=8, k=8, h=6, w=6, r=3, stride=1, pad=1, postpad=0),
+])
+def test_deconvolution_passes(bnd, cfg):
+	"""Backend/Dnn.py:211-231: deconvNd = convNdBackwardData (+ bias over the produced maps), deconvNdBackwardData =
+	convNd, deconvNdBackwardParams = convNdBackwardParams(deconv=True) whose bias gradient sums the OUTPUT gradient's maps
+	(Hip/Wrappers/MIOpen.py:435-436). Oracle: the convolution restatements with the roles swapped."""
+	from puzzlelib_amd.surface import bound
+	Dnn = bound().Dnn
+	rng = np.random.RandomState(8)
+	n, c, k, h, w_, r = cfg["n"], cfg["c"], cfg["k"], cfg["h"], cfg["w"], cfg["r"]
+	st, pad, pp = cfg["stride"], cfg["pad"], cfg["postpad"]
+
+	x = rng.randn(n, c, h, w_).astype(np.float32)                   # deconvolution input: `c` maps
+	wt = rng.randn(c, k, r, r).astype(np.float32)                   # (inmaps, outmaps, r, s) as Modules/DeconvND.py:42
+	bias = rng.randn(1, k, 1, 1).astype(np.float32)
+	oh, ow = (h - 1) * st + r - 2 * pad + pp, (w_ - 1) * st + r - 2 * pad + pp
+	kw = dict(stride=(st, st), pad=(pad, pad), dilation=(1, 1), groups=1)
+
+	gx, gw, gb = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias)
+	algo = bnd.ConvBwdDataAlgo.auto
+	y = Dnn.deconvNd(gx, gw, gb, (st, st), (pad, pad), (1, 1), (pp, pp), 1, algo)
+	y_ref = R.conv2d_bwd_data(x, wt, (n, k, oh, ow), acc=np.float64, **kw) + bias
+	assert y.shape == (n, k, oh, ow)
+	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="deconv forward")
+
+	dy = rng.randn(n, k, oh, ow).astype(np.float32)
+	gdy = gpu(bnd, dy)
+	dx = Dnn.deconvNdBackwardData(gdy, gw, gx, (st, st), (pad, pad), (1, 1), 1, bnd.ConvFwdAlgo.auto)
+	assert_close(dx.get(), R.conv2d_fwd(dy, wt, None, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what="deconv backward data")
+
+	dw, db = Dnn.deconvNdBackwardParams(gx, gdy, gw, gb, (st, st), (pad, pad), (1, 1), 1, None, None, 1.0, 0.0, bnd.ConvBwdFilterAlgo.auto)
+	dw_ref = R.conv2d_bwd_filter(dy, x, wt.shape, withbias=False, acc=np.float64, **kw)
+	assert_close(dw.get(), dw_ref, atol=2e-4, rtol=1e-4, what="deconv filter gradient")
+	assert_close(db.get().ravel(), dy.sum(axis=(0, 2, 3)), atol=1e-4, rtol=1e-4, what="deconv bias gradient")
+
+	# accumulate contract on both gradients
+	wg0, bg0 = rng.randn(*wt.shape).astype(np.float32), rng.randn(k).astype(np.float32)
+	gwg, gbg = gpu(bnd, wg0), gpu(bnd, bg0.reshape(1, k, 1, 1))
+	Dnn.deconvNdBackwardParams(gx, gdy, gw, gb, (st, st), (pad, pad), (1, 1), 1, gwg, gbg, 0.5, 0.9, bnd.ConvBwdFilterAlgo.auto)
+	assert_close(gwg.get(), 0.9 * wg0 + 0.5 * dw_ref, atol=3e-4, rtol=1e-4, what="accumulated filter gradient")
+	assert_close(gbg.get().ravel(), 0.9 * bg0 + 0.5 * dy.sum(axis=(0, 2, 3)), atol=2e-4, rtol=1e-4, what="accumulated bias gradient")
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_deconv2d_module(bnd, groups):
+	"""Modules/Deconv2D.py unittest shape: a Deconv2D step equals the transposed convolution of the oracle, is the adjoint
+	of Conv2D with the same filter, and accumulates parameter gradients like every other module."""
+	from puzzlelib_amd import nn
+	rng = np.random.RandomState(21)
+	n, inmaps, outmaps, h, w_ = 3, 8, 6, 6, 5
+
+	np.random.seed(5)
+	mod = nn.Deconv2D(inmaps, outmaps, 3, stride=2, pad=1, postpad=1, groups=groups, useBias=groups == 1)
+	assert mod.W.shape == (inmaps, outmaps // groups, 3, 3)
+	wt = mod.W.get()
+	bound_ = np.sqrt(3.0 / (inmaps * 9))                      # factorTranspose: fan-in counts the stored dim 0
+	assert np.abs(wt).max() <= bound_ + 1e-6
+
+	x = rng.randn(n, inmaps, h, w_).astype(np.float32)
+	y = mod(gpu(bnd, x))
+	assert y.shape == mod.dataShapeFrom(x.shape) == (n, outmaps, 2 * h, 2 * w_)
+	assert mod.gradShapeFrom(y.shape) == x.shape
+
+	kw = dict(stride=(2, 2), pad=(1, 1), dilation=(1, 1), groups=groups)
+	y_ref = R.conv2d_bwd_data(x, wt, y.shape, acc=np.float64, **kw)
+	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="Deconv2D data")
+
+	dy = rng.randn(*y.shape).astype(np.float32)
+	mod.backward(gpu(bnd, dy))
+	assert_close(mod.grad.get(), R.conv2d_fwd(dy, wt, None, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what="Deconv2D grad")
+	# adjoint identity <deconv(x), dy> == <x, conv(dy)>
+	lhs, rhs = float((y_ref.astype(np.float64) * dy).sum()), float((x.astype(np.float64) * mod.grad.get()).sum())
+	assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+	dw_ref = R.conv2d_bwd_filter(dy, x, wt.shape, withbias=False, acc=np.float64, **kw)
+	assert_close(mod.vars["W"].grad.get(), dw_ref, atol=2e-4, rtol=1e-4, what="Deconv2D filter gradient")
+	if groups == 1:
+		assert_close(mod.vars["b"].grad.get().ravel(), dy.sum(axis=(0, 2, 3)), atol=1e-4, rtol=1e-4, what="Deconv2D bias gradient")
+
+	with pytest.raises(nn.ModuleError, match="Postpad"):
+		nn.Deconv2D(4, 4, 3, stride=2, postpad=2)
