@@ -92,7 +92,7 @@ typedef struct pz_conv_desc {
 	int groups;
 } pz_conv_desc;
 
-enum { PZ_CONV_ALGO_AUTO = -1, PZ_CONV_ALGO_DIRECT = 1, PZ_CONV_ALGO_IMPLICIT_GEMM = 5 };
+enum { PZ_CONV_ALGO_AUTO = -1, PZ_CONV_ALGO_DIRECT = 1, PZ_CONV_ALGO_WINOGRAD = 3, PZ_CONV_ALGO_IMPLICIT_GEMM = 5 };
 enum { PZ_CONV_FWD = 0, PZ_CONV_BWD_DATA = 1, PZ_CONV_BWD_FILTER = 2 };
 
 int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q);

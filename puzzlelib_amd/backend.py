@@ -104,9 +104,11 @@ class ConvPerf:                        # Hip/Wrappers/MIOpen.py:82-100
 
 
 def toAlgoId(algo):
-	"""Any of the reference's algo ids selects the MFMA implicit-GEMM path except `direct` (one thread per output)."""
+	"""The reference's algo ids: `direct` is the one-thread-per-output kernel, `winograd` asks for F(2x2, 3x3) where it
+	applies (3x3 stride-1 forward / backward-data), `implicitGemm` pins the MFMA implicit GEMM, every other id leaves the
+	choice to the library."""
 	algo = algo.value if isinstance(algo, Enum) else algo
-	return lib.CONV_ALGO_DIRECT if algo == 1 else lib.CONV_ALGO_AUTO
+	return {1: lib.CONV_ALGO_DIRECT, 3: lib.CONV_ALGO_WINOGRAD, 5: lib.CONV_ALGO_IMPLICIT_GEMM}.get(algo, lib.CONV_ALGO_AUTO)
 
 
 def pair(v):

@@ -28,6 +28,12 @@ inline int stream_grid(size_t work_items, int per_block) {
 	return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
+// Winograd F(2x2, 3x3) forward / backward-data (wino.hip); `which` is PZ_CONV_FWD or PZ_CONV_BWD_DATA
+bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
+size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
+int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
+              void *workspace, hipStream_t st);
+
 }  // namespace pz
 
 #define PZ_REQUIRE(cond, ...)                                   \

@@ -1274,6 +1274,11 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	return p;
 }
 
+// the Winograd F(2x2, 3x3) path (wino.hip) serves the 3x3 / stride-1 forward and backward-data passes when asked for
+bool uses_winograd(const pz_conv_desc *d, int which, int P, int Q, int algo) {
+	return algo == PZ_CONV_ALGO_WINOGRAD && pz::wino_eligible(d, which, P, Q);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1307,6 +1312,10 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_workspace_bytes: null output");
 	*nbytes = 0;
+	if (uses_winograd(d, which, P, Q, algo)) {
+		*nbytes = pz::wino_workspace_bytes(d, which, P, Q);
+		return PZ_OK;
+	}
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) return PZ_OK;
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
@@ -1342,7 +1351,8 @@ int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(strips != nullptr, "pz_conv2d_fwd_stats_strips: null output");
-	*strips = (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) ? 0 : pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
+	*strips = (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || uses_winograd(d, PZ_CONV_FWD, P, Q, algo))
+	              ? 0 : pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	return PZ_OK;
 }
 
@@ -1357,6 +1367,13 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && w && y, "pz_conv2d_fwd: null tensor");
 	hipStream_t st = pz::as_stream(stream);
+
+	if (uses_winograd(d, PZ_CONV_FWD, P, Q, algo)) {
+		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: the Winograd path does not produce strip statistics");
+		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
+		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, workspace, st);
+	}
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
 		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: this configuration cannot produce strip statistics");
@@ -1446,6 +1463,12 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(dy && w && dx, "pz_conv2d_bwd_data: null tensor");
 	hipStream_t st = pz::as_stream(stream);
+
+	if (bnx == nullptr && uses_winograd(d, PZ_CONV_BWD_DATA, P, Q, algo)) {
+		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q);
+		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, workspace, st);
+	}
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !dgrad_uses_igemm(d) || !igemm_eligible(d, P, Q)) {
 		const size_t total = (size_t)d->n * d->c * d->h * d->w;

@@ -208,7 +208,7 @@ COMM_ID_BYTES = 128
 	OP_SMORMS3, OP_ADD3, OP_IADD, OP_IMUL, OP_ADD3_RELU, OP_ADD3_GATE, OP_COUNT
 ) = range(41)
 
-CONV_ALGO_AUTO, CONV_ALGO_DIRECT, CONV_ALGO_IMPLICIT_GEMM = -1, 1, 5
+CONV_ALGO_AUTO, CONV_ALGO_DIRECT, CONV_ALGO_WINOGRAD, CONV_ALGO_IMPLICIT_GEMM = -1, 1, 3, 5
 CONV_FWD, CONV_BWD_DATA, CONV_BWD_FILTER = 0, 1, 2
 BN_ACT_NONE, BN_ACT_RELU = 0, 1
 

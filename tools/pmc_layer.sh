@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects SQ / TCC counters for one census layer (tools/conv_census.py --only N --passes P), one rocprofv3 pass per
 # counter group, into gpurun_out/pmc_<tag>/; prints per-kernel sums. Usage: tools/pmc_layer.sh <layer> <pass> <tag>
+# PMC_CMD="python tools/wino_check.py --only 5 --reps 2" replaces the profiled command; PMC_GROUPS="1 2" picks counter groups.
 set -e
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -12,10 +13,12 @@ G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 G2="SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_MFMA"
 G3="GRBM_GUI_ACTIVE FETCH_SIZE"
 G4="WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"
+CMD=${PMC_CMD:-python $ROOT/tools/conv_census.py --only $LAYER --passes $PASS --reps 2}
 i=0
 for G in "$G1" "$G2" "$G3" "$G4"; do
 	i=$((i+1))
-	rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- python $ROOT/tools/conv_census.py --only $LAYER --passes $PASS --reps 2 > $OUT/g$i.log 2>&1 || true
+	case " ${PMC_GROUPS:-1 2 3 4} " in *" $i "*) ;; *) continue ;; esac
+	(cd $ROOT && rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/g$i -- $CMD > $OUT/g$i.log 2>&1) || true
 done
 python - <<PY
 import csv, glob, collections, re
