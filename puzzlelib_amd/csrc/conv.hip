@@ -1274,9 +1274,13 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	return p;
 }
 
-// the Winograd F(2x2, 3x3) path (wino.hip) serves the 3x3 / stride-1 forward and backward-data passes when asked for
+// the Winograd F(2x2, 3x3) path (wino.hip) serves the 3x3 / stride-1 forward and backward-data passes: always when asked
+// for by name, and by default from 32 channels on either side (1.6-1.8x the implicit GEMM on every 3x3 layer of the
+// ResNet-50 census, tools/wino_check.py; below that the 64-channel workgroup block is mostly padding)
 bool uses_winograd(const pz_conv_desc *d, int which, int P, int Q, int algo) {
-	return algo == PZ_CONV_ALGO_WINOGRAD && pz::wino_eligible(d, which, P, Q);
+	if (algo != PZ_CONV_ALGO_WINOGRAD && algo != PZ_CONV_ALGO_AUTO) return false;
+	if (!pz::wino_eligible(d, which, P, Q)) return false;
+	return algo == PZ_CONV_ALGO_WINOGRAD || (d->c >= 32 && d->k >= 32);
 }
 
 }  // namespace

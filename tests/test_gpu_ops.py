@@ -384,12 +384,18 @@ def test_conv_epilogue_statistics_feed_batchnorm(bnd, cfg):
 	x = rng.randn(n, c, h, w_).astype(np.float32)
 	wt = (rng.randn(k, c // groups, r, r) / np.sqrt(c // groups * r * r)).astype(np.float32)
 	bias = (3.0 * rng.randn(k)).astype(np.float32) if cfg["bias"] else None          # a large bias: mean >> std per channel
-	okw = dict(stride=(cfg["stride"], ) * 2, pad=(cfg["pad"], ) * 2, dilation=(1, 1), groups=groups)
+	# strip statistics are an epilogue of the implicit GEMM (the Winograd path, which `auto` prefers for wide 3x3 layers,
+	# returns none and lets the BatchNorm make its own pass)
+	okw = dict(stride=(cfg["stride"], ) * 2, pad=(cfg["pad"], ) * 2, dilation=(1, 1), groups=groups,
+			   algo=bnd.ConvFwdAlgo.implicitGemm.value)
 
 	gx, gw, gb = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias) if bias is not None else None
 	y_plain = bnd.dnn.convNd(gx, gw, gb, **okw)
 	y, stats = bnd.dnn.convNd(gx, gw, gb, withStats=True, **okw)
 	assert stats is not None and stats.tensor is y
+	if r == 3 and cfg["stride"] == 1 and groups == 1 and c % 4 == 0:
+		_, none = bnd.dnn.convNd(gx, gw, gb, withStats=True, **dict(okw, algo=bnd.ConvFwdAlgo.winograd.value))
+		assert none is None
 	assert np.array_equal(y.get(), y_plain.get())
 
 	# strip sums -> exact per-channel moments
@@ -751,3 +757,44 @@ def test_deconv2d_module(bnd, groups):
 
 	with pytest.raises(nn.ModuleError, match="Postpad"):
 		nn.Deconv2D(4, 4, 3, stride=2, postpad=2)
+
+
+@pytest.mark.parametrize("cfg", [
+	dict(n=2, c=8, k=8, hw=(6, 6), pad=1),             # the launch's first tile: its first row starts in front of the tensor
+	dict(n=3, c=12, k=20, hw=(7, 9), pad=1),           # odd maps: half tiles at the right / bottom edge, ragged channel block
+	dict(n=2, c=16, k=70, hw=(5, 8), pad=0),           # no padding, two channel blocks
+	dict(n=5, c=36, k=96, hw=(14, 14), pad=1),         # 9 chunks: every pipeline stage and fragment set, tiles = 245 (ragged)
+	dict(n=1, c=4, k=3, hw=(3, 3), pad=1),             # a single chunk, fewer tiles than a block
+	dict(n=4, c=64, k=64, hw=(55, 55), pad=1),         # the reference network's odd stage-2 maps
+])
+def test_winograd_convolution(bnd, cfg):
+	"""ConvFwdAlgo.winograd / ConvBwdDataAlgo.winograd (Hip/Wrappers/MIOpen.py:28,47): F(2x2, 3x3) forward and
+	backward-data against the oracle. Tolerance: the transforms cost a few more roundings than the direct sum — stated
+	here as 2e-5 of the output scale (the implicit GEMM sits near 2e-6), inside the 1e-4 every convolution test allows."""
+	rng = np.random.RandomState(11)
+	n, c, k, (h, w_), pad = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["pad"]
+	x = rng.randn(n, c, h, w_).astype(np.float32)
+	wt = (rng.randn(k, c, 3, 3) / np.sqrt(9 * c)).astype(np.float32)
+	bias = rng.randn(k).astype(np.float32)
+	kw = dict(stride=(1, 1), pad=(pad, pad), dilation=(1, 1), groups=1)
+
+	gx, gw, gb = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias)
+	y = bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.winograd.value, **kw)
+	y_ref = R.conv2d_fwd(x, wt, bias, acc=np.float64, **kw)
+	assert_close(y.get(), y_ref, atol=2e-5 * max(1.0, float(np.abs(y_ref).max())), rtol=0, what="winograd forward")
+
+	y_ig = bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.implicitGemm.value, **kw)
+	assert not np.array_equal(y.get(), y_ig.get()), "the Winograd request fell through to the implicit GEMM"
+	if c >= 32 and k >= 32:
+		assert np.array_equal(bnd.dnn.convNd(gx, gw, gb, **kw).get(), y.get()), "auto picks Winograd for wide 3x3 layers"
+
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	gdy = gpu(bnd, dy)
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, None, gx, algo=bnd.ConvBwdDataAlgo.winograd.value, **kw)
+	dx_ref = R.conv2d_bwd_data(dy, wt, x.shape, acc=np.float64, **kw)
+	if k % 4 == 0 and pad == 1:        # backward-data reduces over k and pads by 2 - pad
+		assert not np.array_equal(dx.get(), bnd.dnn.convNdBackwardData(gdy, gw, None, gx, algo=5, **kw).get())
+	assert_close(dx.get(), dx_ref, atol=2e-5 * max(1.0, float(np.abs(dx_ref).max())), rtol=0, what="winograd backward data")
+
+	# run-to-run determinism
+	assert np.array_equal(bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.winograd.value, **kw).get(), y.get())
