@@ -22,7 +22,8 @@ BATCH = 256
 FLOP_PER_IMAGE = 22.770e9        # fwd + dgrad + wgrad, conv1 dgrad excluded; reported, not used for `value`
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FAMILY = ["igemm_conv_kernel<128,128> (fwd + bwd-data)", "igemm_conv_kernel<64,256> (fwd + bwd-data)",
-		  "wgrad_conv_kernel (bwd-filter)"]
+		  "wgrad_conv_kernel (bwd-filter)", "wino_conv_kernel / wino_wgrad_kernel F(2x2,3x3) (all three passes of the 3x3 layers)"]
+NFAM = len(FAMILY)
 
 
 def cpu_baseline(sample_batch=32):
@@ -142,9 +143,9 @@ def main():
 	elapsed = time.perf_counter() - t0
 
 	lib.pz_conv_profile_enable(0)
-	ms = (ctypes.c_double * 3)()
-	flops = (ctypes.c_double * 3)()
-	launches = (ctypes.c_longlong * 3)()
+	ms = (ctypes.c_double * NFAM)()
+	flops = (ctypes.c_double * NFAM)()
+	launches = (ctypes.c_longlong * NFAM)()
 	lib.pz_conv_profile_collect(ms, flops, launches)
 
 	elapsed = grid.maxOverRanks(elapsed)
@@ -156,13 +157,15 @@ def main():
 	images_per_sec = world * args.batch * args.steps / elapsed
 
 	fams = []
-	for i in range(3):
+	for i in range(NFAM):
 		if launches[i] > 0:
 			fams.append({
 				"kernel": FAMILY[i], "launches": int(launches[i]), "avg_launch_ms": ms[i] / launches[i],
 				"total_ms_per_step": ms[i] / args.steps, "achieved_tflops": flops[i] / (ms[i] * 1e-3) / 1e12
 			})
-	dom = max(range(3), key=lambda i: ms[i])
+			if i == 3:         # direct-convolution FLOP / time; the matrix pipe executes 1/2.25 of them
+				fams[-1]["note"] = "algorithmic (direct-convolution) TFLOP/s; MFMA-executed = achieved / 2.25"
+	dom = max(range(NFAM), key=lambda i: ms[i])
 	achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
 
 	# HBM bytes per launch of the dominant kernel family: memory-side L2 counters of the same command, collected with
@@ -171,7 +174,7 @@ def main():
 	traffic, traffic_note = None, None
 	try:
 		prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-		key = ["igemm_conv_kernel<128, 128", "igemm_conv_kernel<64, 256", "wgrad_conv_kernel<"][dom]
+		key = ["igemm_conv_kernel<128, 128", "igemm_conv_kernel<64, 256", "wgrad_conv_kernel<", "wino_"][dom]
 		rows = [v for k, v in prof["kernels"].items() if key in k]
 		n = sum(v["dispatches"] for v in rows)
 		if n > 0 and args.batch == BATCH:

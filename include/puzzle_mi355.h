@@ -120,8 +120,10 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 /* Launch-level profiling of the convolution kernels (bench.py's roofline leg; the analogue of the reference's
  * Driver timing hooks, Cuda/GPUBackend.py:332-368): while enabled, every MFMA convolution launch is bracketed by
  * HIP events on the launch stream. collect() synchronises, sums per kernel family and resets.
- * family: 0 = igemm 128x128 tile, 1 = igemm 64x256 tile, 2 = backward-filter (all tiles).                    */
-#define PZ_CONV_PROFILE_FAMILIES 3
+ * family: 0 = igemm 128x128 tile, 1 = igemm 64x256 tile, 2 = backward-filter (all tiles), 3 = Winograd F(2x2,3x3)
+ * (forward, backward-data and backward-filter of 3x3 stride-1 layers). `total_flops` is the algorithmic (direct-convolution) count in every family; the Winograd
+ * kernel executes 1/2.25 of it on the matrix pipe (times the padding of odd maps to whole 2x2 tiles).            */
+#define PZ_CONV_PROFILE_FAMILIES 4
 int pz_conv_profile_enable(int on);
 int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double total_flops[PZ_CONV_PROFILE_FAMILIES],
                             long long launches[PZ_CONV_PROFILE_FAMILIES]);

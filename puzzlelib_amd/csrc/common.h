@@ -33,6 +33,10 @@ bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
               void *workspace, hipStream_t st);
+bool wino_wgrad_eligible(const pz_conv_desc *d, int P, int Q);
+size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q);
+int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float *dy, float *dw, float alpha, float beta,
+               void *workspace, hipStream_t st);
 
 }  // namespace pz
 

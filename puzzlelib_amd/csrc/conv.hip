@@ -1279,7 +1279,7 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 // ResNet-50 census, tools/wino_check.py; below that the 64-channel workgroup block is mostly padding)
 bool uses_winograd(const pz_conv_desc *d, int which, int P, int Q, int algo) {
 	if (algo != PZ_CONV_ALGO_WINOGRAD && algo != PZ_CONV_ALGO_AUTO) return false;
-	if (!pz::wino_eligible(d, which, P, Q)) return false;
+	if (!(which == PZ_CONV_BWD_FILTER ? pz::wino_wgrad_eligible(d, P, Q) : pz::wino_eligible(d, which, P, Q))) return false;
 	return algo == PZ_CONV_ALGO_WINOGRAD || (d->c >= 32 && d->k >= 32);
 }
 
@@ -1317,7 +1317,9 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_workspace_bytes: null output");
 	*nbytes = 0;
 	if (uses_winograd(d, which, P, Q, algo)) {
-		*nbytes = pz::wino_workspace_bytes(d, which, P, Q);
+		*nbytes = which == PZ_CONV_BWD_FILTER
+		              ? align256(pz::wino_wgrad_workspace_bytes(d, P, Q)) + align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float))
+		              : pz::wino_workspace_bytes(d, which, P, Q);
 		return PZ_OK;
 	}
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) return PZ_OK;
@@ -1376,6 +1378,7 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: the Winograd path does not produce strip statistics");
 		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
 		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
 		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, workspace, st);
 	}
 
@@ -1471,6 +1474,7 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 	if (bnx == nullptr && uses_winograd(d, PZ_CONV_BWD_DATA, P, Q, algo)) {
 		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q);
 		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
 		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, workspace, st);
 	}
 
@@ -1592,6 +1596,13 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 		direct_bwd_filter_kernel<<<d->k * Cg * d->r * d->s, 256, 0, st>>>(*d, P, Q, x, dy, dw, alpha, beta);
 		PZ_LAUNCH_CHECK();
 		return PZ_OK;
+	}
+
+	if (bnx == nullptr && uses_winograd(d, PZ_CONV_BWD_FILTER, P, Q, algo)) {
+		const size_t need = pz::wino_wgrad_workspace_bytes(d, P, Q);
+		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_filter: workspace %zu < required %zu bytes", ws_bytes, need);
+		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
+		return pz::wino_wgrad(d, P, Q, x, dy, dw, alpha, beta, workspace, st);
 	}
 
 	WgradPlan p = plan_wgrad(d, P, Q);

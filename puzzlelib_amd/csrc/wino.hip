@@ -22,7 +22,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef WN_ABL
-#define WN_ABL 0        // timing-only ablations (wrong results): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no epilogue
+#define WN_ABL 0        // timing-only ablations (wrong results): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no epilogue,
+                        // 16 no barrier, 32 no fragment reads
 #endif
 
 namespace {
@@ -245,8 +246,12 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 		auto body = [&](int ch, Frag &cur, Frag &nxt) {
 			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
 			Frag late;
+#if WN_ABL & 32
+			late = cur, nxt = cur;
+#else
 			read_frags(smem + s_cur * kStage, late, 2);
 			read_frags(smem + s_nxt * kStage, nxt, 0);       // past the last chunk: a stale stage, never used
+#endif
 			// past the last chunk the slices store stale registers into a stage nobody reads any more, and the loads fetch
 			// the last chunk again: no branches in the steady state
 			float *wr = smem + s_wr * kStage;
@@ -277,7 +282,9 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 			issue_loads(min(ch + 3, a.chunks - 1));
 #endif
 			__builtin_amdgcn_sched_barrier(0);
+#if !(WN_ABL & 16)
 			__syncthreads();
+#endif
 			s_cur = s_nxt;
 		};
 
@@ -362,6 +369,333 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward-filter through the same transform:  dU[pos][k][c] = sum over tiles (A dY A^T)[pos] . (B^T d B)[pos],
+// dg = G^T dU G. 16 products [64 k x tiles] . [tiles x 32 c] per workgroup, the reduction running over chunks of 4 tiles
+// that lie side by side in one tile row — so a chunk's geometry (image, tile row, first/last chunk of the row) is
+// wave-uniform: row validity picks the tensor's or a zero-length buffer descriptor, the chunk's place in the tensor is
+// the scalar offset of the loads, and only the transforms and the border-column selects are vector work. The tile range
+// is cut into `splits` slices (blockIdx); each leaves its 16 x 64 x 32 partial sums in a slab, summed and transformed
+// back to 3x3 by the two small kernels below. Signs of row / column 3 of A dY A^T are folded into that last step.
+// ------------------------------------------------------------------------------------------------
+constexpr int CB = 32;                       // reduction-side (input) channels per workgroup
+constexpr int kSlab = 16 * KB * CB;          // floats per (k block, c block) of transformed filter gradients
+
+struct WinoWgradArgs {
+	const float *x, *dy;     // (N, C, H, W), (N, K, P, Q)
+	float *slabs;            // [splits][kblocks][cblocks][16][KB][CB]
+	int N, C, H, W, K, P, Q, pad;
+	int TY, TX4;             // tile rows per image, chunks (4 tiles) per tile row
+	int chunks, splits, kblocks, cblocks;
+	unsigned x_bytes, dy_bytes;
+};
+
+__device__ __forceinline__ float sel_mask(unsigned long long m, float v) {
+	float r;
+	asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+	return r;
+}
+
+__global__ void __launch_bounds__(256, 2) wino_wgrad_kernel(WinoWgradArgs a) {
+	constexpr int kStage = kVFloats + kUFloats;
+	__shared__ __attribute__((aligned(16))) float smem[3 * kStage];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	const int nblk = a.kblocks * a.cblocks;
+	const int split = blockIdx.x / nblk, blk = blockIdx.x - split * nblk;
+	const int kb = blk / a.cblocks, cb = blk - kb * a.cblocks;
+	const int g0 = (int)((long)a.chunks * split / a.splits), g1 = (int)((long)a.chunks * (split + 1) / a.splits);
+	const int nch = g1 - g0;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0, 0x00020000);
+
+	// ---- per-lane constants. Patches: tile lane % 4 of the chunk, channel (lane / 4) + 16 (wave / 2) of the block, half
+	// wave % 2 of the transform. Gradient tiles: tile lane % 4, produced channel (lane / 4) + 16 wave.
+	const int hf = wave & 1, t4 = lane & 3;
+	const int cl = (lane >> 2) + 16 * (wave >> 1), c = cb * CB + cl;
+	const int kl = (lane >> 2) + 16 * wave, k = kb * KB + kl;
+	const unsigned voffx = c < a.C ? (unsigned)(c * a.H * a.W + 2 * t4) * 4u : kOOB;
+	const unsigned voffx_first = c < a.C ? (voffx == 0 ? 0u : voffx - 4u) : kOOB;      // first tensor row: see issue_loads
+	const unsigned voffz = k < a.K ? (unsigned)(k * a.P * a.Q + 2 * t4) * 4u : kOOB;
+
+	// border columns, as lane masks (SGPR pairs): the first chunk of a tile row loses column 0 of tile 0 to the padding,
+	// the last one the columns beyond the map
+	const int jl = a.TX4 - 1;
+	unsigned long long mlast[4], mz[2];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) mlast[j] = __builtin_amdgcn_ballot_w64((unsigned)(8 * jl + 2 * t4 - a.pad + j) < (unsigned)a.W);
+	const unsigned long long mfirst0 = __builtin_amdgcn_ballot_w64(2 * t4 - a.pad >= 0);
+	mz[0] = __builtin_amdgcn_ballot_w64(8 * jl + 2 * t4 < a.Q), mz[1] = __builtin_amdgcn_ballot_w64(8 * jl + 2 * t4 + 1 < a.Q);
+
+	const unsigned vdst = (unsigned)(((t4 >> 1) * CB + cl) * 2 + (t4 & 1)) + (unsigned)(hf * 8) * (2 * CB * 2);
+	const unsigned zdst = (unsigned)kVFloats + (unsigned)(((t4 >> 1) * KB + kl) * 2 + (t4 & 1));
+
+	// chunk g -> (image, tile row, chunk in row), advanced incrementally (scalar)
+	struct Geo {
+		int n, ty, j;
+	};
+	auto geo_of = [&](int g) {
+		Geo q;
+		q.j = g % a.TX4;
+		const int r = g / a.TX4;
+		q.ty = r % a.TY, q.n = r / a.TY;
+		return q;
+	};
+	auto advance = [&](Geo &q) {
+		if (++q.j == a.TX4) {
+			q.j = 0;
+			if (++q.ty == a.TY) q.ty = 0, ++q.n;
+		}
+	};
+
+	f32x4 sp[3];
+	f32x2 sz[2];
+	struct Pend {                                // what the transform of a staged chunk needs to know about it
+		bool first, last, fixrow;
+	};
+
+	auto issue_loads = [&](const Geo &q, Pend &pd) {
+		pd.first = q.j == 0, pd.last = q.j == jl, pd.fixrow = false;
+#pragma unroll
+		for (int e = 0; e < 3; ++e) {
+			const int row = 2 * q.ty - a.pad + hf + e;
+			const bool ok = (unsigned)row < (unsigned)a.H;
+			const long off = (((long)q.n * a.C) * a.H + row) * a.W + 8 * q.j - a.pad;
+			if (ok && off < 0) {
+				// the first row of the tensor with left padding: the scalar offset would be negative. Load one column further
+				// right (the lane at the tensor's first element from that element) and shift that lane when it is consumed.
+				pd.fixrow = true;
+				sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voffx_first, 0, 0));
+			} else {
+				sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? xr : nullr, voffx, ok ? (unsigned)off * 4u : 0u, 0));
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < 2; ++r) {
+			const int row = 2 * q.ty + r;
+			const bool ok = row < a.P;
+			const long off = (((long)q.n * a.K) * a.P + row) * a.Q + 8 * q.j;
+			sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ok ? zr : nullr, voffz, ok ? (unsigned)off * 4u : 0u, 0));
+		}
+	};
+
+	f32x2 tA[2], tB[2], zr1, zr2;
+	auto store_slice = [&](auto half, float *stg, const Pend &pd, int slice) {
+		constexpr int HF = decltype(half)::value;
+		const unsigned long long all = ~0ull;
+		if (slice == 0) {
+			if (pd.fixrow) {                         // wave-uniform, one chunk of the launch
+				const int e = a.pad - HF;
+				if (voffx == 0 && e >= 0 && e < 3) sp[e] = f32x4{0.f, sp[e][0], sp[e][1], sp[e][2]};
+			}
+			const unsigned long long m = (pd.last ? mlast[0] : all) & (pd.first ? mfirst0 : all);
+#pragma unroll
+			for (int e = 0; e < 3; ++e) sp[e][0] = sel_mask(m, sp[e][0]);
+			const unsigned long long m0 = pd.last ? mz[0] : all, m1 = pd.last ? mz[1] : all;
+#pragma unroll
+			for (int r = 0; r < 2; ++r) sz[r][0] = sel_mask(m0, sz[r][0]), sz[r][1] = sel_mask(m1, sz[r][1]);
+		} else if (slice == 2 || slice == 3) {
+			const unsigned long long m = pd.last ? mlast[slice] : all;
+#pragma unroll
+			for (int e = 0; e < 3; ++e) sp[e][slice] = sel_mask(m, sp[e][slice]);
+		}
+		if (slice == 1 || slice == 3) {
+			const int q = slice >> 1;
+			const f32x2 e0 = {sp[0][2 * q], sp[0][2 * q + 1]}, e1 = {sp[1][2 * q], sp[1][2 * q + 1]};
+			const f32x2 e2 = {sp[2][2 * q], sp[2][2 * q + 1]};
+			if constexpr (HF == 0) {
+				tA[q] = e0 - e2, tB[q] = e1 + e2;
+			} else {
+				tA[q] = e1 - e0, tB[q] = e0 - e2;
+			}
+		}
+		if (slice == 1) zr1 = sz[0] + sz[1], zr2 = sz[0] - sz[1];       // rows of A dY: (d0, d0 + d1, d0 - d1, [-]d1)
+		if (slice == 4 || slice == 5) {
+			const f32x2 t01 = slice == 4 ? tA[0] : tB[0], t23 = slice == 4 ? tA[1] : tB[1];
+			f32x2 v01, v23;
+			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
+			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+			float *dst = stg + vdst + (slice - 4) * 4 * (2 * CB * 2);
+			dst[0 * (2 * CB * 2)] = v01[0];
+			dst[1 * (2 * CB * 2)] = v01[1];
+			dst[2 * (2 * CB * 2)] = v23[0];
+			dst[3 * (2 * CB * 2)] = v23[1];
+		}
+		if (slice >= 4) {                            // row (a, b) of A dY -> (a, a + b, a - b, [-]b), one row per slice
+			const int i = slice - 4;
+			const f32x2 row = i == 0 ? sz[0] : i == 1 ? zr1 : i == 2 ? zr2 : sz[1];
+			f32x2 mid;
+			asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(mid) : "v"(row));
+			float *dst = stg + zdst + i * 4 * (2 * KB * 2);
+			dst[0 * (2 * KB * 2)] = row[0];
+			dst[1 * (2 * KB * 2)] = mid[0];
+			dst[2 * (2 * KB * 2)] = mid[1];
+			dst[3 * (2 * KB * 2)] = row[1];
+		}
+	};
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int p = 0; p < 4; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[p][m][r] = 0.f;
+
+	const int vfrag = ((4 * wave * 2 + lhi) * CB + l31) * 2;
+	const int ufrag = kVFloats + ((4 * wave * 2 + lhi) * KB + l31) * 2;
+
+	struct Frag {
+		f32x2 bv[2], av[2][2];
+	};
+	auto read_frags = [&](const float *stg, Frag &f, int p0) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p) {
+			f.bv[p] = *reinterpret_cast<const f32x2 *>(stg + vfrag + (p0 + p) * (2 * CB * 2));
+			f.av[p][0] = *reinterpret_cast<const f32x2 *>(stg + ufrag + (p0 + p) * (2 * KB * 2));
+			f.av[p][1] = *reinterpret_cast<const f32x2 *>(stg + ufrag + (p0 + p) * (2 * KB * 2) + 64);
+		}
+	};
+
+	auto run = [&](auto half) {
+		Frag f0, f1;
+		Geo q = geo_of(g0);
+		Pend pd;
+		issue_loads(q, pd);
+#pragma unroll
+		for (int sl = 0; sl < 8; ++sl) store_slice(half, smem, pd, sl);
+		if (nch > 1) {
+			advance(q);
+			issue_loads(q, pd);
+#pragma unroll
+			for (int sl = 0; sl < 8; ++sl) store_slice(half, smem + kStage, pd, sl);
+		}
+		int issued = nch > 1 ? 2 : 1;                // chunks whose loads have been issued
+		if (nch > 2) advance(q), issue_loads(q, pd), ++issued;
+		__syncthreads();
+		read_frags(smem, f0, 0);
+
+		int s_cur = 0;
+		auto body = [&](Frag &cur, Frag &nxt) {
+			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
+			Frag late;
+			read_frags(smem + s_cur * kStage, late, 2);
+			read_frags(smem + s_nxt * kStage, nxt, 0);
+			float *wr = smem + s_wr * kStage;
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+#pragma unroll
+				for (int m = 0; m < 2; ++m) {
+					const Frag &f = p < 2 ? cur : late;
+					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][0], f.bv[p & 1][0], acc[p][m], 0, 0, 0);
+				}
+			__builtin_amdgcn_sched_barrier(0);
+			const Pend pc = pd;
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+#pragma unroll
+				for (int m = 0; m < 2; ++m) {
+					const Frag &f = p < 2 ? cur : late;
+					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][1], f.bv[p & 1][1], acc[p][m], 0, 0, 0);
+					store_slice(half, wr, pc, p * 2 + m);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+			// past the last chunk: the same chunk again (its stores go to a stage nobody reads any more)
+			if (issued < nch) advance(q), ++issued;
+			issue_loads(q, pd);
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+			s_cur = s_nxt;
+		};
+
+		int ch = 0;
+		for (; ch + 1 < nch; ch += 2) {
+			body(f0, f1);
+			body(f1, f0);
+		}
+		if (ch < nch) body(f0, f1);
+	};
+	if (hf == 0)
+		run(std::integral_constant<int, 0>{});
+	else
+		run(std::integral_constant<int, 1>{});
+
+	// ---- partial sums -> slab[pos][k][c]: register i of a lane is row (k) 8 (i / 4) + 4 (lane / 32) + i % 4, column (c) lane % 32
+	float *slab = a.slabs + (size_t)blockIdx.x * kSlab;
+#pragma unroll
+	for (int p = 0; p < 4; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int kk = m * 32 + 8 * (i >> 2) + 4 * lhi + (i & 3);
+				slab[((4 * wave + p) * KB + kk) * CB + l31] = acc[p][m][i];
+			}
+}
+
+// sums the slabs of `per` consecutive splits (blockIdx.y = group) into one: out[group][block][...]
+__global__ void __launch_bounds__(256) wino_wgrad_sum_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t block_elems,
+                                                             int splits, int groups) {
+	const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (e >= block_elems) return;
+	const int g = blockIdx.y;
+	const int s0 = (int)((long)splits * g / groups), s1 = (int)((long)splits * (g + 1) / groups);
+	float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+	int s = s0;
+	for (; s + 4 <= s1; s += 4) {
+		v0 += slabs[(size_t)s * block_elems + e], v1 += slabs[(size_t)(s + 1) * block_elems + e];
+		v2 += slabs[(size_t)(s + 2) * block_elems + e], v3 += slabs[(size_t)(s + 3) * block_elems + e];
+	}
+	for (; s < s1; ++s) v0 += slabs[(size_t)s * block_elems + e];
+	out[(size_t)g * block_elems + e] = (v0 + v1) + (v2 + v3);
+}
+
+// dg[k][c] = G^T dU G over the (at most a few) remaining partial slabs, dw = alpha dg + beta dw
+__global__ void __launch_bounds__(256) wino_wgrad_finish_kernel(const float *__restrict__ part, int nparts, size_t block_elems, float *dw,
+                                                                int K, int C, int kblocks, int cblocks, float alpha, float beta) {
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= K * C) return;
+	const int k = idx / C, c = idx - k * C;
+	const int kb = k / KB, kl = k - kb * KB, cb = c / CB, cl = c - cb * CB;
+	const float *src = part + (size_t)(kb * cblocks + cb) * kSlab + kl * CB + cl;
+
+	float u[4][4];
+#pragma unroll
+	for (int pos = 0; pos < 16; ++pos) u[pos >> 2][pos & 3] = 0.f;
+	for (int s = 0; s < nparts; ++s)
+#pragma unroll
+		for (int pos = 0; pos < 16; ++pos) u[pos >> 2][pos & 3] += src[(size_t)s * block_elems + pos * (KB * CB)];
+	// row / column 3 of A dY A^T were accumulated with the opposite sign
+#pragma unroll
+	for (int i = 0; i < 4; ++i) u[i][3] = -u[i][3], u[3][i] = -u[3][i];
+
+	float t[3][4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+		t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+		t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+	}
+	float *dst = dw + (size_t)idx * 9;
+#pragma unroll
+	for (int r = 0; r < 3; ++r) {
+		const float g0 = t[r][0] + 0.5f * (t[r][1] + t[r][2]), g1 = 0.5f * (t[r][1] - t[r][2]), g2 = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+		if (beta == 0.f) {
+			dst[r * 3 + 0] = alpha * g0, dst[r * 3 + 1] = alpha * g1, dst[r * 3 + 2] = alpha * g2;
+		} else {
+			dst[r * 3 + 0] = alpha * g0 + beta * dst[r * 3 + 0];
+			dst[r * 3 + 1] = alpha * g1 + beta * dst[r * 3 + 1];
+			dst[r * 3 + 2] = alpha * g2 + beta * dst[r * 3 + 2];
+		}
+	}
+}
+
 }  // namespace
 
 namespace pz {
@@ -416,6 +750,68 @@ int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, c
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
 	wino_conv_kernel<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+// ---- backward-filter
+struct WgradPlanW {
+	int TY, TX4, chunks, kblocks, cblocks, splits, groups;
+	size_t slab_bytes, part_bytes;
+};
+
+static WgradPlanW wino_wgrad_plan(const pz_conv_desc *d, int P, int Q) {
+	WgradPlanW p{};
+	p.TY = (P + 1) / 2, p.TX4 = ((Q + 1) / 2 + 3) / 4;
+	p.chunks = d->n * p.TY * p.TX4;
+	p.kblocks = ceil_div(d->k, KB), p.cblocks = ceil_div(d->c, CB);
+	const int nblk = p.kblocks * p.cblocks;
+	int splits = ceil_div(2 * kNumCU, nblk);                     // two workgroups per CU
+	const int most = p.chunks / 16 > 0 ? p.chunks / 16 : 1;      // ... of at least 16 chunks each
+	p.splits = splits < 1 ? 1 : (splits > most ? most : splits);
+	p.groups = p.splits > 8 ? 8 : p.splits;
+	p.slab_bytes = (size_t)p.splits * nblk * kSlab * sizeof(float);
+	p.part_bytes = p.splits > p.groups ? (size_t)p.groups * nblk * kSlab * sizeof(float) : 0;
+	return p;
+}
+
+bool wino_wgrad_eligible(const pz_conv_desc *d, int P, int Q) {
+	if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
+	if (d->pad_h != d->pad_w || d->pad_h > 1) return false;
+	const size_t lim = 0xfffffff0u;
+	return (size_t)d->n * d->c * d->h * d->w * 4 < lim && (size_t)d->n * d->k * P * Q * 4 < lim;
+}
+
+size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q) {
+	const WgradPlanW p = wino_wgrad_plan(d, P, Q);
+	return p.slab_bytes + p.part_bytes;
+}
+
+int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float *dy, float *dw, float alpha, float beta,
+               void *workspace, hipStream_t st) {
+	const WgradPlanW p = wino_wgrad_plan(d, P, Q);
+	const int nblk = p.kblocks * p.cblocks;
+
+	WinoWgradArgs a{};
+	a.x = x, a.dy = dy, a.slabs = (float *)workspace;
+	a.N = d->n, a.C = d->c, a.H = d->h, a.W = d->w, a.K = d->k, a.P = P, a.Q = Q, a.pad = d->pad_h;
+	a.TY = p.TY, a.TX4 = p.TX4, a.chunks = p.chunks, a.splits = p.splits, a.kblocks = p.kblocks, a.cblocks = p.cblocks;
+	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
+	a.dy_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
+	wino_wgrad_kernel<<<p.splits * nblk, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+
+	const size_t block_elems = (size_t)nblk * kSlab;
+	const float *part = a.slabs;
+	int nparts = p.splits;
+	if (p.splits > p.groups) {
+		float *out = (float *)((char *)workspace + p.slab_bytes);
+		wino_wgrad_sum_kernel<<<dim3((unsigned)((block_elems + 255) / 256), p.groups), 256, 0, st>>>(a.slabs, out, block_elems, p.splits, p.groups);
+		PZ_LAUNCH_CHECK();
+		part = out, nparts = p.groups;
+	}
+	wino_wgrad_finish_kernel<<<ceil_div((long)d->k * d->c, 256), 256, 0, st>>>(part, nparts, block_elems, dw, d->k, d->c, p.kblocks,
+	                                                                          p.cblocks, alpha, beta);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

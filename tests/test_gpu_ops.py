@@ -796,5 +796,21 @@ def test_winograd_convolution(bnd, cfg):
 		assert not np.array_equal(dx.get(), bnd.dnn.convNdBackwardData(gdy, gw, None, gx, algo=5, **kw).get())
 	assert_close(dx.get(), dx_ref, atol=2e-5 * max(1.0, float(np.abs(dx_ref).max())), rtol=0, what="winograd backward data")
 
+	# backward-filter through the same transforms (tile-range slices summed in a fixed order), with the bias gradient
+	# and the accumulate contract of Hip/Wrappers/MIOpen.py:414-455
+	wino = bnd.ConvBwdFilterAlgo.winograd.value
+	dw, db = bnd.dnn.convNdBackwardParams(gx, gdy, gw, withbias=True, algo=wino, **kw)
+	dw_ref, db_ref = R.conv2d_bwd_filter(x, dy, wt.shape, withbias=True, acc=np.float64, **kw)
+	scale = max(1.0, float(np.abs(dw_ref).max()))
+	assert_close(dw.get(), dw_ref, atol=2e-5 * scale, rtol=0, what="winograd backward filter")
+	assert_close(db.get(), db_ref, atol=2e-5 * max(1.0, float(np.abs(db_ref).max())), rtol=0, what="bias gradient")
+	assert not np.array_equal(dw.get(), bnd.dnn.convNdBackwardParams(gx, gdy, gw, algo=5, **kw).get())
+
+	w0 = rng.randn(*wt.shape).astype(np.float32)
+	gw0 = gpu(bnd, w0)
+	bnd.dnn.convNdBackwardParams(gx, gdy, gw, wgrad=gw0, scale=0.5, momentum=0.9, algo=wino, **kw)
+	assert_close(gw0.get(), 0.9 * w0 + 0.5 * dw_ref, atol=2e-5 * scale + 1e-6, rtol=0, what="accumulated filter gradient")
+
 	# run-to-run determinism
 	assert np.array_equal(bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.winograd.value, **kw).get(), y.get())
+	assert np.array_equal(bnd.dnn.convNdBackwardParams(gx, gdy, gw, algo=wino, **kw).get(), dw.get())

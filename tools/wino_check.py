@@ -55,15 +55,21 @@ def main():
 		d3 = dnn.convNdBackwardData(dy, wt, None, x, 1, pad, 1, 0, 1, 3)
 		eb = float(np.abs(d5.get() - d3.get()).max())
 
+		w5 = dnn.convNdBackwardParams(x, dy, wt, 1, pad, 1, 1, False, False, None, None, 1.0, 0.0, 5)
+		w3 = dnn.convNdBackwardParams(x, dy, wt, 1, pad, 1, 1, False, False, None, None, 1.0, 0.0, 3)
+		ew = float(np.abs(w5.get() - w3.get()).max() / max(1e-30, np.abs(w5.get()).max()))
+
 		flops = 2.0 * n * y5.shape[2] * y5.shape[3] * k * c * 9
-		line = "(%d,%d,%d,%d)->%d p%d  fwd err %.2e  dgrad err %.2e" % (n, c, h, w, k, pad, ef, eb)
+		line = "(%d,%d,%d,%d)->%d p%d  fwd err %.2e  dgrad err %.2e  wgrad rel err %.2e" % (n, c, h, w, k, pad, ef, eb, ew)
 		if n >= 64:
 			t5 = timed(lambda: dnn.convNd(x, wt, b, 1, pad, 1, 1, 5, y5))
 			t3 = timed(lambda: dnn.convNd(x, wt, b, 1, pad, 1, 1, 3, y3))
 			u5 = timed(lambda: dnn.convNdBackwardData(dy, wt, None, x, 1, pad, 1, 0, 1, 5, d5))
 			u3 = timed(lambda: dnn.convNdBackwardData(dy, wt, None, x, 1, pad, 1, 0, 1, 3, d3))
-			line += " | fwd igemm %.3f ms (%.0f TF) wino %.3f ms (%.0f TF-eq) | dgrad igemm %.3f wino %.3f" % (
-				t5, flops / t5 / 1e9, t3, flops / t3 / 1e9, u5, u3
+			v5 = timed(lambda: dnn.convNdBackwardParams(x, dy, wt, 1, pad, 1, 1, False, False, w5, None, 1.0, 0.0, 5))
+			v3 = timed(lambda: dnn.convNdBackwardParams(x, dy, wt, 1, pad, 1, 1, False, False, w3, None, 1.0, 0.0, 3))
+			line += " | fwd igemm %.3f ms (%.0f TF) wino %.3f ms (%.0f TF-eq) | dgrad igemm %.3f wino %.3f | wgrad igemm %.3f wino %.3f" % (
+				t5, flops / t5 / 1e9, t3, flops / t3 / 1e9, u5, u3, v5, v3
 			)
 		print(line, flush=True)
 
