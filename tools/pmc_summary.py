@@ -13,7 +13,7 @@ for sub in sorted(os.listdir(root)):
 	for f in files:
 		for r in csv.DictReader(open(f)):
 			k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-			k = re.sub(r"\((pz_|float|unsigned|int|HIP|EltArgs|IgemmArgs|WgradArgs|PackArgs|BnGeom|PoolGeom).*", "", k).strip()
+			k = re.sub(r"\((pz_|float|unsigned|int|HIP|EltArgs|IgemmArgs|WgradArgs|PackArgs|WinoArgs|WinoWgradArgs|WinoFilterArgs|BnGeom|PoolGeom).*", "", k).strip()
 			acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 			seen[k].add(r["Dispatch_Id"])
 	summary[sub] = {k: dict(v, dispatches=len(seen[k])) for k, v in acc.items()}
