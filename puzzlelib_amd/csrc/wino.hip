@@ -26,6 +26,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
                         // 16 no barrier, 32 no fragment reads
 #endif
 
+#ifndef WN_SELFWAVE
+#define WN_SELFWAVE 0   // forward / backward-data: 0 = shared loaders + one barrier per chunk; 1 = barrier-free self-sufficient
+                        // waves (wino_conv_kernel_sw) — measured equal on all four 3x3 layer shapes, kept for the comparison
+#endif
+
 namespace {
 
 constexpr unsigned kOOB = 0xfffffff0u;      // buffer byte offset beyond every tensor: loads return 0, stores are dropped
@@ -94,6 +99,64 @@ struct WinoArgs {
 	int chunks, tblocks;
 	unsigned x_bytes, y_bytes;
 };
+
+// D[m = channel][n = tile] of the 16 positions -> output tensor. Register i of a lane is row 8 (i / 4) + 4 (lane / 32) + i % 4,
+// column lane % 32. The accumulators pass through LDS 16 channels at a time so that one thread holds the 16 positions
+// of a (tile, channel), applies A^T . A, adds the bias and stores the 2x2 outputs (lanes along the tile row).
+__device__ __forceinline__ void wino_epilogue(const WinoArgs &a, f32x16 (&acc)[4][2], float *smem, int kb, int tb, int tid, int wave,
+                                              int lane) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+	float *Ms = smem;                               // [16 positions][16 channels][32 tiles]
+
+	const int t = tb * TB + l31;
+	const bool tv = t < a.tiles;
+	const int n = t / (a.TY * a.TX), rr = t - n * (a.TY * a.TX);
+	const int ty = rr / a.TX, tx = rr - ty * a.TX;
+	const bool row1 = 2 * ty + 1 < a.P, col1 = 2 * tx + 1 < a.Q;
+	const unsigned pq4 = (unsigned)(a.P * a.Q) * 4u;
+	const unsigned obase = (unsigned)((((long)n * a.K) * a.P + 2 * ty) * a.Q + 2 * tx) * 4u;
+
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int kk = 8 * (i >> 2) + 4 * lhi + (i & 3);
+				Ms[((4 * wave + p) * 16 + kk) * 32 + l31] = acc[p][q >> 1][8 * (q & 1) + i];
+			}
+		__syncthreads();
+
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			const int kk = (tid >> 5) + 8 * j;
+			const int k = kb * KB + q * 16 + kk;
+			float m[4][4];
+#pragma unroll
+			for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = Ms[(pos * 16 + kk) * 32 + l31];
+
+			float r0[4], r1[4];
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				r0[v] = m[0][v] + m[1][v] + m[2][v];
+				r1[v] = m[1][v] - m[2][v] - m[3][v];
+			}
+			const float b = (a.bias != nullptr && k < a.K) ? a.bias[k] : 0.f;
+			const float y00 = r0[0] + r0[1] + r0[2] + b, y01 = r0[1] - r0[2] - r0[3] + b;
+			const float y10 = r1[0] + r1[1] + r1[2] + b, y11 = r1[1] - r1[2] - r1[3] + b;
+
+			const bool kv = tv && k < a.K;
+			const unsigned o = obase + (unsigned)k * pq4;
+			const unsigned q4 = (unsigned)a.Q * 4u;
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), yr, kv ? o : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yr, kv && col1 ? o + 4u : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yr, kv && row1 ? o + q4 : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yr, kv && row1 && col1 ? o + q4 + 4u : kOOB, 0, 0);
+		}
+		if (q < 3) __syncthreads();
+	}
+}
 
 __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 	constexpr int kStage = kVFloats + kUFloats;                                      // one chunk of both operands: 24 KB
@@ -316,59 +379,212 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 	}
 #endif
 
-	// ---- epilogue: D[m = channel][n = tile]; register i of a lane is row 8 (i / 4) + 4 (lane / 32) + i % 4, column lane % 32
-	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
-	float *Ms = smem;                               // [16 positions][16 channels][32 tiles]
-
-	const int t = tb * TB + l31;
-	const bool tv = t < a.tiles;
-	const int n = t / (a.TY * a.TX), rr = t - n * (a.TY * a.TX);
-	const int ty = rr / a.TX, tx = rr - ty * a.TX;
-	const bool row1 = 2 * ty + 1 < a.P, col1 = 2 * tx + 1 < a.Q;
-	const unsigned pq4 = (unsigned)(a.P * a.Q) * 4u;
-	const unsigned obase = (unsigned)((((long)n * a.K) * a.P + 2 * ty) * a.Q + 2 * tx) * 4u;
-
-#pragma unroll
-	for (int q = 0; q < 4; ++q) {
-#pragma unroll
-		for (int p = 0; p < 4; ++p)
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const int kk = 8 * (i >> 2) + 4 * lhi + (i & 3);
-				Ms[((4 * wave + p) * 16 + kk) * 32 + l31] = acc[p][q >> 1][8 * (q & 1) + i];
-			}
-		__syncthreads();
-
-#pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			const int kk = (tid >> 5) + 8 * j;
-			const int k = kb * KB + q * 16 + kk;
-			float m[4][4];
-#pragma unroll
-			for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = Ms[(pos * 16 + kk) * 32 + l31];
-
-			float r0[4], r1[4];
-#pragma unroll
-			for (int v = 0; v < 4; ++v) {
-				r0[v] = m[0][v] + m[1][v] + m[2][v];
-				r1[v] = m[1][v] - m[2][v] - m[3][v];
-			}
-			const float b = (a.bias != nullptr && k < a.K) ? a.bias[k] : 0.f;
-			const float y00 = r0[0] + r0[1] + r0[2] + b, y01 = r0[1] - r0[2] - r0[3] + b;
-			const float y10 = r1[0] + r1[1] + r1[2] + b, y11 = r1[1] - r1[2] - r1[3] + b;
-
-			const bool kv = tv && k < a.K;
-			const unsigned o = obase + (unsigned)k * pq4;
-			const unsigned q4 = (unsigned)a.Q * 4u;
-			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), yr, kv ? o : kOOB, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yr, kv && col1 ? o + 4u : kOOB, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yr, kv && row1 ? o + q4 : kOOB, 0, 0);
-			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yr, kv && row1 && col1 ? o + q4 + 4u : kOOB, 0, 0);
-		}
-		if (q < 3) __syncthreads();
-	}
+	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same product with self-sufficient waves (no barrier in the reduction loop). Wave w accumulates positions 4w..4w+3
+// = row w of the transformed patch, and that row needs only two rows of the patch (0: d0-d2, 1: d1+d2, 2: d2-d1,
+// 3: d1-d3): the wave loads those two rows of all 128 patches of a chunk itself (two patches per lane), applies (.) B,
+// and copies its own quarter of the transformed filters — into a private two-stage LDS ring. Nothing a wave reads was
+// written by another wave, LDS executes a wave's accesses in order, so the only barrier is the one in front of the
+// epilogue; the four waves drift apart and fill each other's load / transform phases with MFMAs.
+// Cost: the patch rows are loaded by two waves each (16 instead of 12 KB per chunk per workgroup, L1 hits).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
+	constexpr int kWaveStage = 4 * TB * BC + 4 * KB * BC;        // one wave's V (512) + U (1024) floats of a chunk
+	__shared__ __attribute__((aligned(16))) float smem[4 * 2 * kWaveStage];       // 48 KB
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const int kb = blockIdx.x / a.tblocks, tb = blockIdx.x - kb * a.tblocks;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)(a.u + (size_t)kb * a.chunks * kUFloats), 0, (unsigned)a.chunks * (kUFloats * 4u), 0x00020000);
+	const unsigned hw4 = (unsigned)(a.H * a.W) * 4u;
+	float *mine = smem + wave * (2 * kWaveStage);
+
+	// patch rows of this wave's transform row; lane -> tile lane % 32, channels lane / 32 and lane / 32 + 2 of the chunk
+	const int rowA = wave == 0 ? 0 : wave == 2 ? 2 : 1, rowB = wave == 0 ? 2 : wave == 2 ? 1 : wave == 1 ? 2 : 3;
+	unsigned voff[2][2];
+	bool colok[4], fix[2][2];
+	bool anyfix = false;
+	{
+		const int t = tb * TB + l31;
+		const bool tv = t < a.tiles;
+		const int n = t / (a.TY * a.TX), r = t - n * (a.TY * a.TX);
+		const int ty = r / a.TX, tx = r - ty * a.TX;
+		const int row0 = 2 * ty - a.pad_h, col0 = 2 * tx - a.pad_w;
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int e = 0; e < 2; ++e) {
+				const int row = row0 + (e == 0 ? rowA : rowB);
+				const bool ok = tv && (unsigned)row < (unsigned)a.H;
+				const long off = (((long)n * a.C + lhi + 2 * i) * a.H + row) * a.W + col0;
+				fix[i][e] = ok && off < 0;            // see wino_conv_kernel: the tensor's first row behind the left padding
+				voff[i][e] = ok ? (off < 0 ? 0u : (unsigned)off * 4u) : kOOB;
+				anyfix = anyfix || fix[i][e];
+			}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) colok[j] = (unsigned)(col0 + j) < (unsigned)a.W;
+	}
+	anyfix = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(anyfix) != 0ull)) != 0;
+	const unsigned vdst = (unsigned)(l31 * 2 + lhi);             // + (nu * 2 + i) * 64
+
+	f32x4 sp[2][2], su[4];
+
+	auto issue_loads = [&](int chunk) {
+		const unsigned soff = (unsigned)chunk * (BC * hw4);
+#pragma unroll
+		for (int i = 0; i < 2; ++i)
+#pragma unroll
+			for (int e = 0; e < 2; ++e)
+				sp[i][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[i][e], soff, 0));
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			su[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+			    ur, (unsigned)(wave * (4 * KB * BC) + (lane + i * 64) * 4) * 4u, (unsigned)chunk * (kUFloats * 4u), 0));
+	};
+
+	// slices 0/2: clear the columns outside the image of patch 0/1; 1/3: its row of B^T d, (.) B, four LDS stores;
+	// 4-7: 16 B of filters each
+	auto store_slice = [&](auto row, auto fixed, float *stg, int slice) {
+		constexpr int ROW = decltype(row)::value;
+		if (slice < 4) {
+			const int i = slice >> 1;
+			if ((slice & 1) == 0) {
+#pragma unroll
+				for (int e = 0; e < 2; ++e) {
+					if constexpr (decltype(fixed)::value)
+						if (fix[i][e]) sp[i][e] = f32x4{0.f, sp[i][e][0], sp[i][e][1], sp[i][e][2]};
+#pragma unroll
+					for (int j = 0; j < 4; ++j)
+						if (j != 1) sp[i][e][j] = colok[j] ? sp[i][e][j] : 0.f;
+				}
+			} else {
+				f32x2 t01, t23;
+				const f32x2 a01 = {sp[i][0][0], sp[i][0][1]}, a23 = {sp[i][0][2], sp[i][0][3]};
+				const f32x2 b01 = {sp[i][1][0], sp[i][1][1]}, b23 = {sp[i][1][2], sp[i][1][3]};
+				if constexpr (ROW == 1) {
+					t01 = a01 + b01, t23 = a23 + b23;
+				} else {
+					t01 = a01 - b01, t23 = a23 - b23;
+				}
+				f32x2 v01, v23;                               // (t0 - t2, t1 + t2), (t2 - t1, t1 - t3)
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				float *dst = stg + vdst + i * 64;
+				dst[0 * 128] = v01[0];
+				dst[1 * 128] = v01[1];
+				dst[2 * 128] = v23[0];
+				dst[3 * 128] = v23[1];
+			}
+		} else {
+			reinterpret_cast<f32x4 *>(stg + 4 * TB * BC)[lane + (slice - 4) * 64] = su[slice - 4];
+		}
+	};
+
+	f32x16 acc[4][2];
+#pragma unroll
+	for (int p = 0; p < 4; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[p][m][r] = 0.f;
+
+	const int vfrag = (lhi * TB + l31) * 2;                          // + p * 128
+	const int ufrag = 4 * TB * BC + (lhi * KB + l31) * 2;            // + p * 256 + mt * 64
+
+	struct Frag {
+		f32x2 bv[2], av[2][2];
+	};
+	auto read_frags = [&](const float *stg, Frag &f, int p0) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p) {
+			f.bv[p] = *reinterpret_cast<const f32x2 *>(stg + vfrag + (p0 + p) * 128);
+			f.av[p][0] = *reinterpret_cast<const f32x2 *>(stg + ufrag + (p0 + p) * 256);
+			f.av[p][1] = *reinterpret_cast<const f32x2 *>(stg + ufrag + (p0 + p) * 256 + 64);
+		}
+	};
+
+	auto run = [&](auto row, auto fixed) {
+		issue_loads(0);
+#pragma unroll
+		for (int sl = 0; sl < 8; ++sl) store_slice(row, fixed, mine, sl);
+		issue_loads(min(1, a.chunks - 1));
+
+		// chunk ch lives in stage ch % 2; its successor's staged registers are parked into the other stage while the first
+		// half of its MFMAs run, the chunk after that is loaded into the freed registers
+		auto body = [&](int ch, float *cur_stage, float *oth_stage) {
+			Frag lo, hi;
+			read_frags(cur_stage, lo, 0);
+			read_frags(cur_stage, hi, 2);
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+#pragma unroll
+				for (int m = 0; m < 2; ++m) {
+					const Frag &f = p < 2 ? lo : hi;
+#if !(WN_ABL & 4)
+					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][0], f.bv[p & 1][0], acc[p][m], 0, 0, 0);
+#endif
+#if !(WN_ABL & 2)
+					store_slice(row, fixed, oth_stage, p * 2 + m);
+#endif
+					__builtin_amdgcn_sched_barrier(0);
+				}
+#if !(WN_ABL & 1)
+			issue_loads(min(ch + 2, a.chunks - 1));
+#endif
+			__builtin_amdgcn_sched_barrier(0);
+#if !(WN_ABL & 4)
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+#pragma unroll
+				for (int m = 0; m < 2; ++m) {
+					const Frag &f = p < 2 ? lo : hi;
+					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][1], f.bv[p & 1][1], acc[p][m], 0, 0, 0);
+				}
+#endif
+			__builtin_amdgcn_sched_barrier(0);
+		};
+
+		int ch = 0;
+		for (; ch + 1 < a.chunks; ch += 2) {
+			body(ch, mine, mine + kWaveStage);
+			body(ch + 1, mine + kWaveStage, mine);
+		}
+		if (ch < a.chunks) body(ch, mine, mine + kWaveStage);
+	};
+
+	auto dispatch = [&](auto fixed) {
+		switch (wave) {
+		case 0: run(std::integral_constant<int, 0>{}, fixed); break;
+		case 1: run(std::integral_constant<int, 1>{}, fixed); break;
+		case 2: run(std::integral_constant<int, 2>{}, fixed); break;
+		default: run(std::integral_constant<int, 3>{}, fixed); break;
+		}
+	};
+	if (anyfix)
+		dispatch(std::true_type{});
+	else
+		dispatch(std::false_type{});
+
+#if WN_ABL & 8
+	{
+		float sum = 0.f;
+#pragma unroll
+		for (int p = 0; p < 4; ++p) sum += acc[p][0][p] + acc[p][1][15 - p];
+		a.y[(size_t)blockIdx.x * 256 + tid] = sum;
+		return;
+	}
+#endif
+	__syncthreads();              // every wave is done with its ring before the epilogue reuses the memory
+	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
+}
 
 // ------------------------------------------------------------------------------------------------
 // backward-filter through the same transform:  dU[pos][k][c] = sum over tiles (A dY A^T)[pos] . (B^T d B)[pos],
@@ -749,7 +965,11 @@ int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, c
 	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB);
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
+#if WN_SELFWAVE
+	wino_conv_kernel_sw<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
+#else
 	wino_conv_kernel<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
+#endif
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
