@@ -96,6 +96,9 @@ enum { PZ_CONV_ALGO_AUTO = -1, PZ_CONV_ALGO_DIRECT = 1, PZ_CONV_ALGO_WINOGRAD = 
 enum { PZ_CONV_FWD = 0, PZ_CONV_BWD_DATA = 1, PZ_CONV_BWD_FILTER = 2 };
 
 int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q);
+/* The kernel family a request resolves to: *used = PZ_CONV_ALGO_DIRECT, _WINOGRAD or _IMPLICIT_GEMM for pass `which`
+ * under the requested `algo` (what convNdbenchmark, Hip/Wrappers/MIOpen.py:465-519, enumerates and times). */
+int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used);
 int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
 /* y = conv(x, w) (+ bias[k] when bias != NULL) */
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,

@@ -325,6 +325,13 @@ class DnnContext:
 		return out, ConvStats(out, stats)
 
 
+	def convAlgoUsed(self, desc, which, algo):
+		"""The kernel family (`direct` / `winograd` / `implicitGemm` id) a request resolves to."""
+		used = c_int(0)
+		lib.pz_conv2d_algo_used(byref(desc), which, toAlgoId(algo), byref(used))
+		return used.value
+
+
 	def bnFoldSupported(self, desc, algo):
 		flag = c_int(0)
 		lib.pz_conv2d_bn_fold_supported(byref(desc), algo, byref(flag))
@@ -440,8 +447,8 @@ class DnnContext:
 
 	def convNdbenchmark(self, datashape, Wshape, dtype, stride=1, pad=0, dilation=1, groups=1, algoCount=10,
 						exhaustive=False):
-		"""Times the two algorithms of each pass on scratch tensors: (algo id, seconds, workspace bytes) triples,
-		the result shape of Hip/Wrappers/MIOpen.py:465-519."""
+		"""Times the kernel families that serve each pass (implicit GEMM, Winograd where it applies, direct) on scratch
+		tensors: (algo id, seconds, workspace bytes) triples, the result shape of Hip/Wrappers/MIOpen.py:465-519."""
 		bnd = self.backend
 		data = GPUArray.zeros(datashape, dtype=dtype, allocator=bnd.memoryPool)
 		W = GPUArray.zeros(Wshape, dtype=dtype, allocator=bnd.memoryPool)
@@ -460,7 +467,9 @@ class DnnContext:
 			)),
 		):
 			perfs = []
-			for algo in (ConvFwdAlgo.implicitGemm.value, ConvFwdAlgo.direct.value):
+			for algo in (ConvFwdAlgo.implicitGemm.value, ConvFwdAlgo.winograd.value, ConvFwdAlgo.direct.value):
+				if self.convAlgoUsed(desc, which, algo) != algo:        # e.g. Winograd asked of a layer it does not serve
+					continue
 				size = c_size_t(0)
 				lib.pz_conv2d_workspace_bytes(byref(desc), which, toAlgoId(algo), byref(size))
 				secs, _ = bnd.timeKernel(run, (algo, ), looplength=3, log=False, normalize=True)

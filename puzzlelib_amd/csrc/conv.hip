@@ -1311,6 +1311,17 @@ int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double to
 
 int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q) { return check_desc(d, p, q); }
 
+int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(used != nullptr && which >= PZ_CONV_FWD && which <= PZ_CONV_BWD_FILTER, "pz_conv2d_algo_used: bad arguments");
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || (which == PZ_CONV_BWD_DATA && !dgrad_uses_igemm(d)))
+		*used = PZ_CONV_ALGO_DIRECT;
+	else
+		*used = uses_winograd(d, which, P, Q, algo) ? PZ_CONV_ALGO_WINOGRAD : PZ_CONV_ALGO_IMPLICIT_GEMM;
+	return PZ_OK;
+}
+
 int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;

@@ -98,6 +98,7 @@ _PROTOS = {
 	"pz_conv2d_bwd_data": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 
+	"pz_conv2d_algo_used": [POINTER(ConvDesc), c_int, c_int, POINTER(c_int)],
 	"pz_conv_profile_enable": [c_int],
 	"pz_conv_profile_collect": [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_longlong)],
 

@@ -785,6 +785,12 @@ def test_winograd_convolution(bnd, cfg):
 
 	y_ig = bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.implicitGemm.value, **kw)
 	assert not np.array_equal(y.get(), y_ig.get()), "the Winograd request fell through to the implicit GEMM"
+	desc = bnd.dnn.convDesc(x.shape, wt.shape, 1, pad, 1, 1)
+	from puzzlelib_amd import lib
+	for which in (lib.CONV_FWD, lib.CONV_BWD_FILTER):
+		assert bnd.dnn.convAlgoUsed(desc, which, 3) == 3 and bnd.dnn.convAlgoUsed(desc, which, 5) == 5
+		assert bnd.dnn.convAlgoUsed(desc, which, 1) == 1
+		assert bnd.dnn.convAlgoUsed(desc, which, -1) == (3 if c >= 32 and k >= 32 else 5)
 	if c >= 32 and k >= 32:
 		assert np.array_equal(bnd.dnn.convNd(gx, gw, gb, **kw).get(), y.get()), "auto picks Winograd for wide 3x3 layers"
 
@@ -814,3 +820,31 @@ def test_winograd_convolution(bnd, cfg):
 	# run-to-run determinism
 	assert np.array_equal(bnd.dnn.convNd(gx, gw, gb, algo=bnd.ConvFwdAlgo.winograd.value, **kw).get(), y.get())
 	assert np.array_equal(bnd.dnn.convNdBackwardParams(gx, gdy, gw, algo=wino, **kw).get(), dw.get())
+
+
+def test_optimize_for_shape_enumerates_kernel_families(bnd):
+	"""Modules/ConvND.py:52-61 optimizeForShape over convNdbenchmark (Hip/Wrappers/MIOpen.py:465-519): every family that
+	serves the layer is timed — for a wide 3x3 layer implicit GEMM, Winograd and direct — the fastest within the memory
+	limit is installed, and the module still computes the convolution."""
+	from puzzlelib_amd import nn
+	from puzzlelib_amd.surface import bound
+	Dnn = bound().Dnn
+	rng = np.random.RandomState(3)
+
+	np.random.seed(2)
+	conv = nn.Conv2D(64, 64, 3, pad=1, useBias=False)
+	fwd, bwdFilter, bwdData = Dnn.convNdbenchmark((8, 64, 20, 20), conv.W.shape, conv.stride, conv.pad, conv.dilation, 1, transpose=False)
+	for res in (fwd, bwdFilter, bwdData):
+		assert sorted(r.algo.value for r in res) == [1, 3, 5]
+		assert all(r.time > 0 for r in res) and [r.time for r in res] == sorted(r.time for r in res)
+		assert res[-1].algo.value == 1                       # one thread per output is never the fastest here
+
+	pointwise = Dnn.convNdbenchmark((8, 64, 20, 20), (32, 64, 1, 1), (1, 1), (0, 0), (1, 1), 1, transpose=False)
+	assert sorted(r.algo.value for r in pointwise[0]) == [1, 5]       # Winograd does not serve a 1x1 layer
+
+	conv.optimizeForShape((8, 64, 20, 20))
+	assert conv.fwdAlgo.value in (3, 5) and conv.bwdDataAlgo.value in (3, 5) and conv.bwdFilterAlgo.value in (3, 5)
+	x = rng.randn(8, 64, 20, 20).astype(np.float32)
+	y = conv(gpu(bnd, x))
+	y_ref = R.conv2d_fwd(x, conv.W.get(), None, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, acc=np.float64)
+	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="convolution after optimizeForShape")
