@@ -32,10 +32,15 @@ def dev_randn(bnd, shape, seed):
 	return out
 
 
-def test_config2_conv_full_size_properties(bnd):
+@pytest.mark.parametrize("algo", [3, 5], ids=["winograd", "implicit-gemm"])        # `auto` takes Winograd for this layer
+def test_config2_conv_full_size_properties(bnd, algo):
 	n, c, k, h, w = 128, 64, 128, 56, 56
-	kw = dict(stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	okw = dict(stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	kw = dict(okw, algo=algo)
 	dot = bnd.blas.dot
+	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, 3, 3), 1, 1, 1, 1)
+	assert all(bnd.dnn.convAlgoUsed(desc, which, algo) == algo for which in (0, 1, 2))
+	assert all(bnd.dnn.convAlgoUsed(desc, which, -1) == 3 for which in (0, 1, 2))
 
 	x1, x2 = dev_randn(bnd, (n, c, h, w), 1), dev_randn(bnd, (n, c, h, w), 2)
 	dy = dev_randn(bnd, (n, k, h, w), 3)
@@ -67,14 +72,14 @@ def test_config2_conv_full_size_properties(bnd):
 	# oracle spot check: images 0 and 127 of the batch
 	xh, wh, dyh = x1.get(), wt.get(), dy.get()
 	for img in (0, n - 1):
-		ref = R.conv2d_fwd(xh[img:img + 1], wh, None, acc=np.float64, **kw)
+		ref = R.conv2d_fwd(xh[img:img + 1], wh, None, acc=np.float64, **okw)
 		assert_close(y1.get()[img:img + 1], ref, atol=1e-4, rtol=1e-4, what="forward, image %d" % img)
-		ref = R.conv2d_bwd_data(dyh[img:img + 1], wh, (1, c, h, w), acc=np.float64, **kw)
+		ref = R.conv2d_bwd_data(dyh[img:img + 1], wh, (1, c, h, w), acc=np.float64, **okw)
 		assert_close(dx.get()[img:img + 1], ref, atol=1e-4, rtol=1e-4, what="backward-data, image %d" % img)
 
 	# backward-filter against float64 sums over a 4-image sub-batch
 	dw4 = bnd.dnn.convNdBackwardParams(gpu(bnd, xh[:4]), gpu(bnd, dyh[:4]), wt, **kw)
-	ref = R.conv2d_bwd_filter(xh[:4], dyh[:4], wh.shape, withbias=False, acc=np.float64, **kw)
+	ref = R.conv2d_bwd_filter(xh[:4], dyh[:4], wh.shape, withbias=False, acc=np.float64, **okw)
 	assert_close(dw4.get(), ref, atol=2e-6 * np.sqrt(4 * h * w) * 30, rtol=1e-4, what="backward-filter, 4 images")
 
 
@@ -225,3 +230,32 @@ def test_elementwise_and_norm_edge_cases(bnd):
 	assert np.array_equal(mx.get(), xp.max(axis=(2, 3), keepdims=True))
 	one = bnd.dnn.poolNd(gp, size=(1, 1), stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.max.value, test=True)
 	assert np.array_equal(one.get(), xp)
+
+
+@pytest.mark.parametrize("shape", [(256, 64, 55, 55), (256, 128, 28, 28), (256, 256, 14, 14), (256, 512, 7, 7)])
+def test_resnet_3x3_layers_winograd_agrees_with_implicit_gemm(bnd, shape):
+	"""The four 3x3 layer shapes of ResNet-50 at batch 256, all three passes: the Winograd kernels against the implicit
+	GEMM (itself checked against the oracle at oracle-sized inputs) — two independent algorithms, agreement to 3e-5 of the
+	result's scale — and run-to-run determinism of the Winograd backward-filter's slab reduction."""
+	n, c, h, w = shape
+	kw = dict(stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	x, dy = dev_randn(bnd, shape, 11), dev_randn(bnd, shape, 12)
+	wt = gpu(bnd, (np.random.RandomState(13).randn(c, c, 3, 3) / np.sqrt(c * 9)).astype(np.float32))
+	diff = bnd.GPUArray.empty(shape, dtype=np.float32)
+
+	def max_abs(a, b, out):
+		bnd.addKer(np.float32)(out, a, 1.0, b, -1.0)
+		return max(float(out.max().get()), -float(out.min().get()))
+
+	y3, y5 = bnd.dnn.convNd(x, wt, None, algo=3, **kw), bnd.dnn.convNd(x, wt, None, algo=5, **kw)
+	assert max_abs(y3, y5, diff) < 3e-5 * max(1.0, float(y5.max().get()))
+
+	d3 = bnd.dnn.convNdBackwardData(dy, wt, data=x, algo=3, **kw)
+	d5 = bnd.dnn.convNdBackwardData(dy, wt, data=x, algo=5, **kw)
+	assert max_abs(d3, d5, diff) < 3e-5 * max(1.0, float(d5.max().get()))
+
+	w3 = bnd.dnn.convNdBackwardParams(x, dy, wt, algo=3, **kw)
+	w5 = bnd.dnn.convNdBackwardParams(x, dy, wt, algo=5, **kw)
+	dwdiff = bnd.GPUArray.empty(wt.shape, dtype=np.float32)
+	assert max_abs(w3, w5, dwdiff) < 3e-5 * max(1.0, float(w5.max().get()))
+	assert np.array_equal(bnd.dnn.convNdBackwardParams(x, dy, wt, algo=3, **kw).get(), w3.get())
