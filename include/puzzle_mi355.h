@@ -179,6 +179,14 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
 int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw,
                      const float *xa, const float *mean_a, float *part_a,
                      const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
+/* pz_bn_gate_stats whose two incoming gradients come from stride-2 pointwise convolutions (the first convolutions of a
+ * down-sampling block's two branches, Models/Nets/ResNet.py:36-46) and stay compact: g0c, g1c are (n, c, ceil(h/2),
+ * ceil(w/2)) = the values at pixels (2i, 2j), every other pixel of the (n, c, h, w) gradients being zero. Same results,
+ * bit for bit, as zero-filling them first; their backward-data passes write a quarter of the tensor (as a stride-1
+ * problem on the compact grid) and nothing is memset. */
+int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, float *gout, int n, int c, int h, int w,
+                         const float *xa, const float *mean_a, float *part_a,
+                         const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
 int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                             const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                             float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,

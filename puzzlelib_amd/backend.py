@@ -165,6 +165,34 @@ class DeferredBNGrad:
 		return self.materialize().get(stream)
 
 
+class StridedGrad:
+	"""The input gradient of a stride-2 pointwise convolution that was not zero-filled: `compact` holds the values of the
+	pixels (2i, 2j) — (n, c, ceil(h/2), ceil(w/2)) — every other pixel of the (n, c, h, w) gradient is zero. Produced by
+	DnnContext.convNdBackwardData(compact=True), consumed by DnnContext.bnGateStats; `materialize()` zero-fills for
+	anyone else."""
+	__slots__ = ["compact", "shape", "dense"]
+
+	def __init__(self, compact, shape):
+		self.compact, self.shape, self.dense = compact, tuple(shape), None
+
+	@property
+	def dtype(self):
+		return self.compact.dtype
+
+	@property
+	def ndim(self):
+		return len(self.shape)
+
+	def materialize(self):
+		if self.dense is None:
+			self.dense = GPUArray.zeros(self.shape, dtype=self.compact.dtype)
+			self.dense[:, :, ::2, ::2].set(self.compact)
+		return self.dense
+
+	def get(self, stream=None):
+		return self.materialize().get(stream)
+
+
 class ConvStats:
 	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
 	__slots__ = ["tensor", "stats"]
@@ -338,8 +366,21 @@ class DnnContext:
 		return bool(flag.value)
 
 
+	@staticmethod
+	def compactGradSupported(W, stride, pad, dilation):
+		"""Stride-2 pointwise convolution without padding: its backward-data is a stride-1 problem on the output grid."""
+		return tuple(W.shape[2:]) == (1, 1) and pair(stride) == (2, 2) and pair(pad) == (0, 0) and pair(dilation) == (1, 1)
+
+
 	def convNdBackwardData(self, grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1,
-						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None):
+						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None, compact=False):
+		if compact and data is not None and bias is None and out is None and self.compactGradSupported(W, stride, pad, dilation):
+			# backend-internal (Sequential.planFusion): dx[.., 2i, 2j] = W^T dy[.., i, j] and zero elsewhere — computed on the
+			# compact grid; StridedGrad carries it to the fan-in kernel that knows where the zeros are
+			small = self.convNdBackwardData(grad, W, None, None, 1, 0, 1, 0, groups, algo, None, allocator)
+			assert small.shape[2:] == tuple((d + 1) // 2 for d in data.shape[2:])
+			return StridedGrad(small, data.shape)
+
 		lazy = grad if isinstance(grad, DeferredBNGrad) else None      # backend-internal: BN backward folded into the gather
 		if lazy is not None:
 			grad = lazy.grad
@@ -562,17 +603,27 @@ class DnnContext:
 		"""Backend-internal (Sequential.planFusion): g = (grad0 + grad1) * (outdata > 0) plus, for each of the one or two
 		`targets` = (bnInput, savemean), the partial sums a following batchNormNdBackward(g, bnInput, ..., partials=)
 		would otherwise recompute. Returns (g, [partials...])."""
-		requireF32(grad0, grad1, outdata)
-		assert 1 <= len(targets) <= 2 and grad0.shape == grad1.shape == outdata.shape
+		up2 = isinstance(grad0, StridedGrad) and isinstance(grad1, StridedGrad)
+		if not up2:
+			grad0 = grad0.materialize() if isinstance(grad0, StridedGrad) else grad0
+			grad1 = grad1.materialize() if isinstance(grad1, StridedGrad) else grad1
+		requireF32(grad0 if not up2 else grad0.compact, grad1 if not up2 else grad1.compact, outdata)
+		assert 1 <= len(targets) <= 2 and tuple(grad0.shape) == tuple(grad1.shape) == tuple(outdata.shape)
 		n, c, hw = grad0.shape[0], grad0.shape[1], prod(grad0.shape[2:])
 
-		out = GPUArray.empty(grad0.shape, dtype=grad0.dtype, allocator=allocator)
+		out = GPUArray.empty(outdata.shape, dtype=outdata.dtype, allocator=allocator)
 		size = c_size_t(0)
 		lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
 		parts = [GPUArray.empty((size.value // 4, ), dtype=np.float32, allocator=allocator) for _ in targets]
 
 		(xa, ma), (xb, mb) = targets[0], (targets[1] if len(targets) == 2 else (None, None))
-		assert xa.shape == grad0.shape and (xb is None or xb.shape == grad0.shape)
+		assert xa.shape == outdata.shape and (xb is None or xb.shape == outdata.shape)
+		if up2:
+			lib.pz_bn_gate_stats_up2(
+				grad0.compact.ptr, grad1.compact.ptr, outdata.ptr, out.ptr, n, c, outdata.shape[2], outdata.shape[3],
+				xa.ptr, ma.ptr, parts[0].ptr, ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
+			)
+			return out, parts
 		lib.pz_bn_gate_stats(
 			grad0.ptr, grad1.ptr, outdata.ptr, out.ptr, n, c, hw, xa.ptr, ma.ptr, parts[0].ptr,
 			ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None

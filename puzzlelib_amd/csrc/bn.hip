@@ -67,6 +67,37 @@ __device__ __forceinline__ void channel_foreach(const BnGeom &g, int ch, int spl
 		for (int n = first; n < g.n; n += stride) one((size_t)n * slab + chan + 4 * n4 + t);
 }
 
+// Same walk, for loaders that need to know where a vector sits: vec(u, off, n, e) with e = first element's index inside
+// the (n, ch) plane; one(off, n, e) likewise. Same thread -> element assignment and order as channel_foreach.
+template <int U, typename Vec, typename Use, typename One>
+__device__ __forceinline__ void channel_foreach_pos(const BnGeom &g, int ch, int split, Vec vec, Use use, One one) {
+	const int t = threadIdx.x & (g.nt - 1), ty = threadIdx.x / g.nt, rpp = 256 / g.nt;
+	const int n4 = g.hw >> 2, rem = g.hw & 3;
+	const int first = split * rpp + ty, stride = g.splits * rpp;
+	const size_t slab = (size_t)g.c * g.hw, chan = (size_t)ch * g.hw;
+
+	if (t < n4) {
+		int n = first, v = t;
+		while (n < g.n) {
+			size_t off[U];
+			bool ok[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				ok[u] = n < g.n;
+				off[u] = (size_t)n * slab + chan + 4 * v;
+				if (ok[u]) vec(u, off[u], n, 4 * v);
+				v += g.nt;
+				if (v >= n4) v = t, n += stride;
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				if (ok[u]) use(u, off[u]);
+		}
+	}
+	if (t < rem)
+		for (int n = first; n < g.n; n += stride) one((size_t)n * slab + chan + 4 * n4 + t, n, 4 * n4 + t);
+}
+
 // ---- forward statistics: ws[(ch*S + s)*2 + {0,1}] = {sum(x-K), sum((x-K)^2)}, wsK[ch] = K
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float *__restrict__ x, BnGeom g, float *__restrict__ part,
                                                         float *__restrict__ shift) {
@@ -428,23 +459,49 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 //   partB likewise for the projection-shortcut BN when the block has one
 // One pass writes g and leaves both BNs only their apply pass: same loop structure and accumulation order as
 // bn_bwd_stats_kernel, hence bit-identical partial sums.
-template <bool TWO>
+// UP2: g0 and g1 are the gradients of two stride-2 pointwise convolutions kept compact — (n, c, ceil(h/2), ceil(w/2)),
+// the value of pixel (2i, 2j); every other pixel of the full-size gradient is zero (`up` = {w, compact w, compact
+// plane size, magic for / w}). The sums see exactly the terms of the dense form (x + 0 = x), so results are bit-identical
+// to materialising the zero-filled tensors first; the two 4x larger tensors are neither written nor read.
+struct Up2Geom {
+	int w, qc, plane_c;
+	unsigned magic_w;        // ceil(2^32 / w): e / w == umulhi(e, magic_w) for e < 2^20
+	unsigned bytes_c;        // compact tensor bytes (buffer range)
+};
+
+__device__ __forceinline__ float up2_fetch(__amdgpu_buffer_rsrc_t r, unsigned plane_off, const Up2Geom &up, int e) {
+	const int yy = (int)__umulhi((unsigned)e, up.magic_w), xx = e - yy * up.w;
+	const bool even = ((yy | xx) & 1) == 0;
+	const unsigned off = even ? (plane_off + (unsigned)((yy >> 1) * up.qc + (xx >> 1))) * 4u : 0xfffffff0u;
+	return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+template <bool TWO, bool UP2 = false>
 __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restrict__ g0, const float *__restrict__ g1,
                                                              const float *__restrict__ y, float *__restrict__ gout, BnGeom g,
                                                              const float *__restrict__ xa, const float *__restrict__ mean_a,
                                                              float *__restrict__ part_a, const float *__restrict__ xb,
-                                                             const float *__restrict__ mean_b, float *__restrict__ part_b) {
+                                                             const float *__restrict__ mean_b, float *__restrict__ part_b,
+                                                             Up2Geom up = Up2Geom{}) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
 	const float mua = mean_a[ch], mub = TWO ? mean_b[ch] : 0.f;
 	float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
 	f4u v0[2], v1[2], vy[2], va[2], vb[2];
+	const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void *)g0, 0, UP2 ? up.bytes_c : 0u, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g1, 0, UP2 ? up.bytes_c : 0u, 0x00020000);
 
-	channel_foreach<2>(
+	channel_foreach_pos<2>(
 	    g, ch, s,
-	    [&](int u, size_t off) {
-		    v0[u] = *reinterpret_cast<const f4u *>(g0 + off);
-		    v1[u] = *reinterpret_cast<const f4u *>(g1 + off);
+	    [&](int u, size_t off, int n, int e0) {
+		    if constexpr (UP2) {
+			    const unsigned plane = (unsigned)(n * g.c + ch) * (unsigned)up.plane_c;
+#pragma unroll
+			    for (int e = 0; e < 4; ++e) v0[u][e] = up2_fetch(r0, plane, up, e0 + e), v1[u][e] = up2_fetch(r1, plane, up, e0 + e);
+		    } else {
+			    v0[u] = *reinterpret_cast<const f4u *>(g0 + off);
+			    v1[u] = *reinterpret_cast<const f4u *>(g1 + off);
+		    }
 		    vy[u] = *reinterpret_cast<const f4u *>(y + off);
 		    va[u] = *reinterpret_cast<const f4u *>(xa + off);
 		    if (TWO) vb[u] = *reinterpret_cast<const f4u *>(xb + off);
@@ -457,8 +514,15 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
 		    bn_bwd_acc4(q, va[u], mua, a1, a2);
 		    if (TWO) bn_bwd_acc4(q, vb[u], mub, b1, b2);
 	    },
-	    [&](size_t off) {
-		    const float q = (g0[off] + g1[off]) * (y[off] > 0.f ? 1.f : 0.f);
+	    [&](size_t off, int n, int e0) {
+		    float s0, s1;
+		    if constexpr (UP2) {
+			    const unsigned plane = (unsigned)(n * g.c + ch) * (unsigned)up.plane_c;
+			    s0 = up2_fetch(r0, plane, up, e0), s1 = up2_fetch(r1, plane, up, e0);
+		    } else {
+			    s0 = g0[off], s1 = g1[off];
+		    }
+		    const float q = (s0 + s1) * (y[off] > 0.f ? 1.f : 0.f);
 		    gout[off] = q;
 		    bn_bwd_acc1(q, xa[off], mua, a1, a2);
 		    if (TWO) bn_bwd_acc1(q, xb[off], mub, b1, b2);
@@ -694,6 +758,26 @@ int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *go
 	hipStream_t st = pz::as_stream(stream);
 	if (xb) bn_gate_stats_kernel<true><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b);
 	else bn_gate_stats_kernel<false><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, float *gout, int n, int c, int h, int w,
+                         const float *xa, const float *mean_a, float *part_a, const float *xb, const float *mean_b,
+                         float *part_b, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, h * w)) return rc;
+	PZ_REQUIRE(g0c && g1c && y && gout && xa && mean_a && part_a, "pz_bn_gate_stats_up2: null tensor");
+	PZ_REQUIRE((xb == nullptr) == (mean_b == nullptr) && (xb == nullptr) == (part_b == nullptr),
+	           "pz_bn_gate_stats_up2: the second batch-norm needs all of x, mean and partials");
+	const int pc = (h + 1) / 2, qc = (w + 1) / 2;
+	const size_t bytes_c = (size_t)n * c * pc * qc * sizeof(float);
+	PZ_REQUIRE(h * w < (1 << 20) && bytes_c < 0xfffffff0u, "pz_bn_gate_stats_up2: map or tensor too large");
+	const BnGeom g = bn_geom(n, c, h * w);
+	Up2Geom up{w, qc, pc * qc, (unsigned)((((unsigned long long)1 << 32) + w - 1) / w), (unsigned)bytes_c};
+	const dim3 grid(c, g.splits);
+	hipStream_t st = pz::as_stream(stream);
+	if (xb) bn_gate_stats_kernel<true, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b, up);
+	else bn_gate_stats_kernel<false, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr, up);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

@@ -321,10 +321,12 @@ class Conv2D(Module):
 		self.outStats = None
 
 
+	compactGrad = False      # set per forward pass by the enclosing Sequential (planFusion, fuseStridedGrad)
+
 	def updateGrad(self, grad):
 		self.grad = S().Dnn.convNdBackwardData(
 			grad, self.W, data=self.inData, stride=self.stride, pad=self.pad, dilation=self.dilation,
-			groups=self.groups, algo=self.bwdDataAlgo
+			groups=self.groups, algo=self.bwdDataAlgo, compact=self.compactGrad
 		)
 
 
@@ -908,10 +910,12 @@ class Replicate(Module):
 
 		if self.gateGrad and len(grad) == 2 and targets:
 			# fan-in + ReLU derivative + the statistics pass of the BatchNorm backward(s) this gradient goes to next
+			# (two compact stride-2 gradients are expanded on the fly, see planFusion / fuseStridedGrad)
 			self.grad, parts = S().Dnn.bnGateStats(grad[0], grad[1], self.inData, [(bn.inData, bn.savemean) for bn in targets])
 			for bn, part in zip(targets, parts):
 				bn.bwdPartials = (self.grad, part)
 		else:
+			grad = [g.materialize() if hasattr(g, "compact") else g for g in grad]
 			self.grad = sumTensors(grad, gate=self.inData if self.gateGrad else None)
 
 
@@ -1179,6 +1183,7 @@ class Sequential(Container):
 	fuseBnAdd = True             # residual Add normalises its BatchNorm inputs on the fly (see planFusion)
 	fuseGateStats = True         # gradient fan-in also sums the next BatchNorm backward's statistics (see planFusion)
 	fuseBnBackward = True        # ... and the BatchNorm's apply pass is folded into the backward of the Conv2D in front
+	fuseStridedGrad = True       # input gradients of a down-sampling block's stride-2 1x1 convolutions stay compact
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1240,9 +1245,17 @@ class Sequential(Container):
 					Sequential.fuseBnBackward and mod.train and isinstance(prev, Conv2D) and prev.b is None
 				) else None
 
+		# first convolutions of the branches behind every Replicate: decided below, off unless decided otherwise
+		for i, mod in enumerate(graph):
+			if isinstance(mod, Replicate) and i + 1 < len(graph) and isinstance(graph[i + 1], Parallel):
+				for branch in graph[i + 1].graph:
+					if isinstance(branch, Sequential) and branch.graph and isinstance(branch.graph[0], Conv2D):
+						branch.graph[0].compactGrad = False
+
 		if not on:
 			return
 
+		gated = []
 		for i, mod in enumerate(graph):
 			if not (isinstance(mod, Activation) and mod.fusable() and i > 0):
 				continue
@@ -1258,6 +1271,7 @@ class Sequential(Container):
 
 			if not mod.gradFused and isinstance(nxt, Replicate) and nxt.times == 2:
 				nxt.gateGrad = mod.gradFused = True
+				gated.append(i + 1)
 
 				# [Parallel, Add, ReLU, Replicate]: the fan-in's output is the gradient of the Parallel's branch-tail
 				# BatchNorms (Add passes it through unchanged) -> it also sums their backward statistics
@@ -1266,6 +1280,21 @@ class Sequential(Container):
 						branch.graph[-1] for branch in graph[i - 2].graph
 						if isinstance(branch, Sequential) and branch.graph and isinstance(branch.graph[-1], BatchNorm2D)
 					][:2]
+
+
+		# fuseStridedGrad: [ReLU, Replicate(2), Parallel] whose two branches both start with a stride-2 pointwise convolution
+		# (the down-sampling blocks, Models/Nets/ResNet.py:36-46): their input gradients are non-zero on every other pixel
+		# of every other row only. They stay compact (a quarter of the tensor, no memset, no strided stores) and the
+		# fan-in kernel, which sums them and knows where the zeros are, expands them on the fly; bit-identical.
+		for r in gated:
+			rep, par = graph[r], graph[r + 1] if r + 1 < len(graph) else None
+			if not (Sequential.fuseStridedGrad and rep.statsFor and isinstance(par, Parallel) and len(par.graph) == 2):
+				continue
+			heads = [b.graph[0] if isinstance(b, Sequential) and b.graph else None for b in par.graph]
+			if all(isinstance(h, Conv2D) and h.groups == 1 and
+				   S().Dnn.compactGradSupported(h.W, h.stride, h.pad, h.dilation) for h in heads):
+				for h in heads:
+					h.compactGrad = True
 
 
 	def append(self, mod, acquire=True):

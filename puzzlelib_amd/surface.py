@@ -82,8 +82,10 @@ def bind():
 			memoryPool, withStats=withStats
 		)
 
-	def convNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo):
-		return dnn.convNdBackwardData(grad, W, None, data, stride, pad, dilation, None, groups, algo.value, None, memoryPool)
+	def convNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo, compact=False):
+		return dnn.convNdBackwardData(
+			grad, W, None, data, stride, pad, dilation, None, groups, algo.value, None, memoryPool, compact=compact
+		)
 
 	def convNdBackwardParams(data, grad, W, bias, stride, pad, dilation, groups, wgrad, bgrad, scale, momentum, algo):
 		return dnn.convNdBackwardParams(
@@ -158,7 +160,7 @@ def bind():
 		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool)
 
 	Dnn = SimpleNamespace(
-		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats,
+		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats, compactGradSupported=dnn.compactGradSupported,
 		ConvFwdAlgo=bnd.ConvFwdAlgo, ConvBwdDataAlgo=bnd.ConvBwdDataAlgo, ConvBwdFilterAlgo=bnd.ConvBwdFilterAlgo,
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,

@@ -848,3 +848,54 @@ def test_optimize_for_shape_enumerates_kernel_families(bnd):
 	y = conv(gpu(bnd, x))
 	y_ref = R.conv2d_fwd(x, conv.W.get(), None, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, acc=np.float64)
 	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="convolution after optimizeForShape")
+
+
+@pytest.mark.parametrize("cfg", [dict(n=3, c=16, k=32, hw=(9, 7), two=False), dict(n=2, c=24, k=16, hw=(8, 10), two=True),
+								 dict(n=4, c=64, k=32, hw=(55, 55), two=False)])
+def test_compact_stride2_gradients_through_the_fan_in(bnd, cfg):
+	"""Backend-internal pair convNdBackwardData(compact=True) -> bnGateStats (pz_bn_gate_stats_up2): the input gradients of
+	two stride-2 pointwise convolutions stay (n, c, ceil(h/2), ceil(w/2)); the fan-in expands them on the fly. Everything
+	must equal, bit for bit, the dense route (zero-filled gradients through pz_bn_gate_stats), and the handle must
+	zero-fill correctly for any other consumer."""
+	from puzzlelib_amd import backend
+	rng = np.random.RandomState(31)
+	n, c, k, (h, w_) = cfg["n"], cfg["c"], cfg["k"], cfg["hw"]
+	p, q = (h + 1) // 2, (w_ + 1) // 2
+	x = gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32))
+	w0, w1 = [gpu(bnd, (rng.randn(k, c, 1, 1) / np.sqrt(c)).astype(np.float32)) for _ in range(2)]
+	dy0, dy1 = [gpu(bnd, rng.randn(n, k, p, q).astype(np.float32)) for _ in range(2)]
+	kw = dict(stride=(2, 2), pad=(0, 0), dilation=(1, 1), groups=1)
+
+	dense = [bnd.dnn.convNdBackwardData(dy, wt, data=x, **kw) for dy, wt in ((dy0, w0), (dy1, w1))]
+	lazy = [bnd.dnn.convNdBackwardData(dy, wt, data=x, compact=True, **kw) for dy, wt in ((dy0, w0), (dy1, w1))]
+	assert all(isinstance(g, backend.StridedGrad) and g.compact.shape == (n, c, p, q) and g.shape == x.shape for g in lazy)
+	for a, b in zip(dense, lazy):
+		assert np.array_equal(a.get(), b.get()), "the compact gradient zero-fills to the dense one"
+		full = a.get()
+		assert not full[:, :, 1::2, :].any() and not full[:, :, :, 1::2].any()
+
+	# a 3x3 or padded convolution keeps the dense form
+	w3 = gpu(bnd, rng.randn(k, c, 3, 3).astype(np.float32))
+	dy3 = gpu(bnd, rng.randn(n, k, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1).astype(np.float32))
+	assert not isinstance(bnd.dnn.convNdBackwardData(dy3, w3, data=x, stride=(2, 2), pad=(1, 1), compact=True), backend.StridedGrad)
+
+	out = gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32))                       # the ReLU output that gates the sum
+	targets = [(gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32)), gpu(bnd, rng.randn(c).astype(np.float32)))
+			   for _ in range(2 if cfg["two"] else 1)]
+	g_dense, parts_dense = bnd.dnn.bnGateStats(dense[0], dense[1], out, targets)
+	g_lazy, parts_lazy = bnd.dnn.bnGateStats(lazy[0], lazy[1], out, targets)
+	assert np.array_equal(g_dense.get(), g_lazy.get())
+	# the partial sums are consumed by the BatchNorm backward: same parameter gradients and input gradient, bit for bit
+	scale, invvar = gpu(bnd, rng.randn(c).astype(np.float32)), gpu(bnd, (0.5 + rng.rand(c)).astype(np.float32))
+	for (xt, mean), pa, pb in zip(targets, parts_dense, parts_lazy):
+		ra = bnd.dnn.batchNormNdBackward(g_dense, xt, scale, mean, invvar, 1e-5, partials=pa)
+		rb = bnd.dnn.batchNormNdBackward(g_lazy, xt, scale, mean, invvar, 1e-5, partials=pb)
+		for a, b in zip(ra, rb):
+			assert np.array_equal(a.get(), b.get())
+
+	ref = (dense[0].get() + dense[1].get()) * (out.get() > 0)
+	assert np.array_equal(g_lazy.get(), ref)
+
+	# one compact, one dense operand: the handle is zero-filled
+	g_mixed, _ = bnd.dnn.bnGateStats(lazy[0], dense[1], out, targets)
+	assert np.array_equal(g_mixed.get(), ref)
