@@ -39,6 +39,9 @@
 #ifndef PZ_WG_RUNS
 #define PZ_WG_RUNS 8              // 4-pixel runs per backward-filter k-step: 8 (32 pixels, 2 workgroups/CU) or 4 (16 pixels, 4/CU)
 #endif
+#ifndef PZ_TAIL_MIN_GAIN
+#define PZ_TAIL_MIN_GAIN 24
+#endif
 #ifndef PZ_LB
 #define PZ_LB 4
 #endif
@@ -1148,6 +1151,9 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
 			const double cost = (double)pz::ceil_div((long)rem * sp, pz::kNumCU) / sp;
 			if (cost < best_cost - 1e-9) best_cost = cost, best = sp;
 		}
+		// ... and the slab reduce is a launch of its own (~20 us): a k-tile takes ~1 us of a CU, so the round has to get
+		// PZ_TAIL_MIN_GAIN k-tile-times shorter to pay for it
+		if ((1.0 - best_cost) * nk < PZ_TAIL_MIN_GAIN) best = 1;
 		if (best > 1) p.full_tiles = tiles - rem, p.tail_splits = best;
 	}
 	const int ntail = tiles - p.full_tiles;
