@@ -176,16 +176,18 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
  * accumulation order pz_bn_bwd uses internally (bit-identical), likewise part_b for the optional second BN (xb == NULL:
  * none). Each part needs pz_bn_workspace_bytes. pz_bn_bwd_from_partials is then pz_bn_bwd_acc without its statistics
  * pass.                                                                                                          */
-int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw,
-                     const float *xa, const float *mean_a, float *part_a,
+/* `mask` (optional, from pz_bn_apply_add_mask over the tensor y): the gate is read from one bit per element and y is not
+ * touched (may be NULL) — 1/16 of the bytes; the same predicate, so the same results. */
+int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, const unsigned char *mask, float *gout, int n, int c,
+                     int hw, const float *xa, const float *mean_a, float *part_a,
                      const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
 /* pz_bn_gate_stats whose two incoming gradients come from stride-2 pointwise convolutions (the first convolutions of a
  * down-sampling block's two branches, Models/Nets/ResNet.py:36-46) and stay compact: g0c, g1c are (n, c, ceil(h/2),
  * ceil(w/2)) = the values at pixels (2i, 2j), every other pixel of the (n, c, h, w) gradients being zero. Same results,
  * bit for bit, as zero-filling them first; their backward-data passes write a quarter of the tensor (as a stride-1
  * problem on the compact grid) and nothing is memset. */
-int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, float *gout, int n, int c, int h, int w,
-                         const float *xa, const float *mean_a, float *part_a,
+int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, const unsigned char *mask, float *gout, int n,
+                         int c, int h, int w, const float *xa, const float *mean_a, float *part_a,
                          const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
 int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                             const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
@@ -216,6 +218,11 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
                           int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream);
 int pz_bn_apply_add(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
                     int n, int c, int hw, int relu, pz_stream_t stream);
+/* ... also leaving the sign mask of the fused ReLU's output (pz_relu_mask_bytes bytes: one bit per element, a byte per 4
+ * consecutive elements of a (n, channel) plane) for pz_bn_gate_stats, which then does not read `out` back. */
+int pz_relu_mask_bytes(int n, int c, int hw, size_t *nbytes);
+int pz_bn_apply_add_mask(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
+                         unsigned char *mask, int n, int c, int hw, int relu, pz_stream_t stream);
 int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, void *workspace, size_t ws_bytes, pz_stream_t stream);

@@ -193,6 +193,15 @@ class StridedGrad:
 		return self.materialize().get(stream)
 
 
+class ReluMask:
+	"""(y > 0) of a fused ReLU's output `tensor`, one bit per element (pz_bn_apply_add_mask); valid for exactly that tensor
+	object. Lets the gradient fan-in gate without reading y back."""
+	__slots__ = ["tensor", "bits"]
+
+	def __init__(self, tensor, bits):
+		self.tensor, self.bits = tensor, bits
+
+
 class ConvStats:
 	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
 	__slots__ = ["tensor", "stats"]
@@ -599,7 +608,7 @@ class DnnContext:
 		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
 
 
-	def bnGateStats(self, grad0, grad1, outdata, targets, allocator=None):
+	def bnGateStats(self, grad0, grad1, outdata, targets, allocator=None, mask=None):
 		"""Backend-internal (Sequential.planFusion): g = (grad0 + grad1) * (outdata > 0) plus, for each of the one or two
 		`targets` = (bnInput, savemean), the partial sums a following batchNormNdBackward(g, bnInput, ..., partials=)
 		would otherwise recompute. Returns (g, [partials...])."""
@@ -618,22 +627,25 @@ class DnnContext:
 
 		(xa, ma), (xb, mb) = targets[0], (targets[1] if len(targets) == 2 else (None, None))
 		assert xa.shape == outdata.shape and (xb is None or xb.shape == outdata.shape)
+		# `mask` (ReluMask of exactly `outdata`, from bnApplyAdd): the gate comes from one bit per element, outdata is not read
+		mptr = mask.bits.ptr if mask is not None and mask.tensor is outdata else None
 		if up2:
 			lib.pz_bn_gate_stats_up2(
-				grad0.compact.ptr, grad1.compact.ptr, outdata.ptr, out.ptr, n, c, outdata.shape[2], outdata.shape[3],
+				grad0.compact.ptr, grad1.compact.ptr, outdata.ptr, mptr, out.ptr, n, c, outdata.shape[2], outdata.shape[3],
 				xa.ptr, ma.ptr, parts[0].ptr, ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
 			)
 			return out, parts
 		lib.pz_bn_gate_stats(
-			grad0.ptr, grad1.ptr, outdata.ptr, out.ptr, n, c, hw, xa.ptr, ma.ptr, parts[0].ptr,
+			grad0.ptr, grad1.ptr, outdata.ptr, mptr, out.ptr, n, c, hw, xa.ptr, ma.ptr, parts[0].ptr,
 			ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
 		)
 		return out, parts
 
 
-	def bnApplyAdd(self, first, second, relu=False, allocator=None):
+	def bnApplyAdd(self, first, second, relu=False, allocator=None, withMask=False):
 		"""out = act(bn(first) + second') for a DeferredBN `first` and `second` = DeferredBN | GPUArray | None
-		(None: out = bn(first), no activation). Backend-internal (see Sequential.planFusion)."""
+		(None: out = bn(first), no activation). Backend-internal (see Sequential.planFusion).
+		`withMask` (with relu): also return the ReluMask of `out` -> (out, mask)."""
 		x1 = first.tensor
 		n, c, hw = x1.shape[0], x1.shape[1], prod(x1.shape[2:])
 		if isinstance(second, DeferredBN):
@@ -645,8 +657,14 @@ class DnnContext:
 		requireF32(x1, x2)
 
 		out = GPUArray.empty(x1.shape, dtype=x1.dtype, allocator=allocator)
+		if withMask and relu:
+			size = c_size_t(0)
+			lib.pz_relu_mask_bytes(n, c, hw, byref(size))
+			bits = GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator)
+			lib.pz_bn_apply_add_mask(x1.ptr, first.coef.ptr, ptrOf(x2), ptrOf(coef2), out.ptr, bits.ptr, n, c, hw, 1, None)
+			return out, ReluMask(out, bits)
 		lib.pz_bn_apply_add(x1.ptr, first.coef.ptr, ptrOf(x2), ptrOf(coef2), out.ptr, n, c, hw, int(bool(relu)), None)
-		return out
+		return (out, None) if withMask else out
 
 
 	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,

@@ -252,10 +252,15 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restric
 // out = act( (a1*x1 + b1) + (AFF2 ? a2*x2 + b2 : x2) )   /   out = a1*x1 + b1 when x2 == nullptr
 // — the residual sum of ResNet blocks (Modules/Add.py after two BatchNorm branches) with the normalisations applied on
 // the fly: bit-identical to materialising both BN outputs first (same fma, same order), 8 B/elem less traffic per BN.
+// Sign mask of a fused ReLU's output, for the backward kernels that only need (y > 0): one byte per 4 consecutive elements
+// of a (n, ch) plane (bit e = element e of the vector), then one byte per trailing element; `relu_mask_stride` bytes per
+// plane. 1/16 of the bytes of reading y back.
+__host__ __device__ inline int relu_mask_stride(int hw) { return (hw >> 2) + 3; }
+
 template <bool RELU, bool AFF2>
 __global__ void __launch_bounds__(256) bn_apply_add_kernel(const float *__restrict__ x1, const float *__restrict__ coef1,
                                                             const float *__restrict__ x2, const float *__restrict__ coef2,
-                                                            float *__restrict__ out, BnGeom g) {
+                                                            float *__restrict__ out, BnGeom g, unsigned char *__restrict__ mask = nullptr) {
 	const int ch = blockIdx.x, s = blockIdx.y;
 	const float a1 = coef1[2 * ch], b1 = coef1[2 * ch + 1];
 	const float a2 = AFF2 ? coef2[2 * ch] : 1.f, b2 = AFF2 ? coef2[2 * ch + 1] : 0.f;
@@ -270,17 +275,26 @@ __global__ void __launch_bounds__(256) bn_apply_add_kernel(const float *__restri
 	};
 
 	f4u xv[4], yv[4];
-	channel_foreach<4>(
+	size_t mi[4];
+	const int ms = relu_mask_stride(g.hw);
+	channel_foreach_pos<4>(
 	    g, ch, s,
-	    [&](int u, size_t off) {
+	    [&](int u, size_t off, int n, int e0) {
 		    xv[u] = *reinterpret_cast<const f4u *>(x1 + off);
 		    yv[u] = has2 ? *reinterpret_cast<const f4u *>(x2 + off) : f4u{0.f, 0.f, 0.f, 0.f};
+		    mi[u] = (size_t)(n * g.c + ch) * ms + (e0 >> 2);
 	    },
 	    [&](int u, size_t off) {
-		    *reinterpret_cast<f4u *>(out + off) =
-		        f4u{one(xv[u][0], yv[u][0]), one(xv[u][1], yv[u][1]), one(xv[u][2], yv[u][2]), one(xv[u][3], yv[u][3])};
+		    const f4u r = f4u{one(xv[u][0], yv[u][0]), one(xv[u][1], yv[u][1]), one(xv[u][2], yv[u][2]), one(xv[u][3], yv[u][3])};
+		    *reinterpret_cast<f4u *>(out + off) = r;
+		    if (RELU && mask)
+			    mask[mi[u]] = (unsigned char)((r[0] > 0.f ? 1 : 0) | (r[1] > 0.f ? 2 : 0) | (r[2] > 0.f ? 4 : 0) | (r[3] > 0.f ? 8 : 0));
 	    },
-	    [&](size_t off) { out[off] = one(x1[off], has2 ? x2[off] : 0.f); });
+	    [&](size_t off, int n, int e0) {
+		    const float r = one(x1[off], has2 ? x2[off] : 0.f);
+		    out[off] = r;
+		    if (RELU && mask) mask[(size_t)(n * g.c + ch) * ms + (g.hw >> 2) + (e0 & 3)] = r > 0.f ? 1 : 0;
+	    });
 }
 
 template <bool RELU, bool PRE = false>
@@ -482,12 +496,13 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
                                                              const float *__restrict__ xa, const float *__restrict__ mean_a,
                                                              float *__restrict__ part_a, const float *__restrict__ xb,
                                                              const float *__restrict__ mean_b, float *__restrict__ part_b,
-                                                             Up2Geom up = Up2Geom{}) {
+                                                             Up2Geom up = Up2Geom{}, const unsigned char *__restrict__ mask = nullptr) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
 	const float mua = mean_a[ch], mub = TWO ? mean_b[ch] : 0.f;
 	float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
 	f4u v0[2], v1[2], vy[2], va[2], vb[2];
+	const int ms = relu_mask_stride(g.hw);           // with `mask` the gate is a bit per element and y is not read
 	const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void *)g0, 0, UP2 ? up.bytes_c : 0u, 0x00020000);
 	const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void *)g1, 0, UP2 ? up.bytes_c : 0u, 0x00020000);
 
@@ -502,7 +517,13 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
 			    v0[u] = *reinterpret_cast<const f4u *>(g0 + off);
 			    v1[u] = *reinterpret_cast<const f4u *>(g1 + off);
 		    }
-		    vy[u] = *reinterpret_cast<const f4u *>(y + off);
+		    if (mask) {
+			    const unsigned m = mask[(size_t)(n * g.c + ch) * ms + (e0 >> 2)];
+#pragma unroll
+			    for (int e = 0; e < 4; ++e) vy[u][e] = (m >> e) & 1u ? 1.f : 0.f;
+		    } else {
+			    vy[u] = *reinterpret_cast<const f4u *>(y + off);
+		    }
 		    va[u] = *reinterpret_cast<const f4u *>(xa + off);
 		    if (TWO) vb[u] = *reinterpret_cast<const f4u *>(xb + off);
 	    },
@@ -522,7 +543,8 @@ __global__ void __launch_bounds__(256) bn_gate_stats_kernel(const float *__restr
 		    } else {
 			    s0 = g0[off], s1 = g1[off];
 		    }
-		    const float q = (s0 + s1) * (y[off] > 0.f ? 1.f : 0.f);
+		    const bool pos = mask ? mask[(size_t)(n * g.c + ch) * ms + (g.hw >> 2) + (e0 & 3)] != 0 : y[off] > 0.f;
+		    const float q = (s0 + s1) * (pos ? 1.f : 0.f);
 		    gout[off] = q;
 		    bn_bwd_acc1(q, xa[off], mua, a1, a2);
 		    if (TWO) bn_bwd_acc1(q, xb[off], mub, b1, b2);
@@ -639,17 +661,30 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
 	return PZ_OK;
 }
 
+int pz_relu_mask_bytes(int n, int c, int hw, size_t *nbytes) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(nbytes != nullptr, "pz_relu_mask_bytes: null output");
+	*nbytes = (size_t)n * c * relu_mask_stride(hw);
+	return PZ_OK;
+}
+
 int pz_bn_apply_add(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out, int n, int c, int hw,
                     int relu, pz_stream_t stream) {
+	return pz_bn_apply_add_mask(x1, coef1, x2, coef2, out, nullptr, n, c, hw, relu, stream);
+}
+
+int pz_bn_apply_add_mask(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out, unsigned char *mask,
+                         int n, int c, int hw, int relu, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x1 && coef1 && out, "pz_bn_apply_add: null tensor");
 	PZ_REQUIRE(x2 || (!coef2 && !relu), "pz_bn_apply_add: a second operand is needed for its coefficients / the fused ReLU");
+	PZ_REQUIRE(mask == nullptr || relu, "pz_bn_apply_add_mask: the sign mask belongs to the fused ReLU");
 	const BnGeom g = bn_geom(n, c, hw);
 	const dim3 grid(c, g.splits);
 	hipStream_t st = pz::as_stream(stream);
 
-	if (relu && coef2) bn_apply_add_kernel<true, true><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g);
-	else if (relu) bn_apply_add_kernel<true, false><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g);
+	if (relu && coef2) bn_apply_add_kernel<true, true><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g, mask);
+	else if (relu) bn_apply_add_kernel<true, false><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g, mask);
 	else if (coef2) bn_apply_add_kernel<false, true><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g);
 	else bn_apply_add_kernel<false, false><<<grid, 256, 0, st>>>(x1, coef1, x2, coef2, out, g);
 	PZ_LAUNCH_CHECK();
@@ -746,27 +781,27 @@ int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_m
 	return PZ_OK;
 }
 
-int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, float *gout, int n, int c, int hw, const float *xa,
-                     const float *mean_a, float *part_a, const float *xb, const float *mean_b, float *part_b,
+int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, const unsigned char *mask, float *gout, int n, int c, int hw,
+                     const float *xa, const float *mean_a, float *part_a, const float *xb, const float *mean_b, float *part_b,
                      pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
-	PZ_REQUIRE(g0 && g1 && y && gout && xa && mean_a && part_a, "pz_bn_gate_stats: null tensor");
+	PZ_REQUIRE(g0 && g1 && (y || mask) && gout && xa && mean_a && part_a, "pz_bn_gate_stats: null tensor");
 	PZ_REQUIRE((xb == nullptr) == (mean_b == nullptr) && (xb == nullptr) == (part_b == nullptr),
 	           "pz_bn_gate_stats: the second batch-norm needs all of x, mean and partials");
 	const BnGeom g = bn_geom(n, c, hw);
 	const dim3 grid(c, g.splits);
 	hipStream_t st = pz::as_stream(stream);
-	if (xb) bn_gate_stats_kernel<true><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b);
-	else bn_gate_stats_kernel<false><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr);
+	if (xb) bn_gate_stats_kernel<true><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b, Up2Geom{}, mask);
+	else bn_gate_stats_kernel<false><<<grid, 256, 0, st>>>(g0, g1, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr, Up2Geom{}, mask);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
 
-int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, float *gout, int n, int c, int h, int w,
-                         const float *xa, const float *mean_a, float *part_a, const float *xb, const float *mean_b,
+int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, const unsigned char *mask, float *gout, int n, int c,
+                         int h, int w, const float *xa, const float *mean_a, float *part_a, const float *xb, const float *mean_b,
                          float *part_b, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, h * w)) return rc;
-	PZ_REQUIRE(g0c && g1c && y && gout && xa && mean_a && part_a, "pz_bn_gate_stats_up2: null tensor");
+	PZ_REQUIRE(g0c && g1c && (y || mask) && gout && xa && mean_a && part_a, "pz_bn_gate_stats_up2: null tensor");
 	PZ_REQUIRE((xb == nullptr) == (mean_b == nullptr) && (xb == nullptr) == (part_b == nullptr),
 	           "pz_bn_gate_stats_up2: the second batch-norm needs all of x, mean and partials");
 	const int pc = (h + 1) / 2, qc = (w + 1) / 2;
@@ -776,8 +811,8 @@ int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, flo
 	Up2Geom up{w, qc, pc * qc, (unsigned)((((unsigned long long)1 << 32) + w - 1) / w), (unsigned)bytes_c};
 	const dim3 grid(c, g.splits);
 	hipStream_t st = pz::as_stream(stream);
-	if (xb) bn_gate_stats_kernel<true, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b, up);
-	else bn_gate_stats_kernel<false, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr, up);
+	if (xb) bn_gate_stats_kernel<true, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, xb, mean_b, part_b, up, mask);
+	else bn_gate_stats_kernel<false, true><<<grid, 256, 0, st>>>(g0c, g1c, y, gout, g, xa, mean_a, part_a, nullptr, nullptr, nullptr, up, mask);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

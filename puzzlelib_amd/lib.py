@@ -116,8 +116,10 @@ _PROTOS = {
 	"pz_conv2d_bn_fold_supported": [POINTER(ConvDesc), c_int, POINTER(c_int)],
 	"pz_conv2d_bwd_data_bn": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter_bn": [POINTER(ConvDesc), P, P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
-	"pz_bn_gate_stats": [P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P],
-	"pz_bn_gate_stats_up2": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+	"pz_bn_gate_stats": [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P],
+	"pz_bn_gate_stats_up2": [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
+	"pz_relu_mask_bytes": [c_int, c_int, c_int, POINTER(c_size_t)],
+	"pz_bn_apply_add_mask": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
 	"pz_bn_bwd_from_partials": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, c_float, c_float, P, P],
 	"pz_bn_bwd_acc": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P, c_float, c_float, P, c_size_t, P],
 	"pz_bn_bwd_act": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, c_size_t, P],

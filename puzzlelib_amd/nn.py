@@ -855,14 +855,20 @@ class Add(Module):
 		super().__init__(name)
 		self.movesGrad = True
 		self.fusedRelu = False       # set per forward pass by Sequential (planFusion)
+		self.emitMask = False        # ... the fused ReLU's sign mask is wanted by the gradient fan-in behind it (fuseReluMask)
+		self.reluMask = None
 
 
 	def updateData(self, data):
+		self.reluMask = None
 		lazy = [isDeferred(d) for d in data]
 		if any(lazy):
 			if len(data) == 2:            # normalise the deferred BatchNorm outputs while summing them
 				first, second = (data[0], data[1]) if lazy[0] else (data[1], data[0])
-				self.data = S().Dnn.bnApplyAdd(first, second, relu=self.fusedRelu)
+				if self.fusedRelu and self.emitMask:
+					self.data, self.reluMask = S().Dnn.bnApplyAdd(first, second, relu=True, withMask=True)
+				else:
+					self.data = S().Dnn.bnApplyAdd(first, second, relu=self.fusedRelu)
 				return
 			data = [d.materialize() if isDeferred(d) else d for d in data]
 
@@ -898,6 +904,7 @@ class Replicate(Module):
 		self.times = times
 		self.gateGrad = False        # set per forward pass by Sequential (planFusion): input is an in-place ReLU's output
 		self.statsFor = []           # ... and BatchNorms of the block in front whose backward statistics the fan-in also sums
+		self.maskFrom = None         # ... and the Add that produced the input together with its sign mask
 
 
 	def updateData(self, data):
@@ -911,7 +918,10 @@ class Replicate(Module):
 		if self.gateGrad and len(grad) == 2 and targets:
 			# fan-in + ReLU derivative + the statistics pass of the BatchNorm backward(s) this gradient goes to next
 			# (two compact stride-2 gradients are expanded on the fly, see planFusion / fuseStridedGrad)
-			self.grad, parts = S().Dnn.bnGateStats(grad[0], grad[1], self.inData, [(bn.inData, bn.savemean) for bn in targets])
+			mask = self.maskFrom.reluMask if self.maskFrom is not None else None
+			self.grad, parts = S().Dnn.bnGateStats(
+				grad[0], grad[1], self.inData, [(bn.inData, bn.savemean) for bn in targets], mask=mask
+			)
 			for bn, part in zip(targets, parts):
 				bn.bwdPartials = (self.grad, part)
 		else:
@@ -1184,6 +1194,7 @@ class Sequential(Container):
 	fuseGateStats = True         # gradient fan-in also sums the next BatchNorm backward's statistics (see planFusion)
 	fuseBnBackward = True        # ... and the BatchNorm's apply pass is folded into the backward of the Conv2D in front
 	fuseStridedGrad = True       # input gradients of a down-sampling block's stride-2 1x1 convolutions stay compact
+	fuseReluMask = True          # Add+ReLU leaves its output's sign mask for the fan-in that would read the output back
 
 	def __init__(self, name=None):
 		super().__init__(name)
@@ -1218,7 +1229,9 @@ class Sequential(Container):
 			elif isinstance(mod, (BatchNorm2D, Add)):
 				mod.fusedRelu = False
 			elif isinstance(mod, Replicate):
-				mod.gateGrad, mod.statsFor = False, []
+				mod.gateGrad, mod.statsFor, mod.maskFrom = False, [], None
+			if isinstance(mod, Add):
+				mod.emitMask = False
 
 			if isinstance(mod, Conv2D):
 				mod.emitStats = False
@@ -1280,6 +1293,10 @@ class Sequential(Container):
 						branch.graph[-1] for branch in graph[i - 2].graph
 						if isinstance(branch, Sequential) and branch.graph and isinstance(branch.graph[-1], BatchNorm2D)
 					][:2]
+					# fuseReluMask: the Add's kernel also leaves (y > 0) as one bit per element and the fan-in gates with
+					# that instead of reading y back (4 B -> 1/4 B per element; same predicate, bit-identical)
+					if Sequential.fuseReluMask and nxt.statsFor and prev.fusedRelu:
+						prev.emitMask, nxt.maskFrom = True, prev
 
 
 		# fuseStridedGrad: [ReLU, Replicate(2), Parallel] whose two branches both start with a stride-2 pointwise convolution

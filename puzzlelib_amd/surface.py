@@ -153,11 +153,11 @@ def bind():
 		fwd, bwdData, bwdParam = bnd.convNdbenchmark(datashape, Wshape, np.float32, stride, pad, dilation, groups)
 		return fwd, bwdParam, bwdData
 
-	def bnGateStats(grad0, grad1, outdata, targets):
-		return dnn.bnGateStats(grad0, grad1, outdata, [(x, m.ravel()) for x, m in targets], allocator=memoryPool)
+	def bnGateStats(grad0, grad1, outdata, targets, mask=None):
+		return dnn.bnGateStats(grad0, grad1, outdata, [(x, m.ravel()) for x, m in targets], allocator=memoryPool, mask=mask)
 
-	def bnApplyAdd(first, second, relu=False):
-		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool)
+	def bnApplyAdd(first, second, relu=False, withMask=False):
+		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool, withMask=withMask)
 
 	Dnn = SimpleNamespace(
 		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats, compactGradSupported=dnn.compactGradSupported,

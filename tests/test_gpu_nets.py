@@ -140,12 +140,13 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 	data, labels = mini_golden["data"], mini_golden["labels"]
 
 	results = {}
-	for fused in (False, True, "no-bn-add", "no-gate-stats", "no-strided-grad"):
+	for fused in (False, True, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask"):
 		nn.Sequential.fuseBnBackward = False           # covered by its own test below (same values up to fp32 rounding, not bit-identical)
 		nn.Sequential.fuseInplaceRelu = bool(fused)
-		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats", "no-strided-grad")      # else the residual Add reads materialised BN outputs
-		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add", "no-strided-grad")      # else BN backward sums its own statistics
+		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats", "no-strided-grad", "no-relu-mask")      # else the residual Add reads materialised BN outputs
+		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add", "no-strided-grad", "no-relu-mask")      # else BN backward sums its own statistics
 		nn.Sequential.fuseStridedGrad = fused != "no-strided-grad"      # else the stride-2 1x1 convolutions zero-fill their input gradients
+		nn.Sequential.fuseReluMask = fused != "no-relu-mask"            # else the fan-in reads the block output back for its sign
 		try:
 			np.random.seed(7)
 			net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
@@ -167,7 +168,10 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 			params = {name: var.data.get() for name, var in nets.namedVariables(net).items()}
 
 			convs = [m for m in allModules(net) if isinstance(m, nn.Conv2D)]
-			assert sum(m.compactGrad for m in convs) == (2 if fused in (True, "no-bn-add") else 0), \
+			adds = [m for m in allModules(net) if isinstance(m, nn.Add)]
+			assert sum(m.reluMask is not None for m in adds) == (2 if fused in (True, "no-strided-grad") else 0), \
+				"the Adds of blocks 1 and 2 leave the sign mask their fan-in gates with"
+			assert sum(m.compactGrad for m in convs) == (2 if fused in (True, "no-bn-add", "no-relu-mask") else 0), \
 				"the down-sampling block's two stride-2 1x1 convolutions keep their input gradients compact"
 			if fused is True:
 				reps = [m for m in allModules(net) if isinstance(m, nn.Replicate)]
@@ -182,10 +186,10 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 			results[fused] = (logits, float(cost.devErr.get()), grads, params)
 		finally:
 			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = nn.Sequential.fuseGateStats = True
-			nn.Sequential.fuseBnBackward = nn.Sequential.fuseStridedGrad = True
+			nn.Sequential.fuseBnBackward = nn.Sequential.fuseStridedGrad = nn.Sequential.fuseReluMask = True
 
 	(l1, e1, g1, p1) = results[True]
-	for other in (False, "no-bn-add", "no-gate-stats", "no-strided-grad"):
+	for other in (False, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask"):
 		l0, e0, g0, p0 = results[other]
 		assert np.array_equal(l0, l1) and e0 == e1
 		for name in g0:

@@ -899,3 +899,46 @@ def test_compact_stride2_gradients_through_the_fan_in(bnd, cfg):
 	# one compact, one dense operand: the handle is zero-filled
 	g_mixed, _ = bnd.dnn.bnGateStats(lazy[0], dense[1], out, targets)
 	assert np.array_equal(g_mixed.get(), ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 9, 7), (2, 8, 4, 4), (4, 64, 55, 55), (5, 3, 1, 1)])
+def test_relu_sign_mask_gates_the_fan_in(bnd, shape):
+	"""pz_bn_apply_add_mask -> pz_bn_gate_stats(mask=): the residual Add's kernel leaves (out > 0) as one bit per element
+	(a byte per 4 consecutive elements of a plane, then a byte per trailing element), and the fan-in gates with it instead
+	of reading `out` back. Layout, and bit-identity with the y-gated kernel for dense and compact gradients."""
+	from puzzlelib_amd import backend
+	rng = np.random.RandomState(17)
+	n, c, h, w_ = shape
+	hw = h * w_
+	x1, x2 = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
+	coef = rng.randn(c, 2).astype(np.float32)
+	first = backend.DeferredBN(gpu(bnd, x1), gpu(bnd, coef.ravel()), bnd.dnn)
+
+	out, mask = bnd.dnn.bnApplyAdd(first, gpu(bnd, x2), relu=True, withMask=True)
+	plain = bnd.dnn.bnApplyAdd(first, gpu(bnd, x2), relu=True)
+	assert np.array_equal(out.get(), plain.get()) and mask.tensor is out
+
+	pos = out.get().reshape(n * c, hw) > 0
+	stride = hw // 4 + 3
+	bits = mask.bits.get().reshape(n * c, stride)
+	n4 = hw // 4
+	expect = np.zeros((n * c, n4), np.uint8)
+	for e in range(4):
+		expect |= (pos[:, e:4 * n4:4].astype(np.uint8) << e)
+	assert np.array_equal(bits[:, :n4], expect)
+	assert np.array_equal(bits[:, n4:n4 + hw % 4], pos[:, 4 * n4:].astype(np.uint8))
+
+	g0, g1 = gpu(bnd, rng.randn(*shape).astype(np.float32)), gpu(bnd, rng.randn(*shape).astype(np.float32))
+	targets = [(gpu(bnd, rng.randn(*shape).astype(np.float32)), gpu(bnd, rng.randn(c).astype(np.float32)))]
+	ga, pa = bnd.dnn.bnGateStats(g0, g1, out, targets)
+	gb, pb = bnd.dnn.bnGateStats(g0, g1, out, targets, mask=mask)
+	assert np.array_equal(ga.get(), gb.get())
+	scale, invvar = gpu(bnd, rng.randn(c).astype(np.float32)), gpu(bnd, (0.5 + rng.rand(c)).astype(np.float32))
+	ra = bnd.dnn.batchNormNdBackward(ga, targets[0][0], scale, targets[0][1], invvar, 1e-5, partials=pa[0])
+	rb = bnd.dnn.batchNormNdBackward(gb, targets[0][0], scale, targets[0][1], invvar, 1e-5, partials=pb[0])
+	assert all(np.array_equal(a.get(), b.get()) for a, b in zip(ra, rb))
+
+	# a mask of some other tensor is ignored (the gate falls back to reading y)
+	other = gpu(bnd, out.get())
+	gc, _ = bnd.dnn.bnGateStats(g0, g1, other, targets, mask=mask)
+	assert np.array_equal(gc.get(), ga.get())
