@@ -7,7 +7,7 @@ Hip/Backend.py:19-71 on top of Cuda/GPUBackend.py:17-433): GPUArray, memoryPool,
 `<name>Ker` kernel objects, enums, SharedArray, stream/event managers, RNG, copy/concatenate/split/tile, timeKernel.
 Underneath every entry is one or two calls into libpuzzle_mi355.so — no MIOpen, no rocBLAS, no JIT.
 """
-import sys, time, ctypes
+import os, sys, time, ctypes
 from ctypes import byref, c_int, c_size_t, c_void_p
 from enum import Enum
 from collections import OrderedDict
@@ -324,6 +324,59 @@ class DnnContext:
 		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
 
 
+	# ---- filter gradients on a side stream. Backward-data and backward-filter of a layer read the same incoming gradient
+	# and nothing of each other: with overlapFilterGrad the filter-gradient launches (pack / main kernel / slab reduce) go
+	# to a second stream behind an event, so that the two chains fill each other's tails and tiny launches. Every tensor
+	# those launches touch is kept referenced until joinFilterGrads() — the pool must not hand its memory to the main
+	# stream while the side stream still uses it.
+	# Only inside a module-driven backward pass (beginBackward / endBackward, nn.backwardScope): its end joins the streams,
+	# so nobody sees a half-finished gradient; direct calls of convNdBackwardParams stay on the main stream.
+	overlapFilterGrad = os.environ.get("PUZZLE_MI355_OVERLAP_WGRAD", "1") == "1"
+	backwardDepth = 0
+
+	def beginBackward(self):
+		self.backwardDepth += 1
+
+
+	def endBackward(self):
+		self.backwardDepth -= 1
+		if self.backwardDepth == 0:
+			self.joinFilterGrads()
+
+
+	def filterGradStream(self):
+		if not DnnContext.overlapFilterGrad or self.backwardDepth == 0:
+			return None
+		if getattr(self, "sideStream", None) is None:
+			self.sideStream, self.sideRefs, self.sideLaunches = driver.Stream(), [], 0
+		self.sideLaunches += 1
+		ready = driver.Event()
+		ready.record(None)                          # everything issued so far on the main stream (the incoming gradient)
+		self.sideStream.waitEvent(ready)
+		self.sideRefs.append(ready)
+		return self.sideStream
+
+
+	def filterGradEvent(self):
+		"""An event behind everything queued on the side stream so far (None when it is idle or off): what a consumer of
+		freshly accumulated filter gradients on another stream has to wait for besides the main stream."""
+		if getattr(self, "sideStream", None) is None or not self.sideRefs:
+			return None
+		event = driver.Event()
+		event.record(self.sideStream)
+		return event
+
+
+	def joinFilterGrads(self):
+		"""Main stream waits for the side stream; the references held for it are dropped."""
+		if getattr(self, "sideStream", None) is None or not self.sideRefs:
+			return
+		done = driver.Event()
+		done.record(self.sideStream)
+		lib.pz_stream_wait_event(None, done.handle)
+		self.sideRefs = [done]                       # (the event itself must outlive the wait it was queued for)
+
+
 	def convNd(self, data, W, bias=None, stride=1, pad=0, dilation=1, groups=1, algo=ConvFwdAlgo.auto.value,
 			   out=None, allocator=None, withStats=False):
 		"""`withStats` (backend-internal): also return the per-strip channel sums of the output for a BatchNorm that
@@ -472,19 +525,26 @@ class DnnContext:
 		if withbias:
 			bg = GPUArray.empty((biasof.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
 
-		if lazy is not None and not withbias and self.bnFoldSupported(desc, algo):
-			lib.pz_conv2d_bwd_filter_bn(
-				byref(desc), data.ptr, grad.ptr, lazy.data.ptr, lazy.coef.ptr, wgrad.ptr, wcoef[0], wcoef[1], algo,
-				ptrOf(ws), size.value, None
-			)
-			return wgrad
-		if lazy is not None:
+		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
+		folded = lazy is not None and not withbias and self.bnFoldSupported(desc, algo)
+		if lazy is not None and not folded:
 			grad = lazy.materialize()
 
-		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
+		side = self.filterGradStream() if (not withbias or fused) else None
+		st = side.handle if side is not None else None
+		if side is not None:
+			self.sideRefs.append((data, grad, lazy, ws, wgrad, bg))
+
+		if folded:
+			lib.pz_conv2d_bwd_filter_bn(
+				byref(desc), data.ptr, grad.ptr, lazy.data.ptr, lazy.coef.ptr, wgrad.ptr, wcoef[0], wcoef[1], algo,
+				ptrOf(ws), size.value, st
+			)
+			return wgrad
+
 		lib.pz_conv2d_bwd_filter(
 			byref(desc), data.ptr, grad.ptr, wgrad.ptr, ptrOf(bg) if fused else None, wcoef[0], wcoef[1], algo,
-			ptrOf(ws), size.value, None
+			ptrOf(ws), size.value, st
 		)
 
 		if withbias and not fused:

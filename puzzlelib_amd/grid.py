@@ -250,16 +250,21 @@ class HipReduceOps:
 
 	def markReady(self):
 		from puzzlelib_amd import driver
+		from puzzlelib_amd.surface import bound
 		event = driver.Event()
 		event.record(None)
-		return event
+		# filter gradients may have been queued on the backend's side stream (DnnContext.overlapFilterGrad)
+		return (event, bound().Dnn.filterGradEvent())
 
 
 	def allreduce(self, start, stop, token):
 		from puzzlelib_amd import lib, driver
 		node = self.node
 
-		node.commStream.waitEvent(token)
+		main, side = token
+		node.commStream.waitEvent(main)
+		if side is not None:
+			node.commStream.waitEvent(side)
 		ptr = self.tensor.ptr + start
 		lib.pz_comm_allreduce_sum_f32(node.comm, ptr, ptr, (stop - start) // 4, node.commStream.handle)
 
@@ -289,6 +294,8 @@ class HostStagedReduceOps:
 
 	def markReady(self):
 		from puzzlelib_amd import driver
+		from puzzlelib_amd.surface import bound
+		bound().Dnn.joinFilterGrads()               # (synchronous transport: no point in keeping the side stream apart)
 		event = driver.Event()
 		event.record(None)
 		return event

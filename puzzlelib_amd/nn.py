@@ -116,6 +116,17 @@ def dtypesOf(data):
 	return [dtypesOf(d) for d in data] if isinstance(data, (tuple, list)) else data.dtype
 
 
+class backwardScope:
+	"""Brackets a module-driven backward pass for the backend: filter gradients issued inside may run on its side stream
+	(DnnContext.overlapFilterGrad); leaving the outermost scope joins the streams."""
+	def __enter__(self):
+		S().Dnn.beginBackward()
+
+	def __exit__(self, *exc):
+		S().Dnn.endBackward()
+		return False
+
+
 class Module:
 	paramGradsHook = None      # set by puzzlelib_amd.grid.enableOverlap: called after a module's parameter gradients are final
 
@@ -177,13 +188,14 @@ class Module:
 			self.checkGradType(dtypesOf(grad))
 
 		self.grad = None
-		if updGrad:
-			self.updateGrad(grad)
-		if updParamGrads and self.train:
-			self.accGradParams(grad, scale=scale, momentum=momentum)
+		with backwardScope():
+			if updGrad:
+				self.updateGrad(grad)
+			if updParamGrads and self.train:
+				self.accGradParams(grad, scale=scale, momentum=momentum)
 
-			if Module.paramGradsHook is not None and self.vars:
-				Module.paramGradsHook(self)
+				if Module.paramGradsHook is not None and self.vars:
+					Module.paramGradsHook(self)
 
 
 	def updateData(self, data):
@@ -1369,14 +1381,15 @@ class Sequential(Container):
 		gradient are unaffected. Set Sequential.honourUpdGrad = False for the reference's literal behaviour."""
 		last = len(self.graph) - 1
 
-		for i, mod in enumerate(reversed(self.graph)):
-			first = i == last and Sequential.honourUpdGrad
-			try:
-				mod.backward(grad, updParamGrads=updParamGrads, updGrad=updGrad if first else True, scale=scale,
-							 momentum=momentum)
-			except ModuleError as e:
-				raise ModuleError("%s:\nGrad error in module %d (%s):\n%s" % (self, len(self.graph) - 1 - i, mod, e))
-			grad = mod.grad
+		with backwardScope():
+			for i, mod in enumerate(reversed(self.graph)):
+				first = i == last and Sequential.honourUpdGrad
+				try:
+					mod.backward(grad, updParamGrads=updParamGrads, updGrad=updGrad if first else True, scale=scale,
+								 momentum=momentum)
+				except ModuleError as e:
+					raise ModuleError("%s:\nGrad error in module %d (%s):\n%s" % (self, len(self.graph) - 1 - i, mod, e))
+				grad = mod.grad
 
 		self.grad = grad
 
@@ -1425,12 +1438,13 @@ class Parallel(Container):
 		assert len(grad) == len(self.graph)
 		self.grad = []
 
-		for i, mod in enumerate(self.graph):
-			try:
-				mod.backward(grad[i], updParamGrads=updParamGrads, updGrad=updGrad, scale=scale, momentum=momentum)
-			except ModuleError as e:
-				raise ModuleError("%s:\nGrad error in module %d (%s):\n%s" % (self, i, mod, e))
-			self.grad.append(mod.grad)
+		with backwardScope():
+			for i, mod in enumerate(self.graph):
+				try:
+					mod.backward(grad[i], updParamGrads=updParamGrads, updGrad=updGrad, scale=scale, momentum=momentum)
+				except ModuleError as e:
+					raise ModuleError("%s:\nGrad error in module %d (%s):\n%s" % (self, i, mod, e))
+				self.grad.append(mod.grad)
 
 
 	def dataShapeFrom(self, shapes):

@@ -161,6 +161,8 @@ def bind():
 
 	Dnn = SimpleNamespace(
 		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats, compactGradSupported=dnn.compactGradSupported,
+		joinFilterGrads=dnn.joinFilterGrads, filterGradEvent=dnn.filterGradEvent,
+		beginBackward=dnn.beginBackward, endBackward=dnn.endBackward,
 		ConvFwdAlgo=bnd.ConvFwdAlgo, ConvBwdDataAlgo=bnd.ConvBwdDataAlgo, ConvBwdFilterAlgo=bnd.ConvBwdFilterAlgo,
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,

@@ -140,11 +140,15 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 	data, labels = mini_golden["data"], mini_golden["labels"]
 
 	results = {}
-	for fused in (False, True, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask"):
+	from puzzlelib_amd import backend
+	dnn = bnd.dnn
+	for fused in (False, True, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask", "no-overlap"):
+		backend.DnnContext.overlapFilterGrad = fused != "no-overlap"    # else filter gradients stay on the main stream
+		launched = getattr(dnn, "sideLaunches", 0)
 		nn.Sequential.fuseBnBackward = False           # covered by its own test below (same values up to fp32 rounding, not bit-identical)
 		nn.Sequential.fuseInplaceRelu = bool(fused)
-		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats", "no-strided-grad", "no-relu-mask")      # else the residual Add reads materialised BN outputs
-		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add", "no-strided-grad", "no-relu-mask")      # else BN backward sums its own statistics
+		nn.Sequential.fuseBnAdd = fused in (True, "no-gate-stats", "no-strided-grad", "no-relu-mask", "no-overlap")      # else the residual Add reads materialised BN outputs
+		nn.Sequential.fuseGateStats = fused in (True, "no-bn-add", "no-strided-grad", "no-relu-mask", "no-overlap")      # else BN backward sums its own statistics
 		nn.Sequential.fuseStridedGrad = fused != "no-strided-grad"      # else the stride-2 1x1 convolutions zero-fill their input gradients
 		nn.Sequential.fuseReluMask = fused != "no-relu-mask"            # else the fan-in reads the block output back for its sign
 		try:
@@ -169,9 +173,11 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 
 			convs = [m for m in allModules(net) if isinstance(m, nn.Conv2D)]
 			adds = [m for m in allModules(net) if isinstance(m, nn.Add)]
-			assert sum(m.reluMask is not None for m in adds) == (2 if fused in (True, "no-strided-grad") else 0), \
+			assert getattr(dnn, "sideLaunches", 0) - launched == (0 if fused == "no-overlap" else len(convs)), \
+				"every convolution's filter gradient went to the side stream (and none with the switch off)"
+			assert sum(m.reluMask is not None for m in adds) == (2 if fused in (True, "no-strided-grad", "no-overlap") else 0), \
 				"the Adds of blocks 1 and 2 leave the sign mask their fan-in gates with"
-			assert sum(m.compactGrad for m in convs) == (2 if fused in (True, "no-bn-add", "no-relu-mask") else 0), \
+			assert sum(m.compactGrad for m in convs) == (2 if fused in (True, "no-bn-add", "no-relu-mask", "no-overlap") else 0), \
 				"the down-sampling block's two stride-2 1x1 convolutions keep their input gradients compact"
 			if fused is True:
 				reps = [m for m in allModules(net) if isinstance(m, nn.Replicate)]
@@ -187,9 +193,10 @@ def test_inplace_relu_fusion_is_bit_identical_and_matches_oracle(bnd, mini_golde
 		finally:
 			nn.Sequential.fuseInplaceRelu = nn.Sequential.fuseBnAdd = nn.Sequential.fuseGateStats = True
 			nn.Sequential.fuseBnBackward = nn.Sequential.fuseStridedGrad = nn.Sequential.fuseReluMask = True
+			backend.DnnContext.overlapFilterGrad = True
 
 	(l1, e1, g1, p1) = results[True]
-	for other in (False, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask"):
+	for other in (False, "no-bn-add", "no-gate-stats", "no-strided-grad", "no-relu-mask", "no-overlap"):
 		l0, e0, g0, p0 = results[other]
 		assert np.array_equal(l0, l1) and e0 == e1
 		for name in g0:
