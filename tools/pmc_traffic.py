@@ -41,7 +41,8 @@ for name in sorted(set(fetch) | set(write)):
 	wb = w.get("WRITE_SIZE", 0.0) * 1024.0 * wf / n
 	kernels[name] = {"dispatches": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb}
 
-steps = 4        # bench.py --steps 3 --warmup 1
+# steps of the profiled run = launches of the optimizer kernel (warm-up + timed + the roofline steps of bench.py)
+steps = max([v["dispatches"] for k, v in kernels.items() if "OpAdam" in k] or [4])
 total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kernels.values())
 out = {
 	"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 1 "
