@@ -221,6 +221,8 @@ def main():
 				"FALLBACK: host-staged gloo all-reduce (RCCL communicator could not be created)"
 			)
 		},
+		"model_tflops_note": "direct-convolution FLOP of the network / step time; the 3x3 layers' Winograd kernels execute "
+							 "1/2.25 of their share on the matrix pipe",
 		"model_tflops_per_gpu": images_per_sec / world * FLOP_PER_IMAGE / 1e12,
 		"pct_of_f32_mfma_peak": images_per_sec / world * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,
 		"final_loss": loss,

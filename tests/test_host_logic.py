@@ -211,3 +211,41 @@ def test_header_and_ctypes_binding_agree():
 	names = [m for m in re.findall(r"\b(PZ_OP_[A-Z0-9_]+)\b", enum)]
 	for index, name in enumerate(names):
 		assert getattr(lib, name[3:]) == index, "%s is %d in the header, %s in lib.py" % (name, index, getattr(lib, name[3:]))
+
+
+def test_convolution_family_resolution_without_device():
+	"""pz_conv2d_algo_used / workspace sizes are host logic: which kernel family serves a layer under each requested algo
+	(Hip/Wrappers/MIOpen.py:23-49 ids: direct 1, winograd 3, implicitGemm 5, auto -1)."""
+	import ctypes
+	from puzzlelib_amd import lib
+	from puzzlelib_amd.lib import ConvDesc
+
+	def used(desc, which, algo):
+		out = ctypes.c_int(0)
+		lib.pz_conv2d_algo_used(ctypes.byref(desc), which, algo, ctypes.byref(out))
+		return out.value
+
+	c3 = ConvDesc(256, 128, 28, 28, 128, 3, 3, 1, 1, 1, 1, 1, 1, 1)          # ResNet-50 stage-3 3x3 layer
+	c1 = ConvDesc(256, 256, 14, 14, 1024, 1, 1, 1, 1, 0, 0, 1, 1, 1)         # 1x1 layer
+	s2 = ConvDesc(256, 128, 28, 28, 128, 3, 3, 2, 2, 1, 1, 1, 1, 1)          # strided 3x3
+	thin = ConvDesc(8, 16, 20, 20, 16, 3, 3, 1, 1, 1, 1, 1, 1, 1)            # 3x3 with few channels
+	grouped = ConvDesc(8, 64, 20, 20, 64, 3, 3, 1, 1, 1, 1, 1, 1, 2)
+
+	for which in (lib.CONV_FWD, lib.CONV_BWD_DATA, lib.CONV_BWD_FILTER):
+		assert used(c3, which, lib.CONV_ALGO_AUTO) == lib.CONV_ALGO_WINOGRAD
+		assert used(c3, which, lib.CONV_ALGO_IMPLICIT_GEMM) == lib.CONV_ALGO_IMPLICIT_GEMM
+		assert used(c3, which, lib.CONV_ALGO_DIRECT) == lib.CONV_ALGO_DIRECT
+		assert used(thin, which, lib.CONV_ALGO_AUTO) == lib.CONV_ALGO_IMPLICIT_GEMM          # below 32 channels: not by default
+		assert used(thin, which, lib.CONV_ALGO_WINOGRAD) == lib.CONV_ALGO_WINOGRAD            # ... but on request
+		for desc in (c1, s2, grouped):
+			assert used(desc, which, lib.CONV_ALGO_WINOGRAD) == lib.CONV_ALGO_IMPLICIT_GEMM   # not a Winograd layer
+			assert used(desc, which, lib.CONV_ALGO_AUTO) == lib.CONV_ALGO_IMPLICIT_GEMM
+
+	size = ctypes.c_size_t()
+	lib.pz_conv2d_workspace_bytes(ctypes.byref(c3), lib.CONV_FWD, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
+	assert size.value == 2 * 32 * 16 * 64 * 4 * 4          # 2 channel blocks x 32 chunks x 16 positions x 64 x 4 floats
+	lib.pz_conv2d_workspace_bytes(ctypes.byref(c3), lib.CONV_BWD_FILTER, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
+	assert 0 < size.value < 1 << 30
+
+	lib.pz_relu_mask_bytes(256, 256, 55 * 55, ctypes.byref(size))
+	assert size.value == 256 * 256 * (55 * 55 // 4 + 3)
