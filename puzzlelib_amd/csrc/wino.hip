@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 }
 
 
+#if WN_SELFWAVE
 // ------------------------------------------------------------------------------------------------
 // The same product with self-sufficient waves (no barrier in the reduction loop). Wave w accumulates positions 4w..4w+3
 // = row w of the transformed patch, and that row needs only two rows of the patch (0: d0-d2, 1: d1+d2, 2: d2-d1,
@@ -585,6 +586,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
 	__syncthreads();              // every wave is done with its ring before the epilogue reuses the memory
 	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
 }
+#endif  // WN_SELFWAVE
 
 // ------------------------------------------------------------------------------------------------
 // backward-filter through the same transform:  dU[pos][k][c] = sum over tiles (A dY A^T)[pos] . (B^T d B)[pos],
