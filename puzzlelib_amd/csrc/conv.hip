@@ -1182,14 +1182,19 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 }
 
 template <int BM, int BN, int WM, int WN>
-void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st) {
+void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
 	constexpr int lds_pad = 0;
-	if (a.x2)
-		igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
-	else if (a.tapmajor)
-		igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
-	else
-		igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+	{
+		// profile bracket = the MFMA kernel alone (what rocprofv3 lists under its name); all of the launch's algorithmic
+		// FLOP are its work — the slab reduce of a k-sliced last round only adds
+		ProfScope prof(st, BM == 64 ? 1 : 0, flops);
+		if (a.x2)
+			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+		else if (a.tapmajor)
+			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+		else
+			igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+	}
 	if (p.tail_splits > 1)
 		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 256, 0, st>>>(a);
 }
@@ -1197,11 +1202,10 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 void run_igemm(const FwdPlan &p, IgemmArgs a, float *slabs, int groups, hipStream_t st, double flops) {
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
 	a.full_tiles = p.full_tiles, a.tail_splits = p.tail_splits, a.slabs = slabs;
-	ProfScope prof(st, p.bm == 64 ? 1 : 0, flops);
 	if (p.bm == 64)
-		launch_igemm<64, 256, 1, 4>(p, a, groups, st);
+		launch_igemm<64, 256, 1, 4>(p, a, groups, st, flops);
 	else
-		launch_igemm<128, 128, 2, 2>(p, a, groups, st);
+		launch_igemm<128, 128, 2, 2>(p, a, groups, st, flops);
 }
 
 // backward-data residue classes
