@@ -26,6 +26,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
                         // 16 no barrier, 32 no fragment reads
 #endif
 
+#ifndef WN_WAVES
+#define WN_WAVES 8      // forward / backward-data workgroup: 8 waves (2 positions each, 4 waves per SIMD) or 4 (4 positions, 2 per SIMD)
+#endif
 #ifndef WN_SELFWAVE
 #define WN_SELFWAVE 0   // forward / backward-data: 0 = shared loaders + one barrier per chunk; 1 = barrier-free self-sufficient
                         // waves (wino_conv_kernel_sw) — measured equal on all four 3x3 layer shapes, kept for the comparison
@@ -382,6 +385,259 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
 }
 
+
+#if WN_WAVES == 8
+// ------------------------------------------------------------------------------------------------
+// The same workgroup block (32 tiles x 64 channels x 16 positions, 3-stage ring) on 8 waves: wave w accumulates positions
+// 2w, 2w+1 (64 accumulator registers), so two workgroups per CU put 4 waves on every SIMD instead of 2 — per SIMD the same
+// MFMAs and the same loader work, spread over twice as many instruction streams. Waves 0-3 gather and transform the
+// patches exactly as wino_conv_kernel's four waves do, waves 4-7 copy the transformed filters (4 x 16 B per thread).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_epilogue8(const WinoArgs &a, f32x16 (&acc)[2][2], float *smem, int kb, int tb, int tid, int wave,
+                                               int lane) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+	float *Ms = smem;                               // [16 positions][16 channels][32 tiles]
+
+	const int t = tb * TB + l31;
+	const bool tv = t < a.tiles;
+	const int n = t / (a.TY * a.TX), rr = t - n * (a.TY * a.TX);
+	const int ty = rr / a.TX, tx = rr - ty * a.TX;
+	const bool row1 = 2 * ty + 1 < a.P, col1 = 2 * tx + 1 < a.Q;
+	const unsigned pq4 = (unsigned)(a.P * a.Q) * 4u;
+	const unsigned obase = (unsigned)((((long)n * a.K) * a.P + 2 * ty) * a.Q + 2 * tx) * 4u;
+
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p)
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int kk = 8 * (i >> 2) + 4 * lhi + (i & 3);
+				Ms[((2 * wave + p) * 16 + kk) * 32 + l31] = acc[p][q >> 1][8 * (q & 1) + i];
+			}
+		__syncthreads();
+
+		{
+			const int kk = tid >> 5;                    // 512 threads = 32 tiles x 16 channels
+			const int k = kb * KB + q * 16 + kk;
+			float m[4][4];
+#pragma unroll
+			for (int pos = 0; pos < 16; ++pos) m[pos >> 2][pos & 3] = Ms[(pos * 16 + kk) * 32 + l31];
+
+			float r0[4], r1[4];
+#pragma unroll
+			for (int v = 0; v < 4; ++v) {
+				r0[v] = m[0][v] + m[1][v] + m[2][v];
+				r1[v] = m[1][v] - m[2][v] - m[3][v];
+			}
+			const float b = (a.bias != nullptr && k < a.K) ? a.bias[k] : 0.f;
+			const float y00 = r0[0] + r0[1] + r0[2] + b, y01 = r0[1] - r0[2] - r0[3] + b;
+			const float y10 = r1[0] + r1[1] + r1[2] + b, y11 = r1[1] - r1[2] - r1[3] + b;
+
+			const bool kv = tv && k < a.K;
+			const unsigned o = obase + (unsigned)k * pq4;
+			const unsigned q4 = (unsigned)a.Q * 4u;
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y00), yr, kv ? o : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yr, kv && col1 ? o + 4u : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yr, kv && row1 ? o + q4 : kOOB, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yr, kv && row1 && col1 ? o + q4 + 4u : kOOB, 0, 0);
+		}
+		if (q < 3) __syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) wino_conv_kernel8(WinoArgs a) {
+	constexpr int kStage = kVFloats + kUFloats;
+	__shared__ __attribute__((aligned(16))) float smem[3 * kStage];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const int kb = blockIdx.x / a.tblocks, tb = blockIdx.x - kb * a.tblocks;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)(a.u + (size_t)kb * a.chunks * kUFloats), 0, (unsigned)a.chunks * (kUFloats * 4u), 0x00020000);
+	const unsigned hw4 = (unsigned)(a.H * a.W) * 4u;
+
+	// patch role (waves 0-3), as in wino_conv_kernel
+	const int pw = wave & 3, hf = pw & 1;
+	const int lt = 16 * (pw >> 1) + (lane & 15), lc = lane >> 4;
+	unsigned voff[3];
+	bool colok[4], fix[3];
+	bool anyfix = false;
+	{
+		const int t = tb * TB + lt;
+		const bool tv = t < a.tiles && wave < 4;
+		const int n = t / (a.TY * a.TX), r = t - n * (a.TY * a.TX);
+		const int ty = r / a.TX, tx = r - ty * a.TX;
+		const int row0 = 2 * ty - a.pad_h + hf, col0 = 2 * tx - a.pad_w;
+		const long base = (((long)n * a.C + lc) * a.H + row0) * a.W + col0;
+#pragma unroll
+		for (int e = 0; e < 3; ++e) {
+			const bool ok = tv && (unsigned)(row0 + e) < (unsigned)a.H;
+			const long off = base + (long)e * a.W;
+			fix[e] = ok && off < 0;
+			voff[e] = ok ? (off < 0 ? 0u : (unsigned)off * 4u) : kOOB;
+			anyfix = anyfix || fix[e];
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) colok[j] = (unsigned)(col0 + j) < (unsigned)a.W;
+	}
+	anyfix = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(anyfix) != 0ull)) != 0;
+	const unsigned vdst = (unsigned)(((lc >> 1) * TB + lt) * 2 + (lc & 1)) + (unsigned)(hf * 8) * (TB * BC);
+	const unsigned uidx = (unsigned)(tid & 255);          // filter role (waves 4-7): 16-byte element of the chunk's block
+
+	f32x4 st[4];                                // staged chunk: 3 patch rows or 4 x 16 B of filters
+
+	auto issue_loads = [&](auto role, int chunk) {
+		if constexpr (decltype(role)::value == 0) {
+			const unsigned soff = (unsigned)chunk * (BC * hw4);
+#pragma unroll
+			for (int e = 0; e < 3; ++e) st[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[e], soff, 0));
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, (uidx + i * 256u) * 16u,
+				                                                                          (unsigned)chunk * (kUFloats * 4u), 0));
+		}
+	};
+
+	f32x2 tA[2], tB[2];
+	auto store_slice = [&](auto role, auto half, auto fixed, float *stg, int slice) {
+		constexpr int HF = decltype(half)::value;
+		if constexpr (decltype(role)::value == 1) {
+			if (slice >= 4) reinterpret_cast<f32x4 *>(stg + kVFloats)[uidx + (slice - 4) * 256] = st[slice - 4];
+			return;
+		} else {
+			if (slice < 2) return;                    // the staged rows are needed from the third MFMA on
+			const int sl = slice - 2;                 // 0-3: columns, 4-5: rows
+			if (sl < 4) {
+				if constexpr (decltype(fixed)::value)
+					if (sl == 0) {
+#pragma unroll
+						for (int e = 0; e < 3; ++e)
+							if (fix[e]) st[e] = f32x4{0.f, st[e][0], st[e][1], st[e][2]};
+					}
+				if (sl != 1) {
+#pragma unroll
+					for (int e = 0; e < 3; ++e) st[e][sl] = colok[sl] ? st[e][sl] : 0.f;
+				}
+				if (sl == 1 || sl == 3) {
+					const int q = sl >> 1;
+					const f32x2 e0 = {st[0][2 * q], st[0][2 * q + 1]}, e1 = {st[1][2 * q], st[1][2 * q + 1]};
+					const f32x2 e2 = {st[2][2 * q], st[2][2 * q + 1]};
+					if constexpr (HF == 0) {
+						tA[q] = e0 - e2, tB[q] = e1 + e2;
+					} else {
+						tA[q] = e1 - e0, tB[q] = e0 - e2;
+					}
+				}
+			} else {
+				const f32x2 t01 = sl == 4 ? tA[0] : tB[0], t23 = sl == 4 ? tA[1] : tB[1];
+				f32x2 v01, v23;
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				float *dst = stg + vdst + (sl - 4) * 4 * (TB * BC);
+				dst[0 * (TB * BC)] = v01[0];
+				dst[1 * (TB * BC)] = v01[1];
+				dst[2 * (TB * BC)] = v23[0];
+				dst[3 * (TB * BC)] = v23[1];
+			}
+		}
+	};
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[p][m][r] = 0.f;
+
+	const int vfrag = ((2 * wave * 2 + lhi) * TB + l31) * 2;
+	const int ufrag = kVFloats + ((2 * wave * 2 + lhi) * KB + l31) * 2;
+
+	struct Frag {
+		f32x2 bv[2], av[2][2];
+	};
+	auto read_frags = [&](const float *stg, Frag &f) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p) {
+			f.bv[p] = *reinterpret_cast<const f32x2 *>(stg + vfrag + p * (2 * TB * 2));
+			f.av[p][0] = *reinterpret_cast<const f32x2 *>(stg + ufrag + p * (2 * KB * 2));
+			f.av[p][1] = *reinterpret_cast<const f32x2 *>(stg + ufrag + p * (2 * KB * 2) + 64);
+		}
+	};
+
+	auto run = [&](auto role, auto half, auto fixed) {
+		Frag f0, f1;
+		issue_loads(role, 0);
+#pragma unroll
+		for (int sl = 0; sl < 8; ++sl) store_slice(role, half, fixed, smem, sl);
+		if (a.chunks > 1) {
+			issue_loads(role, 1);
+#pragma unroll
+			for (int sl = 0; sl < 8; ++sl) store_slice(role, half, fixed, smem + kStage, sl);
+		}
+		if (a.chunks > 2) issue_loads(role, 2);
+		__syncthreads();
+		read_frags(smem, f0);
+
+		int s_cur = 0;
+		auto body = [&](int ch, Frag &cur, Frag &nxt) {
+			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
+			read_frags(smem + s_nxt * kStage, nxt);
+			float *wr = smem + s_wr * kStage;
+#pragma unroll
+			for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+				for (int p = 0; p < 2; ++p)
+#pragma unroll
+					for (int m = 0; m < 2; ++m) {
+#if !(WN_ABL & 4)
+						acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[p][m][s2], cur.bv[p][s2], acc[p][m], 0, 0, 0);
+#endif
+#if !(WN_ABL & 2)
+						store_slice(role, half, fixed, wr, s2 * 4 + p * 2 + m);
+#endif
+						__builtin_amdgcn_sched_barrier(0);
+					}
+#if !(WN_ABL & 1)
+			issue_loads(role, min(ch + 3, a.chunks - 1));
+#endif
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+			s_cur = s_nxt;
+		};
+
+		int ch = 0;
+		for (; ch + 1 < a.chunks; ch += 2) {
+			body(ch, f0, f1);
+			body(ch + 1, f1, f0);
+		}
+		if (ch < a.chunks) body(ch, f0, f1);
+	};
+
+	using R0 = std::integral_constant<int, 0>;
+	using R1 = std::integral_constant<int, 1>;
+	if (wave >= 4) {
+		run(R1{}, R0{}, std::false_type{});
+	} else if (anyfix) {
+		if (hf == 0)
+			run(R0{}, R0{}, std::true_type{});
+		else
+			run(R0{}, R1{}, std::true_type{});
+	} else if (hf == 0) {
+		run(R0{}, R0{}, std::false_type{});
+	} else {
+		run(R0{}, R1{}, std::false_type{});
+	}
+
+	wino_epilogue8(a, acc, smem, kb, tb, tid, wave, lane);
+}
+#endif  // WN_WAVES == 8
 
 #if WN_SELFWAVE
 // ------------------------------------------------------------------------------------------------
@@ -857,6 +1113,249 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_kernel(WinoWgradArgs a) {
 			}
 }
 
+#if WN_WAVES == 8
+// The same workgroup block on 8 waves (see wino_conv_kernel8): wave w accumulates positions 2w, 2w+1; waves 0-3 load and
+// transform the patches, waves 4-7 the gradient tiles — half the loader work per thread, four waves per SIMD.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) wino_wgrad_kernel8(WinoWgradArgs a) {
+	constexpr int kStage = kVFloats + kUFloats;
+	__shared__ __attribute__((aligned(16))) float smem[3 * kStage];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	const int nblk = a.kblocks * a.cblocks;
+	const int split = blockIdx.x / nblk, blk = blockIdx.x - split * nblk;
+	const int kb = blk / a.cblocks, cb = blk - kb * a.cblocks;
+	const int g0 = (int)((long)a.chunks * split / a.splits), g1 = (int)((long)a.chunks * (split + 1) / a.splits);
+	const int nch = g1 - g0;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0, 0x00020000);
+
+	const int pw = wave & 3, hf = pw & 1, t4 = lane & 3;
+	const int cl = (lane >> 2) + 16 * (pw >> 1), c = cb * CB + cl;
+	const int kl = (lane >> 2) + 16 * pw, k = kb * KB + kl;
+	const unsigned voffx = c < a.C ? (unsigned)(c * a.H * a.W + 2 * t4) * 4u : kOOB;
+	const unsigned voffx_first = c < a.C ? (voffx == 0 ? 0u : voffx - 4u) : kOOB;
+	const unsigned voffz = k < a.K ? (unsigned)(k * a.P * a.Q + 2 * t4) * 4u : kOOB;
+
+	const int jl = a.TX4 - 1;
+	unsigned long long mlast[4], mz[2];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) mlast[j] = __builtin_amdgcn_ballot_w64((unsigned)(8 * jl + 2 * t4 - a.pad + j) < (unsigned)a.W);
+	const unsigned long long mfirst0 = __builtin_amdgcn_ballot_w64(2 * t4 - a.pad >= 0);
+	mz[0] = __builtin_amdgcn_ballot_w64(8 * jl + 2 * t4 < a.Q), mz[1] = __builtin_amdgcn_ballot_w64(8 * jl + 2 * t4 + 1 < a.Q);
+
+	const unsigned vdst = (unsigned)(((t4 >> 1) * CB + cl) * 2 + (t4 & 1)) + (unsigned)(hf * 8) * (2 * CB * 2);
+	const unsigned zdst = (unsigned)kVFloats + (unsigned)(((t4 >> 1) * KB + kl) * 2 + (t4 & 1));
+
+	struct Geo {
+		int n, ty, j;
+	};
+	auto geo_of = [&](int g) {
+		Geo q;
+		q.j = g % a.TX4;
+		const int r = g / a.TX4;
+		q.ty = r % a.TY, q.n = r / a.TY;
+		return q;
+	};
+	auto advance = [&](Geo &q) {
+		if (++q.j == a.TX4) {
+			q.j = 0;
+			if (++q.ty == a.TY) q.ty = 0, ++q.n;
+		}
+	};
+
+	f32x4 sp[3];
+	f32x2 sz[2];
+	struct Pend {
+		bool first, last, fixrow;
+	};
+
+	auto issue_loads = [&](auto role, const Geo &q, Pend &pd) {
+		pd.first = q.j == 0, pd.last = q.j == jl, pd.fixrow = false;
+		if constexpr (decltype(role)::value == 0) {
+#pragma unroll
+			for (int e = 0; e < 3; ++e) {
+				const int row = 2 * q.ty - a.pad + hf + e;
+				const bool ok = (unsigned)row < (unsigned)a.H;
+				const long off = (((long)q.n * a.C) * a.H + row) * a.W + 8 * q.j - a.pad;
+				if (ok && off < 0) {
+					pd.fixrow = true;
+					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voffx_first, 0, 0));
+				} else {
+					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? xr : nullr, voffx, ok ? (unsigned)off * 4u : 0u, 0));
+				}
+			}
+		} else {
+#pragma unroll
+			for (int r = 0; r < 2; ++r) {
+				const int row = 2 * q.ty + r;
+				const bool ok = row < a.P;
+				const long off = (((long)q.n * a.K) * a.P + row) * a.Q + 8 * q.j;
+				sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ok ? zr : nullr, voffz, ok ? (unsigned)off * 4u : 0u, 0));
+			}
+		}
+	};
+
+	// slice s rides behind MFMA s of the chunk; the staged registers are first needed behind the third MFMA
+	f32x2 tA[2], tB[2], zr1, zr2;
+	auto store_slice = [&](auto role, auto half, float *stg, const Pend &pd, int slice) {
+		constexpr int HF = decltype(half)::value;
+		const unsigned long long all = ~0ull;
+		const int w = slice - 2;
+		if (w < 0) return;
+		if constexpr (decltype(role)::value == 0) {
+			if (w == 0) {
+				if (pd.fixrow) {
+					const int e = a.pad - HF;
+					if (voffx == 0 && e >= 0 && e < 3) sp[e] = f32x4{0.f, sp[e][0], sp[e][1], sp[e][2]};
+				}
+				const unsigned long long m = (pd.last ? mlast[0] : all) & (pd.first ? mfirst0 : all);
+#pragma unroll
+				for (int e = 0; e < 3; ++e) sp[e][0] = sel_mask(m, sp[e][0]);
+			} else if (w == 2 || w == 3) {
+				const unsigned long long m = pd.last ? mlast[w] : all;
+#pragma unroll
+				for (int e = 0; e < 3; ++e) sp[e][w] = sel_mask(m, sp[e][w]);
+			}
+			if (w == 1 || w == 3) {
+				const int q = w >> 1;
+				const f32x2 e0 = {sp[0][2 * q], sp[0][2 * q + 1]}, e1 = {sp[1][2 * q], sp[1][2 * q + 1]};
+				const f32x2 e2 = {sp[2][2 * q], sp[2][2 * q + 1]};
+				if constexpr (HF == 0) {
+					tA[q] = e0 - e2, tB[q] = e1 + e2;
+				} else {
+					tA[q] = e1 - e0, tB[q] = e0 - e2;
+				}
+			}
+			if (w == 4 || w == 5) {
+				const f32x2 t01 = w == 4 ? tA[0] : tB[0], t23 = w == 4 ? tA[1] : tB[1];
+				f32x2 v01, v23;
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
+				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				float *dst = stg + vdst + (w - 4) * 4 * (2 * CB * 2);
+				dst[0 * (2 * CB * 2)] = v01[0];
+				dst[1 * (2 * CB * 2)] = v01[1];
+				dst[2 * (2 * CB * 2)] = v23[0];
+				dst[3 * (2 * CB * 2)] = v23[1];
+			}
+		} else {
+			if (w == 0) {
+				const unsigned long long m0 = pd.last ? mz[0] : all, m1 = pd.last ? mz[1] : all;
+#pragma unroll
+				for (int r = 0; r < 2; ++r) sz[r][0] = sel_mask(m0, sz[r][0]), sz[r][1] = sel_mask(m1, sz[r][1]);
+			} else if (w == 1) {
+				zr1 = sz[0] + sz[1], zr2 = sz[0] - sz[1];
+			} else {
+				const int i = w - 2;                     // row (a, b) of A dY -> (a, a + b, a - b, [-]b)
+				const f32x2 row = i == 0 ? sz[0] : i == 1 ? zr1 : i == 2 ? zr2 : sz[1];
+				f32x2 mid;
+				asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(mid) : "v"(row));
+				float *dst = stg + zdst + i * 4 * (2 * KB * 2);
+				dst[0 * (2 * KB * 2)] = row[0];
+				dst[1 * (2 * KB * 2)] = mid[0];
+				dst[2 * (2 * KB * 2)] = mid[1];
+				dst[3 * (2 * KB * 2)] = row[1];
+			}
+		}
+	};
+
+	f32x16 acc[2][2];
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[p][m][r] = 0.f;
+
+	const int vfrag = ((2 * wave * 2 + lhi) * CB + l31) * 2;
+	const int ufrag = kVFloats + ((2 * wave * 2 + lhi) * KB + l31) * 2;
+
+	struct Frag {
+		f32x2 bv[2], av[2][2];
+	};
+	auto read_frags = [&](const float *stg, Frag &f) {
+#pragma unroll
+		for (int p = 0; p < 2; ++p) {
+			f.bv[p] = *reinterpret_cast<const f32x2 *>(stg + vfrag + p * (2 * CB * 2));
+			f.av[p][0] = *reinterpret_cast<const f32x2 *>(stg + ufrag + p * (2 * KB * 2));
+			f.av[p][1] = *reinterpret_cast<const f32x2 *>(stg + ufrag + p * (2 * KB * 2) + 64);
+		}
+	};
+
+	auto run = [&](auto role, auto half) {
+		Frag f0, f1;
+		Geo q = geo_of(g0);
+		Pend pd;
+		issue_loads(role, q, pd);
+#pragma unroll
+		for (int sl = 0; sl < 8; ++sl) store_slice(role, half, smem, pd, sl);
+		if (nch > 1) {
+			advance(q);
+			issue_loads(role, q, pd);
+#pragma unroll
+			for (int sl = 0; sl < 8; ++sl) store_slice(role, half, smem + kStage, pd, sl);
+		}
+		int issued = nch > 1 ? 2 : 1;
+		if (nch > 2) advance(q), issue_loads(role, q, pd), ++issued;
+		__syncthreads();
+		read_frags(smem, f0);
+
+		int s_cur = 0;
+		auto body = [&](Frag &cur, Frag &nxt) {
+			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
+			read_frags(smem + s_nxt * kStage, nxt);
+			float *wr = smem + s_wr * kStage;
+			const Pend pc = pd;
+#pragma unroll
+			for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+				for (int p = 0; p < 2; ++p)
+#pragma unroll
+					for (int m = 0; m < 2; ++m) {
+						acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[p][m][s2], cur.bv[p][s2], acc[p][m], 0, 0, 0);
+						store_slice(role, half, wr, pc, s2 * 4 + p * 2 + m);
+						__builtin_amdgcn_sched_barrier(0);
+					}
+			if (issued < nch) advance(q), ++issued;
+			issue_loads(role, q, pd);
+			__builtin_amdgcn_sched_barrier(0);
+			__syncthreads();
+			s_cur = s_nxt;
+		};
+
+		int ch = 0;
+		for (; ch + 1 < nch; ch += 2) {
+			body(f0, f1);
+			body(f1, f0);
+		}
+		if (ch < nch) body(f0, f1);
+	};
+	using R0 = std::integral_constant<int, 0>;
+	using R1 = std::integral_constant<int, 1>;
+	if (wave >= 4)
+		run(R1{}, R0{});
+	else if (hf == 0)
+		run(R0{}, R0{});
+	else
+		run(R0{}, R1{});
+
+	float *slab = a.slabs + (size_t)blockIdx.x * kSlab;
+#pragma unroll
+	for (int p = 0; p < 2; ++p)
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int kk = m * 32 + 8 * (i >> 2) + 4 * lhi + (i & 3);
+				slab[((2 * wave + p) * KB + kk) * CB + l31] = acc[p][m][i];
+			}
+}
+#endif  // WN_WAVES == 8
+
 // sums the slabs of `per` consecutive splits (blockIdx.y = group) into one: out[group][block][...]
 __global__ void __launch_bounds__(256) wino_wgrad_sum_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t block_elems,
                                                              int splits, int groups) {
@@ -967,7 +1466,9 @@ int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, c
 	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB);
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
-#if WN_SELFWAVE
+#if WN_WAVES == 8
+	wino_conv_kernel8<<<a.tblocks * fa.kblocks, 512, 0, st>>>(a);
+#elif WN_SELFWAVE
 	wino_conv_kernel_sw<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
 #else
 	wino_conv_kernel<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
@@ -1020,7 +1521,11 @@ int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float 
 	a.TY = p.TY, a.TX4 = p.TX4, a.chunks = p.chunks, a.splits = p.splits, a.kblocks = p.kblocks, a.cblocks = p.cblocks;
 	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 	a.dy_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
+#if WN_WAVES == 8
+	wino_wgrad_kernel8<<<p.splits * nblk, 512, 0, st>>>(a);
+#else
 	wino_wgrad_kernel<<<p.splits * nblk, 256, 0, st>>>(a);
+#endif
 	PZ_LAUNCH_CHECK();
 
 	const size_t block_elems = (size_t)nblk * kSlab;
