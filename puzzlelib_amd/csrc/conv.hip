@@ -39,6 +39,9 @@
 #ifndef PZ_WG_RUNS
 #define PZ_WG_RUNS 8              // 4-pixel runs per backward-filter k-step: 8 (32 pixels, 2 workgroups/CU) or 4 (16 pixels, 4/CU)
 #endif
+#ifndef PZ_WG_WAVES
+#define PZ_WG_WAVES 4             // waves per backward-filter workgroup: 4, or 8 for tiles of >= 8 MFMA tiles (measured equal, +-2 %)
+#endif
 #ifndef PZ_TAIL_MIN_GAIN
 #define PZ_TAIL_MIN_GAIN 24
 #endif
@@ -641,13 +644,18 @@ struct WgradArgs {
 // GATHER: 0 = any stride (element-wise x gathers), 1 = unit stride along w (16-byte x runs with edge masks),
 //         2 = pointwise 1x1 / stride 1 / pad 0 (16-byte runs, only the row tail is masked: no per-tap address or
 //             mask arithmetic — VALU instructions serialise with the MFMAs, see tools/probes/lds_mfma.hip)
+// WM x WN = 4 or 8 waves. With 8 (PZ_WG_WAVES=8, tiles of at least 8 MFMA tiles) a wave owns half as many accumulators
+// and gathers half as many runs, so two workgroups per CU (the LDS limit) put 4 waves on every SIMD instead of 2 — what
+// gave the Winograd kernels 6-11 % changes nothing here (every census layer within +-2 %), so 4 stays the default.
 template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false>
-__global__ void __launch_bounds__(256, RUNS == 8 ? 2 : 4) wgrad_conv_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(RUNS == 8 ? WM * WN / 2 : 4, 8)))
+wgrad_conv_kernel(WgradArgs a) {
 	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
-	constexpr int RP = 256 / RUNS;               // tile rows loaded per pass (one 16-byte run per thread)
+	constexpr int NT = 64 * WM * WN;
+	constexpr int RP = NT / RUNS;                // tile rows loaded per pass (one 16-byte run per thread)
 	static_assert(RUNS % 2 == 0, "runs are consumed in pairs (one per lane half)");
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-	static_assert(WM * WN == 4, "4 waves per workgroup");
+	static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 waves per workgroup");
 
 	// double buffered (one barrier per k-step). A run is one 16-byte cell [run pair][run of the pair][row]: parked with one
 	// ds_write_b128, and the fragment of lane (row, half h) is the whole cell of run 2g+h = four k2-steps per ds_read_b128.
@@ -1661,16 +1669,22 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	const bool unit_w = d->stride_w == 1;
 	const bool pointwise = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && unit_w;
-#define PZ_WGRAD_LAUNCH(BM_, BN_) \
-	(a.bnx     ? (pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS, true><<<grid, 256, 0, st>>>(a) \
-	                        : wgrad_conv_kernel<BM_, BN_, 2, 2, 0, PZ_WG_RUNS, true><<<grid, 256, 0, st>>>(a)) \
-	 : pointwise ? wgrad_conv_kernel<BM_, BN_, 2, 2, 2, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
-	 : unit_w  ? wgrad_conv_kernel<BM_, BN_, 2, 2, 1, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a) \
-	           : wgrad_conv_kernel<BM_, BN_, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a))
-	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128);
-	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64);
-	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128);
-	else PZ_WGRAD_LAUNCH(64, 64);
+#define PZ_WGRAD_LAUNCH(BM_, BN_, WM_, WN_) \
+	(a.bnx     ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	                        : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a)) \
+	 : pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	 : unit_w  ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 1, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	           : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a))
+#if PZ_WG_WAVES == 8
+	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128, 2, 4);
+	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64, 4, 2);
+	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128, 2, 4);
+#else
+	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128, 2, 2);
+	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64, 2, 2);
+	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128, 2, 2);
+#endif
+	else PZ_WGRAD_LAUNCH(64, 64, 2, 2);
 #undef PZ_WGRAD_LAUNCH
 	}
 	PZ_LAUNCH_CHECK();
