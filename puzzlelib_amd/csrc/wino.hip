@@ -602,12 +602,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #if !(WN_ABL & 2)
 						store_slice(role, half, fixed, wr, s2 * 4 + p * 2 + m);
 #endif
+#if !(WN_ABL & 1)
+						// the patch rows are consumed by slice 5, the filter registers by the last slice
+						if (s2 * 4 + p * 2 + m == (decltype(role)::value == 0 ? 5 : 7)) issue_loads(role, min(ch + 3, a.chunks - 1));
+#endif
 						__builtin_amdgcn_sched_barrier(0);
 					}
-#if !(WN_ABL & 1)
-			issue_loads(role, min(ch + 3, a.chunks - 1));
-#endif
-			__builtin_amdgcn_sched_barrier(0);
 			__syncthreads();
 			s_cur = s_nxt;
 		};
@@ -1131,8 +1131,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 	const int nch = g1 - g0;
 
 	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
-	const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, 0, 0x00020000);
 
 	const int pw = wave & 3, hf = pw & 1, t4 = lane & 3;
 	const int cl = (lane >> 2) + 16 * (pw >> 1), c = cb * CB + cl;
@@ -1151,20 +1149,38 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 	const unsigned vdst = (unsigned)(((t4 >> 1) * CB + cl) * 2 + (t4 & 1)) + (unsigned)(hf * 8) * (2 * CB * 2);
 	const unsigned zdst = (unsigned)kVFloats + (unsigned)(((t4 >> 1) * KB + kl) * 2 + (t4 & 1));
 
+	// chunk g -> (image, tile row, chunk in row) and the element offsets of its first patch row / gradient row, all kept
+	// in scalar registers and advanced by additions (the scalar unit is shared by the CU's 16 waves: recomputing the
+	// offsets with 64-bit multiplies per chunk saturated it)
 	struct Geo {
 		int n, ty, j;
+		int row0;        // first patch row this wave loads: 2 ty - pad + hf
+		int xo, zo;      // element offset of x(n, 0, row0, 8 j - pad) (negative only in front of the tensor) / dy(n, 0, 2 ty, 8 j)
 	};
+	const int x_img = a.C * a.H * a.W, z_img = a.K * a.P * a.Q;
 	auto geo_of = [&](int g) {
 		Geo q;
 		q.j = g % a.TX4;
 		const int r = g / a.TX4;
 		q.ty = r % a.TY, q.n = r / a.TY;
+		q.row0 = 2 * q.ty - a.pad + hf;
+		q.xo = q.n * x_img + q.row0 * a.W + 8 * q.j - a.pad;
+		q.zo = q.n * z_img + 2 * q.ty * a.Q + 8 * q.j;
 		return q;
 	};
 	auto advance = [&](Geo &q) {
 		if (++q.j == a.TX4) {
 			q.j = 0;
-			if (++q.ty == a.TY) q.ty = 0, ++q.n;
+			if (++q.ty == a.TY) {
+				q.ty = 0, ++q.n;
+				q.row0 = hf - a.pad;
+				q.xo = q.n * x_img + q.row0 * a.W - a.pad, q.zo = q.n * z_img;
+			} else {
+				q.row0 += 2;
+				q.xo += 2 * a.W - 8 * (a.TX4 - 1), q.zo += 2 * a.Q - 8 * (a.TX4 - 1);
+			}
+		} else {
+			q.xo += 8, q.zo += 8;
 		}
 	};
 
@@ -1174,42 +1190,44 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		bool first, last, fixrow;
 	};
 
-	auto issue_loads = [&](auto role, const Geo &q, Pend &pd) {
+	// `head`: the launch's very first chunk (image 0, tile row 0, chunk 0) can start in front of the tensor; only the
+	// prologue ever loads it, so the steady-state loop carries neither that test nor the shift of the affected lane
+	auto issue_loads = [&](auto role, auto head, const Geo &q, Pend &pd) {
 		pd.first = q.j == 0, pd.last = q.j == jl, pd.fixrow = false;
 		if constexpr (decltype(role)::value == 0) {
 #pragma unroll
 			for (int e = 0; e < 3; ++e) {
-				const int row = 2 * q.ty - a.pad + hf + e;
-				const bool ok = (unsigned)row < (unsigned)a.H;
-				const long off = (((long)q.n * a.C) * a.H + row) * a.W + 8 * q.j - a.pad;
-				if (ok && off < 0) {
+				const bool ok = (unsigned)(q.row0 + e) < (unsigned)a.H;
+				const int off = q.xo + e * a.W;
+				if (decltype(head)::value && ok && off < 0) {
 					pd.fixrow = true;
 					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voffx_first, 0, 0));
 				} else {
-					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ok ? xr : nullr, voffx, ok ? (unsigned)off * 4u : 0u, 0));
+					// a row outside the image reads through a zero-length descriptor (one scalar select of its size word)
+					const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, ok ? a.x_bytes : 0u, 0x00020000);
+					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffx, ok ? (unsigned)off * 4u : 0u, 0));
 				}
 			}
 		} else {
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
-				const int row = 2 * q.ty + r;
-				const bool ok = row < a.P;
-				const long off = (((long)q.n * a.K) * a.P + row) * a.Q + 8 * q.j;
-				sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ok ? zr : nullr, voffz, ok ? (unsigned)off * 4u : 0u, 0));
+				const bool ok = 2 * q.ty + r < a.P;
+				const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, ok ? a.dy_bytes : 0u, 0x00020000);
+				sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voffz, ok ? (unsigned)(q.zo + r * a.Q) * 4u : 0u, 0));
 			}
 		}
 	};
 
 	// slice s rides behind MFMA s of the chunk; the staged registers are first needed behind the third MFMA
 	f32x2 tA[2], tB[2], zr1, zr2;
-	auto store_slice = [&](auto role, auto half, float *stg, const Pend &pd, int slice) {
+	auto store_slice = [&](auto role, auto half, auto head, float *stg, const Pend &pd, int slice) {
 		constexpr int HF = decltype(half)::value;
 		const unsigned long long all = ~0ull;
 		const int w = slice - 2;
 		if (w < 0) return;
 		if constexpr (decltype(role)::value == 0) {
 			if (w == 0) {
-				if (pd.fixrow) {
+				if (decltype(head)::value && pd.fixrow) {
 					const int e = a.pad - HF;
 					if (voffx == 0 && e >= 0 && e < 3) sp[e] = f32x4{0.f, sp[e][0], sp[e][1], sp[e][2]};
 				}
@@ -1290,17 +1308,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		Frag f0, f1;
 		Geo q = geo_of(g0);
 		Pend pd;
-		issue_loads(role, q, pd);
+		issue_loads(role, std::true_type{}, q, pd);
 #pragma unroll
-		for (int sl = 0; sl < 8; ++sl) store_slice(role, half, smem, pd, sl);
+		for (int sl = 0; sl < 8; ++sl) store_slice(role, half, std::true_type{}, smem, pd, sl);
 		if (nch > 1) {
 			advance(q);
-			issue_loads(role, q, pd);
+			issue_loads(role, std::false_type{}, q, pd);
 #pragma unroll
-			for (int sl = 0; sl < 8; ++sl) store_slice(role, half, smem + kStage, pd, sl);
+			for (int sl = 0; sl < 8; ++sl) store_slice(role, half, std::false_type{}, smem + kStage, pd, sl);
 		}
 		int issued = nch > 1 ? 2 : 1;
-		if (nch > 2) advance(q), issue_loads(role, q, pd), ++issued;
+		if (nch > 2) advance(q), issue_loads(role, std::false_type{}, q, pd), ++issued;
 		__syncthreads();
 		read_frags(smem, f0);
 
@@ -1317,12 +1335,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
 					for (int m = 0; m < 2; ++m) {
 						acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[p][m][s2], cur.bv[p][s2], acc[p][m], 0, 0, 0);
-						store_slice(role, half, wr, pc, s2 * 4 + p * 2 + m);
+						store_slice(role, half, std::false_type{}, wr, pc, s2 * 4 + p * 2 + m);
+						// the patch rows are consumed by slice 5 (the gradient rows by the last one): their next loads go out
+						// two MFMAs earlier. Past the last chunk: the same chunk again, parked in a stage nobody reads any
+						// more (were it the launch's first chunk, its row in front of the tensor would read as zeros — unused)
+						if (s2 * 4 + p * 2 + m == (decltype(role)::value == 0 ? 5 : 7)) {
+							if (issued < nch) advance(q), ++issued;
+							issue_loads(role, std::false_type{}, q, pd);
+						}
 						__builtin_amdgcn_sched_barrier(0);
 					}
-			if (issued < nch) advance(q), ++issued;
-			issue_loads(role, q, pd);
-			__builtin_amdgcn_sched_barrier(0);
 			__syncthreads();
 			s_cur = s_nxt;
 		};
