@@ -1156,8 +1156,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		int n, ty, j;
 		int row0;        // first patch row this wave loads: 2 ty - pad + hf
 		int xo, zo;      // element offset of x(n, 0, row0, 8 j - pad) (negative only in front of the tensor) / dy(n, 0, 2 ty, 8 j)
+		unsigned xsz[3], zsz[2];     // descriptor size word of each row load: the tensor's bytes, or 0 for a row outside the map
 	};
 	const int x_img = a.C * a.H * a.W, z_img = a.K * a.P * a.Q;
+	auto set_rows = [&](Geo &q) {              // per tile row, not per chunk
+#pragma unroll
+		for (int e = 0; e < 3; ++e) q.xsz[e] = (unsigned)(q.row0 + e) < (unsigned)a.H ? a.x_bytes : 0u;
+#pragma unroll
+		for (int r = 0; r < 2; ++r) q.zsz[r] = 2 * q.ty + r < a.P ? a.dy_bytes : 0u;
+	};
 	auto geo_of = [&](int g) {
 		Geo q;
 		q.j = g % a.TX4;
@@ -1166,6 +1173,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		q.row0 = 2 * q.ty - a.pad + hf;
 		q.xo = q.n * x_img + q.row0 * a.W + 8 * q.j - a.pad;
 		q.zo = q.n * z_img + 2 * q.ty * a.Q + 8 * q.j;
+		set_rows(q);
 		return q;
 	};
 	auto advance = [&](Geo &q) {
@@ -1179,6 +1187,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 				q.row0 += 2;
 				q.xo += 2 * a.W - 8 * (a.TX4 - 1), q.zo += 2 * a.Q - 8 * (a.TX4 - 1);
 			}
+			set_rows(q);
 		} else {
 			q.xo += 8, q.zo += 8;
 		}
@@ -1197,23 +1206,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		if constexpr (decltype(role)::value == 0) {
 #pragma unroll
 			for (int e = 0; e < 3; ++e) {
-				const bool ok = (unsigned)(q.row0 + e) < (unsigned)a.H;
+				const bool ok = q.xsz[e] != 0u;
 				const int off = q.xo + e * a.W;
 				if (decltype(head)::value && ok && off < 0) {
 					pd.fixrow = true;
 					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voffx_first, 0, 0));
 				} else {
 					// a row outside the image reads through a zero-length descriptor (one scalar select of its size word)
-					const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, ok ? a.x_bytes : 0u, 0x00020000);
-					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffx, ok ? (unsigned)off * 4u : 0u, 0));
+					// (the scalar offset of a row outside the image is never used: zero records fail the range check first)
+					const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, q.xsz[e], 0x00020000);
+					sp[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffx, (unsigned)off * 4u, 0));
 				}
 			}
 		} else {
 #pragma unroll
 			for (int r = 0; r < 2; ++r) {
-				const bool ok = 2 * q.ty + r < a.P;
-				const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, ok ? a.dy_bytes : 0u, 0x00020000);
-				sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voffz, ok ? (unsigned)(q.zo + r * a.Q) * 4u : 0u, 0));
+				const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, q.zsz[r], 0x00020000);
+				sz[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voffz, (unsigned)(q.zo + r * a.Q) * 4u, 0));
 			}
 		}
 	};
@@ -1322,11 +1331,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 		__syncthreads();
 		read_frags(smem, f0);
 
-		int s_cur = 0;
+		int o_cur = 0, o_nxt = kStage, o_wr = 2 * kStage;      // float offsets of the three stages, rotated by renaming
 		auto body = [&](Frag &cur, Frag &nxt) {
-			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
-			read_frags(smem + s_nxt * kStage, nxt);
-			float *wr = smem + s_wr * kStage;
+			read_frags(smem + o_nxt, nxt);
+			float *wr = smem + o_wr;
 			const Pend pc = pd;
 #pragma unroll
 			for (int s2 = 0; s2 < 2; ++s2)
@@ -1346,7 +1354,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 						__builtin_amdgcn_sched_barrier(0);
 					}
 			__syncthreads();
-			s_cur = s_nxt;
+			const int t = o_cur;
+			o_cur = o_nxt, o_nxt = o_wr, o_wr = t;
 		};
 
 		int ch = 0;
