@@ -39,6 +39,10 @@
 #ifndef PZ_WG_RUNS
 #define PZ_WG_RUNS 8              // 4-pixel runs per backward-filter k-step: 8 (32 pixels, 2 workgroups/CU) or 4 (16 pixels, 4/CU)
 #endif
+#ifndef PZ_IG_TALL
+#define PZ_IG_TALL 0              // 1: 256x128 implicit-GEMM tiles on 8 waves for layers with a multiple of 256 output rows
+                                  // (half the pixel gathers per MFMA; measured 3-12 % slower on every such 1x1 layer)
+#endif
 #ifndef PZ_WG_WAVES
 #define PZ_WG_WAVES 4             // waves per backward-filter workgroup: 4, or 8 for tiles of >= 8 MFMA tiles (measured equal, +-2 %)
 #endif
@@ -339,15 +343,18 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 	}
 }
 
+// 4 waves (128x128, 64x256 tiles; 4 workgroups per CU) or 8 waves (256x128 tiles for >= 256 output rows: the gathered pixel
+// panel serves twice as many rows, half the gathers per MFMA; 2 workgroups per CU = the same 4 waves per SIMD)
 template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false>
-__global__ void __launch_bounds__(256, BNX ? 3 : PZ_LB) igemm_conv_kernel(IgemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(BNX && WM * WN == 4 ? 3 : 4, 8)))
+igemm_conv_kernel(IgemmArgs a) {
 	static_assert(!BNX || TAPMAJOR, "the BatchNorm-backward gather rides on the tap-major order");
-	constexpr int BK = 16, NT = 256;
+	constexpr int BK = 16, NT = 64 * WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+	static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 waves per workgroup");
 
 	// one LDS block: operand tiles during the k loop, per-wave transposition scratch in the epilogue
-	static_assert(2 * BK * (BM + BN) >= 4 * kEpiFloatsPerWave, "epilogue scratch does not fit the operand tiles");
+	static_assert(2 * BK * (BM + BN) >= WM * WN * kEpiFloatsPerWave, "epilogue scratch does not fit the operand tiles");
 	__shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
 	float(*As)[BK][BM] = reinterpret_cast<float(*)[BK][BM]>(smem);
 	float(*Bs)[BK][BN] = reinterpret_cast<float(*)[BK][BN]>(smem + 2 * BK * BM);
@@ -452,12 +459,14 @@ __global__ void __launch_bounds__(256, BNX ? 3 : PZ_LB) igemm_conv_kernel(IgemmA
 	};
 
 	auto load_part = [&](int kt, int j) {
-		constexpr int PER = NB / (BK / 2);          // gathers per k2-step
+		constexpr int PER = NB >= BK / 2 ? NB / (BK / 2) : 1;          // gathers per k2-step (NB < 8: one every (BK/2)/NB steps)
+		constexpr int EVERY = NB >= BK / 2 ? 1 : (BK / 2) / NB;
 		if (j < NA)
 			ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[j], (unsigned)(kt * BK * a.mpad) * 4u, 0));
+		if (j % EVERY != 0) return;
 #pragma unroll
 		for (int t = 0; t < PER; ++t) {
-			const int i = j * PER + t;
+			const int i = (j / EVERY) * PER + t;
 			if constexpr (TAPMAJOR) {
 				rb[i] = buf_load_f32(xr, voff_tile, soff_tile + (unsigned)i * hw4);
 				if constexpr (BNX) rb2[i] = buf_load_f32(x2r, voff_tile, soff_tile + (unsigned)i * hw4);
@@ -572,8 +581,8 @@ __global__ void __launch_bounds__(256, BNX ? 3 : PZ_LB) igemm_conv_kernel(IgemmA
 
 // sums the k-slices of one tail tile (fixed order) and writes it out like a whole tile
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) igemm_tail_reduce_kernel(IgemmArgs a) {
-	constexpr int NT = 256, TM = BM / WM / 32, TN = BN / WN / 32;
+__global__ void __launch_bounds__(64 * WM * WN) igemm_tail_reduce_kernel(IgemmArgs a) {
+	constexpr int NT = 64 * WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int wm = wave / WN, wn = wave % WN;
@@ -602,7 +611,7 @@ __global__ void __launch_bounds__(256) igemm_tail_reduce_kernel(IgemmArgs a) {
 	}
 
 	if (a.contig) {
-		__shared__ __attribute__((aligned(16))) float smem[4 * kEpiFloatsPerWave];
+		__shared__ __attribute__((aligned(16))) float smem[WM * WN * kEpiFloatsPerWave];
 		igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, smem);
 	} else {
 		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
@@ -1137,6 +1146,10 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
 	const bool narrow = M <= 64 || pz::ceil_div(M, 64) * 64 < pz::ceil_div(M, 128) * 128;
 	p.bm = narrow ? 64 : 128;
 	p.bn = narrow ? 256 : 128;
+#if PZ_IG_TALL
+	// 256 x 128 tiles (8 waves) when the row axis fills them: half the pixel gathers per MFMA
+	if (!narrow && M >= 256 && M % 256 == 0) p.bm = 256;
+#endif
 	p.tiles_m = pz::ceil_div(M, p.bm);
 	p.tiles_n = pz::ceil_div(npix, p.bn);
 	p.mpad = p.tiles_m * p.bm;
@@ -1197,20 +1210,22 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 		// FLOP are its work — the slab reduce of a k-sliced last round only adds
 		ProfScope prof(st, BM == 64 ? 1 : 0, flops);
 		if (a.x2)
-			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else if (a.tapmajor)
-			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else
-			igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 256, lds_pad, st>>>(a);
+			igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 	}
 	if (p.tail_splits > 1)
-		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 256, 0, st>>>(a);
+		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 64 * WM * WN, 0, st>>>(a);
 }
 
 void run_igemm(const FwdPlan &p, IgemmArgs a, float *slabs, int groups, hipStream_t st, double flops) {
 	a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
 	a.full_tiles = p.full_tiles, a.tail_splits = p.tail_splits, a.slabs = slabs;
-	if (p.bm == 64)
+	if (p.bm == 256)
+		launch_igemm<256, 128, 4, 2>(p, a, groups, st, flops);
+	else if (p.bm == 64)
 		launch_igemm<64, 256, 1, 4>(p, a, groups, st, flops);
 	else
 		launch_igemm<128, 128, 2, 2>(p, a, groups, st, flops);
