@@ -21,10 +21,12 @@ constexpr int kNumCU = 256;
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
-// grid for bandwidth kernels: enough workgroups to fill 256 CUs several times over, grid-stride the rest
+// grid for bandwidth kernels: one workgroup per `per_block` items, dispatched in address order — the chip then sweeps
+// the operands as one moving window (6.3 TB/s in tools/probes/stream_bw.hip; the same accesses as a grid-stride loop of
+// a few thousand workgroups reach 4.6-5.2). The kernels keep their grid-stride loops for the (huge) remainder beyond the cap.
 inline int stream_grid(size_t work_items, int per_block) {
 	size_t blocks = (work_items + per_block - 1) / per_block;
-	size_t cap = (size_t)kNumCU * 8;
+	size_t cap = (size_t)1 << 22;
 	return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
