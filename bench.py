@@ -1,17 +1,27 @@
 """
 bench.py — ResNet-50 (the reference's variant, Models/Nets/ResNet.py:69-121) training step on synthetic ImageNet-shaped
 fp32 data, batch 256 per GPU: forward + cross-entropy + zero-grad + backward + Adam (Handlers/Trainer.py:28-35), data
-already resident in HBM. One process per GPU; for N > 1 launch with
+already resident in HBM. One process per GPU: `python bench.py --gpus N` starts its N ranks itself; under
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
-(weak scaling: 256 images per GPU, gradients mean-all-reduced over RCCL, overlapped with backward).
+it is one of the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment). Weak scaling: 256 images per
+GPU, gradients mean-all-reduced over RCCL, bucketed and overlapped with backward.
+
+What is timed is the DROP-IN path: the executor (puzzlelib_amd/engine.py + optim.py) sends the backend exactly the call
+sequence the reference's own Modules / Containers / Optimizer / Trainer send — tests/golden/trace_resnet50_b8.json was
+recorded from the reference's Python on this backend and tests/test_host_logic.py holds the executor to it — every
+wrapper with the reference's signature, conv1's (unused) input gradient included as the reference computes it. All
+fusion happens behind those calls (puzzlelib_amd/lazy.py).
 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   roofline      dominant kernel family (fp32 MFMA implicit-GEMM convolution): algorithmic FLOP / measured launch time
-                (HIP events around every launch of the timed region, recorded on the launch stream) vs 157.3 TFLOP/s
+                (HIP events around every launch, recorded on the launch stream) vs 157.3 TFLOP/s
   cpu_baseline  the numpy oracle (a restatement of the reference's CPU algorithm, extended with backward) timed on this
                 host's cores on a bounded sample (rank 0, N == 1 only)
+  dropin        the same step with the backend's lazy fusion switched off (one kernel per call, what a literal backend
+                does with this call sequence) and with the harness allowed to skip conv1's input gradient
+  configs       config 2 (Conv2D 3x3 64->128 56x56 b128, three passes, both kernel families) and config 3 (NiN b128 step)
 """
-import argparse, json, os, sys, time
+import argparse, json, os, subprocess, sys, time
 
 import numpy as np
 
@@ -20,6 +30,8 @@ sys.path.insert(0, ROOT)
 
 BATCH = 256
 FLOP_PER_IMAGE = 22.770e9        # fwd + dgrad + wgrad, conv1 dgrad excluded; reported, not used for `value`
+FLOP_CONV1_DGRAD = 0.236e9       # per image; executed on the drop-in path, not counted as algorithmic work
+WINO_FLOP_PER_IMAGE = 3 * 3.67482e9             # direct-convolution FLOP of the 16 3x3 stride-1 layers, three passes
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FAMILY = ["igemm_conv_kernel<128,128> (fwd + bwd-data)", "igemm_conv_kernel<64,256> (fwd + bwd-data)",
 		  "wgrad_conv_kernel (bwd-filter)", "wino_conv_kernel / wino_wgrad_kernel F(2x2,3x3) (all three passes of the 3x3 layers)"]
@@ -74,6 +86,81 @@ def cpu_baseline(sample_batch=32):
 	}
 
 
+def spawnRanks(args):
+	"""`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
+	import socket
+	with socket.socket() as s:
+		s.bind(("127.0.0.1", 0))
+		port = s.getsockname()[1]
+
+	procs = []
+	for rank in range(args.gpus):
+		env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+				   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+	codes = [p.wait() for p in procs]
+	sys.exit(max(codes))
+
+
+def timeSteps(step, n, lib, grid):
+	lib.pz_device_sync()
+	grid.barrier()
+	t0 = time.perf_counter()
+	for _ in range(n):
+		step()
+	lib.pz_device_sync()
+	grid.barrier()
+	return grid.maxOverRanks(time.perf_counter() - t0)
+
+
+def sideConfigs(gpuarray, lib, optim, nets, bnd):
+	"""configs 2 and 3 of BASELINE.json as extra keys (parity for both lives in tests/; these are timings only)"""
+	out = {}
+	dnn = bnd.dnn
+	x = gpuarray.to_gpu(np.random.randn(128, 64, 56, 56).astype(np.float32))
+	W = gpuarray.to_gpu((np.random.randn(128, 64, 3, 3) * 0.05).astype(np.float32))
+	dy = gpuarray.to_gpu(np.random.randn(128, 128, 56, 56).astype(np.float32))
+	flop = 2.0 * 128 * 128 * 56 * 56 * 64 * 9
+	c2 = {}
+	for label, algo in (("implicit_gemm", bnd.ConvFwdAlgo.implicitGemm.value), ("winograd_auto", bnd.ConvFwdAlgo.auto.value)):
+		row = {}
+		for name, fn in (
+			("fwd", lambda: dnn.convNd(x, W, None, 1, 1, 1, 1, algo, None, bnd.memoryPool)),
+			("bwd_data", lambda: dnn.convNdBackwardData(dy, W, None, x, 1, 1, 1, 0, 1, algo, None, bnd.memoryPool).rptr),
+			("bwd_filter", lambda: dnn.convNdBackwardParams(x, dy, W, 1, 1, 1, 1, False, False, None, None, 1.0, 0.0, algo,
+															 bnd.memoryPool).rptr),
+		):
+			secs, _ = bnd.timeKernel(fn, (), looplength=10, log=False, normalize=True)
+			row[name + "_ms"] = secs * 1e3
+			row[name + "_tflops_direct_equiv"] = flop / secs / 1e12
+		c2[label] = row
+	out["config2_conv3x3_64to128_56x56_b128"] = c2
+
+	np.random.seed(1234)
+	net = nets.buildNiN()
+	opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9)
+	opt.setupOn(net, useGlobalState=True)
+	opt.addHook(optim.WeightDecay(1e-4))
+	trainer = optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=128)
+	data = gpuarray.to_gpu(np.random.randn(128, 3, 32, 32).astype(np.float32))
+	labels = gpuarray.to_gpu(np.random.randint(0, 10, size=(128, )).astype(np.int32))
+	net.trainMode()
+
+	def step():
+		trainer.step([data, labels])
+		net.reset()
+	for _ in range(5):
+		step()
+	lib.pz_device_sync()
+	t0 = time.perf_counter()
+	for _ in range(30):
+		step()
+	lib.pz_device_sync()
+	ms = (time.perf_counter() - t0) / 30 * 1e3
+	out["config3_nin_cifar10_b128"] = {"ms_per_step": ms, "images_per_sec": 128 / ms * 1e3}
+	return out
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -81,12 +168,16 @@ def main():
 	ap.add_argument("--warmup", type=int, default=3)
 	ap.add_argument("--batch", type=int, default=BATCH, help=argparse.SUPPRESS)
 	ap.add_argument("--no-cpu-baseline", action="store_true")
+	ap.add_argument("--no-extras", action="store_true", help="skip the dropin / config 2 / config 3 side measurements")
 	args = ap.parse_args()
+
+	if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+		spawnRanks(args)
 
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	rank = int(os.environ.get("RANK", "0"))
 	local = int(os.environ.get("PUZZLE_MI355_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-	assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+	assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
 	from puzzlelib_amd.settings import Config
 	from puzzlelib_amd import grid
@@ -101,32 +192,32 @@ def main():
 	Config.logger = log
 	nodeinfo = grid.nodeFromEnv()
 
-	from puzzlelib_amd import nets, train, lib, backend
+	from puzzlelib_amd import nets, optim, lib, lazy, engine
 	from puzzlelib_amd.surface import bound
 	import ctypes
 
-	gpuarray = bound().gpuarray
+	surf = bound()
+	gpuarray, bnd = surf.gpuarray, surf.backend
 
 	np.random.seed(1234)                        # identical seeds -> identical initial parameters on every rank
-	# actInplace=True is the reference's own flag (Models/Nets/ResNet.py:63): ReLUs overwrite their input, which lets
-	# this backend fold them into the neighbouring BatchNorm / Add / Replicate kernels (bit-identical results)
+	# actInplace=True is the reference's own flag (Models/Nets/ResNet.py:63): ReLUs overwrite their input
 	net = nets.loadResNet(None, "50", actInplace=True, initscheme="he")
 
 	rng = np.random.RandomState(1234 + rank)    # each rank trains on its own shard of the global mini-batch
 	data = gpuarray.to_gpu(rng.randn(args.batch, 3, 224, 224).astype(np.float32))
 	labels = gpuarray.to_gpu(rng.randint(0, 1000, size=(args.batch, )).astype(np.int32))
 
-	optimizer = train.Adam(alpha=1e-3, nodeinfo=nodeinfo)
+	optimizer = optim.Adam(alpha=1e-3, nodeinfo=nodeinfo)
 	optimizer.setupOn(net, useGlobalState=True)
 	if nodeinfo is not None:
 		grid.enableOverlap(optimizer, nodeinfo)
 
-	cost = train.CrossEntropy()
-	trainer = train.Trainer(net, cost, optimizer, batchsize=args.batch)
+	cost = optim.CrossEntropy()
+	trainer = optim.Trainer(net, cost, optimizer, batchsize=args.batch)
 	net.trainMode()
 
 	def step():
-		trainer.handleBatch([data, labels], 0, None)
+		trainer.step([data, labels])
 		net.reset()
 
 	for _ in range(args.warmup):
@@ -152,23 +243,55 @@ def main():
 
 	elapsed = grid.maxOverRanks(elapsed)
 	loss = float(cost.getMeanError())
+	fusion_counts = dict(lazy.counters)
 
 	# Kernel roofline. In the timed region the filter-gradient launches of every layer run on a second stream next to the
-	# backward-data chain (DnnContext.overlapFilterGrad): the step gets shorter, but two kernels then share the CUs and a
-	# launch's event-to-event time contains its neighbour's work. A kernel's own rate is therefore taken from ROOF_STEPS
-	# more steps of the same loop with that overlap switched off (same kernels, same launches, one at a time); the
-	# timed-region figures are reported next to it.
-	concurrent = backend.DnnContext.overlapFilterGrad
+	# backward-data chain: the step gets shorter, but two kernels then share the CUs and a launch's event-to-event time
+	# contains its neighbour's work. A kernel's own rate is therefore taken from ROOF_STEPS more steps of the same loop
+	# with that stream off (same kernels, same launches, one at a time); the timed-region figures are reported next to it.
+	concurrent = lazy.on("sidestream")
 	if concurrent:
-		backend.DnnContext.overlapFilterGrad = False
+		lazy.disabled.add("sidestream")
+		step()
 		lib.pz_conv_profile_enable(1)
 		for _ in range(ROOF_STEPS):
 			step()
 		lib.pz_device_sync()
 		lib.pz_conv_profile_enable(0)
 		lib.pz_conv_profile_collect(ms, flops, launches)
-		backend.DnnContext.overlapFilterGrad = True
+		lazy.disabled.discard("sidestream")
 	roof_steps = ROOF_STEPS if concurrent else args.steps
+
+	# the same call sequence on a literal backend (no lazy fusion: every call launches its own kernel(s)), and the
+	# executor's one permitted deviation (conv1's input gradient, which nobody reads, left out)
+	dropin = None
+	if not args.no_extras:
+		n = max(3, min(args.steps, 5))
+		engine.Net.skipInputGrad = True
+		step()
+		t_skip = timeSteps(step, n, lib, grid) / n
+		engine.Net.skipInputGrad = False
+		lazy.enabled = False
+		step()
+		t_literal = timeSteps(step, n, lib, grid) / n
+		lazy.enabled = True
+		step()
+		dropin = {
+			"caller": "reference-literal call sequence through wrappers with the reference's signatures only "
+					  "(tests/golden/trace_resnet50_b8.json, recorded from the reference's own Python on this backend)",
+			"images_per_sec": world * args.batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+			"note": "this IS `value`: there is no patched caller any more; fusion is decided inside the backend",
+			"lazy_fusion_off": {"images_per_sec": world * args.batch / t_literal, "ms_per_step": t_literal * 1e3,
+								"what": "PUZZLE_MI355_LAZY=0: one kernel (or two) per reference call, nothing deferred"},
+			"harness_skips_conv1_input_grad": {"images_per_sec": world * args.batch / t_skip, "ms_per_step": t_skip * 1e3,
+											   "what": "engine.Net.skipInputGrad=True: updGrad=False honoured (the reference "
+													   "means to, Containers/Sequential.py:215-218 is unreachable)"},
+		}
+
+	extras = None
+	if rank == 0 and world == 1 and not args.no_extras and args.batch == BATCH:
+		net.reset()
+		extras = sideConfigs(gpuarray, lib, optim, nets, bnd)
 
 	if rank != 0:
 		return
@@ -194,19 +317,29 @@ def main():
 
 	# HBM bytes per launch of the dominant kernel family: memory-side L2 counters of the same command, collected with
 	# rocprofv3 --pmc in separate passes and corrected as MI355X_MICROARCH.md prescribes (tools/pmc_bench.sh ->
-	# profiles/r01_hbm_traffic.json). PMC collection cannot run inside the timed process, hence the committed summary.
-	traffic, traffic_note = None, None
+	# profiles/*_hbm_traffic.json). PMC collection cannot run inside the timed process; the summary is only used when it was
+	# taken from a library built from the very sources loaded now (build id recorded in the summary), else null.
+	traffic, traffic_note = None, "no PMC summary for build %s under profiles/" % lib.buildId()
 	try:
-		prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-		key = ["igemm_conv_kernel<128, 128", "igemm_conv_kernel<64, 256", "wgrad_conv_kernel<", "wino_"][dom]
-		rows = [v for k, v in prof["kernels"].items() if key in k]
-		n = sum(v["dispatches"] for v in rows)
-		if n > 0 and args.batch == BATCH:
-			traffic = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in rows) / n
-			traffic_note = "bytes per launch, mean over %d profiled launches; %s" % (n, prof["calibration"]["note"])
+		import glob
+		for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")), reverse=True):
+			prof = json.load(open(path))
+			if prof.get("build_id") != lib.buildId() or args.batch != BATCH:
+				continue
+			key = ["igemm_conv_kernel<128, 128", "igemm_conv_kernel<64, 256", "wgrad_conv_kernel<", "wino_"][dom]
+			rows = [v for k, v in prof["kernels"].items() if key in k]
+			n = sum(v["dispatches"] for v in rows)
+			if n > 0:
+				traffic = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in rows) / n
+				traffic_note = "bytes per launch, mean over %d profiled launches (%s); %s" % (
+					n, os.path.basename(path), prof["calibration"]["note"]
+				)
+				break
 	except (OSError, KeyError, ValueError):
 		pass
 
+	per_gpu = images_per_sec / world
+	executed = (FLOP_PER_IMAGE - WINO_FLOP_PER_IMAGE * (1.0 - 1.0 / 2.25) + FLOP_CONV1_DGRAD) * per_gpu / 1e12
 	result = {
 		"metric": "images/sec fwd+bwd+Adam ResNet-50 224x224 fp32 b256 per GPU", "value": images_per_sec,
 		"unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,31 +347,41 @@ def main():
 		"dtype": "f32", "data": "synthetic",
 		"config": {
 			"workload": "ResNet-50 (PuzzleLib variant, 55x55 stage 2) synthetic ImageNet 224x224 fp32, batch %d per GPU, "
-						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True)" % args.batch,
+						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True), reference-literal "
+						"call sequence (conv1 input gradient computed as the reference does)" % args.batch,
 			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
 			"grad_allreduce": "none" if world == 1 else (
-				"RCCL sum + 1/N, 25 MB buckets overlapped with backward" if nodeinfo.transport == "rccl" else
-				"FALLBACK: host-staged gloo all-reduce (RCCL communicator could not be created)"
+				"RCCL sum + 1/N, 25 MB buckets in reverse execution order, overlapped with backward"
+				if nodeinfo.transport == "rccl" else
+				"FALLBACK: host-staged all-reduce over TCP (RCCL communicator could not be created)"
 			)
 		},
-		"model_tflops_note": "direct-convolution FLOP of the network / step time; the 3x3 layers' Winograd kernels execute "
-							 "1/2.25 of their share on the matrix pipe",
-		"model_tflops_per_gpu": images_per_sec / world * FLOP_PER_IMAGE / 1e12,
-		"pct_of_f32_mfma_peak": images_per_sec / world * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,
+		"build": {"library_build_id": lib.buildId(), "source_id": lib.sourceId(),
+				  "matches_sources": lib.sourceId() in (None, lib.buildId())},
+		"model_tflops_note": "direct-convolution FLOP of the network (conv1 dgrad not counted) / step time",
+		"model_tflops_per_gpu": per_gpu * FLOP_PER_IMAGE / 1e12,
+		"pct_of_f32_mfma_peak": per_gpu * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,
+		"pct_of_f32_mfma_peak_executed": executed / PEAK_F32_MFMA_TFLOPS * 100.0,
+		"pct_executed_note": "FLOP the matrix pipe actually executes per step: the 3x3 layers' Winograd kernels do 1/2.25 of "
+							 "their direct-convolution share; conv1's input gradient is executed and counted here",
 		"final_loss": loss,
+		"backend_fusion_counts_total": fusion_counts,
 		"roofline": {
 			"kernel": FAMILY[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
 			"frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
 			"avg_launch_ms": ms[dom] / max(launches[dom], 1), "launches_measured": int(launches[dom]),
 			"measured_over": (
-				"%d extra steps of the timed loop, run right after it with the filter-gradient side stream off "
-				"(PUZZLE_MI355_OVERLAP_WGRAD=0 semantics): in the timed region backward-data and backward-filter launches "
-				"run concurrently and share the CUs, so their event-to-event times are not the kernels' own; see "
-				"conv_kernel_families[].timed_region_concurrent" % ROOF_STEPS
+				"%d extra steps of the timed loop, run right after it with the filter-gradient side stream off: in the timed "
+				"region backward-data and backward-filter launches run concurrently and share the CUs, so their event-to-event "
+				"times are not the kernels' own; see conv_kernel_families[].timed_region_concurrent" % ROOF_STEPS
 			) if concurrent else "the timed region (every launch runs alone)"
 		},
 		"conv_kernel_families": fams,
 	}
+	if dropin is not None:
+		result["dropin"] = dropin
+	if extras is not None:
+		result["configs"] = extras
 
 	if world == 1 and not args.no_cpu_baseline:
 		result["cpu_baseline"] = cpu_baseline()

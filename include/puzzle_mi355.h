@@ -37,6 +37,7 @@ typedef struct pz_comm *pz_comm_t;
 
 /* ---- library / device: replaces Driver.Device (Cuda/Source/Core/Device.c:160-173) -------------- */
 int pz_version(void);
+const char *pz_build_id(void);                            /* first 16 hex digits of sha256 over the sources this .so was built from */
 const char *pz_last_error(void);
 int pz_init(int device);                                  /* hipSetDevice + arch check (gfx950)  */
 int pz_device_count(int *count);
@@ -80,6 +81,7 @@ int pz_event_create(pz_event_t *event);
 int pz_event_destroy(pz_event_t event);
 int pz_event_record(pz_event_t event, pz_stream_t stream);
 int pz_event_sync(pz_event_t event);
+int pz_event_query(pz_event_t event, int *done);       /* Stream.c:219-239 (event.query()): 1 once everything recorded before it has run */
 int pz_event_elapsed_ms(pz_event_t start, pz_event_t end, float *ms);
 
 /* ---- convolution: replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams
@@ -193,6 +195,23 @@ int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, i
                             const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                             float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
                             pz_stream_t stream);
+/* Training-mode forward without the normalisation pass (what miopenBatchNormalizationForwardTraining computes per channel,
+ * Hip/Wrappers/MIOpen.py:634-664, minus writing y): statistics from the producing convolution's strip sums (`stats`,
+ * pz_conv2d_fwd_stats) or, with stats == NULL, from a pass over x; saved / running statistics; coef[2k..2k+1] = {a, b} of
+ * y = a*x + b for whoever reads the normalised tensor (pz_bn_apply_add). Workspace: pz_bn_workspace_bytes.            */
+int pz_bn_fwd_train_coef(const float *x, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
+                         float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor,
+                         const float *stats, int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* pz_bn_bwd whose incoming gradient is first gated with (y > 0), y = a*x + b re-created from x with the forward's own
+ * pairs `gate_coef` (pz_bn_fwd_train_coef): BatchNormND.backward + Activation(relu, inplace).backward of the reference
+ * (Modules/BatchNormND.py:75-88, Modules/Activation.py:62-70) in one pair of passes.                                */
+int pz_bn_bwd_gate(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                   const float *save_mean, const float *save_invvar, float *dscale, float *dbias, const float *gate_coef,
+                   void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* the statistics pass of pz_bn_bwd alone: `partials` (pz_bn_workspace_bytes) in the layout pz_bn_bwd_coef /
+ * pz_bn_bwd_from_partials consume                                                                                  */
+int pz_bn_bwd_stats(const float *x, const float *dy, int n, int c, int hw, const float *save_mean, float *partials,
+                    pz_stream_t stream);
 /* BatchNorm backward folded into the gathers of the convolution in front of it (Conv2D -> BatchNorm2D, both backward):
  * pz_bn_bwd_coef turns the partial sums (pz_bn_gate_stats) into the parameter gradients and coef[4k..4k+2] = {A, B, C}
  * with dx_bn = A*dy + B*x + C per channel; pz_conv2d_bwd_data_bn / pz_conv2d_bwd_filter_bn are pz_conv2d_bwd_data /
@@ -202,6 +221,9 @@ int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, i
 int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_mean, const float *save_invvar,
                    float *dscale, float *dbias, float *dscale_acc, float *dbias_acc, float alpha, float beta,
                    const float *partials, float *coef, pz_stream_t stream);
+/* the same expression written out, dx = A*dy + (B*x + C), for a consumer that cannot fold it */
+int pz_bn_bwd_apply_coef(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *coef,
+                         pz_stream_t stream);
 int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported);
 int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef,
                           const float *w, float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
@@ -328,6 +350,13 @@ int pz_rng_fill_normal(pz_rng_t rng, float *out, size_t count, float mean, float
 int pz_comm_unique_id(char id[PZ_COMM_ID_BYTES]);
 int pz_comm_init_rank(pz_comm_t *comm, int nranks, const char id[PZ_COMM_ID_BYTES], int rank);
 int pz_comm_destroy(pz_comm_t comm);
+/* health: pz_comm_probe loads librccl (0 = usable) without creating anything — ranks vote on it before entering the
+ * collective pz_comm_init_rank; pz_comm_async_error polls ncclCommGetAsyncError; pz_comm_wait_event waits on the host
+ * for an event recorded behind collectives, polling the communicator, and aborts it after timeout_s (<= 0: no limit)
+ * — the reference's star has neither (a dead child blocks the parent's queue.get() forever, Grid.py:117-121).      */
+int pz_comm_probe(void);
+int pz_comm_async_error(pz_comm_t comm);
+int pz_comm_wait_event(pz_comm_t comm, pz_event_t event, double timeout_s);
 int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, size_t count, pz_stream_t stream);
 int pz_comm_broadcast(pz_comm_t comm, void *buf, size_t nbytes, int root, pz_stream_t stream);
 

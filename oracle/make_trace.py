@@ -1,0 +1,105 @@
+"""
+TEST INFRASTRUCTURE (build container only). Runs the REFERENCE's own Python — Models/Nets/ResNet.py on Modules/ and
+Containers/, Cost/CrossEntropy.py, Optimizers/Adam.py, Handlers/Trainer.py, imported from /root/reference — on top of
+this repository's backend object in dry-run mode (PUZZLE_MI355_DRYRUN=1: no device; every C-ABI call is recorded instead
+of executed) and writes the recorded call sequence of two training steps to tests/golden/trace_*.json.
+
+The reference reaches the backend exactly as INTEGRATION.md §2 describes: `PuzzleLib.Hip.Backend` is a module whose
+getBackend / getDeviceCount forward to puzzlelib_amd.backend — nothing else of the reference is touched.
+
+tests/test_host_logic.py replays the build's own executor (puzzlelib_amd/engine.py + optim.py) the same way and
+requires the identical sequence: same entry points, same order, same descriptors and scalars. That is the evidence that
+(a) an unmodified PuzzleLib drops onto this backend, fusions included, and (b) the harness bench.py times sends the
+backend what PuzzleLib would.
+
+    PUZZLE_MI355_DRYRUN=1 python oracle/make_trace.py [--check]
+"""
+import json, os, sys, types
+
+os.environ["PUZZLE_MI355_DRYRUN"] = "1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np
+
+CASES = {
+	# name: (builder of the reference network, input shape, classes)
+	"resnet50_b8": (lambda: refResNet(), (8, 3, 224, 224), 1000),
+	"lenet_b16": (lambda: refLeNet(), (16, 1, 28, 28), 10),
+}
+SKIP = ("pz_pool_", "pz_event_", "pz_stream_", "pz_malloc", "pz_free", "pz_device_", "pz_init")
+
+
+def refResNet():
+	from PuzzleLib.Models.Nets.ResNet import loadResNet
+	net = loadResNet(None, layers="50", actInplace=True, initscheme="none")
+	net.pop()                                     # the trailing SoftMax: training uses raw scores (CrossEntropy)
+	return net
+
+
+def refLeNet():
+	from PuzzleLib.Models.Nets.LeNet import loadLeNet
+	return loadLeNet(None, initscheme="none")
+
+
+def compute(trace):
+	"""the recorded calls that do arithmetic or move tensor data, pointers already reduced to given / null"""
+	return [[name, list(args)] for name, args in trace if not name.startswith(SKIP)]
+
+
+def installBackend():
+	import refimport
+	Config = refimport.setup()
+	Config.backend = Config.Backend.hip
+
+	import puzzlelib_amd.backend as ours
+	shim = types.ModuleType("PuzzleLib.Hip.Backend")
+	shim.getBackend, shim.getDeviceCount = ours.getBackend, ours.getDeviceCount
+	sys.modules["PuzzleLib.Hip.Backend"] = shim
+	import PuzzleLib.Hip
+	PuzzleLib.Hip.Backend = shim
+	return Config
+
+
+def record(case):
+	from puzzlelib_amd import lib
+	from PuzzleLib.Backend import gpuarray
+	from PuzzleLib.Cost.CrossEntropy import CrossEntropy
+	from PuzzleLib.Optimizers.Adam import Adam
+	from PuzzleLib.Handlers.Trainer import Trainer
+
+	build, shape, classes = CASES[case]
+	net = build()
+	data = gpuarray.to_gpu(np.zeros(shape, np.float32))
+	labels = gpuarray.to_gpu(np.zeros(shape[:1], np.int32))
+
+	optimizer = Adam(alpha=1e-3)
+	optimizer.setupOn(net, useGlobalState=True)
+	trainer = Trainer(net, CrossEntropy(), optimizer, batchsize=shape[0])
+
+	steps = []
+	for _ in range(2):
+		lib.trace.clear()
+		trainer.train(data, labels, random=False)
+		steps.append(compute(lib.trace))
+	return steps
+
+
+def main():
+	installBackend()
+	check = "--check" in sys.argv
+	for case in CASES:
+		steps = record(case)
+		path = os.path.join(ROOT, "tests", "golden", "trace_%s.json" % case)
+		if check:
+			assert json.load(open(path))["steps"] == json.loads(json.dumps(steps)), "trace of %s changed" % case
+			print("trace %s: unchanged (%d + %d calls)" % (case, len(steps[0]), len(steps[1])))
+		else:
+			json.dump({"case": case, "steps": steps}, open(path, "w"), separators=(",", ":"))
+			print("wrote %s (%d + %d calls)" % (path, len(steps[0]), len(steps[1])))
+
+
+if __name__ == "__main__":
+	main()

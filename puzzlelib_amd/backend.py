@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from puzzlelib_amd import lib, driver
+from puzzlelib_amd import lib, driver, lazy, fusion
 from puzzlelib_amd.lib import HipError, ConvDesc, PoolDesc
 from puzzlelib_amd.driver import streamHandle
 from puzzlelib_amd.gpuarray import GPUArray, prod, eltwise
@@ -115,101 +115,6 @@ def pair(v):
 	return (int(v), int(v)) if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
 
 
-class DeferredBN:
-	"""A batch-normalised tensor that was not written: the un-normalised input plus per-channel {a, b} of y = a*x + b
-	(pz_bn_fwd_train_defer). Only DnnContext.bnApplyAdd consumes it; `materialize()` writes it out for anyone else."""
-	__slots__ = ["tensor", "coef", "dnn"]
-
-	def __init__(self, tensor, coef, dnn):
-		self.tensor, self.coef, self.dnn = tensor, coef, dnn
-
-	@property
-	def shape(self):
-		return self.tensor.shape
-
-	@property
-	def dtype(self):
-		return self.tensor.dtype
-
-	def materialize(self, allocator=None):
-		return self.dnn.bnApplyAdd(self, None, relu=False, allocator=allocator)
-
-	def get(self, stream=None):
-		"""the normalised values on the host (what BatchNorm2D.data.get() gives when nothing is deferred)"""
-		return self.materialize().get(stream)
-
-
-class DeferredBNGrad:
-	"""The input gradient of a BatchNorm that was not written: dx = A*grad + B*data + C per channel (pz_bn_bwd_coef).
-	DnnContext.convNdBackwardData / convNdBackwardParams of the convolution in front evaluate it while gathering;
-	`materialize()` runs the apply pass for anyone else."""
-	__slots__ = ["grad", "data", "coef", "apply", "dense"]
-
-	def __init__(self, grad, data, coef, apply):
-		self.grad, self.data, self.coef, self.apply, self.dense = grad, data, coef, apply, None
-
-	@property
-	def shape(self):
-		return self.grad.shape
-
-	@property
-	def dtype(self):
-		return self.grad.dtype
-
-	def materialize(self):
-		if self.dense is None:
-			self.dense = self.apply()
-		return self.dense
-
-	def get(self, stream=None):
-		return self.materialize().get(stream)
-
-
-class StridedGrad:
-	"""The input gradient of a stride-2 pointwise convolution that was not zero-filled: `compact` holds the values of the
-	pixels (2i, 2j) — (n, c, ceil(h/2), ceil(w/2)) — every other pixel of the (n, c, h, w) gradient is zero. Produced by
-	DnnContext.convNdBackwardData(compact=True), consumed by DnnContext.bnGateStats; `materialize()` zero-fills for
-	anyone else."""
-	__slots__ = ["compact", "shape", "dense"]
-
-	def __init__(self, compact, shape):
-		self.compact, self.shape, self.dense = compact, tuple(shape), None
-
-	@property
-	def dtype(self):
-		return self.compact.dtype
-
-	@property
-	def ndim(self):
-		return len(self.shape)
-
-	def materialize(self):
-		if self.dense is None:
-			self.dense = GPUArray.zeros(self.shape, dtype=self.compact.dtype)
-			self.dense[:, :, ::2, ::2].set(self.compact)
-		return self.dense
-
-	def get(self, stream=None):
-		return self.materialize().get(stream)
-
-
-class ReluMask:
-	"""(y > 0) of a fused ReLU's output `tensor`, one bit per element (pz_bn_apply_add_mask); valid for exactly that tensor
-	object. Lets the gradient fan-in gate without reading y back."""
-	__slots__ = ["tensor", "bits"]
-
-	def __init__(self, tensor, bits):
-		self.tensor, self.bits = tensor, bits
-
-
-class ConvStats:
-	"""Per-strip channel sums of a convolution output (pz_conv2d_fwd_stats), valid for exactly that tensor object."""
-	__slots__ = ["tensor", "stats"]
-
-	def __init__(self, tensor, stats):
-		self.tensor, self.stats = tensor, stats
-
-
 def requireF32(*arrays):
 	for ary in arrays:
 		if ary is None:
@@ -220,8 +125,8 @@ def requireF32(*arrays):
 			raise ValueError("gpuarray is not contiguous")
 
 
-def ptrOf(ary):
-	return None if ary is None else ary.ptr
+def rptrOf(ary):
+	return None if ary is None else ary.rptr
 
 
 # ---------------------------------------------------------------------------------------------- BLAS
@@ -259,7 +164,8 @@ class BlasContext:
 			raise ValueError("gemm output has shape %s, expected %s" % (out.shape, (m, n)))
 
 		lib.pz_gemm(
-			int(transpA), int(transpB), m, n, k, alpha, A.ptr, A.shape[1], B.ptr, B.shape[1], beta, out.ptr, n, None
+			int(transpA), int(transpB), m, n, k, alpha, A.rptr, A.shape[1], B.rptr, B.shape[1], beta,
+			out.optr if beta == 0.0 else out.wptr, n, None
 		)
 		return out
 
@@ -275,14 +181,14 @@ class BlasContext:
 	def dot(self, x, y):
 		requireF32(x, y)
 		out = self.scalarOut()
-		lib.pz_dot(x.ptr, y.ptr, x.size, out.ptr, None)
+		lib.pz_dot(x.rptr, y.rptr, x.size, out.optr, None)
 		return float(out.get())
 
 
 	def l1norm(self, x):
 		requireF32(x)
 		out = self.scalarOut()
-		lib.pz_asum(x.ptr, x.size, out.ptr, None)
+		lib.pz_asum(x.rptr, x.size, out.optr, None)
 		return float(out.get())
 
 
@@ -292,10 +198,19 @@ class BlasContext:
 
 # ---------------------------------------------------------------------------------------------- DNN
 class DnnContext:
-	"""conv / pool / softmax / batch-norm entry points with the signatures of Hip/Wrappers/MIOpen.py:333-751."""
+	"""conv / pool / softmax / batch-norm / LRN entry points with the signatures of Hip/Wrappers/MIOpen.py:333-751 —
+	nothing more: every fusion this backend does is decided here from what the tensors carry (lazy.py, fusion.py)."""
+
+	# Conv2D -> BatchNorm2D: the convolution's epilogue can leave per-strip channel sums so that the BatchNorm skips its
+	# statistics pass. "adaptive": a convolution starts doing so once a BatchNorm has been seen reading its output
+	# (keyed by the filter's address); "always" / "never" pin it (tests).
+	convStatsPolicy = os.environ.get("PUZZLE_MI355_CONV_STATS", "adaptive")
 
 	def __init__(self, backend):
 		self.backend = backend
+		self.statsWanted = set()
+		self.sideStream = None
+		self.sideLaunches = 0
 
 
 	def enableTensorOps(self, _):
@@ -308,9 +223,15 @@ class DnnContext:
 
 
 	@staticmethod
+	def to4d(shape):
+		"""1-D and 3-D convolutions run on the 2-D core: (n, c, w) is (n, c, 1, w); 3-D is handled by the caller."""
+		return tuple(shape[:2]) + (1, ) * (4 - len(shape)) + tuple(shape[2:])
+
+
+	@staticmethod
 	def convDesc(dataShape, Wshape, stride, pad, dilation, groups):
 		if len(dataShape) != 4 or len(Wshape) != 4:
-			raise NotImplementedError("only 2-D convolution (4-d tensors) is implemented on this backend")
+			raise NotImplementedError("convolution descriptors are 2-D (1-D tensors are lifted by the callers)")
 
 		(sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dilation)
 		n, c, h, w = dataShape
@@ -324,64 +245,34 @@ class DnnContext:
 		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
 
 
-	# ---- filter gradients on a side stream. Backward-data and backward-filter of a layer read the same incoming gradient
-	# and nothing of each other: with overlapFilterGrad the filter-gradient launches (pack / main kernel / slab reduce) go
-	# to a second stream behind an event, so that the two chains fill each other's tails and tiny launches. Every tensor
-	# those launches touch is kept referenced until joinFilterGrads() — the pool must not hand its memory to the main
-	# stream while the side stream still uses it.
-	# Only inside a module-driven backward pass (beginBackward / endBackward, nn.backwardScope): its end joins the streams,
-	# so nobody sees a half-finished gradient; direct calls of convNdBackwardParams stay on the main stream.
-	overlapFilterGrad = os.environ.get("PUZZLE_MI355_OVERLAP_WGRAD", "1") == "1"
-	backwardDepth = 0
+	# ---- 1-D / 3-D convolutions on the 2-D core (Modules/ConvND.py:14-95 passes nd-tuples straight through)
+	@staticmethod
+	def lift(ary, nd):
+		"""(n, c, w) -> (n, c, 1, w)"""
+		return ary if ary is None or nd == 2 else ary.reshape(ary.shape[:2] + (1, ) + ary.shape[2:])
 
-	def beginBackward(self):
-		self.backwardDepth += 1
+	@staticmethod
+	def lift1(v, fill):
+		v = (v, ) if isinstance(v, (int, np.integer)) else tuple(v)
+		return (fill, int(v[0]))
 
-
-	def endBackward(self):
-		self.backwardDepth -= 1
-		if self.backwardDepth == 0:
-			self.joinFilterGrads()
-
-
-	def filterGradStream(self):
-		if not DnnContext.overlapFilterGrad or self.backwardDepth == 0:
-			return None
-		if getattr(self, "sideStream", None) is None:
-			self.sideStream, self.sideRefs, self.sideLaunches = driver.Stream(), [], 0
-		self.sideLaunches += 1
-		ready = driver.Event()
-		ready.record(None)                          # everything issued so far on the main stream (the incoming gradient)
-		self.sideStream.waitEvent(ready)
-		self.sideRefs.append(ready)
-		return self.sideStream
-
-
-	def filterGradEvent(self):
-		"""An event behind everything queued on the side stream so far (None when it is idle or off): what a consumer of
-		freshly accumulated filter gradients on another stream has to wait for besides the main stream."""
-		if getattr(self, "sideStream", None) is None or not self.sideRefs:
-			return None
-		event = driver.Event()
-		event.record(self.sideStream)
-		return event
-
-
-	def joinFilterGrads(self):
-		"""Main stream waits for the side stream; the references held for it are dropped."""
-		if getattr(self, "sideStream", None) is None or not self.sideRefs:
-			return
-		done = driver.Event()
-		done.record(self.sideStream)
-		lib.pz_stream_wait_event(None, done.handle)
-		self.sideRefs = [done]                       # (the event itself must outlive the wait it was queued for)
+	@staticmethod
+	def unlift(ary, nd):
+		return ary if nd == 2 else ary.reshape(ary.shape[:2] + ary.shape[3:])
 
 
 	def convNd(self, data, W, bias=None, stride=1, pad=0, dilation=1, groups=1, algo=ConvFwdAlgo.auto.value,
-			   out=None, allocator=None, withStats=False):
-		"""`withStats` (backend-internal): also return the per-strip channel sums of the output for a BatchNorm that
-		reads it next -> (out, ConvStats | None); see batchNormNd(convStats=)."""
+			   out=None, allocator=None):
 		assert data.ndim == W.ndim and data.shape[1] == W.shape[1] * groups
+		nd = data.ndim - 2
+		if nd == 1:
+			res = self.convNd(
+				self.lift(data, 1), self.lift(W, 1), bias, self.lift1(stride, 1), self.lift1(pad, 0), self.lift1(dilation, 1),
+				groups, algo, self.lift(out, 1), allocator
+			)
+			return out if out is not None else self.unlift(res, 1)
+		if nd == 3:
+			return conv3d.forward(self, data, W, bias, stride, pad, dilation, groups, algo, out, allocator)
 		requireF32(data, W, bias, out)
 
 		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
@@ -389,6 +280,7 @@ class DnnContext:
 		lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
 		outshape = (data.shape[0], W.shape[0], p.value, q.value)
 
+		given = out is not None
 		out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator) if out is None else out
 		if out.shape != outshape:
 			raise ValueError("conv output has shape %s, expected %s" % (out.shape, outshape))
@@ -398,21 +290,26 @@ class DnnContext:
 		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_FWD, algo, byref(size))
 		ws = self.workspace(size.value, allocator)
 
-		if not withStats:
-			lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
-			return out
-
+		key = W.gpudata.ptr
+		policy = DnnContext.convStatsPolicy
+		want = lazy.on("convstats") and not given and (policy == "always" or (policy == "adaptive" and key in self.statsWanted))
 		strips = c_int(0)
-		lib.pz_conv2d_fwd_stats_strips(byref(desc), algo, byref(strips))
-		if strips.value == 0:
-			lib.pz_conv2d_fwd(byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, algo, ptrOf(ws), size.value, None)
-			return out, None
+		if want:
+			lib.pz_conv2d_fwd_stats_strips(byref(desc), algo, byref(strips))
 
-		stats = GPUArray.empty((W.shape[0], strips.value, 4), dtype=np.float32, allocator=allocator)
-		lib.pz_conv2d_fwd_stats(
-			byref(desc), data.ptr, W.ptr, ptrOf(bias), out.ptr, stats.ptr, algo, ptrOf(ws), size.value, None
-		)
-		return out, ConvStats(out, stats)
+		if strips.value == 0:
+			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), size.value, None)
+		else:
+			stats = GPUArray.empty((W.shape[0], strips.value, 4), dtype=np.float32, allocator=allocator)
+			lib.pz_conv2d_fwd_stats(
+				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), size.value, None
+			)
+			lazy.setFact(out, "convstats", stats)
+			lazy.count("conv_stats")
+
+		if lazy.enabled and not given:
+			lazy.setFact(out, "fromconv", key)
+		return out
 
 
 	def convAlgoUsed(self, desc, which, algo):
@@ -435,20 +332,32 @@ class DnnContext:
 
 
 	def convNdBackwardData(self, grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1,
-						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None, compact=False):
-		if compact and data is not None and bias is None and out is None and self.compactGradSupported(W, stride, pad, dilation):
-			# backend-internal (Sequential.planFusion): dx[.., 2i, 2j] = W^T dy[.., i, j] and zero elsewhere — computed on the
-			# compact grid; StridedGrad carries it to the fan-in kernel that knows where the zeros are
+						   algo=ConvBwdDataAlgo.auto.value, out=None, allocator=None):
+		assert grad.ndim == W.ndim and grad.shape[1] == W.shape[0]
+		nd = grad.ndim - 2
+		if nd == 1:
+			res = self.convNdBackwardData(
+				self.lift(grad, 1), self.lift(W, 1), bias, self.lift(data, 1), self.lift1(stride, 1), self.lift1(pad, 0),
+				self.lift1(dilation, 1), self.lift1(postpad if postpad is not None else 0, 0), groups, algo, self.lift(out, 1),
+				allocator
+			)
+			return out if out is not None else self.unlift(res, 1)
+		if nd == 3:
+			return conv3d.backwardData(self, grad, W, bias, data, stride, pad, dilation, postpad, groups, algo, out, allocator)
+
+		if data is not None and bias is None and out is None and lazy.on("up2") and groups == 1 and \
+				self.compactGradSupported(W, stride, pad, dilation) and data.shape[2] > 1 and data.shape[3] > 1:
+			# dx[.., 2i, 2j] = W^T dy[.., i, j] and zero elsewhere: computed on the compact grid (a quarter of the tensor, no
+			# memset, dense stores); whoever reads dx either knows where the zeros are (the gradient fan-in,
+			# pz_bn_gate_stats_up2) or has it expanded first
 			small = self.convNdBackwardData(grad, W, None, None, 1, 0, 1, 0, groups, algo, None, allocator)
 			assert small.shape[2:] == tuple((d + 1) // 2 for d in data.shape[2:])
-			return StridedGrad(small, data.shape)
+			out = GPUArray.empty(data.shape, dtype=grad.dtype, allocator=allocator)
+			lazy.attach(out, fusion.Up2(small))
+			lazy.count("compact_dgrad")
+			return out
 
-		lazy = grad if isinstance(grad, DeferredBNGrad) else None      # backend-internal: BN backward folded into the gather
-		if lazy is not None:
-			grad = lazy.grad
-		assert grad.ndim == W.ndim and grad.shape[1] == W.shape[0]
 		requireF32(grad, W, bias, out)
-
 		(sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dilation)
 
 		if data is not None:
@@ -475,31 +384,67 @@ class DnnContext:
 		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_DATA, algo, byref(size))
 		ws = self.workspace(size.value, allocator)
 
-		if lazy is not None and self.bnFoldSupported(desc, algo):
+		# the gradient is the un-written input gradient of a BatchNorm (fusion.BnBwdApply): evaluate it while gathering
+		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
+		if bn is not None and self.bnFoldSupported(desc, algo):
 			lib.pz_conv2d_bwd_data_bn(
-				byref(desc), grad.ptr, lazy.data.ptr, lazy.coef.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None
+				byref(desc), bn.dy.rptr, bn.x.rptr, fusion.raw(bn.coef), W.rptr, out.optr, algo, rptrOf(ws), size.value, None
 			)
+			lazy.count("dgrad_bn_fold")
 		else:
-			if lazy is not None:
-				grad = lazy.materialize()
-			lib.pz_conv2d_bwd_data(byref(desc), grad.ptr, W.ptr, out.ptr, algo, ptrOf(ws), size.value, None)
+			lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), size.value, None)
 
 		if bias is not None:           # deconvolution forward: bias over the produced maps, rows of the (n*maps, pixels) view
 			assert bias.size == out.shape[1]
 			lib.pz_bias_add(
-				out.ptr, out.ptr, bias.ptr, 1, out.shape[0] * out.shape[1], prod(out.shape[2:]), out.shape[1], 0, None
+				out.wptr, out.rptr, bias.rptr, 1, out.shape[0] * out.shape[1], prod(out.shape[2:]), out.shape[1], 0, None
 			)
 
 		return out
 
 
+	# ---- filter gradients on a side stream. Backward-data and backward-filter of a layer read the same incoming gradient
+	# and nothing of each other, so every filter-gradient call (pack / main kernel / slab reduce) goes to a second HIP
+	# stream behind an event of the main stream; the two chains fill each other's tails and tiny launches. Nobody has to
+	# join the streams explicitly: the launch leaves its completion event on the buffers it touched (lazy.foreignEnd) —
+	# the optimizer, `.get()`, the all-reduce or the next step's zero fill wait for it when they touch the gradient arena,
+	# and the tensors the side stream reads stay referenced (and guarded against overwrites) until the event has passed.
+	def filterGradStream(self):
+		if not lazy.on("sidestream"):
+			return None
+		if self.sideStream is None:
+			self.sideStream = driver.Stream()
+		self.sideLaunches += 1
+		return self.sideStream
+
+
+	def sideEvent(self):
+		"""An event behind everything queued on the side stream so far (None when it never ran): what a consumer of fresh
+		filter gradients on a third stream (the all-reduce) waits for besides the main stream."""
+		if self.sideStream is None:
+			return None
+		event = driver.Event()
+		event.record(self.sideStream)
+		return event
+
+
 	def convNdBackwardParams(self, data, grad, W, stride=1, pad=0, dilation=1, groups=1, withbias=False, deconv=False,
 							 wgrad=None, bgrad=None, scale=1.0, momentum=0.0, algo=ConvBwdFilterAlgo.auto.value,
 							 allocator=None):
-		lazy = grad if isinstance(grad, DeferredBNGrad) else None
-		if lazy is not None:
-			grad = lazy.grad
 		assert data.ndim == grad.ndim and grad.shape[1] == W.shape[0] and data.shape[1] == W.shape[1] * groups
+		nd = data.ndim - 2
+		if nd == 1:
+			res = self.convNdBackwardParams(
+				self.lift(data, 1), self.lift(grad, 1), self.lift(W, 1), self.lift1(stride, 1), self.lift1(pad, 0),
+				self.lift1(dilation, 1), groups, withbias, deconv, self.lift(wgrad, 1), bgrad, scale, momentum, algo, allocator
+			)
+			if not withbias:
+				return wgrad if wgrad is not None else self.unlift(res, 1)
+			return (wgrad if wgrad is not None else self.unlift(res[0], 1)), res[1]
+		if nd == 3:
+			return conv3d.backwardParams(
+				self, data, grad, W, stride, pad, dilation, groups, withbias, deconv, wgrad, bgrad, scale, momentum, algo, allocator
+			)
 		requireF32(data, grad, wgrad, bgrad)
 		# deconv=True (Backend/Dnn.py wrapDeconvNdBackwardParams passes the deconvolution's output gradient as `data` and its
 		# input as `grad`): the filter gradient is the same contraction; only the bias gradient sums over `data`'s maps
@@ -526,26 +471,38 @@ class DnnContext:
 			bg = GPUArray.empty((biasof.shape[1], ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
 
 		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
-		folded = lazy is not None and not withbias and self.bnFoldSupported(desc, algo)
-		if lazy is not None and not folded:
-			grad = lazy.materialize()
+		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
+		folded = bn is not None and not withbias and self.bnFoldSupported(desc, algo)
 
 		side = self.filterGradStream() if (not withbias or fused) else None
 		st = side.handle if side is not None else None
-		if side is not None:
-			self.sideRefs.append((data, grad, lazy, ws, wgrad, bg))
+		reads = [data, bn.dy, bn.x] if folded else [data, grad]
+		writes = [wgrad] + ([bg] if fused else [])
+
+		def rp(ary):
+			return ary.rptr if side is None else ary.ptrOn(side, False)
+
+		def wp(ary):
+			return ary.wptr if side is None else ary.ptrOn(side, True)
+
+		rptrs = [rp(a) for a in reads]
+		wptrs = [wp(a) for a in writes]
+		ready = lazy.foreignBegin(side) if side is not None else None
 
 		if folded:
 			lib.pz_conv2d_bwd_filter_bn(
-				byref(desc), data.ptr, grad.ptr, lazy.data.ptr, lazy.coef.ptr, wgrad.ptr, wcoef[0], wcoef[1], algo,
-				ptrOf(ws), size.value, st
+				byref(desc), rptrs[0], rptrs[1], rptrs[2], fusion.raw(bn.coef), wptrs[0], wcoef[0], wcoef[1], algo,
+				rptrOf(ws), size.value, st
 			)
-			return wgrad
+			lazy.count("wgrad_bn_fold")
+		else:
+			lib.pz_conv2d_bwd_filter(
+				byref(desc), rptrs[0], rptrs[1], wptrs[0], wptrs[1] if fused else None, wcoef[0], wcoef[1], algo,
+				rptrOf(ws), size.value, st
+			)
 
-		lib.pz_conv2d_bwd_filter(
-			byref(desc), data.ptr, grad.ptr, wgrad.ptr, ptrOf(bg) if fused else None, wcoef[0], wcoef[1], algo,
-			ptrOf(ws), size.value, st
-		)
+		if side is not None:
+			lazy.foreignEnd(side, ready, reads=reads, writes=writes, keep=(ws, bn.coef if folded else None))
 
 		if withbias and not fused:
 			n, k = biasof.shape[:2]
@@ -562,7 +519,9 @@ class DnnContext:
 		bnd = self.backend
 		data = GPUArray.zeros(datashape, dtype=dtype, allocator=bnd.memoryPool)
 		W = GPUArray.zeros(Wshape, dtype=dtype, allocator=bnd.memoryPool)
-		desc = self.convDesc(datashape, Wshape, stride, pad, dilation, groups)
+		desc = self.convDesc(self.to4d(datashape), self.to4d(Wshape), self.lift1(stride, 1) if len(datashape) == 3 else stride,
+							 self.lift1(pad, 0) if len(datashape) == 3 else pad,
+							 self.lift1(dilation, 1) if len(datashape) == 3 else dilation, groups)
 
 		out = self.convNd(data, W, None, stride, pad, dilation, groups, allocator=bnd.memoryPool)
 		results = []
@@ -571,10 +530,10 @@ class DnnContext:
 			(lib.CONV_FWD, lambda a: self.convNd(data, W, None, stride, pad, dilation, groups, a, None, bnd.memoryPool)),
 			(lib.CONV_BWD_DATA, lambda a: self.convNdBackwardData(
 				out, W, None, data, stride, pad, dilation, 0, groups, a, None, bnd.memoryPool
-			)),
+			).rptr),
 			(lib.CONV_BWD_FILTER, lambda a: self.convNdBackwardParams(
 				data, out, W, stride, pad, dilation, groups, False, False, None, None, 1.0, 0.0, a, bnd.memoryPool
-			)),
+			).rptr),
 		):
 			perfs = []
 			for algo in (ConvFwdAlgo.implicitGemm.value, ConvFwdAlgo.winograd.value, ConvFwdAlgo.direct.value):
@@ -598,6 +557,12 @@ class DnnContext:
 
 
 	def poolNd(self, data, size=2, stride=2, pad=0, mode=PoolMode.max.value, test=False, out=None, allocator=None):
+		if data.ndim == 3:
+			res = self.poolNd(
+				self.lift(data, 1), self.lift1(size, 1), self.lift1(stride, 1), self.lift1(pad, 0), mode, test, self.lift(out, 1),
+				allocator
+			)
+			return self.unlift(res, 1) if test else (self.unlift(res[0], 1), res[1])
 		assert data.ndim == 4
 		requireF32(data, out)
 
@@ -614,22 +579,28 @@ class DnnContext:
 			nbytes = prod(outshape) if mode == PoolMode.max.value else 4
 			workspace = GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
 
-		index = workspace.ptr if (workspace is not None and mode == PoolMode.max.value) else None
-		lib.pz_pool2d_fwd(byref(desc), data.ptr, out.ptr, index, None)
+		index = workspace.optr if (workspace is not None and mode == PoolMode.max.value) else None
+		lib.pz_pool2d_fwd(byref(desc), data.rptr, out.optr, index, None)
 
 		return out if test else (out, workspace)
 
 
 	def poolNdBackward(self, grad, indata, outdata, workspace, size=2, stride=2, pad=0, mode=PoolMode.max.value,
 					   out=None, allocator=None):
+		if grad.ndim == 3:
+			res = self.poolNdBackward(
+				self.lift(grad, 1), self.lift(indata, 1), self.lift(outdata, 1), workspace, self.lift1(size, 1),
+				self.lift1(stride, 1), self.lift1(pad, 0), mode, self.lift(out, 1), allocator
+			)
+			return self.unlift(res, 1)
 		assert grad.ndim == 4
 		requireF32(grad, indata, outdata, out)
 
 		desc = self.poolDesc(indata.shape, size, stride, pad, mode)
 		out = GPUArray.empty(indata.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
 
-		index = workspace.ptr if (workspace is not None and mode == PoolMode.max.value) else None
-		lib.pz_pool2d_bwd(byref(desc), grad.ptr, indata.ptr, outdata.ptr, index, out.ptr, None)
+		index = workspace.rptr if (workspace is not None and mode == PoolMode.max.value) else None
+		lib.pz_pool2d_bwd(byref(desc), grad.rptr, indata.rptr, outdata.rptr, index, out.optr, None)
 		return out
 
 
@@ -649,7 +620,7 @@ class DnnContext:
 		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
 
 		n, c, spatial = self.softmaxGeometry(data, mode)
-		lib.pz_softmax_fwd(data.ptr, out.ptr, n, c, spatial, None)
+		lib.pz_softmax_fwd(data.rptr, out.optr, n, c, spatial, None)
 		return out
 
 
@@ -658,7 +629,7 @@ class DnnContext:
 		out = GPUArray.empty(grad.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
 
 		n, c, spatial = self.softmaxGeometry(grad, mode)
-		lib.pz_softmax_bwd(grad.ptr, outdata.ptr, out.ptr, n, c, spatial, None)
+		lib.pz_softmax_bwd(grad.rptr, outdata.rptr, out.optr, n, c, spatial, None)
 		return out
 
 
@@ -668,166 +639,131 @@ class DnnContext:
 		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
 
 
-	def bnGateStats(self, grad0, grad1, outdata, targets, allocator=None, mask=None):
-		"""Backend-internal (Sequential.planFusion): g = (grad0 + grad1) * (outdata > 0) plus, for each of the one or two
-		`targets` = (bnInput, savemean), the partial sums a following batchNormNdBackward(g, bnInput, ..., partials=)
-		would otherwise recompute. Returns (g, [partials...])."""
-		up2 = isinstance(grad0, StridedGrad) and isinstance(grad1, StridedGrad)
-		if not up2:
-			grad0 = grad0.materialize() if isinstance(grad0, StridedGrad) else grad0
-			grad1 = grad1.materialize() if isinstance(grad1, StridedGrad) else grad1
-		requireF32(grad0 if not up2 else grad0.compact, grad1 if not up2 else grad1.compact, outdata)
-		assert 1 <= len(targets) <= 2 and tuple(grad0.shape) == tuple(grad1.shape) == tuple(outdata.shape)
-		n, c, hw = grad0.shape[0], grad0.shape[1], prod(grad0.shape[2:])
-
-		out = GPUArray.empty(outdata.shape, dtype=outdata.dtype, allocator=allocator)
-		size = c_size_t(0)
-		lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
-		parts = [GPUArray.empty((size.value // 4, ), dtype=np.float32, allocator=allocator) for _ in targets]
-
-		(xa, ma), (xb, mb) = targets[0], (targets[1] if len(targets) == 2 else (None, None))
-		assert xa.shape == outdata.shape and (xb is None or xb.shape == outdata.shape)
-		# `mask` (ReluMask of exactly `outdata`, from bnApplyAdd): the gate comes from one bit per element, outdata is not read
-		mptr = mask.bits.ptr if mask is not None and mask.tensor is outdata else None
-		if up2:
-			lib.pz_bn_gate_stats_up2(
-				grad0.compact.ptr, grad1.compact.ptr, outdata.ptr, mptr, out.ptr, n, c, outdata.shape[2], outdata.shape[3],
-				xa.ptr, ma.ptr, parts[0].ptr, ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
-			)
-			return out, parts
-		lib.pz_bn_gate_stats(
-			grad0.ptr, grad1.ptr, outdata.ptr, mptr, out.ptr, n, c, hw, xa.ptr, ma.ptr, parts[0].ptr,
-			ptrOf(xb), ptrOf(mb), parts[1].ptr if xb is not None else None, None
-		)
-		return out, parts
-
-
-	def bnApplyAdd(self, first, second, relu=False, allocator=None, withMask=False):
-		"""out = act(bn(first) + second') for a DeferredBN `first` and `second` = DeferredBN | GPUArray | None
-		(None: out = bn(first), no activation). Backend-internal (see Sequential.planFusion).
-		`withMask` (with relu): also return the ReluMask of `out` -> (out, mask)."""
-		x1 = first.tensor
-		n, c, hw = x1.shape[0], x1.shape[1], prod(x1.shape[2:])
-		if isinstance(second, DeferredBN):
-			x2, coef2 = second.tensor, second.coef
-		else:
-			x2, coef2 = second, None
-		if x2 is not None and x2.shape != x1.shape:
-			raise ValueError("bnApplyAdd: operand shapes %s and %s differ" % (x1.shape, x2.shape))
-		requireF32(x1, x2)
-
-		out = GPUArray.empty(x1.shape, dtype=x1.dtype, allocator=allocator)
-		if withMask and relu:
-			size = c_size_t(0)
-			lib.pz_relu_mask_bytes(n, c, hw, byref(size))
-			bits = GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator)
-			lib.pz_bn_apply_add_mask(x1.ptr, first.coef.ptr, ptrOf(x2), ptrOf(coef2), out.ptr, bits.ptr, n, c, hw, 1, None)
-			return out, ReluMask(out, bits)
-		lib.pz_bn_apply_add(x1.ptr, first.coef.ptr, ptrOf(x2), ptrOf(coef2), out.ptr, n, c, hw, int(bool(relu)), None)
-		return (out, None) if withMask else out
+	@staticmethod
+	def bnGeometry(data, mode):
+		"""(n, channels, pixels) of the statistics: per channel over (n, h, w) for spatial mode; per activation over n only
+		— the tensor then is n slabs of c*h*w one-pixel channels (Hip/Wrappers/MIOpen.py:634-664 honours `mode`)."""
+		if mode == BatchNormMode.spatial.value:
+			return data.shape[0], data.shape[1], prod(data.shape[2:])
+		return data.shape[0], prod(data.shape[1:]), 1
 
 
 	def batchNormNd(self, data, mean, var, scale, bias, epsilon=1e-5, factor=1.0, test=False,
-					mode=BatchNormMode.spatial.value, out=None, allocator=None, fuseRelu=False, convStats=None,
-					defer=False):
-		"""`fuseRelu` (backend-internal, train mode only): write relu(bn(data)) — used by Sequential for a BatchNorm
-		followed by an in-place ReLU; the matching backward is batchNormNdBackward(..., bias=, fuseRelu=True)."""
+					mode=BatchNormMode.spatial.value, out=None, allocator=None):
 		assert mean.ndim == 1 and var.ndim == 1 and scale.ndim == 1 and bias.ndim == 1
-		assert data.dimAt(1) == mean.dimAt(0)
 		requireF32(data, mean, var, scale, bias, out)
-		if mode != BatchNormMode.spatial.value:
-			raise NotImplementedError("per-activation batch normalisation is not implemented on this backend")
+		n, c, hw = self.bnGeometry(data, mode)
+		assert c == mean.dimAt(0)
 
-		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
-
-		if defer and not test and not fuseRelu and out is None and convStats is not None and convStats.tensor is data:
-			# statistics from the convolution's strip sums, normalisation left to the consumer (bnApplyAdd)
-			savemean = GPUArray.empty(mean.shape, dtype=data.dtype, allocator=allocator)
-			saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
-			coef = GPUArray.empty((c, 2), dtype=data.dtype, allocator=allocator)
-			ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
-			lib.pz_bn_fwd_train_defer(
-				n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr, epsilon, factor,
-				convStats.stats.ptr, convStats.stats.shape[1], coef.ptr, ws.ptr, nbytes, None
-			)
-			return DeferredBN(data, coef, self), savemean, saveinvvar
-
+		given = out is not None
 		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
 
 		if test:
-			lib.pz_bn_fwd_infer(data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, epsilon, None)
+			lib.pz_bn_fwd_infer(data.rptr, out.optr, n, c, hw, scale.rptr, bias.rptr, mean.rptr, var.rptr, epsilon, None)
 			return out
 
 		savemean = GPUArray.empty(mean.shape, dtype=data.dtype, allocator=allocator)
 		saveinvvar = GPUArray.empty(var.shape, dtype=data.dtype, allocator=allocator)
+		coef = GPUArray.empty((c, 2), dtype=data.dtype, allocator=allocator)
 		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 
-		act = lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE
+		# statistics: the producing convolution's strip sums when it left them; otherwise tell that convolution (by its
+		# filter's address) that a BatchNorm reads its output, so that it does from the next pass on
+		stats = lazy.fact(data, "convstats") if mode == BatchNormMode.spatial.value else None
+		if stats is None and DnnContext.convStatsPolicy == "adaptive":
+			key = lazy.fact(data, "fromconv")
+			if key is not None:
+				self.statsWanted.add(key)
 
-		if convStats is not None and convStats.tensor is data:
-			# the producing convolution already summed this tensor per strip: no statistics pass over `data`
-			lib.pz_bn_fwd_train_pre(
-				data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
-				epsilon, factor, act, convStats.stats.ptr, convStats.stats.shape[1], ws.ptr, nbytes, None
-			)
+		lib.pz_bn_fwd_train_coef(
+			data.rptr, n, c, hw, scale.rptr, bias.rptr, mean.wptr, var.wptr, savemean.optr, saveinvvar.optr, epsilon, factor,
+			None if stats is None else stats.rptr, 0 if stats is None else stats.shape[1], coef.optr, ws.optr, nbytes, None
+		)
+
+		# the normalisation itself is only described: y = a*x + b (fusion.BnApply). An in-place ReLU joins the description,
+		# a residual Add / a convolution's gather applies it on the fly, anyone else has it written first.
+		thunk = fusion.BnApply(data.reshape(n, c, hw, 1) if data.ndim != 4 or mode != BatchNormMode.spatial.value else data, coef)
+		if lazy.on("bnapply") and not given and lazy.whole(out) and not lazy.sameBuffer(out, data):
+			lazy.attach(out, thunk)
+			if lazy.enabled:
+				lazy.setFact(data, "bnsaved", savemean)
 		else:
-			lib.pz_bn_fwd_train_act(
-				data.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr, mean.ptr, var.ptr, savemean.ptr, saveinvvar.ptr,
-				epsilon, factor, act, ws.ptr, nbytes, None
-			)
+			out.optr
+			thunk.run(out)
 		return out, savemean, saveinvvar
 
 
 	def batchNormNdBackward(self, grad, data, scale, savemean=None, saveinvvar=None, epsilon=1e-5,
-							mode=BatchNormMode.spatial.value, out=None, allocator=None, bias=None, fuseRelu=False,
-							accumulate=None, partials=None, lazyGrad=False):
-		"""`accumulate` (backend-internal) = (scalegradDst, biasgradDst, alpha, beta): additionally
-		dst = alpha*fresh + beta*dst for both parameter gradients inside the same launch."""
+							mode=BatchNormMode.spatial.value, out=None, allocator=None):
 		assert data.ndim == grad.ndim
-		requireF32(grad, data, scale, savemean, saveinvvar, out, bias)
-		if fuseRelu and bias is None:
-			raise ValueError("batchNormNdBackward: the fused ReLU gate needs the layer's bias")
+		requireF32(grad, data, scale, savemean, saveinvvar, out)
 		if savemean is None or saveinvvar is None:
 			raise ValueError("batchNormNdBackward needs the saved mean / inverse variance of the forward pass")
 
+		given = out is not None
 		out = GPUArray.empty(grad.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
 		scalegrad = GPUArray.empty(scale.shape, dtype=scale.dtype, allocator=allocator)
 		bgrad = GPUArray.empty(scale.shape, dtype=scale.dtype, allocator=allocator)
 
-		n, c, hw = data.shape[0], data.shape[1], prod(data.shape[2:])
-		ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+		n, c, hw = self.bnGeometry(data, mode)
+		spatial = mode == BatchNormMode.spatial.value and data.ndim == 4
 
-		sdst, bdst, alpha, beta = accumulate if accumulate is not None else (None, None, 1.0, 0.0)
-		requireF32(sdst, bdst)
-
-		if partials is not None and not fuseRelu and lazyGrad:
-			# statistics already summed (bnGateStats) and the consumer folds the apply pass into its gathers
-			coef = GPUArray.empty((c, 4), dtype=np.float32, allocator=allocator)
-			lib.pz_bn_bwd_coef(
-				n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, ptrOf(sdst), ptrOf(bdst), alpha, beta,
-				partials.ptr, coef.ptr, None
-			)
-
-			def apply():
-				lib.pz_bn_bwd_from_partials(
-					data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
-					None, None, 1.0, 0.0, partials.ptr, None
+		# (1) the gradient still carries the derivative of THIS layer's in-place ReLU (reluDerKer(g, g, y) with
+		# y = relu(bn(x)), fusion.Gate): gate while loading, y re-created from x with the forward's own {a, b}
+		gate = lazy.pending(grad, fusion.Gate) if (spatial and lazy.on("bnrelubwd")) else None
+		if gate is not None:
+			desc = lazy.fact(gate.y, "bnapply")
+			if desc is None:
+				waiting = lazy.pending(gate.y, fusion.BnApply)
+				desc = None if waiting is None else (waiting.x, waiting.coef, waiting.relu)
+			if desc is not None and desc[2] and lazy.sameBuffer(desc[0], data):
+				ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+				lib.pz_bn_bwd_gate(
+					data.rptr, lazy.rawRead(grad), out.optr, n, c, hw, scale.rptr, savemean.rptr, saveinvvar.rptr,
+					scalegrad.optr, bgrad.optr, fusion.raw(desc[1]), ws.optr, nbytes, None
 				)
-				return out
+				lazy.count("bn_bwd_gate")
+				return out, scalegrad, bgrad
 
-			return DeferredBNGrad(grad, data, coef, apply), scalegrad, bgrad
+		# (2) the gradient is an un-written gated fan-in (fusion.Sum): write it and sum this layer's backward statistics —
+		# and those of the other BatchNorm that fed the same residual Add — in the same pass
+		parts = None
+		if spatial and lazy.on("gatestats"):
+			waiting = lazy.pending(grad, fusion.Sum)
+			if waiting is not None and waiting.gate is not None:
+				targets = [(data, savemean)]
+				for other in (lazy.fact(waiting.gate, "bnterms") or ()):
+					saved = lazy.fact(other, "bnsaved")
+					if saved is not None and not lazy.sameBuffer(other, data) and other.shape == data.shape and len(targets) < 2:
+						targets.append((other, saved))
+				fusion.settleWithStats(grad, targets)
+			for x, mean_, part in (lazy.fact(grad, "bwdparts") or ()):
+				if lazy.sameBuffer(x, data) and lazy.sameBuffer(mean_, savemean):
+					parts = part
 
-		if partials is not None and not fuseRelu:           # statistics already summed by bnGateStats: apply pass only
-			lib.pz_bn_bwd_from_partials(
-				data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, savemean.ptr, saveinvvar.ptr, scalegrad.ptr, bgrad.ptr,
-				ptrOf(sdst), ptrOf(bdst), alpha, beta, partials.ptr, None
+		if parts is None:
+			ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
+			lib.pz_bn_bwd_acc(
+				data.rptr, grad.rptr, out.optr, n, c, hw, scale.rptr, None, savemean.rptr, saveinvvar.rptr, scalegrad.optr,
+				bgrad.optr, lib.BN_ACT_NONE, None, None, 1.0, 0.0, ws.optr, nbytes, None
 			)
 			return out, scalegrad, bgrad
-		lib.pz_bn_bwd_acc(
-			data.ptr, grad.ptr, out.ptr, n, c, hw, scale.ptr, bias.ptr if fuseRelu else None, savemean.ptr,
-			saveinvvar.ptr, scalegrad.ptr, bgrad.ptr, lib.BN_ACT_RELU if fuseRelu else lib.BN_ACT_NONE,
-			ptrOf(sdst), ptrOf(bdst), alpha, beta, ws.ptr, nbytes, None
-		)
+
+		# (3) statistics known: the input gradient is dx = A*dy + B*x + C per channel — described, not written; the 1x1
+		# convolution in front evaluates it inside its backward gathers (pz_conv2d_bwd_{data,filter}_bn)
+		lazy.count("bn_bwd_from_partials")
+		if lazy.on("bnbwdfold") and not given and lazy.whole(out):
+			coef = GPUArray.empty((c, 4), dtype=np.float32, allocator=allocator)
+			lib.pz_bn_bwd_coef(
+				n, c, hw, scale.rptr, savemean.rptr, saveinvvar.rptr, scalegrad.optr, bgrad.optr, None, None, 1.0, 0.0,
+				fusion.raw(parts), coef.optr, None
+			)
+			lazy.attach(out, fusion.BnBwdApply(grad, data, coef))
+		else:
+			lib.pz_bn_bwd_from_partials(
+				data.rptr, grad.rptr, out.optr, n, c, hw, scale.rptr, savemean.rptr, saveinvvar.rptr, scalegrad.optr, bgrad.optr,
+				None, None, 1.0, 0.0, fusion.raw(parts), None
+			)
 		return out, scalegrad, bgrad
 
 
@@ -836,6 +772,16 @@ class DnnContext:
 
 
 	lrnBackward = lrn
+
+
+class conv3d:
+	"""3-D convolutions (Modules/Conv3D.py) on the 2-D core — not implemented yet."""
+
+	@staticmethod
+	def forward(*args):
+		raise NotImplementedError("3-D convolution is not implemented on this backend")
+
+	backwardData = backwardParams = forward
 
 
 # ---------------------------------------------------------------------------------------------- matrix-vector module
@@ -857,10 +803,10 @@ class MatModule:
 			assert out.shape == outshape
 
 		if axis == tensor.ndim - 1:
-			lib.pz_reduce_sum_rows(tensor.ptr, prod(tensor.shape[:-1]), tensor.shape[-1], out.ptr, alpha, beta, None)
+			lib.pz_reduce_sum_rows(tensor.rptr, prod(tensor.shape[:-1]), tensor.shape[-1], out.wptr, alpha, beta, None)
 		else:
 			z, h, w = prod(tensor.shape[:axis]), tensor.shape[axis], prod(tensor.shape[axis + 1:])
-			lib.pz_reduce_sum_cols(tensor.ptr, z, h, w, out.ptr, alpha, beta, None)
+			lib.pz_reduce_sum_cols(tensor.rptr, z, h, w, out.wptr, alpha, beta, None)
 
 		return out
 
@@ -872,10 +818,10 @@ class MatModule:
 		idx = GPUArray.empty(tensor.shape[:axis] + tensor.shape[axis + 1:], dtype=np.int32, allocator=allocator)
 
 		if axis == tensor.ndim - 1:
-			lib.pz_argmax_rows(tensor.ptr, prod(tensor.shape[:-1]), tensor.shape[-1], idx.ptr, None)
+			lib.pz_argmax_rows(tensor.rptr, prod(tensor.shape[:-1]), tensor.shape[-1], idx.optr, None)
 		else:
 			z, h, w = prod(tensor.shape[:axis]), tensor.shape[axis], prod(tensor.shape[axis + 1:])
-			lib.pz_argmax_cols(tensor.ptr, z, h, w, idx.ptr, None)
+			lib.pz_argmax_cols(tensor.rptr, z, h, w, idx.optr, None)
 
 		return idx
 
@@ -899,7 +845,7 @@ class MatModule:
 
 		if tiled:          # one vector shared by every matrix of the batch
 			for b in range(z):
-				lib.pz_bias_add(out.ptr + b * n * m * 4, mat.ptr + b * n * m * 4, vec.ptr, 1, n, m, vec.shape[-1], axis, None)
+				lib.pz_bias_add(out.wptr + b * n * m * 4, mat.rptr + b * n * m * 4, vec.rptr, 1, n, m, vec.shape[-1], axis, None)
 			return out
 
 		if axis == 1:
@@ -907,7 +853,7 @@ class MatModule:
 		else:
 			assert mat.dimAt(-2) == vec.dimAt(-1)
 
-		lib.pz_bias_add(out.ptr, mat.ptr, vec.ptr, z, n, m, vec.dimAt(-1), axis, None)
+		lib.pz_bias_add(out.wptr, mat.rptr, vec.rptr, z, n, m, vec.dimAt(-1), axis, None)
 		return out
 
 
@@ -938,7 +884,7 @@ class CostModule:
 			def calcAccuracy(x, y, allocator=None):
 				assert x.dtype == np.int32 and y.dtype == np.int32 and x.size == y.size
 				out = GPUArray.empty((), dtype=np.float32, allocator=allocator)
-				lib.pz_count_neq_i32(x.ptr, y.ptr, x.size, out.ptr, None)
+				lib.pz_count_neq_i32(x.rptr, y.rptr, x.size, out.optr, None)
 				return out
 
 			krl = self.accKernelCache[name] = ReductionCallable(calcAccuracy)
@@ -959,7 +905,7 @@ class CostModule:
 
 		ws = GPUArray.empty((n * spatial, ), dtype=np.float32, allocator=allocator)
 		lib.pz_cross_entropy(
-			scores.ptr, labels.ptr, ptrOf(weights), n, c, spatial, grad.ptr, error.ptr, ws.ptr, ws.nbytes, None
+			scores.rptr, labels.rptr, rptrOf(weights), n, c, spatial, grad.optr, error.optr, ws.optr, ws.nbytes, None
 		)
 		return error, grad
 
@@ -1067,13 +1013,104 @@ class StubModule:
 
 
 # ---------------------------------------------------------------------------------------------- element-wise kernel objects
+def absorbRelu(arrays, scalars):
+	"""reluKer(out, in): in place on a described tensor the ReLU joins the description (Modules/Activation.py:52-60 with
+	inplace=True after BatchNorm2D or Add); out of place on a described BatchNorm output, `out` gets the description."""
+	out, inp = arrays
+	waiting = lazy.pending(inp)
+	if waiting is None:
+		return False
+
+	if lazy.sameBuffer(out, inp):
+		if isinstance(waiting, lazy.Zero):
+			return True                                      # relu(0) = 0
+		if isinstance(waiting, fusion.BnApply) and not waiting.relu and lazy.on("bnrelu"):
+			waiting.relu = True
+			return True
+		if isinstance(waiting, fusion.Sum) and not waiting.relu and waiting.gate is None and lazy.on("addrelu"):
+			waiting.relu = True
+			return True
+		return False
+
+	if isinstance(waiting, fusion.BnApply) and not waiting.relu and lazy.on("bnrelu") and lazy.whole(out) and \
+			out.shape == inp.shape and lazy.pending(out) is None:
+		out.optr
+		lazy.attach(out, fusion.BnApply(waiting.x, waiting.coef, relu=True))
+		return True
+	return False
+
+
+def absorbReluDer(arrays, scalars):
+	"""reluDerKer(ingrad, outgrad, outdata) in place (Modules/Activation.py:62-70, inplace=True): the gate (outdata > 0)
+	joins a described fan-in, or becomes a description of its own on a written gradient — the batch-norm backward that
+	reads it next applies it while loading."""
+	ingrad, outgrad, outdata = arrays
+	if not lazy.sameBuffer(ingrad, outgrad) or not lazy.whole(ingrad) or ingrad.shape != outdata.shape or \
+			lazy.sameBuffer(ingrad, outdata):
+		return False
+
+	waiting = lazy.pending(ingrad)
+	root = ingrad.gpudata.root
+	if isinstance(waiting, fusion.Sum) and not waiting.relu and waiting.gate is None and lazy.on("addgate"):
+		waiting.gate = outdata
+		lazy.depend(outdata, root)
+		return True
+
+	if lazy.on("gate"):
+		ingrad.wptr                                          # whatever is pending gets written; dependents are settled
+		lazy.attach(ingrad, fusion.Gate(outdata))
+		return True
+	return False
+
+
+def absorbAxpy(arrays, scalars):
+	"""toVectorAddVectorKer(y, x, alpha) with alpha == 1 onto a zero-filled / summed accumulator (Modules/Add.py:20-22,
+	Replicate.py:27-29): x becomes a term of y's description."""
+	y, x = arrays
+	if float(scalars[0]) != 1.0 or x.size != y.size or x.dtype != y.dtype or not lazy.on("sum"):
+		return False
+	waiting = lazy.pending(y)
+	if not isinstance(waiting, (lazy.Zero, fusion.Sum)) or x.gpudata.root is y.gpudata.root:
+		return False
+	if isinstance(waiting, fusion.Sum) and (waiting.relu or waiting.gate is not None or len(waiting.terms) >= 4):
+		return False
+
+	root = y.gpudata.root
+	if isinstance(waiting, lazy.Zero):
+		total = fusion.Sum()
+		total.shape, total.dtype = waiting.shape, waiting.dtype
+		root.lz.thunk = waiting = total
+
+	src = lazy.pending(x)
+	if isinstance(src, fusion.BnApply) and not src.relu and lazy.on("bnadd") and len(waiting.shape) == 4 and \
+			tuple(src.x.shape) == tuple(waiting.shape):
+		term = ("bn", src.x, src.coef)
+	elif isinstance(src, fusion.Up2) and lazy.on("up2") and len(waiting.shape) == 4:
+		term = ("up2", src.compact)
+	else:
+		term = ("arr", x)
+
+	waiting.terms.append(term)
+	lazy.depend(term[1], root)
+	return True
+
+
 class EltwiseKernel:
 	"""Callable with the launch signature of the reference kernel objects:
 	ker(*arrays_then_scalars, slice=None, stream=None) — Cuda/SourceModule.py:203-226."""
 
+	# optimizer updates write every array but the gradient (index 1); everything else writes its first array only
+	writesAll = frozenset((
+		lib.OP_ADAM, lib.OP_CLASSIC_MOM_SGD, lib.OP_NESTEROV_MOM_SGD, lib.OP_RMSPROP, lib.OP_ADAGRAD, lib.OP_ADADELTA,
+		lib.OP_RMSPROP_GRAVES, lib.OP_SMORMS3
+	))
+
 	def __init__(self, op, narrays, nscalars, name, rawScalar=()):
 		self.op, self.narrays, self.nscalars, self.name = op, narrays, nscalars, name
 		self.rawScalar = rawScalar      # indices of scalars that are integers travelling as raw 32-bit words
+		self.readonly = (1, ) if op in self.writesAll else tuple(range(1, narrays))
+		# a call the lazy-buffer layer can absorb into a tensor's description returns without launching (fusion.py)
+		self.absorb = {lib.OP_RELU: absorbRelu, lib.OP_RELU_DER: absorbReluDer, lib.OP_AXPY: absorbAxpy}.get(op, None)
 
 
 	def __call__(self, *args, **kwargs):
@@ -1085,6 +1122,10 @@ class EltwiseKernel:
 			if not ary.contiguous:
 				raise ValueError("gpuarray is not contiguous")
 
+		slc, stream = kwargs.get("slice", None), kwargs.get("stream", None)
+		if self.absorb is not None and lazy.enabled and slc is None and stream is None and self.absorb(arrays, scalars):
+			return
+
 		words = np.empty(len(scalars), dtype=np.float32)
 		for i, value in enumerate(scalars):
 			if i in self.rawScalar:
@@ -1092,7 +1133,7 @@ class EltwiseKernel:
 			else:
 				words[i] = value
 
-		eltwise(self.op, arrays[0].size, arrays, words, slc=kwargs.get("slice", None), stream=kwargs.get("stream", None))
+		eltwise(self.op, arrays[0].size, arrays, words, slc=slc, stream=stream, readonly=self.readonly)
 
 
 def memoizedKernel(op, narrays, nscalars, name, rawScalar=()):
@@ -1182,17 +1223,17 @@ class RandomNumberGenerator:
 
 	def fillInteger(self, data):
 		assert data.contiguous and data.dtype.itemsize == 4
-		lib.pz_rng_fill_u32(self.handle, data.ptr, data.size, None)
+		lib.pz_rng_fill_u32(self.handle, data.optr, data.size, None)
 
 
 	def fillUniform(self, data):
 		requireF32(data)
-		lib.pz_rng_fill_uniform(self.handle, data.ptr, data.size, None)
+		lib.pz_rng_fill_uniform(self.handle, data.optr, data.size, None)
 
 
 	def fillNormal(self, data, mean=0.0, stddev=1.0):
 		requireF32(data)
-		lib.pz_rng_fill_normal(self.handle, data.ptr, data.size, mean, stddev, None)
+		lib.pz_rng_fill_normal(self.handle, data.optr, data.size, mean, stddev, None)
 
 
 	def __del__(self):

@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) bn_apply_add_kernel(const float *__restri
 
 	auto one = [&](float u, float v) {
 		const float y1 = __builtin_fmaf(u, a1, b1);
-		if (!has2) return y1;
+		if (!has2) return RELU ? (y1 > 0.f ? y1 : 0.f) : y1;      // bn_act<RELU>: what bn_apply_train_kernel writes
 		const float y2 = AFF2 ? __builtin_fmaf(v, a2, b2) : v;
 		const float t = y1 + y2;
 		return RELU ? t * (t > 0.f ? 1.f : 0.f) : t;            // reluKer's x * (x > 0)
@@ -424,13 +424,17 @@ template <bool RELU>
 __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float *__restrict__ x, const float *__restrict__ dy, BnGeom g,
                                                             const float *__restrict__ save_mean,
                                                             const float *__restrict__ save_invvar, const float *__restrict__ scale,
-                                                            const float *__restrict__ bias, float *__restrict__ part) {
+                                                            const float *__restrict__ bias, float *__restrict__ part,
+                                                            const float *__restrict__ gate_coef = nullptr) {
 	__shared__ float red[16];
 	const int ch = blockIdx.x, s = blockIdx.y;
 
 	const float mu = save_mean[ch];
 	float a = 0.f, b = 0.f;
-	if (RELU) bn_affine(save_invvar[ch], mu, scale[ch], bias[ch], a, b);
+	if (RELU) {          // the forward's own {a, b} when the caller kept them (pz_bn_bwd_gate), else re-derived the same way
+		if (gate_coef) a = gate_coef[2 * ch], b = gate_coef[2 * ch + 1];
+		else bn_affine(save_invvar[ch], mu, scale[ch], bias[ch], a, b);
+	}
 	float s1 = 0.f, s2 = 0.f;
 	f4u xv[4], gv[4];
 
@@ -465,7 +469,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
                                                             const float *__restrict__ save_mean,
                                                             const float *__restrict__ save_invvar, float *__restrict__ dscale,
                                                             float *__restrict__ dbias, float *__restrict__ dscale_acc,
-                                                            float *__restrict__ dbias_acc, float alpha, float beta) {
+                                                            float *__restrict__ dbias_acc, float alpha, float beta,
+                                                            const float *__restrict__ gate_coef = nullptr) {
 	const int ch = blockIdx.x, s = blockIdx.y;
 
 	double S1, S2;
@@ -486,7 +491,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 	const float inv_m = 1.f / ((float)g.n * (float)g.hw);
 	const float k0 = sc * rstd, k1 = db * inv_m, k2 = ds * inv_m * rstd;
 	float a = 0.f, b = 0.f;
-	if (RELU) bn_affine(rstd, mu, sc, bias[ch], a, b);
+	if (RELU) {
+		if (gate_coef) a = gate_coef[2 * ch], b = gate_coef[2 * ch + 1];
+		else bn_affine(rstd, mu, sc, bias[ch], a, b);
+	}
 	f4u xv[4], gv[4];
 
 	channel_foreach<4>(
@@ -503,6 +511,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float *x, const
 		    *reinterpret_cast<f4u *>(dx + off) = q;
 	    },
 	    [&](size_t off) { dx[off] = k0 * (bn_gate<RELU>(dy[off], x[off], a, b) - k1 - (x[off] - mu) * k2); });
+}
+
+// dx = A*dy + (B*x + C) per channel from the coefficient form of the backward (pz_bn_bwd_coef) — the expression the
+// convolution kernels evaluate while gathering (conv.hip, BNX), written out for consumers that cannot fold it.
+__global__ void __launch_bounds__(256) bn_bwd_apply_coef_kernel(const float *x, const float *dy, float *dx, BnGeom g,
+                                                                 const float4 *__restrict__ coef) {
+	const int ch = blockIdx.x, s = blockIdx.y;
+	const float4 k = coef[ch];
+	f4u xv[4], gv[4];
+	channel_foreach<4>(
+	    g, ch, s,
+	    [&](int u, size_t off) {
+		    xv[u] = *reinterpret_cast<const f4u *>(x + off);
+		    gv[u] = *reinterpret_cast<const f4u *>(dy + off);
+	    },
+	    [&](int u, size_t off) {
+		    f4u q;
+#pragma unroll
+		    for (int e = 0; e < 4; ++e) q[e] = __builtin_fmaf(k.x, gv[u][e], __builtin_fmaf(k.y, xv[u][e], k.z));
+		    *reinterpret_cast<f4u *>(dx + off) = q;
+	    },
+	    [&](size_t off) { dx[off] = __builtin_fmaf(k.x, dy[off], __builtin_fmaf(k.y, x[off], k.z)); });
 }
 
 // Gradient fan-in of a residual block fused with the statistics pass of the batch-norm backward(s) that consume it:
@@ -708,6 +738,52 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
 	return PZ_OK;
 }
 
+// Per channel {mean, var} from the statistics pass's merged shifted sums (what bn_apply_train_kernel<.., false> derives
+// in every workgroup): pre[2ch] = mean, pre[2ch+1] = var — the input format of bn_finalize_kernel.
+__global__ void __launch_bounds__(256) bn_parts_to_pre_kernel(const float *__restrict__ part, const float *__restrict__ shift, int c,
+                                                               double cnt, float *__restrict__ pre) {
+	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+	if (ch >= c) return;
+	double S1, S2;
+	bn_merge(part, ch, S1, S2);
+	const double m1 = S1 / cnt;
+	double var = S2 / cnt - m1 * m1;
+	var = var > 0.0 ? var : 0.0;
+	pre[2 * ch] = (float)((double)shift[ch] + m1);
+	pre[2 * ch + 1] = (float)var;
+}
+
+// Training-mode forward without the normalisation pass: statistics (from the producing convolution's strip sums when
+// `stats` is given, else from a pass over x), saved / running statistics, and coef[ch] = {a, b} of y = a*x + b. Whoever
+// reads the normalised tensor applies the pair on the fly (pz_bn_apply_add, pz_conv2d_fwd_bn); the lazy-buffer layer of
+// the backend (puzzlelib_amd/lazy.py) decides whether the tensor is ever written.
+int pz_bn_fwd_train_coef(const float *x, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
+                         float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor, const float *stats,
+                         int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	if (stats)
+		return pz_bn_fwd_train_defer(n, c, hw, scale, bias, run_mean, run_var, save_mean, save_invvar, epsilon, factor, stats,
+		                             strips, coef, workspace, ws_bytes, stream);
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && scale && bias && run_mean && run_var && save_mean && save_invvar && coef, "pz_bn_fwd_train_coef: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g) && ws_bytes >= bn_pre_ws_bytes(c), "pz_bn_fwd_train_coef: workspace too small");
+
+	const BnGeom gc = bn_geom_coarse(n, c, hw);
+	float *part = (float *)workspace, *shift = part + bn_parts_offset_floats(c) + (size_t)c * g.splits * 2;
+	hipStream_t st = pz::as_stream(stream);
+	bn_stats_kernel<<<dim3(c, gc.splits), 256, 0, st>>>(x, gc, part, shift);
+	PZ_LAUNCH_CHECK();
+	bn_reduce_parts(part, gc.splits, c, st);
+	// {mean, var} overwrite the per-workgroup partials, dead once bn_reduce_parts has folded them into the merged totals
+	float *pre = part + bn_parts_offset_floats(c);
+	bn_parts_to_pre_kernel<<<(c + 255) / 256, 256, 0, st>>>(part, shift, c, (double)n * hw, pre);
+	PZ_LAUNCH_CHECK();
+	bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(pre, c, (double)n * hw, scale, bias, run_mean, run_var, save_mean,
+	                                                    save_invvar, epsilon, factor, coef);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 int pz_relu_mask_bytes(int n, int c, int hw, size_t *nbytes) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(nbytes != nullptr, "pz_relu_mask_bytes: null output");
@@ -724,7 +800,7 @@ int pz_bn_apply_add_mask(const float *x1, const float *coef1, const float *x2, c
                          int n, int c, int hw, int relu, pz_stream_t stream) {
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(x1 && coef1 && out, "pz_bn_apply_add: null tensor");
-	PZ_REQUIRE(x2 || (!coef2 && !relu), "pz_bn_apply_add: a second operand is needed for its coefficients / the fused ReLU");
+	PZ_REQUIRE(x2 || !coef2, "pz_bn_apply_add: coefficients of a second operand without the operand");
 	PZ_REQUIRE(mask == nullptr || relu, "pz_bn_apply_add_mask: the sign mask belongs to the fused ReLU");
 	const BnGeom g = bn_geom(n, c, hw);
 	const dim3 grid(c, g.splits);
@@ -792,6 +868,43 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
 	return PZ_OK;
 }
 
+// Backward of a BatchNorm whose output went through a ReLU, the gate (y > 0) re-created from x with the forward's own
+// coefficient pairs `gate_coef` = {a, b} per channel (pz_bn_fwd_train_coef): dy is masked on load in both passes, the
+// ReLU's output is not read and its derivative costs no pass of its own.
+int pz_bn_bwd_gate(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *save_mean,
+                   const float *save_invvar, float *dscale, float *dbias, const float *gate_coef, void *workspace,
+                   size_t ws_bytes, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias && gate_coef, "pz_bn_bwd_gate: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_bwd_gate: workspace too small");
+	float *part = (float *)workspace;
+	hipStream_t st = pz::as_stream(stream);
+	dim3 grid(c, g.splits);
+	bn_bwd_stats_kernel<true><<<grid, 256, 0, st>>>(x, dy, g, save_mean, save_invvar, scale, nullptr, part, gate_coef);
+	PZ_LAUNCH_CHECK();
+	bn_reduce_parts(part, g.splits, c, st);
+	bn_bwd_apply_kernel<true><<<grid, 256, 0, st>>>(x, dy, dx, g, part, scale, nullptr, save_mean, save_invvar, dscale, dbias,
+	                                                nullptr, nullptr, 1.f, 0.f, gate_coef);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+// Statistics pass of the backward alone: partial sums {sum dy, sum dy*(x - mean)} in the layout pz_bn_bwd_coef /
+// pz_bn_bwd_from_partials read (what pz_bn_gate_stats leaves when the gradient comes out of a fan-in).
+int pz_bn_bwd_stats(const float *x, const float *dy, int n, int c, int hw, const float *save_mean, float *partials,
+                    pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && save_mean && partials, "pz_bn_bwd_stats: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	hipStream_t st = pz::as_stream(stream);
+	bn_bwd_stats_kernel<false><<<dim3(c, g.splits), 256, 0, st>>>(x, dy, g, save_mean, nullptr, nullptr, nullptr, partials);
+	PZ_LAUNCH_CHECK();
+	bn_reduce_parts(partials, g.splits, c, st);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 // Backward coefficients: dx = A*dy + B*x + C per channel (A = gamma*rstd, B = -A*k2, C = A*(mean*k2 - k1) with
 // k1 = dbias/m, k2 = dgamma*rstd/m) plus the parameter gradients, from the partial sums — for consumers that apply the
 // BatchNorm backward while they gather dy (pz_conv2d_bwd_data_bn / pz_conv2d_bwd_filter_bn): the 12 B/elem apply pass
@@ -826,6 +939,15 @@ int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_m
 	bn_bwd_coef_kernel<<<(c + 255) / 256, 256, 0, pz::as_stream(stream)>>>(
 	    partials, g.splits, c, 1.f / ((float)n * (float)hw), scale, save_mean, save_invvar, dscale, dbias, dscale_acc, dbias_acc,
 	    alpha, beta, reinterpret_cast<float4 *>(coef));
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_bn_bwd_apply_coef(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *coef, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && dx && coef, "pz_bn_bwd_apply_coef: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	bn_bwd_apply_coef_kernel<<<dim3(c, g.splits), 256, 0, pz::as_stream(stream)>>>(x, dy, dx, g, reinterpret_cast<const float4 *>(coef));
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

@@ -5,6 +5,8 @@
 #include "common.h"
 
 #include <dlfcn.h>
+#include <chrono>
+#include <thread>
 
 namespace {
 
@@ -22,6 +24,8 @@ struct Rccl {
 	ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
+	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 Rccl g_rccl;
@@ -49,6 +53,8 @@ int load_rccl() {
 	PZ_SYM(AllReduce, "ncclAllReduce")
 	PZ_SYM(Broadcast, "ncclBroadcast")
 	PZ_SYM(GetErrorString, "ncclGetErrorString")
+	PZ_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
+	PZ_SYM(CommAbort, "ncclCommAbort")
 #undef PZ_SYM
 
 	g_rccl.lib = lib;
@@ -93,22 +99,59 @@ int pz_comm_init_rank(pz_comm_t *comm, int nranks, const char id[PZ_COMM_ID_BYTE
 	return PZ_OK;
 }
 
+int pz_comm_probe(void) {
+	return load_rccl();
+}
+
+int pz_comm_async_error(pz_comm_t comm) {
+	PZ_REQUIRE(comm != nullptr, "pz_comm_async_error: null communicator");
+	ncclResult_t state = 0;
+	PZ_NCCL(g_rccl.CommGetAsyncError(comm->comm, &state));
+	if (state != 0 && state != 7 /* ncclInProgress */) {
+		pz::set_error("RCCL communicator of rank %d/%d reports an asynchronous error: %s", comm->rank, comm->nranks,
+		              g_rccl.GetErrorString(state));
+		return PZ_ERR_COMM;
+	}
+	return PZ_OK;
+}
+
+int pz_comm_wait_event(pz_comm_t comm, pz_event_t event, double timeout_s) {
+	PZ_REQUIRE(comm != nullptr && event != nullptr, "pz_comm_wait_event: null argument");
+	const auto t0 = std::chrono::steady_clock::now();
+	for (;;) {
+		const hipError_t rc = hipEventQuery((hipEvent_t)event);
+		if (rc == hipSuccess) return PZ_OK;
+		if (rc != hipErrorNotReady) PZ_HIP(rc);
+		if (int err = pz_comm_async_error(comm)) return err;
+		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if (timeout_s > 0.0 && waited > timeout_s) {
+			// a collective some rank never joined would otherwise block the stream (and every later sync) for good
+			g_rccl.CommAbort(comm->comm);
+			comm->comm = nullptr;
+			pz::set_error("RCCL collective of rank %d/%d did not complete within %.1f s: communicator aborted", comm->rank,
+			              comm->nranks, timeout_s);
+			return PZ_ERR_COMM;
+		}
+		std::this_thread::sleep_for(std::chrono::microseconds(50));
+	}
+}
+
 int pz_comm_destroy(pz_comm_t comm) {
 	if (!comm) return PZ_OK;
-	PZ_NCCL(g_rccl.CommDestroy(comm->comm));
+	if (comm->comm) PZ_NCCL(g_rccl.CommDestroy(comm->comm));
 	delete comm;
 	return PZ_OK;
 }
 
 int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, size_t count, pz_stream_t stream) {
-	PZ_REQUIRE(comm != nullptr && send && recv, "pz_comm_allreduce_sum_f32: null argument");
+	PZ_REQUIRE(comm != nullptr && comm->comm && send && recv, "pz_comm_allreduce_sum_f32: null argument or aborted communicator");
 	if (count == 0) return PZ_OK;
 	PZ_NCCL(g_rccl.AllReduce(send, recv, count, ncclFloat32, ncclSum, comm->comm, pz::as_stream(stream)));
 	return PZ_OK;
 }
 
 int pz_comm_broadcast(pz_comm_t comm, void *buf, size_t nbytes, int root, pz_stream_t stream) {
-	PZ_REQUIRE(comm != nullptr && buf, "pz_comm_broadcast: null argument");
+	PZ_REQUIRE(comm != nullptr && comm->comm && buf, "pz_comm_broadcast: null argument or aborted communicator");
 	if (nbytes == 0) return PZ_OK;
 	PZ_NCCL(g_rccl.Broadcast(buf, buf, nbytes, ncclUint8, root, comm->comm, pz::as_stream(stream)));
 	return PZ_OK;

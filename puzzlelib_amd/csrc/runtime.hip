@@ -374,6 +374,14 @@ int pz_event_sync(pz_event_t event) {
 	return PZ_OK;
 }
 
+int pz_event_query(pz_event_t event, int *done) {
+	PZ_REQUIRE(event && done, "pz_event_query: null argument");
+	const hipError_t rc = hipEventQuery((hipEvent_t)event);
+	if (rc != hipSuccess && rc != hipErrorNotReady) PZ_HIP(rc);
+	*done = rc == hipSuccess;
+	return PZ_OK;
+}
+
 int pz_event_elapsed_ms(pz_event_t start, pz_event_t end, float *ms) {
 	PZ_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)end));
 	return PZ_OK;

@@ -113,6 +113,12 @@ class Event:
 		lib.pz_event_sync(self.handle)
 
 
+	def query(self):
+		done = c_int(0)
+		lib.pz_event_query(self.handle, byref(done))
+		return bool(done.value)
+
+
 	def timeTill(self, end):
 		ms = c_float(0.0)
 		lib.pz_event_elapsed_ms(self.handle, end.handle, byref(ms))
@@ -135,11 +141,15 @@ def streamHandle(stream):
 class Buffer:
 	"""A span of device memory. `parent` is the MemoryPool (or None for a raw allocation) for an owning buffer and
 	the sliced Buffer for a view — the same convention the reference uses (Cuda/GPUArray.py:146-154)."""
-	__slots__ = ["ptr", "size", "parent", "owner", "__weakref__"]
+	__slots__ = ["ptr", "size", "parent", "owner", "root", "lz", "__weakref__"]
 
 
 	def __init__(self, ptr, size, parent=None, owner=False):
 		self.ptr, self.size, self.parent, self.owner = ptr, size, parent, owner
+		# `root`: the allocation this span lies in (itself unless it is a view); `lz`: that allocation's lazy state
+		# (puzzlelib_amd/lazy.py — pending contents, dependents, foreign-stream events), None for most buffers
+		self.root = parent.root if isinstance(parent, Buffer) else self
+		self.lz = None
 
 
 	@classmethod
@@ -177,8 +187,20 @@ class Buffer:
 			pass
 
 
+	def access(self, write=False, whole=False):
+		"""The span's address after the lazy-buffer barriers (lazy.py) for a main-stream read or write."""
+		root = self.root
+		if root.lz is not None:
+			from puzzlelib_amd import lazy
+			if write:
+				lazy.writeBarrier(root, whole and self.size == root.size)
+			else:
+				lazy.readBarrier(root)
+		return self.ptr
+
+
 	def fillD32(self, value, stream=None):
-		lib.pz_memset_d32(self.ptr, int(value) & 0xffffffff, self.size // 4, streamHandle(stream))
+		lib.pz_memset_d32(self.access(True, True), int(value) & 0xffffffff, self.size // 4, streamHandle(stream))
 		return self
 
 
@@ -188,16 +210,16 @@ class Buffer:
 		elif dst.size < self.size:
 			raise ValueError("destination buffer is too small")
 
-		lib.pz_memcpy_d2d(dst.ptr, self.ptr, self.size, streamHandle(stream))
+		lib.pz_memcpy_d2d(dst.access(True), self.access(), self.size, streamHandle(stream))
 		return dst
 
 
 	def set(self, hostptr, nbytes, stream=None):
-		lib.pz_memcpy_h2d(self.ptr, hostptr, nbytes, streamHandle(stream))
+		lib.pz_memcpy_h2d(self.access(True), hostptr, nbytes, streamHandle(stream))
 
 
 	def get(self, hostptr, nbytes, stream=None):
-		lib.pz_memcpy_d2h(hostptr, self.ptr, nbytes, streamHandle(stream))
+		lib.pz_memcpy_d2h(hostptr, self.access(), nbytes, streamHandle(stream))
 		lib.pz_stream_sync(streamHandle(stream))
 
 
@@ -250,7 +272,7 @@ class MemoryPool:
 
 def memcpy2D(width, height, src, srcPitch, dst, dstPitch, srcX=0, dstX=0, stream=None):
 	"""Pitched device-to-device copy; argument order of Driver.memcpy2D as used by Cuda/GPUBackend.py:296,320."""
-	lib.pz_memcpy_2d(dst.ptr + dstX, dstPitch, src.ptr + srcX, srcPitch, width, height, streamHandle(stream))
+	lib.pz_memcpy_2d(dst.access(True) + dstX, dstPitch, src.access() + srcX, srcPitch, width, height, streamHandle(stream))
 
 
 def allocateFromIPCHandle(handle, size):

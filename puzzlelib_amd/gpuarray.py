@@ -7,10 +7,10 @@ empty/zeros/emptyLike/zerosLike/toGpu, __getitem__; Python part Cuda/GPUArray.py
 fill/astype/min/max/+/*/+=/*=/__setitem__), re-implemented over raw device pointers and the C ABI. Views share the
 parent's Buffer; ops never retain their inputs. All arithmetic runs in HIP kernels (pz_eltwise / pz_reduce_*).
 """
-import ctypes
+import ctypes, os
 import numpy as np
 
-from puzzlelib_amd import lib
+from puzzlelib_amd import lib, lazy
 from puzzlelib_amd.driver import Buffer, Device, streamHandle
 
 
@@ -71,6 +71,7 @@ class GPUArray:
 	__slots__ = ["shape", "strides", "dtype", "gpudata", "size", "ndim", "nbytes", "contiguous", "__weakref__"]
 
 	defaultAllocator = None        # set by the backend: its memory pool
+	debugFill = os.environ.get("PUZZLE_MI355_DEBUG_ALLOC", "0") == "1"     # setupDebugAllocator (Cuda/Utils.py:97-114)
 
 
 	def __init__(self, shape, dtype, allocator=None, gpudata=None, strides=None):
@@ -92,6 +93,10 @@ class GPUArray:
 		if gpudata is None:
 			allocator = GPUArray.defaultAllocator if allocator is None else allocator
 			gpudata = allocator.allocate(self.nbytes) if allocator is not None else Buffer.allocate(self.nbytes)
+			if GPUArray.debugFill and self.nbytes >= 4:
+				# the reference's debug allocator poisons fresh memory with NaNs so that reads of unwritten data show up
+				# (Cuda/Utils.py:97-114, switched on by Unittester.py:52-55)
+				lib.pz_memset_d32(gpudata.ptr, 0x7fc00000, self.nbytes // 4, None)
 
 		elif self.contiguous and gpudata.size < self.nbytes:
 			raise ValueError("gpudata buffer is too small (%d < %d bytes)" % (gpudata.size, self.nbytes))
@@ -100,9 +105,50 @@ class GPUArray:
 
 
 	# ------------------------------------------------------------------ properties
+	# Device addresses are handed out behind the lazy-buffer barriers (puzzlelib_amd/lazy.py): `rptr` for reading, `wptr`
+	# for partial or read-modify-write access, `optr` when the whole array is about to be overwritten, `ptr` (the
+	# reference attribute, Array.c:1462-1512) when the use is not known = read + write.
 	@property
-	def ptr(self):
-		return self.gpudata.ptr
+	def rptr(self):
+		buf = self.gpudata
+		root = buf.root
+		if root.lz is not None:
+			lazy.readBarrier(root)
+		return buf.ptr
+
+
+	@property
+	def wptr(self):
+		buf = self.gpudata
+		root = buf.root
+		if root.lz is not None:
+			lazy.writeBarrier(root)
+		return buf.ptr
+
+
+	@property
+	def optr(self):
+		buf = self.gpudata
+		root = buf.root
+		if root.lz is not None:
+			lazy.writeBarrier(root, self.contiguous and buf.ptr == root.ptr and self.nbytes == root.size)
+		return buf.ptr
+
+
+	ptr = wptr
+
+
+	def ptrOn(self, stream, write):
+		"""Address for a launch on a foreign stream: pending contents are settled (on the main stream, which the foreign
+		stream is made to follow), events of *other* streams are waited for by `stream`."""
+		buf = self.gpudata
+		root = buf.root
+		if root.lz is not None:
+			if write:
+				lazy.writeBarrier(root, False, stream)
+			else:
+				lazy.readBarrier(root, stream)
+		return buf.ptr
 
 
 	@property
@@ -168,7 +214,7 @@ class GPUArray:
 	def stridedCopyFrom(self, src, stream=None):
 		self.enforceWordSized()
 		shape = (ctypes.c_int64 * max(self.ndim, 1))(*self.shape)
-		lib.pz_strided_copy(self.ptr, self.elemStrides(), src.ptr, src.elemStrides(), shape, self.ndim, streamHandle(stream))
+		lib.pz_strided_copy(self.wptr, self.elemStrides(), src.rptr, src.elemStrides(), shape, self.ndim, streamHandle(stream))
 
 
 	def get(self, stream=None):
@@ -176,7 +222,7 @@ class GPUArray:
 		out = np.empty(self.shape, dtype=self.dtype)
 
 		if self.nbytes > 0:
-			lib.pz_memcpy_d2h(out.ctypes.data, src.ptr, self.nbytes, streamHandle(stream))
+			lib.pz_memcpy_d2h(out.ctypes.data, src.rptr, self.nbytes, streamHandle(stream))
 			lib.pz_stream_sync(streamHandle(stream))
 
 		return out
@@ -190,7 +236,7 @@ class GPUArray:
 				))
 
 			if self.contiguous and ary.contiguous:
-				lib.pz_memcpy_d2d(self.ptr, ary.ptr, self.nbytes, streamHandle(stream))
+				lib.pz_memcpy_d2d(self.optr, ary.rptr, self.nbytes, streamHandle(stream))
 			else:
 				self.stridedCopyFrom(ary, stream)
 			return
@@ -206,7 +252,7 @@ class GPUArray:
 			return
 
 		if self.contiguous:
-			lib.pz_memcpy_h2d(self.ptr, ary.ctypes.data, self.nbytes, streamHandle(stream))
+			lib.pz_memcpy_h2d(self.optr, ary.ctypes.data, self.nbytes, streamHandle(stream))
 			lib.pz_stream_sync(streamHandle(stream))      # the host array may die right after this call
 		else:
 			self.stridedCopyFrom(GPUArray.toGpu(ary), stream)
@@ -309,11 +355,18 @@ class GPUArray:
 		item = self.dtype.type(value)
 		if self.dtype.itemsize == 4:
 			word = int(np.array(item).view(np.uint32))
-			lib.pz_memset_d32(self.ptr, word, self.size, None)
+			if word == 0 and lazy.enabled and self.dtype == np.float32 and self.nbytes >= lazy.Zero.threshold and \
+					self.gpudata.root is self.gpudata and self.nbytes == self.gpudata.size:
+				# a big tensor zeroed right after its allocation is the accumulator of a residual Add / gradient fan-in
+				# (Modules/Add.py:15-22, Replicate.py:22-29): the zeros are written only if somebody asks for them
+				self.optr
+				lazy.attach(self, lazy.Zero())
+				return self
+			lib.pz_memset_d32(self.optr, word, self.size, None)
 
 		elif self.dtype.itemsize == 1 and self.nbytes % 4 == 0:
 			byte = int(np.array(item).view(np.uint8))
-			lib.pz_memset_d32(self.ptr, byte * 0x01010101, self.nbytes // 4, None)
+			lib.pz_memset_d32(self.optr, byte * 0x01010101, self.nbytes // 4, None)
 
 		else:
 			self.set(np.full(self.shape, item, dtype=self.dtype))
@@ -329,9 +382,9 @@ class GPUArray:
 		if dtype == self.dtype:
 			out.set(self)
 		elif self.dtype == np.int32 and dtype == np.float32:
-			lib.pz_cast_i32_f32(out.ptr, self.ptr, self.size, None)
+			lib.pz_cast_i32_f32(out.optr, self.rptr, self.size, None)
 		elif self.dtype == np.float32 and dtype == np.int32:
-			lib.pz_cast_f32_i32(out.ptr, self.ptr, self.size, None)
+			lib.pz_cast_f32_i32(out.optr, self.rptr, self.size, None)
 		else:
 			raise NotImplementedError("astype %s -> %s" % (self.dtype, dtype))
 
@@ -343,9 +396,9 @@ class GPUArray:
 		out = GPUArray((), self.dtype, allocator=findParentAllocator(self.gpudata))
 
 		if self.dtype == np.float32:
-			lib.pz_reduce_minmax_f32(self.ptr, self.size, int(isMax), out.ptr, None)
+			lib.pz_reduce_minmax_f32(self.rptr, self.size, int(isMax), out.optr, None)
 		elif self.dtype == np.int32:
-			lib.pz_reduce_minmax_i32(self.ptr, self.size, int(isMax), out.ptr, None)
+			lib.pz_reduce_minmax_i32(self.rptr, self.size, int(isMax), out.optr, None)
 		else:
 			raise NotImplementedError(self.dtype)
 
@@ -400,7 +453,7 @@ class GPUArray:
 
 
 	def __repr__(self):
-		return "GPUArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.ptr or 0)
+		return "GPUArray(shape=%s, dtype=%s, ptr=0x%x)" % (self.shape, self.dtype, self.gpudata.ptr or 0)
 
 
 def findParentAllocator(*buffers):
@@ -417,10 +470,20 @@ def findParentAllocator(*buffers):
 	return None
 
 
-def eltwise(op, count, arrays, scalars=(), slc=None, stream=None):
-	"""One launch of the element-wise family: pz_eltwise(op, count, ptrs, scalars, start, stop, step)."""
+def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None):
+	"""One launch of the element-wise family: pz_eltwise(op, count, ptrs, scalars, start, stop, step).
+	`readonly`: indices of arrays the op only reads (default: every array but the first)."""
 	nptrs = len(arrays)
-	ptrs = (ctypes.c_void_p * nptrs)(*[a.ptr for a in arrays])
+	if readonly is None:
+		readonly = range(1, nptrs)
+
+	if stream is None:
+		ptrs = (ctypes.c_void_p * nptrs)(*[a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)])
+	else:
+		# a borrowed stream (Optimizer.update(useStreams=True)): it follows the main stream up to here, and what it writes
+		# carries its completion event, so the main stream waits exactly when it touches those buffers again
+		ptrs = (ctypes.c_void_p * nptrs)(*[a.ptrOn(stream, i not in readonly) for i, a in enumerate(arrays)])
+		ready = lazy.foreignBegin(stream)
 
 	# scalars travel as raw float32 words (bit patterns such as the dropout threshold must survive untouched)
 	sc = np.ascontiguousarray(scalars, dtype=np.float32) if not isinstance(scalars, np.ndarray) else scalars
@@ -435,3 +498,9 @@ def eltwise(op, count, arrays, scalars=(), slc=None, stream=None):
 		step = 1 if slc.step is None else slc.step
 
 	lib.pz_eltwise(op, count, ptrs, nptrs, scptr, nsc, start, stop, step, streamHandle(stream))
+
+	if stream is not None:
+		lazy.foreignEnd(
+			stream, ready, reads=[a for i, a in enumerate(arrays) if i in readonly],
+			writes=[a for i, a in enumerate(arrays) if i not in readonly]
+		)

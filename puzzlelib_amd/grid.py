@@ -11,18 +11,127 @@ but sits on RCCL collectives over xGMI:
   sumTensor(name, tensor)        ->  g <- (g_0 + ... + g_{N-1}) / N  via ncclAllReduce(sum) + one scale kernel
   meanValue(value)               ->  scalar mean over ranks
 
-and the gradient exchange is bucketed and overlapped with backward: the flat arena is cut into buckets of ~25 MB
-(contiguous ranges, i.e. sets of variables); a module-level hook marks variables complete as backward produces them,
-and as soon as a bucket's completion set is full its all-reduce is queued on a dedicated communication stream behind
-an event recorded on the compute stream. `sumTensor` at update time only queues what is still missing, makes the
-compute stream wait for the communication stream and scales by 1/N.
+and the gradient exchange is bucketed and overlapped with backward: the flat arena — laid out in the order backward
+finishes the gradients (puzzlelib_amd/optim.py, Optimizer.arenaOrder) — is cut into buckets of ~25 MB; the executor
+reports layers whose parameter gradients are final, and as soon as a bucket's completion set is full its all-reduce is
+queued on a dedicated communication stream behind events of the compute stream and of the filter-gradient stream.
+`sumTensor` at update time only queues what is still missing, makes the compute stream wait and scales by 1/N.
 
-Processes are started by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT);
-torch.distributed's gloo group is used ONLY to hand the 128-byte RCCL unique id to the other ranks and for host scalars.
+Ranks are separate processes (started by `python -m torch.distributed.run`, or by bench.py itself); everything they
+exchange on the host — the 128-byte RCCL id, yes/no votes, scalar means, barriers — goes over a plain TCP star on
+MASTER_ADDR (`HostGroup`): no PyTorch in the product path.
 """
-import os
+import os, socket, struct, sys, time
 
 import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------- host-side group (TCP star)
+class HostGroup:
+	"""Rank 0 listens on (MASTER_ADDR, port) and keeps one connection per peer. Collectives are a gather to rank 0
+	followed by a scatter of the result: bytes broadcast, float64 reductions, float32 array sums (the fallback gradient
+	transport), barrier. Messages are length-prefixed; every call is made by all ranks in the same order."""
+
+	def __init__(self, rank, world, addr, port, timeout=120.0):
+		self.rank, self.world = rank, world
+		self.peers = []
+		if world == 1:
+			return
+
+		if rank == 0:
+			server = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+			server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+			server.bind((addr, port))
+			server.listen(world)
+			server.settimeout(timeout)
+			slots = [None] * world
+			for _ in range(world - 1):
+				conn, _ = server.accept()
+				conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+				conn.settimeout(None)
+				peer = struct.unpack("<i", self.recvExact(conn, 4))[0]
+				slots[peer] = conn
+			server.close()
+			self.peers = slots
+		else:
+			deadline = time.time() + timeout
+			while True:
+				try:
+					conn = socket.create_connection((addr, port), timeout=5.0)
+					break
+				except OSError:
+					if time.time() > deadline:
+						raise
+					time.sleep(0.05)
+			conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+			conn.settimeout(None)
+			conn.sendall(struct.pack("<i", rank))
+			self.root = conn
+
+	@staticmethod
+	def recvExact(conn, n):
+		chunks = []
+		while n > 0:
+			part = conn.recv(min(n, 1 << 20))
+			if not part:
+				raise ConnectionError("peer closed the host group connection")
+			chunks.append(part)
+			n -= len(part)
+		return b"".join(chunks)
+
+	@classmethod
+	def send(cls, conn, payload):
+		conn.sendall(struct.pack("<q", len(payload)) + payload)
+
+	@classmethod
+	def recv(cls, conn):
+		(n, ) = struct.unpack("<q", cls.recvExact(conn, 8))
+		return cls.recvExact(conn, n)
+
+	def gatherScatter(self, payload, combine):
+		"""rank 0 applies `combine([payload_0, ..., payload_{N-1}]) -> bytes`; every rank returns the result"""
+		if self.world == 1:
+			return combine([payload])
+		if self.rank == 0:
+			parts = [payload] + [self.recv(self.peers[r]) for r in range(1, self.world)]
+			result = combine(parts)
+			for r in range(1, self.world):
+				self.send(self.peers[r], result)
+			return result
+		self.send(self.root, payload)
+		return self.recv(self.root)
+
+	def broadcast(self, payload):
+		return self.gatherScatter(payload if self.rank == 0 else b"", lambda parts: parts[0])
+
+	def reduce(self, value, op="sum"):
+		fn = {"sum": sum, "min": min, "max": max}[op]
+		out = self.gatherScatter(
+			struct.pack("<d", float(value)), lambda parts: struct.pack("<d", fn(struct.unpack("<d", p)[0] for p in parts))
+		)
+		return struct.unpack("<d", out)[0]
+
+	def sumArray(self, array):
+		"""in-place element-wise sum of a float32 array over the ranks (ascending rank order on every element)"""
+		def combine(parts):
+			total = np.frombuffer(parts[0], dtype=np.float32).copy()
+			for part in parts[1:]:
+				total += np.frombuffer(part, dtype=np.float32)
+			return total.tobytes()
+		array[...] = np.frombuffer(self.gatherScatter(array.tobytes(), combine), dtype=np.float32).reshape(array.shape)
+
+	def barrier(self):
+		self.reduce(0.0)
+
+	def close(self):
+		for conn in self.peers[1:] if self.rank == 0 else ([self.root] if self.world > 1 else []):
+			try:
+				conn.close()
+			except OSError:
+				pass
+
+
+hostGroup = None          # set by nodeFromEnv
 
 
 # ---------------------------------------------------------------------------------------------- bucket planning (pure host logic)
@@ -35,9 +144,9 @@ class Bucket:
 
 
 def planBuckets(blocks, bucketBytes):
-	"""blocks: ordered [(name, byteOffset, nbytes)] of the flat arena (registration order = sorted names, 16-B aligned,
-	Cuda/Utils.py:39-55). Returns contiguous buckets [(startByte, stopByte, [names])] of at least `bucketBytes`
-	(except the last), covering the arena from 0 to the end of the last block without gaps."""
+	"""blocks: ordered [(name, byteOffset, nbytes)] of the flat arena (16-B aligned, Cuda/Utils.py:39-55). Returns
+	contiguous buckets [(startByte, stopByte, [names])] of at least `bucketBytes` (except the last), covering the arena
+	from 0 to the end of the last block without gaps."""
 	buckets, names, start = [], [], 0
 	end = 0
 
@@ -63,7 +172,7 @@ def planBuckets(blocks, bucketBytes):
 
 class GradReducer:
 	"""Completion-set bucketing of one flat gradient arena. Device work is delegated to `ops`:
-	  ops.markReady()                 record 'gradients up to here are final' on the compute stream -> token
+	  ops.markReady()                 record 'gradients up to here are final' on the compute stream(s) -> token
 	  ops.allreduce(start, stop, tok) queue an in-place sum all-reduce of arena bytes [start, stop) after `tok`
 	  ops.finish(scale)               make compute wait for all queued collectives, then scale the arena by `scale`
 	"""
@@ -72,28 +181,25 @@ class GradReducer:
 		self.ops, self.gridsize = ops, gridsize
 		self.buckets = [Bucket(*b) for b in planBuckets(blocks, bucketBytes)]
 		self.owner = {name: bucket for bucket in self.buckets for name in bucket.names}
-
+		self.launchedBytes = []       # bytes already handed to the transport after each variableReady (tests, tools)
 
 	def beginStep(self):
+		self.launchedBytes = []
 		for bucket in self.buckets:
 			bucket.pending, bucket.launched = set(bucket.names), False
 
-
 	def variableReady(self, name):
 		bucket = self.owner.get(name, None)
-		if bucket is None or bucket.launched:
-			return
-
-		bucket.pending.discard(name)
-		if not bucket.pending:
-			self.launch(bucket)
-
+		if bucket is not None and not bucket.launched:
+			bucket.pending.discard(name)
+			if not bucket.pending:
+				self.launch(bucket)
+		self.launchedBytes.append(sum(b.stop - b.start for b in self.buckets if b.launched))
 
 	def launch(self, bucket):
 		token = self.ops.markReady()
 		self.ops.allreduce(bucket.start, bucket.stop, token)
 		bucket.launched = True
-
 
 	def finishStep(self):
 		for bucket in self.buckets:
@@ -122,64 +228,51 @@ class NodeInfo:
 
 
 class RcclNodeInfo(NodeInfo):
-	def __init__(self, index, gridsize, device, uniqueId, hostGroup=None, bucketBytes=25 << 20):
-		super().__init__(index, gridsize, device)
-		self.uniqueId, self.hostGroup, self.bucketBytes = uniqueId, hostGroup, bucketBytes
-
-		self.comm = None
-		self.commStream = None
-		self.reducers = {}
-		self.lastEvents = []
-
-
-	# ---- lazy device side (the backend must be bound to Config.deviceIdx == self.device first)
 	transport = "rccl"
+	timeout = float(os.environ.get("PUZZLE_MI355_COMM_TIMEOUT_S", "0"))     # > 0: host-side watchdog on every step's exchange
 
-	def allRanksOk(self, ok):
-		"""True iff every rank reports success (host all-reduce over the bootstrap group)."""
-		if self.gridsize == 1:
-			return ok
+	def __init__(self, index, gridsize, device, uniqueId, group, bucketBytes=25 << 20):
+		super().__init__(index, gridsize, device)
+		self.uniqueId, self.group, self.bucketBytes = uniqueId, group, bucketBytes
+		self.comm = self.commStream = None
+		self.reducers = {}
 
-		import torch, torch.distributed as dist
-		if not (dist.is_available() and dist.is_initialized()):
-			return ok
-		flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-		dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.hostGroup)
-		return bool(flag.item())
-
+	def vote(self, ok):
+		"""True iff every rank says yes"""
+		return bool(self.group.reduce(1.0 if ok else 0.0, "min")) if self.gridsize > 1 else ok
 
 	def ensureComm(self):
+		"""Creates the communicator — after a vote that every rank can: ncclCommInitRank is itself a collective, a rank
+		entering it alone would wait forever for peers that already fell back."""
 		if self.comm is not None or self.transport != "rccl":
 			return
 
-		import ctypes, sys
+		import ctypes
 		from puzzlelib_amd import lib, driver
 
-		handle, error = ctypes.c_void_p(), None
+		reason = None
 		try:
+			lib.pz_comm_probe()
 			if self.uniqueId is None:
-				raise lib.CommError("no RCCL unique id (librccl could not be loaded on some rank)")
-			lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+				reason = "rank 0 could not create an RCCL id"
 		except lib.HipError as e:
-			error = e
+			reason = str(e)
 
-		if self.allRanksOk(error is None):
-			self.comm = handle.value
-			self.commStream = driver.Stream()
+		if self.vote(reason is None):
+			handle = ctypes.c_void_p()
+			lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+			self.comm, self.commStream = handle.value, driver.Stream()
 			return
 
-		if self.gridsize == 1 and error is not None:
-			raise error
+		if self.gridsize == 1:
+			raise lib.CommError(reason)
 
-		# RCCL is the design; if it cannot be brought up on every rank the run continues on a host-staged gloo exchange
+		# RCCL is the design; if it cannot be brought up on every rank the run continues on a host-staged exchange
 		# (correct, not overlapped, slow) and says so loudly — bench.py reports the transport in its config
-		if error is None and handle.value:
-			lib.pz_comm_destroy(handle.value)
-		self.transport = "gloo-host-staged"
-		print("[puzzlelib_amd.grid] rank %d: RCCL communicator unavailable (%s) — falling back to a host-staged gloo "
-			  "all-reduce; expect poor scaling" % (self.index, error if error is not None else "failed on another rank"),
+		self.transport = "host-staged"
+		print("[puzzlelib_amd.grid] rank %d: RCCL unavailable (%s) — falling back to a host-staged all-reduce over TCP; "
+			  "expect poor scaling" % (self.index, reason if reason is not None else "failed on another rank"),
 			  file=sys.stderr, flush=True)
-
 
 	def close(self):
 		if self.comm is not None:
@@ -187,41 +280,30 @@ class RcclNodeInfo(NodeInfo):
 			lib.pz_comm_destroy(self.comm)
 			self.comm = None
 
-
 	def meanValue(self, value):
-		if self.gridsize == 1:
-			return value
-
-		import torch, torch.distributed as dist
-		t = torch.tensor([float(value)], dtype=torch.float64)
-		dist.all_reduce(t, group=self.hostGroup)
-		return t.item() / self.gridsize
-
+		return value if self.gridsize == 1 else self.group.reduce(value, "sum") / self.gridsize
 
 	def broadcastBuffer(self, name, buffer):
 		from puzzlelib_amd import lib
 		self.ensureComm()
 		if self.transport == "rccl":
-			lib.pz_comm_broadcast(self.comm, buffer.ptr, buffer.size, 0, None)
+			lib.pz_comm_broadcast(self.comm, buffer.access(True), buffer.size, 0, None)
 			return
 
-		import torch, torch.distributed as dist
 		host = np.empty(buffer.size, dtype=np.uint8)
-		lib.pz_memcpy_d2h(host.ctypes.data, buffer.ptr, buffer.size, None)
+		lib.pz_memcpy_d2h(host.ctypes.data, buffer.access(), buffer.size, None)
 		lib.pz_stream_sync(None)
-		dist.broadcast(torch.from_numpy(host), src=0, group=self.hostGroup)
-		lib.pz_memcpy_h2d(buffer.ptr, host.ctypes.data, buffer.size, None)
+		host = np.frombuffer(self.group.broadcast(host.tobytes()), dtype=np.uint8)
+		lib.pz_memcpy_h2d(buffer.access(True), host.ctypes.data, buffer.size, None)
 		lib.pz_stream_sync(None)
-
 
 	# ---- gradient exchange
 	def attach(self, name, tensor, blocks):
-		"""Registers the flat arena `tensor` (1-d fp32 GPUArray) with its variable blocks for overlapped reduction."""
+		"""Registers the flat arena `tensor` (1-d fp32 GPUArray) with its parameter blocks for overlapped reduction."""
 		self.ensureComm()
 		ops = HipReduceOps(self, tensor) if self.transport == "rccl" else HostStagedReduceOps(self, tensor)
 		self.reducers[name] = GradReducer(blocks, ops, self.gridsize, self.bucketBytes)
 		return self.reducers[name]
-
 
 	def sumTensor(self, name, tensor):
 		reducer = self.reducers.get(name, None)
@@ -232,7 +314,8 @@ class RcclNodeInfo(NodeInfo):
 			from puzzlelib_amd.gpuarray import eltwise
 			self.ensureComm()
 			if self.transport == "rccl":
-				lib.pz_comm_allreduce_sum_f32(self.comm, tensor.ptr, tensor.ptr, tensor.size, None)
+				ptr = tensor.wptr
+				lib.pz_comm_allreduce_sum_f32(self.comm, ptr, ptr, tensor.size, None)
 			else:
 				HostStagedReduceOps(self, tensor).allreduce(0, tensor.nbytes, None)
 			eltwise(lib.OP_LINEAR, tensor.size, (tensor, tensor), np.array([1.0 / self.gridsize, 0.0], dtype=np.float32))
@@ -247,15 +330,14 @@ class HipReduceOps:
 		self.node, self.tensor = node, tensor
 		self.events = []
 
-
 	def markReady(self):
+		"""'final up to here' = an event on the compute stream plus one behind the filter-gradient stream, where the
+		gradients of this bucket were accumulated (DnnContext.filterGradStream)"""
 		from puzzlelib_amd import driver
 		from puzzlelib_amd.surface import bound
 		event = driver.Event()
 		event.record(None)
-		# filter gradients may have been queued on the backend's side stream (DnnContext.overlapFilterGrad)
-		return (event, bound().Dnn.filterGradEvent())
-
+		return (event, bound().backend.dnn.sideEvent())
 
 	def allreduce(self, start, stop, token):
 		from puzzlelib_amd import lib, driver
@@ -265,18 +347,20 @@ class HipReduceOps:
 		node.commStream.waitEvent(main)
 		if side is not None:
 			node.commStream.waitEvent(side)
-		ptr = self.tensor.ptr + start
+		ptr = self.tensor.gpudata.ptr + start      # ordering is carried by the two events, not by the arena's barrier
 		lib.pz_comm_allreduce_sum_f32(node.comm, ptr, ptr, (stop - start) // 4, node.commStream.handle)
 
 		done = driver.Event()
 		done.record(node.commStream)
 		self.events.append((token, done))
 
-
 	def finish(self, scale):
 		from puzzlelib_amd import lib
 		from puzzlelib_amd.gpuarray import eltwise
 
+		lib.pz_comm_async_error(self.node.comm)
+		if self.node.timeout > 0.0 and self.events:
+			lib.pz_comm_wait_event(self.node.comm, self.events[-1][1].handle, self.node.timeout)
 		for _, done in self.events:
 			lib.pz_stream_wait_event(None, done.handle)
 		self.events = []
@@ -285,35 +369,25 @@ class HipReduceOps:
 
 
 class HostStagedReduceOps:
-	"""Fallback transport when RCCL cannot be initialised: device -> host -> gloo all-reduce -> device, synchronous.
+	"""Fallback transport when RCCL cannot be initialised: device -> host -> TCP star -> device, synchronous.
 	Same call protocol as HipReduceOps (GradReducer drives both)."""
 
 	def __init__(self, node, tensor):
 		self.node, self.tensor = node, tensor
 
-
 	def markReady(self):
-		from puzzlelib_amd import driver
-		from puzzlelib_amd.surface import bound
-		bound().Dnn.joinFilterGrads()               # (synchronous transport: no point in keeping the side stream apart)
-		event = driver.Event()
-		event.record(None)
-		return event
-
+		return None
 
 	def allreduce(self, start, stop, token):
-		import torch, torch.distributed as dist
 		from puzzlelib_amd import lib
 
-		if token is not None:
-			token.synchronize()
+		ptr = self.tensor.wptr + start          # (the barrier makes the main stream wait for the filter-gradient stream)
 		host = np.empty((stop - start) // 4, dtype=np.float32)
-		lib.pz_memcpy_d2h(host.ctypes.data, self.tensor.ptr + start, stop - start, None)
+		lib.pz_memcpy_d2h(host.ctypes.data, ptr, stop - start, None)
 		lib.pz_stream_sync(None)
-		dist.all_reduce(torch.from_numpy(host), group=self.node.hostGroup)
-		lib.pz_memcpy_h2d(self.tensor.ptr + start, host.ctypes.data, stop - start, None)
+		self.node.group.sumArray(host)
+		lib.pz_memcpy_h2d(ptr, host.ctypes.data, stop - start, None)
 		lib.pz_stream_sync(None)
-
 
 	def finish(self, scale):
 		from puzzlelib_amd import lib
@@ -323,37 +397,29 @@ class HostStagedReduceOps:
 
 def arenaBlocks(sharedArray):
 	"""[(name, byteOffset, nbytes)] of a built SharedArray, in arena order."""
-	base = sharedArray.ary.ptr
-	return [(name, block.ptr - base, block.nbytes) for name, block in sharedArray.blocks.items()]
+	base = sharedArray.ary.gpudata.ptr
+	return [(name, block.gpudata.ptr - base, block.nbytes) for name, block in sharedArray.blocks.items()]
 
 
 def enableOverlap(optimizer, nodeinfo):
 	"""Wires the overlapped reducer into an optimizer in global-state mode: registers the flat fp32 gradient arena and
-	installs the module hook that reports finished variables during backward."""
-	from puzzlelib_amd import nn
-
-	shGrads = optimizer.shGrads[np.float32]
-	reducer = nodeinfo.attach("grad", shGrads.ary, arenaBlocks(shGrads))
+	has the executor report layers whose parameter gradients are final during backward."""
+	reducer = nodeinfo.attach("grad", optimizer.grads.ary, arenaBlocks(optimizer.grads))
 	reducer.beginStep()
 
-	# variable object -> arena name
-	names = {}
-	for var, varnames in optimizer.module.getVarTable().items():
-		names[id(var)] = varnames[0]
+	def onLayerDone(layer):
+		for key in layer.params:
+			reducer.variableReady("%s.%s" % (layer.name, key))
 
-	def onParamGrads(module):
-		for var in module.vars.values():
-			name = names.get(id(var), None)
-			if name is not None:
-				reducer.variableReady(name)
-
-	nn.Module.paramGradsHook = staticmethod(onParamGrads)
+	optimizer.net.gradsReady = onLayerDone
 	return reducer
 
 
 # ---------------------------------------------------------------------------------------------- process bootstrap
 def nodeFromEnv(bucketBytes=25 << 20):
-	"""Builds the NodeInfo of this rank from the torchrun environment. Returns None for a single-process run."""
+	"""Builds the NodeInfo of this rank from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (set by
+	torch.distributed.run or by bench.py's own launcher). Returns None for a single-process run."""
+	global hostGroup
 	world = int(os.environ.get("WORLD_SIZE", "1"))
 	if world == 1:
 		return None
@@ -363,9 +429,9 @@ def nodeFromEnv(bucketBytes=25 << 20):
 	# refuses two ranks on one device unless it is built/configured to allow it)
 	local = int(os.environ.get("PUZZLE_MI355_DEVICE", local))
 
-	import torch.distributed as dist
-	if not dist.is_initialized():
-		dist.init_process_group(backend="gloo")
+	# MASTER_PORT itself belongs to the launcher's rendezvous store; the host group takes the next port unless told otherwise
+	port = int(os.environ.get("PUZZLE_MI355_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+	hostGroup = HostGroup(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
 
 	from puzzlelib_amd.settings import Config
 	Config.deviceIdx = local
@@ -374,29 +440,23 @@ def nodeFromEnv(bucketBytes=25 << 20):
 	from puzzlelib_amd import lib
 	import ctypes
 
-	ids = [None]
+	uid = b""
 	if rank == 0:
 		try:
 			buf = ctypes.create_string_buffer(lib.COMM_ID_BYTES)
 			lib.pz_comm_unique_id(buf)
-			ids = [buf.raw]
+			uid = buf.raw
 		except lib.HipError:
-			ids = [None]            # RcclNodeInfo.ensureComm falls back (on every rank) to the host-staged exchange
+			uid = b""              # RcclNodeInfo.ensureComm falls back (on every rank) to the host-staged exchange
 
-	dist.broadcast_object_list(ids, src=0)
-	return RcclNodeInfo(rank, world, local, ids[0], bucketBytes=bucketBytes)
+	uid = hostGroup.broadcast(uid)
+	return RcclNodeInfo(rank, world, local, uid if len(uid) == lib.COMM_ID_BYTES else None, hostGroup, bucketBytes=bucketBytes)
 
 
 def barrier():
-	import torch.distributed as dist
-	if dist.is_available() and dist.is_initialized():
-		dist.barrier()
+	if hostGroup is not None:
+		hostGroup.barrier()
 
 
 def maxOverRanks(value):
-	import torch, torch.distributed as dist
-	if not (dist.is_available() and dist.is_initialized()):
-		return value
-	t = torch.tensor([float(value)], dtype=torch.float64)
-	dist.all_reduce(t, op=dist.ReduceOp.MAX)
-	return t.item()
+	return value if hostGroup is None else hostGroup.reduce(value, "max")

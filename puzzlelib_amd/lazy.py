@@ -1,0 +1,254 @@
+"""
+Lazy device buffers: how this backend fuses across the reference's operator calls without any change to their signatures.
+
+The reference's modules talk to a backend through fixed wrappers (Backend/Dnn.py:131-268, Backend/Blas.py:43-75,
+Backend/Kernels/ElementWise.py) — one call per operator, tensors in, tensors out. A ResNet block therefore arrives as
+`convNd`, `batchNormNd`, `reluKer(y, y)`, ..., `fill(0)`, `toVectorAddVector` x2, `reluKer` — each of which a literal
+backend turns into at least one pass over HBM. This backend instead lets an operator return a tensor whose contents are
+*described* but not yet written (a pending `Thunk` on the tensor's device buffer) whenever the description is cheap to
+keep — a batch-norm's affine pair, a zero fill, a sum of terms, a ReLU on top, a gate below — and runs one fused kernel
+when somebody needs the values. Consumers that can evaluate the description on the fly (the residual sum, the gradient
+fan-in, the 1x1 convolution's backward gathers) never make the tensor exist at all.
+
+Correctness does not depend on who calls what next: every access to device memory goes through `GPUArray.rptr`
+(read), `.wptr` (read-modify-write or partial write), `.optr` (whole overwrite) or `.ptr` (unknown use = both), and
+those are the barriers —
+  read   : a pending thunk on the buffer is run first; a write by another stream is waited for;
+  write  : additionally every buffer whose thunk or derived facts (`meta`) depend on the old contents is settled first
+           (thunks run, facts dropped), and reads by another stream are waited for.
+State lives on the *root* allocation (`Buffer.root.lz`), so reshapes / ravels / slices of a tensor share it. A buffer
+without state (the overwhelmingly common case) costs one attribute test per access.
+
+The same machinery orders work across streams: a kernel launched on a foreign stream (the filter-gradient stream of
+DnnContext, an optimizer's borrowed streams) leaves its completion event on the buffers it touched; the main stream
+waits only when — and if — it touches them.
+
+`enabled = False` (PUZZLE_MI355_LAZY=0) runs every producer's thunk on the spot: the literal one-kernel-per-call
+behaviour, used by the parity tests as the reference point the fused paths must reproduce bit for bit.
+"""
+import os, weakref
+from collections import deque
+
+from puzzlelib_amd import lib
+
+enabled = os.environ.get("PUZZLE_MI355_LAZY", "1") == "1"
+disabled = set(filter(None, os.environ.get("PUZZLE_MI355_LAZY_OFF", "").split(",")))      # individual patterns, for tests
+counters = {}                      # pattern name -> times taken (tests and tools read it)
+
+
+def count(name):
+	counters[name] = counters.get(name, 0) + 1
+
+
+def on(pattern):
+	return enabled and pattern not in disabled
+
+
+class State:
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev")
+
+	def __init__(self):
+		self.thunk, self.deps, self.meta, self.wev, self.rev = None, None, None, None, None
+
+
+def stateOf(root):
+	lz = root.lz
+	if lz is None:
+		lz = root.lz = State()
+	return lz
+
+
+class Thunk:
+	"""Description of a buffer's contents. `inputs()` lists the GPUArrays it reads (kept alive by the thunk);
+	`run(out)` writes the values into `out` (a GPUArray over the whole buffer) and may return facts for `meta`."""
+	shape = dtype = None
+
+	def inputs(self):
+		return ()
+
+	def run(self, out):
+		raise NotImplementedError()
+
+
+def attach(ary, thunk):
+	"""Makes `thunk` the pending contents of `ary`'s buffer (which must be covered entirely by `ary`)."""
+	root = ary.gpudata.root
+	lz = stateOf(root)
+	assert lz.thunk is None
+	thunk.shape, thunk.dtype = ary.shape, ary.dtype
+	lz.thunk = thunk
+	for src in thunk.inputs():
+		depend(src, root)
+	if not enabled:
+		settle(root)
+
+
+def depend(src, root):
+	"""`root`'s pending contents or facts derive from `src`'s current contents."""
+	slz = stateOf(src.gpudata.root)
+	if slz.deps is None:
+		slz.deps = []
+	slz.deps.append(weakref.ref(root))
+
+
+def pending(ary, kind=None):
+	"""The thunk waiting on `ary`'s buffer if `ary` covers that buffer entirely (and is of class `kind`), else None."""
+	buf = ary.gpudata
+	lz = buf.root.lz
+	if lz is None or lz.thunk is None:
+		return None
+	if ary.nbytes != buf.root.size or buf.ptr != buf.root.ptr or not ary.contiguous:
+		return None
+	return lz.thunk if kind is None or isinstance(lz.thunk, kind) else None
+
+
+def fact(ary, key):
+	lz = ary.gpudata.root.lz
+	if lz is None or lz.meta is None:
+		return None
+	return lz.meta.get(key, None)
+
+
+def setFact(ary, key, value, sources=()):
+	root = ary.gpudata.root
+	lz = stateOf(root)
+	if lz.meta is None:
+		lz.meta = {}
+	lz.meta[key] = value
+	for src in sources:
+		depend(src, root)
+
+
+def settle(root):
+	"""Runs the pending thunk of a root buffer."""
+	lz = root.lz
+	thunk = lz.thunk
+	if thunk is None:
+		return
+	lz.thunk = None                       # first: run() reads its inputs through the barriers, never itself
+	from puzzlelib_amd.gpuarray import GPUArray
+	out = GPUArray(thunk.shape, thunk.dtype, gpudata=root)
+	facts = thunk.run(out)
+	if facts:
+		if lz.meta is None:
+			lz.meta = {}
+		lz.meta.update(facts)
+		for src in thunk.inputs():          # the facts describe `out` in terms of the inputs' contents
+			depend(src, root)
+
+
+def waitEvents(lz, read, stream=None):
+	"""Cross-stream ordering: before the accessing stream reads (writes) the buffer, foreign writes (and reads) finish."""
+	for name in (("wev", ) if read else ("wev", "rev")):
+		pair = getattr(lz, name)
+		if pair is not None:
+			event, owner = pair
+			if owner is not stream:
+				lib.pz_stream_wait_event(None if stream is None else stream.handle, event.handle)
+				if stream is None:
+					setattr(lz, name, None)
+
+
+def readBarrier(root, stream=None):
+	lz = root.lz
+	if lz.thunk is not None:
+		settle(root)
+	if lz.wev is not None:
+		waitEvents(lz, True, stream)
+
+
+def writeBarrier(root, whole=False, stream=None):
+	lz = root.lz
+	if lz.thunk is not None:
+		if whole:
+			lz.thunk = None
+		else:
+			settle(root)
+	if lz.deps is not None:
+		deps, lz.deps = lz.deps, None
+		for ref in deps:
+			other = ref()
+			if other is not None and other.lz is not None and other is not root:
+				if other.lz.thunk is not None:
+					settle(other)
+				other.lz.meta = None
+	lz.meta = None
+	if lz.wev is not None or lz.rev is not None:
+		waitEvents(lz, False, stream)
+
+
+# ---------------------------------------------------------------------------------------------- foreign streams
+held = deque()           # (event, objects) kept alive until the event has passed: memory a foreign stream still uses
+
+
+def prune(block=False):
+	while held:
+		event, _ = held[0]
+		if block:
+			event.synchronize()
+		else:
+			done = lib.c_int(0)
+			lib.pz_event_query(event.handle, lib.byref(done))
+			if not done.value:
+				break
+		held.popleft()
+
+
+def foreignBegin(stream):
+	"""Everything issued on the main stream so far happens before what `stream` is given next."""
+	from puzzlelib_amd.driver import Event
+	prune()
+	ready = Event()
+	ready.record(None)
+	stream.waitEvent(ready)
+	return ready
+
+
+def foreignEnd(stream, ready, reads=(), writes=(), keep=()):
+	"""Marks the buffers a foreign-stream launch touched with its completion event; the main stream waits for it when (and
+	only when) it touches them; the memory stays referenced until the event has passed."""
+	from puzzlelib_amd.driver import Event
+	done = Event()
+	done.record(stream)
+	for ary in writes:
+		stateOf(ary.gpudata.root).wev = (done, stream)
+	for ary in reads:
+		stateOf(ary.gpudata.root).rev = (done, stream)
+	held.append((done, (ready, tuple(reads), tuple(writes), tuple(keep))))
+	return done
+
+
+def joinAll():
+	"""The main stream waits for everything foreign streams were given (device-wide ordering point)."""
+	prune()
+	for event, _ in held:
+		lib.pz_stream_wait_event(None, event.handle)
+
+
+# ---------------------------------------------------------------------------------------------- the simplest thunk
+class Zero(Thunk):
+	"""All zeros (GPUArray.fill(0) on a whole fresh tensor). Terms added to it turn it into fusion.Sum."""
+	threshold = 4096          # bytes; smaller tensors are simply memset
+
+	def run(self, out):
+		lib.pz_memset_d32(out.gpudata.ptr, 0, out.size, None)
+
+
+def whole(ary):
+	"""`ary` spans its entire allocation contiguously (so a description of the array is a description of the buffer)"""
+	buf = ary.gpudata
+	root = buf.root
+	return ary.contiguous and buf.ptr == root.ptr and ary.nbytes == root.size
+
+
+def sameBuffer(a, b):
+	return a.gpudata.root is b.gpudata.root and a.gpudata.ptr == b.gpudata.ptr and a.nbytes == b.nbytes
+
+
+def rawRead(ary):
+	"""Address of a buffer's *stored* bytes (a pending in-place description such as fusion.Gate is not applied):
+	only foreign-stream writes are waited for."""
+	lz = ary.gpudata.root.lz
+	if lz is not None and lz.wev is not None:
+		waitEvents(lz, True)
+	return ary.gpudata.ptr

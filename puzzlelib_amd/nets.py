@@ -9,8 +9,8 @@ spec into a module graph on the MI355X backend.
                 block (ResNet.py:42).
 
 Spec entries are documented in oracle/cpu_net.py (the CPU checker consumes the same data; it shares no
-code with this package). Module names follow the reference so that parameter names — and therefore the
-sorted layout of the optimizer's flat arena (Optimizers/Optimizer.py:66-68) — match.
+code with this package). Layer names are the reference's module names (the block ReLUs and the containers have no
+counterpart object here, so parameter paths are "<layer>.<param>", not the reference's container-qualified ones).
 """
 import string
 
@@ -160,79 +160,18 @@ def spec_out_shape(spec, shape):
 
 
 # ------------------------------------------------------------------------------------------------
-# builders (device graph on the MI355X backend)
+# builders (device networks on the MI355X backend)
 # ------------------------------------------------------------------------------------------------
 
 def build(spec, name=None, initscheme=None, wscale=1.0, actInplace=False, bnInplace=False):
-	"""Turns a spec into Sequential/Parallel module graphs exactly as the reference builders do."""
-	from puzzlelib_amd import nn
-
-	net = nn.Sequential(name=name)
-	_extend(net, spec, initscheme, wscale, actInplace, bnInplace)
-	return net
-
-
-def _extend(seq, spec, initscheme, wscale, actInplace, bnInplace):
-	from puzzlelib_amd import nn
-
-	for layer in spec:
-		kind = layer[0]
-
-		if kind == "conv":
-			_, name, cin, cout, size, stride, pad, bias = layer
-			seq.append(nn.Conv2D(
-				cin, cout, size, stride=stride, pad=pad, useBias=bias, initscheme=initscheme, wscale=wscale,
-				name=_auto(name)
-			))
-
-		elif kind == "bn":
-			seq.append(nn.BatchNorm2D(layer[2], name=_auto(layer[1]), inplace=bnInplace))
-
-		elif kind == "relu":
-			seq.append(nn.Activation(nn.relu, inplace=actInplace, name=_auto(layer[1])))
-
-		elif kind == "maxpool":
-			seq.append(nn.MaxPool2D(layer[2], layer[3], layer[4], name=_auto(layer[1])))
-
-		elif kind == "avgpool":
-			seq.append(nn.AvgPool2D(layer[2], layer[3], layer[4], name=_auto(layer[1])))
-
-		elif kind == "dropout":
-			seq.append(nn.Dropout(layer[2], name=_auto(layer[1])))
-
-		elif kind == "flatten":
-			seq.append(nn.Flatten(name=_auto(layer[1])))
-
-		elif kind == "linear":
-			seq.append(nn.Linear(layer[2], layer[3], initscheme=initscheme, wscale=wscale, name=_auto(layer[1])))
-
-		elif kind == "softmax":
-			seq.append(nn.SoftMax(name=_auto(layer[1])))
-
-		elif kind == "resid":
-			branch, shortcut = nn.Sequential(), nn.Sequential()
-			_extend(branch, layer[1], initscheme, wscale, actInplace, bnInplace)
-
-			if len(layer[2]) > 0:
-				_extend(shortcut, layer[2], initscheme, wscale, actInplace, bnInplace)
-			else:
-				shortcut.append(nn.Identity())
-
-			seq.append(nn.Replicate(2))
-			seq.append(nn.Parallel().append(branch).append(shortcut))
-			seq.append(nn.Add())
-
-		else:
-			raise NotImplementedError(kind)
-
-
-def _auto(name):
-	# purely numeric spec names stand for "unnamed": the container assigns the index itself
-	return None if name.isdigit() else name
+	"""A spec as an executable network (puzzlelib_amd/engine.py). Parameters are drawn in spec order with the reference's
+	RNG calls, so a numpy seed reproduces the reference builders' initial values."""
+	from puzzlelib_amd.engine import Net
+	return Net(spec, name=name, initscheme=initscheme, wscale=wscale, actInplace=actInplace, bnInplace=bnInplace)
 
 
 def loadLeNet(modelpath=None, initscheme="none", name="lenet-5-like"):
-	"""Models/Nets/LeNet.py:13-33 (checkpoint loading is out of scope: modelpath must be None)."""
+	"""Models/Nets/LeNet.py:13-33 (checkpoints: puzzlelib_amd/checkpoint.py; modelpath must be None here)."""
 	assert modelpath is None
 	return build(lenet_spec(), name=name, initscheme=initscheme)
 
@@ -243,7 +182,7 @@ def buildNiN():
 
 
 def loadResNet(modelpath=None, layers="50", actInplace=False, bnInplace=False, initscheme="none", name=None):
-	"""Models/Nets/ResNet.py:69-121 (layers "50" only; checkpoint loading out of scope)."""
+	"""Models/Nets/ResNet.py:69-121 (layers "50" only)."""
 	assert modelpath is None
 	stages = {"50": ((64, 3), (128, 4), (256, 6), (512, 3))}[layers]
 
@@ -254,24 +193,10 @@ def loadResNet(modelpath=None, layers="50", actInplace=False, bnInplace=False, i
 
 
 def namedVariables(net):
-	"""{"<module name>.<param>": Variable} — keys as used by the specs/oracle (module names are unique in these nets)."""
-	out = {}
-	for var, names in net.getVarTable().items():
-		for full in names:
-			parts = full.split(".")
-			out[".".join(parts[-2:])] = var
-	return out
+	"""{"<layer name>.<param>": Param} — keys as used by the specs / the oracle."""
+	return net.namedParams()
 
 
-def namedAttrs(net, out=None):
-	"""{"<module name>.<attr>": GPUArray} for module attributes (batch-norm running mean / var)."""
-	from puzzlelib_amd import nn
-
-	out = {} if out is None else out
-	for mod in net.modules.values():
-		if isinstance(mod, nn.Container):
-			namedAttrs(mod, out)
-		else:
-			for attrName, attr in mod.attrs.items():
-				out["%s.%s" % (mod.name, attrName)] = attr
-	return out
+def namedAttrs(net):
+	"""{"<layer name>.<attr>": GPUArray} (batch-norm running mean / var)."""
+	return net.namedAttrs()

@@ -5,8 +5,11 @@ In PuzzleLib the modules import function objects from Backend/{gpuarray,Blas,Dnn
 `initHip()`/`initGPU()` wrap a backend object (Backend/gpuarray.py:60-113, Backend/Blas.py:43-102,
 Backend/Dnn.py:124-268, Backend/Kernels/{ElementWise,MatVec,Costs}.py). Those files stay as they are when this backend
 is plugged into PuzzleLib itself. For the stand-alone harness of this repository (the reference
-package does not travel to the GPU box) the same wrapper signatures are restated here, grouped in namespaces with
-the reference's names: `bound().gpuarray`, `.Blas`, `.Dnn`, `.ElementWise`, `.MatVec`, `.Costs`.
+package does not travel to the GPU box) the same wrappers are restated here with exactly the reference's positional
+signatures and nothing else — no extra keyword, no extra entry: whatever the backend fuses, it fuses behind these calls
+(puzzlelib_amd/lazy.py). Namespaces carry the reference's names: `bound().gpuarray`, `.Blas`, `.Dnn`, `.ElementWise`,
+`.MatVec`, `.Costs`. tests/test_host_logic.py replays the reference's own modules against the same backend object in
+dry-run mode and checks that this harness issues the identical call sequence.
 
 Binding is lazy (first call to `bound()`), so host-only code can import the module graph without a device; the
 device is then required — there is no other backend to fall back to.
@@ -76,16 +79,13 @@ def bind():
 	)
 
 	# ------------------------------------------------------------------ Dnn (Backend/Dnn.py:124-268)
-	def convNd(data, W, bias, stride, pad, dilation, groups, algo, withStats=False):
+	def convNd(data, W, bias, stride, pad, dilation, groups, algo):
 		return dnn.convNd(
-			data, W, bias.ravel() if bias is not None else None, stride, pad, dilation, groups, algo.value, None,
-			memoryPool, withStats=withStats
+			data, W, bias.ravel() if bias is not None else None, stride, pad, dilation, groups, algo.value, None, memoryPool
 		)
 
-	def convNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo, compact=False):
-		return dnn.convNdBackwardData(
-			grad, W, None, data, stride, pad, dilation, None, groups, algo.value, None, memoryPool, compact=compact
-		)
+	def convNdBackwardData(grad, W, data, stride, pad, dilation, groups, algo):
+		return dnn.convNdBackwardData(grad, W, None, data, stride, pad, dilation, None, groups, algo.value, None, memoryPool)
 
 	def convNdBackwardParams(data, grad, W, bias, stride, pad, dilation, groups, wgrad, bgrad, scale, momentum, algo):
 		return dnn.convNdBackwardParams(
@@ -117,12 +117,11 @@ def bind():
 	def poolNdBackward(indata, outdata, grad, workspace, size, stride, pad, mode):
 		return dnn.poolNdBackward(grad, indata, outdata, workspace, size, stride, pad, mode.value, None, memoryPool)
 
-	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None,
-					fuseRelu=False, convStats=None, defer=False):
+	def batchNormNd(data, scale, bias, mean, var, epsilon, factor, test, mode=bnd.BatchNormMode.spatial, out=None):
 		shape = scale.shape
 		result = dnn.batchNormNd(
 			data, mean.ravel(), var.ravel(), scale.ravel(), bias.ravel(), epsilon, factor, test, mode.value, out=out,
-			allocator=memoryPool, fuseRelu=fuseRelu, convStats=convStats, defer=defer
+			allocator=memoryPool
 		)
 		if test:
 			return result
@@ -130,15 +129,10 @@ def bind():
 		outdata, savemean, saveinvvar = result
 		return outdata, savemean.reshape(shape), saveinvvar.reshape(shape)
 
-	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial,
-							bias=None, fuseRelu=False, accumulate=None, partials=None, lazyGrad=False):
+	def batchNormNdBackward(data, grad, scale, savemean, saveinvvar, epsilon, mode=bnd.BatchNormMode.spatial):
 		shape = scale.shape
-		if accumulate is not None:
-			accumulate = (accumulate[0].ravel(), accumulate[1].ravel(), accumulate[2], accumulate[3])
 		ingrad, scalegrad, bgrad = dnn.batchNormNdBackward(
-			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool,
-			bias=None if bias is None else bias.ravel(), fuseRelu=fuseRelu, accumulate=accumulate, partials=partials,
-			lazyGrad=lazyGrad
+			grad, data, scale.ravel(), savemean.ravel(), saveinvvar.ravel(), epsilon, mode.value, allocator=memoryPool
 		)
 		return ingrad, scalegrad.reshape(shape), bgrad.reshape(shape)
 
@@ -153,16 +147,7 @@ def bind():
 		fwd, bwdData, bwdParam = bnd.convNdbenchmark(datashape, Wshape, np.float32, stride, pad, dilation, groups)
 		return fwd, bwdParam, bwdData
 
-	def bnGateStats(grad0, grad1, outdata, targets, mask=None):
-		return dnn.bnGateStats(grad0, grad1, outdata, [(x, m.ravel()) for x, m in targets], allocator=memoryPool, mask=mask)
-
-	def bnApplyAdd(first, second, relu=False, withMask=False):
-		return dnn.bnApplyAdd(first, second, relu=relu, allocator=memoryPool, withMask=withMask)
-
 	Dnn = SimpleNamespace(
-		bnApplyAdd=bnApplyAdd, bnGateStats=bnGateStats, compactGradSupported=dnn.compactGradSupported,
-		joinFilterGrads=dnn.joinFilterGrads, filterGradEvent=dnn.filterGradEvent,
-		beginBackward=dnn.beginBackward, endBackward=dnn.endBackward,
 		ConvFwdAlgo=bnd.ConvFwdAlgo, ConvBwdDataAlgo=bnd.ConvBwdDataAlgo, ConvBwdFilterAlgo=bnd.ConvBwdFilterAlgo,
 		PoolMode=bnd.PoolMode, BatchNormMode=bnd.BatchNormMode, SoftMaxMode=bnd.SoftMaxMode,
 		RNNMode=bnd.RNNMode, DirectionMode=bnd.DirectionMode,
@@ -180,8 +165,7 @@ def bind():
 		"leakyReluDerKer", "eluKer", "eluDerKer", "softPlusKer", "softPlusDerKer", "clipKer", "clipDerKer", "geluKer",
 		"geluDerKer", "dropoutKer", "dropout2dKer", "toVectorAddVectorKer", "classicMomSGDKer", "nesterovMomSGDKer",
 		"rmspropKer", "adamKer", "rmspropGravesKer", "adagradKer", "adadeltaKer", "smorms3Ker", "addKer", "mulKer",
-		"linearKer", "rbmKer", "absKer", "weightDecayKer", "l1penaltyKer", "l1gradKer", "add3Ker", "add3ReluKer",
-		"add3GateKer"
+		"linearKer", "rbmKer", "absKer", "weightDecayKer", "l1penaltyKer", "l1gradKer"
 	]
 	ElementWise = SimpleNamespace(**{name: getattr(bnd, name) for name in kernelNames})
 

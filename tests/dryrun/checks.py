@@ -1,0 +1,224 @@
+"""
+Host-logic checks that need the backend's Python side to *run* without a device: executed in a child process with
+PUZZLE_MI355_DRYRUN=1 (the library then records C-ABI calls instead of executing them — puzzlelib_amd/lib.py) by
+tests/test_dryrun_backend.py. Usage: python tests/dryrun/checks.py <check name>
+"""
+import json, os, sys
+
+assert os.environ.get("PUZZLE_MI355_DRYRUN") == "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+from puzzlelib_amd import nets, optim, lib, lazy, fusion, grid
+from puzzlelib_amd.surface import bound
+
+SKIP = ("pz_pool_", "pz_event_", "pz_stream_", "pz_malloc", "pz_free", "pz_device_", "pz_init")
+
+
+def names(trace=None):
+	return [n for n, _ in (lib.trace if trace is None else trace) if not n.startswith(SKIP)]
+
+
+def trainerFor(net, batch):
+	opt = optim.Adam(alpha=1e-3)
+	opt.setupOn(net, useGlobalState=True)
+	return optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=batch), opt
+
+
+# ------------------------------------------------------------------------------------------------ drop-in call traces
+def executor_trace(case):
+	g = bound().gpuarray
+	if case == "resnet50_b8":
+		net = nets.loadResNet(None, "50", actInplace=True, initscheme="none")
+		net.layers.pop()                                   # the trailing SoftMax (training on raw scores)
+		shape = (8, 3, 224, 224)
+	else:
+		net, shape = nets.loadLeNet(None), (16, 1, 28, 28)
+	trainer, _ = trainerFor(net, shape[0])
+	data, labels = g.to_gpu(np.zeros(shape, np.float32)), g.to_gpu(np.zeros(shape[:1], np.int32))
+	steps = []
+	for _ in range(2):
+		lib.trace.clear()
+		trainer.train(data, labels, random=False)
+		steps.append([[n, list(a)] for n, a in lib.trace if not n.startswith(SKIP)])
+	return json.loads(json.dumps(steps))
+
+
+def check_trace(case):
+	"""the executor sends the backend what the reference's own modules send (fixture recorded by oracle/make_trace.py)"""
+	ref = json.load(open(os.path.join(ROOT, "tests", "golden", "trace_%s.json" % case)))["steps"]
+	ours = executor_trace(case)
+	for step, (a, b) in enumerate(zip(ours, ref)):
+		assert len(a) == len(b), "%s step %d: %d calls, the reference's modules make %d" % (case, step, len(a), len(b))
+		for i, (x, y) in enumerate(zip(a, b)):
+			assert x == y, "%s step %d call %d: executor %s, reference modules %s" % (case, step, i, x, y)
+	print("trace %s: identical (%d + %d calls)" % (case, len(ref[0]), len(ref[1])))
+
+
+def trace_resnet50():
+	check_trace("resnet50_b8")
+
+
+def trace_lenet():
+	check_trace("lenet_b16")
+
+
+# ------------------------------------------------------------------------------------------------ lazy-buffer semantics
+def lazy_barriers():
+	surf = bound()
+	g, bnd, dnn = surf.gpuarray, surf.backend, surf.backend.dnn
+	f32 = np.float32
+
+	def bnInputs(c=8):
+		return (g.to_gpu(np.ones((1, c, 1, 1), f32)), g.zeros((1, c, 1, 1), f32), g.zeros((1, c, 1, 1), f32),
+				g.to_gpu(np.ones((1, c, 1, 1), f32)))
+
+	x = g.to_gpu(np.zeros((4, 8, 16, 16), f32))
+	scale, bias, mean, var = bnInputs()
+
+	# (1) batchNormNd describes its output; nothing but the coefficient launch happens until somebody reads it
+	lib.trace.clear()
+	y, sm, si = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	assert names() == ["pz_bn_fwd_train_coef"] and isinstance(lazy.pending(y), fusion.BnApply)
+	surf.ElementWise.reluKer(f32)(y, y)                                   # in place: joins the description
+	assert names() == ["pz_bn_fwd_train_coef"] and lazy.pending(y).relu
+	y.get()                                                               # a read writes it, fused
+	assert names()[1:] == ["pz_bn_apply_add", "pz_memcpy_d2h"] and lazy.pending(y) is None
+	assert lazy.fact(y, "bnapply") is not None
+
+	# (2) a write to the input of a pending description settles the description first (it needs the old values) ...
+	lib.trace.clear()
+	y2, _, _ = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	x.fill(0)
+	assert names() == ["pz_bn_fwd_train_coef", "pz_bn_apply_add", "pz_memset_d32"] or \
+		names()[:2] == ["pz_bn_fwd_train_coef", "pz_bn_apply_add"], names()
+	assert lazy.pending(y2) is None
+	# ... and drops facts derived from the old contents (y's "this is relu(bn(x))")
+	assert lazy.fact(y, "bnapply") is None and lazy.fact(y2, "bnapply") is None
+
+	# (3) overwriting a described tensor entirely drops the description without running it
+	lib.trace.clear()
+	y3, _, _ = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	y3.set(np.zeros(y3.shape, f32))
+	assert "pz_bn_apply_add" not in names() and lazy.pending(y3) is None
+
+	# (4) a partial write (a view) runs it first
+	lib.trace.clear()
+	y4, _, _ = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	y4[0:1].set(np.zeros((1, 8, 16, 16), f32))
+	assert names()[:2] == ["pz_bn_fwd_train_coef", "pz_bn_apply_add"]
+
+	# (5) the residual sum: zeros + axpy + axpy + relu is one kernel, whoever reads it; a third reader sees a plain tensor
+	a, _, _ = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	b = g.to_gpu(np.zeros(x.shape, f32))
+	lib.trace.clear()
+	total = g.empty(x.shape, dtype=f32)
+	total.fill(0)
+	surf.Blas.toVectorAddVector(total.ravel(), a.ravel())
+	surf.Blas.toVectorAddVector(total.ravel(), b.ravel())
+	surf.ElementWise.reluKer(f32)(total, total)
+	assert names() == [] and isinstance(lazy.pending(total), fusion.Sum)
+	total.get()
+	assert names() == ["pz_bn_apply_add_mask", "pz_memcpy_d2h"], names()
+	assert lazy.pending(a) is not None, "the BatchNorm output itself was never written"
+	assert lazy.fact(total, "relumask") is not None and len(lazy.fact(total, "bnterms")) == 1
+
+	# (6) alpha != 1 or an accumulator somebody already read: the literal kernels
+	lib.trace.clear()
+	acc = g.empty(x.shape, dtype=f32)
+	acc.fill(0)
+	surf.Blas.toVectorAddVector(acc.ravel(), b.ravel(), alpha=0.5)
+	assert names() == ["pz_memset_d32", "pz_eltwise"], names()
+
+	# (7) with the layer switched off every call launches on the spot
+	lazy.enabled = False
+	lib.trace.clear()
+	y7, _, _ = surf.Dnn.batchNormNd(x, scale, bias, mean, var, 1e-5, 1.0, False)
+	surf.ElementWise.reluKer(f32)(y7, y7)
+	assert names() == ["pz_bn_fwd_train_coef", "pz_bn_apply_add", "pz_eltwise"], names()
+	lazy.enabled = True
+
+	# (8) a kernel on a borrowed stream leaves its event on what it wrote; the main stream waits when it touches it
+	stream = g.streamManager.borrow(1)[0]
+	p, q = g.to_gpu(np.zeros(64, f32)), g.to_gpu(np.zeros(64, f32))
+	lib.trace.clear()
+	surf.ElementWise.toVectorAddVectorKer(f32)(p, q, 1.0, stream=stream)
+	assert p.gpudata.root.lz.wev is not None and q.gpudata.root.lz.rev is not None
+	before = len([n for n, _ in lib.trace if n == "pz_stream_wait_event"])
+	p.get()
+	after = len([n for n, _ in lib.trace if n == "pz_stream_wait_event"])
+	assert after == before + 1 and p.gpudata.root.lz.wev is None
+	print("lazy barriers: OK")
+
+
+def fused_step_counts():
+	"""a mini-ResNet step takes every fused path; the same step with the layer off takes none and launches more"""
+	g = bound().gpuarray
+	spec = nets.resnet_spec(stages=((32, 1), (64, 2)), classes=10, stem=16, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	data, labels = g.to_gpu(np.zeros((4, 3, 64, 64), np.float32)), g.to_gpu(np.zeros((4, ), np.int32))
+
+	counts = {}
+	for mode in (True, False):
+		lazy.enabled = mode
+		np.random.seed(1)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		trainer, _ = trainerFor(net, 4)
+		trainer.train(data, labels, random=False)
+		lib.trace.clear()
+		lazy.counters.clear()
+		trainer.train(data, labels, random=False)
+		counts[mode] = (len(names()), dict(lazy.counters))
+	lazy.enabled = True
+
+	fusedCalls, fused = counts[True]
+	literalCalls, literal = counts[False]
+	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 7), ("bn_bwd_gate", 7), ("wgrad_bn_fold", 4), ("dgrad_bn_fold", 4),
+				   ("gate_stats", 1), ("gate_stats_up2", 1), ("compact_dgrad", 2), ("conv_stats", 9), ("gate_by_mask", 2)):
+		assert fused.get(key, 0) == n, "%s taken %d times, expected %d (%s)" % (key, fused.get(key, 0), n, fused)
+	assert not any(k in literal for k in ("bn_apply_add", "bn_bwd_gate", "wgrad_bn_fold", "gate_stats", "compact_dgrad"))
+	assert literalCalls > fusedCalls + 30, (literalCalls, fusedCalls)
+	print("fused step: %d launches against %d with the lazy layer off" % (fusedCalls, literalCalls))
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel planning
+def dp_bucket_progress():
+	"""the real ResNet-50 arena, in the order the optimizer lays it out: as backward reports layers, all-reduce buckets
+	must go out progressively — at least 75 % of the bytes before the last layer reports"""
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="none")
+	opt = optim.Adam()
+	opt.setupOn(net, useGlobalState=True)
+	blocks = grid.arenaBlocks(opt.grads)
+	assert [b[0] for b in blocks] == optim.Optimizer.arenaOrder(net)
+	assert blocks[0][0].startswith("fc1000") and blocks[-1][0].startswith(("conv1", "bn_conv1"))
+
+	class Ops:
+		def markReady(self): return None
+		def allreduce(self, *a): pass
+		def finish(self, scale): pass
+
+	red = grid.GradReducer(blocks, Ops(), gridsize=8, bucketBytes=25 << 20)
+	red.beginStep()
+	order = []
+	net.gradsReady = lambda layer: [order.append("%s.%s" % (layer.name, k)) for k in layer.params]
+	g = bound().gpuarray
+	trainer = optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=2)
+	trainer.step([g.to_gpu(np.zeros((2, 3, 224, 224), np.float32)), g.to_gpu(np.zeros((2, ), np.int32))])
+	assert order == [b[0] for b in blocks], "backward finishes gradients in arena order"
+
+	for name in order:
+		red.variableReady(name)
+	total = blocks[-1][1] + blocks[-1][2]
+	before_last = red.launchedBytes[-2] / total
+	assert before_last >= 0.75, "only %.0f %% of the gradient bytes were handed to the transport before the last layer" % (100 * before_last)
+	assert len(red.buckets) >= 4 and red.launchedBytes[-1] == sum(b.stop - b.start for b in red.buckets)
+	half = next(i for i, b in enumerate(red.launchedBytes) if b / total >= 0.5) / len(order)
+	print("dp buckets: %d buckets, %.0f %% of bytes out before the last layer, half of them after %.0f %% of the layers" % (
+		len(red.buckets), 100 * before_last, 100 * half
+	))
+
+
+if __name__ == "__main__":
+	globals()[sys.argv[1]]()

@@ -19,7 +19,7 @@ out = sys.argv[1]
 Config.deviceIdx = int(os.environ.get("PUZZLE_MI355_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 nodeinfo = grid.nodeFromEnv(bucketBytes=64 << 10)          # small buckets: several exchanges overlap with backward
 
-from puzzlelib_amd import nets, train
+from puzzlelib_amd import nets, optim
 from puzzlelib_amd.surface import bound
 
 gpuarray = bound().gpuarray
@@ -34,12 +34,12 @@ if rank == 0:
 	for name, var in nets.namedVariables(net).items():
 		var.data.set(golden["init_" + name])
 
-optimizer = train.Adam(alpha=1e-3, nodeinfo=nodeinfo)
+optimizer = optim.Adam(alpha=1e-3, nodeinfo=nodeinfo)
 optimizer.setupOn(net, useGlobalState=True)
 if nodeinfo is not None:
 	grid.enableOverlap(optimizer, nodeinfo)
 
-trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=4)
+trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=4)
 data, labels = gpuarray.to_gpu(golden["data"]), gpuarray.to_gpu(golden["labels"])
 for _ in range(3):
 	trainer.train(data, labels, random=False)

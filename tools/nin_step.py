@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from puzzlelib_amd import nets, train, lib
+from puzzlelib_amd import nets, optim, lib
 from puzzlelib_amd.surface import bound
 
 gpuarray = bound().gpuarray
@@ -15,18 +15,18 @@ labels = gpuarray.to_gpu(rng.randint(0, 10, size=(128, )).astype(np.int32))
 
 np.random.seed(1)
 net = nets.buildNiN()
-optimizer = train.MomentumSGD(learnRate=0.01, momRate=0.9)
+optimizer = optim.MomentumSGD(learnRate=0.01, momRate=0.9)
 optimizer.setupOn(net, useGlobalState=True)
-trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=128)
+trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=128)
 net.trainMode()
 
 for _ in range(20):
-	trainer.handleBatch([data, labels], 0, None)
+	trainer.step([data, labels])
 	net.reset()
 lib.pz_device_sync()
 t0 = time.perf_counter()
 for _ in range(steps):
-	trainer.handleBatch([data, labels], 0, None)
+	trainer.step([data, labels])
 	net.reset()
 t1 = time.perf_counter()
 lib.pz_device_sync()

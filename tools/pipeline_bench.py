@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from puzzlelib_amd import nets, train, lib
+from puzzlelib_amd import nets, optim, lib
 from puzzlelib_amd.surface import bound
 
 bound()
@@ -18,12 +18,12 @@ data = rng.randn(n, *shape).astype(np.float32)
 labels = rng.randint(0, classes, size=(n, )).astype(np.int32)
 
 for mode in (False, True, False, True):
-	train.Handler.asyncUpload = mode
+	optim.Loop.asyncUpload = mode
 	np.random.seed(1)
 	net = nets.buildNiN() if which == "nin" else nets.loadResNet(None, "50", actInplace=True, initscheme="he")
-	optimizer = train.MomentumSGD(learnRate=0.01, momRate=0.9)
+	optimizer = optim.MomentumSGD(learnRate=0.01, momRate=0.9)
 	optimizer.setupOn(net, useGlobalState=True)
-	trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=batch)
+	trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=batch)
 	trainer.trainFromHost(data[:2 * macro], labels[:2 * macro], macroBatchSize=macro, random=False)      # warm-up (sizes the staging slots)
 	lib.pz_device_sync()
 	t0 = time.perf_counter()
