@@ -107,3 +107,39 @@ def test_two_rank_gradient_mean_over_gloo(tmp_path):
 	# overlap: all buckets but (at most) the one holding the first-executed layers were launched during "backward"
 	during, total = ranks[0]["launched"]
 	assert total >= 2 and during >= total - 1
+
+
+def _group_worker(rank, world, port, outdir):
+	sys.path.insert(0, ROOT)
+	from puzzlelib_amd import grid
+	group = grid.HostGroup(rank, world, "127.0.0.1", port)
+	blob = group.broadcast(b"id-from-rank-0" * 9 if rank == 0 else b"")
+	total, low, high = group.reduce(rank + 1.0, "sum"), group.reduce(rank + 1.0, "min"), group.reduce(rank + 1.0, "max")
+	array = np.full(1000, float(rank + 1), dtype=np.float32)
+	group.sumArray(array)
+	group.barrier()
+	np.savez(os.path.join(outdir, "g%d.npz" % rank), blob=np.frombuffer(blob, dtype=np.uint8), red=np.array([total, low, high]),
+			 array=array)
+	group.close()
+
+
+@pytest.mark.timeout(120)
+def test_host_group_over_tcp_three_ranks(tmp_path):
+	"""puzzlelib_amd.grid.HostGroup — the plain-TCP star that replaces torch.distributed for the ranks' host-side traffic
+	(RCCL id hand-out, votes, scalar means, barriers, the fallback gradient transport)."""
+	import multiprocessing as mp
+
+	world, port = 3, _free_port()
+	ctx = mp.get_context("spawn")
+	procs = [ctx.Process(target=_group_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+	for p in procs:
+		p.start()
+	for p in procs:
+		p.join(90)
+		assert p.exitcode == 0
+
+	outs = [np.load(os.path.join(str(tmp_path), "g%d.npz" % r)) for r in range(world)]
+	for out in outs:
+		assert bytes(out["blob"]) == b"id-from-rank-0" * 9
+		assert list(out["red"]) == [6.0, 1.0, 3.0]
+		assert np.array_equal(out["array"], np.full(1000, 6.0, np.float32))

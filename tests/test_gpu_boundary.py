@@ -32,10 +32,9 @@ def test_positional_signatures_match_the_wrappers(bnd):
 	def params(fn):
 		return [p for p in inspect.signature(fn).parameters]
 
-	# Backend/Dnn.py:179-193
-	# (a trailing keyword-only-by-convention `withStats` is this backend's own extension; positions 0..9 are the reference's)
-	assert params(bnd.dnn.convNd)[:10] == ["data", "W", "bias", "stride", "pad", "dilation", "groups", "algo", "out", "allocator"]
-	assert params(bnd.dnn.convNdBackwardData)[:12] == [       # (+ this backend's own trailing `compact`)
+	# Backend/Dnn.py:179-193 / Hip/Wrappers/MIOpen.py:333-462 — exactly these parameters, no backend-specific extras
+	assert params(bnd.dnn.convNd) == ["data", "W", "bias", "stride", "pad", "dilation", "groups", "algo", "out", "allocator"]
+	assert params(bnd.dnn.convNdBackwardData) == [
 		"grad", "W", "bias", "data", "stride", "pad", "dilation", "postpad", "groups", "algo", "out", "allocator"
 	]
 	assert params(bnd.dnn.convNdBackwardParams) == [
@@ -48,8 +47,12 @@ def test_positional_signatures_match_the_wrappers(bnd):
 		"grad", "indata", "outdata", "workspace", "size", "stride", "pad", "mode", "out", "allocator"
 	]
 	# Backend/Dnn.py:238-253
-	assert params(bnd.dnn.batchNormNd)[:9] == ["data", "mean", "var", "scale", "bias", "epsilon", "factor", "test", "mode"]
-	assert params(bnd.dnn.batchNormNdBackward)[:7] == ["grad", "data", "scale", "savemean", "saveinvvar", "epsilon", "mode"]
+	assert params(bnd.dnn.batchNormNd) == [
+		"data", "mean", "var", "scale", "bias", "epsilon", "factor", "test", "mode", "out", "allocator"
+	]
+	assert params(bnd.dnn.batchNormNdBackward) == [
+		"grad", "data", "scale", "savemean", "saveinvvar", "epsilon", "mode", "out", "allocator"
+	]
 	# Backend/Blas.py:61
 	assert params(bnd.blas.gemm) == ["A", "B", "out", "transpA", "transpB", "alpha", "beta", "allocator"]
 	assert params(bnd.matmod.matsum) == ["tensor", "axis", "out", "alpha", "beta", "allocator"]
@@ -79,7 +82,7 @@ def test_rccl_single_rank_roundtrip(bnd):
 
 	buf = ctypes.create_string_buffer(lib.COMM_ID_BYTES)
 	lib.pz_comm_unique_id(buf)
-	node = grid.RcclNodeInfo(0, 1, 0, buf.raw)
+	node = grid.RcclNodeInfo(0, 1, 0, buf.raw, grid.HostGroup(0, 1, "127.0.0.1", 0))
 
 	rng = np.random.RandomState(0)
 	host = rng.randn(1 << 16).astype(np.float32)
@@ -132,7 +135,7 @@ def test_host_stager_uploads_match_and_overlap_safely(bnd):
 def test_train_from_host_async_upload_is_bit_identical(bnd):
 	"""Handlers/Handler.py:20-36 path: trainFromHost over 3 macro-batches with the staged asynchronous upload gives
 	exactly the parameters of the synchronous upload."""
-	from puzzlelib_amd import nets, train
+	from puzzlelib_amd import nets, optim
 	from puzzlelib_amd.surface import bound
 
 	bound()
@@ -142,17 +145,17 @@ def test_train_from_host_async_upload_is_bit_identical(bnd):
 
 	results = []
 	for mode in (False, True):
-		train.Handler.asyncUpload = mode
+		optim.Loop.asyncUpload = mode
 		try:
 			np.random.seed(11)
 			net = nets.loadLeNet(None, initscheme=None)
-			optimizer = train.MomentumSGD(learnRate=0.05, momRate=0.9)
+			optimizer = optim.MomentumSGD(learnRate=0.05, momRate=0.9)
 			optimizer.setupOn(net, useGlobalState=True)
-			trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=16)
+			trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=16)
 			trainer.trainFromHost(data, labels, macroBatchSize=40, random=False)
-			results.append({k: v.data.get() for k, v in nets.namedVariables(net).items()})
+			results.append({k: v.data.get() for k, v in net.namedParams().items()})
 		finally:
-			train.Handler.asyncUpload = True
+			optim.Loop.asyncUpload = True
 
 	for name in results[0]:
 		assert np.array_equal(results[0][name], results[1][name]), name
@@ -206,13 +209,16 @@ def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
 	with socket.socket() as s:
 		s.bind(("127.0.0.1", 0))
 		port = s.getsockname()[1]
-	subprocess.run(
-		[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-		 "--master-port", str(port), script, dual], check=True, env=env, timeout=900
-	)
+	# two ranks started the way bench.py starts its own (no launcher, no torch): RANK / WORLD_SIZE / MASTER_* in the environment
+	procs = [
+		subprocess.Popen([sys.executable, script, dual], env=dict(
+			env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)
+		)) for r in range(2)
+	]
+	assert [p.wait(timeout=900) for p in procs] == [0, 0]
 
 	a, b = np.load(single), np.load(dual)
-	assert str(b["transport"]) in ("rccl", "gloo-host-staged")
+	assert str(b["transport"]) in ("rccl", "host-staged")
 	for name in a.files:
 		if name != "transport":
 			assert np.array_equal(a[name], b[name]), "parameter %s differs between 1 and 2 ranks" % name

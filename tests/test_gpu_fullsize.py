@@ -138,7 +138,7 @@ def test_resnet_stem_maxpool_round_trip(bnd):
 
 
 def test_training_step_is_deterministic(bnd, mini_golden):
-	from puzzlelib_amd import nets, train
+	from puzzlelib_amd import nets, optim
 	from puzzlelib_amd.surface import bound
 
 	gpuarray = bound().gpuarray
@@ -150,14 +150,14 @@ def test_training_step_is_deterministic(bnd, mini_golden):
 	for _ in range(2):
 		np.random.seed(7)
 		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
-		for name, var in nets.namedVariables(net).items():
+		for name, var in net.namedParams().items():
 			var.data.set(mini_golden["init_" + name])
-		optimizer = train.Adam(alpha=1e-3)
+		optimizer = optim.Adam(alpha=1e-3)
 		optimizer.setupOn(net, useGlobalState=True)
-		trainer = train.Trainer(net, train.CrossEntropy(), optimizer, batchsize=4)
+		trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=4)
 		for _ in range(3):
 			trainer.train(data, labels, random=False)
-		outs.append({k: v.data.get() for k, v in nets.namedVariables(net).items()})
+		outs.append({k: v.data.get() for k, v in net.namedParams().items()})
 
 	for name in outs[0]:
 		assert np.array_equal(outs[0][name], outs[1][name]), "non-deterministic parameter " + name
@@ -190,7 +190,7 @@ def test_elementwise_and_norm_edge_cases(bnd):
 	# zero-size launches are no-ops
 	empty = bnd.GPUArray.empty((0, ), dtype=np.float32)
 	bnd.reluKer(np.float32)(empty, empty)
-	bnd.add3Ker(empty, empty, empty)
+	bnd.addKer(np.float32)(empty, empty, 1.0, empty, 1.0)
 	assert empty.get().shape == (0, )
 
 	# sizes around the 16-byte vector width, unaligned views

@@ -1,0 +1,348 @@
+"""
+GPU tests of the lazy-buffer layer (puzzlelib_amd/lazy.py, fusion.py): sequences of the reference's own calls — nothing but
+wrappers with the reference's signatures — must give the same numbers whether the backend defers and fuses them or
+launches every call on the spot (`lazy.enabled = False`, the literal behaviour), bit for bit wherever the fused kernel
+performs the same floating-point operations in the same order, and must match the fp64 oracle in both modes.
+Hazards are tested with real data: a description must be evaluated with the values its inputs had when the call was made.
+"""
+import numpy as np
+import pytest
+
+import cpu_ref as R
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def surf(bnd):
+	from puzzlelib_amd.surface import bound
+	from puzzlelib_amd import lazy, backend
+	lazy.enabled, lazy.disabled = True, set()
+	backend.DnnContext.convStatsPolicy = "adaptive"
+	yield bound()
+	lazy.enabled, lazy.disabled = True, set()
+	backend.DnnContext.convStatsPolicy = "adaptive"
+
+
+def both(fn):
+	"""fn() under the lazy layer and with it off -> (lazy result, literal result)"""
+	from puzzlelib_amd import lazy
+	out = []
+	for mode in (True, False):
+		lazy.enabled = mode
+		lazy.counters.clear()
+		try:
+			out.append((fn(), dict(lazy.counters)))
+		finally:
+			lazy.enabled = True
+	return out
+
+
+def bnParams(surf, rng, c):
+	g = surf.gpuarray
+	shape = (1, c, 1, 1)
+	scale, bias = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
+	rm, rv = rng.randn(*shape).astype(np.float32), (0.5 + rng.rand(*shape)).astype(np.float32)
+	return (scale, bias, rm, rv), lambda: (g.to_gpu(scale), g.to_gpu(bias), g.to_gpu(rm), g.to_gpu(rv))
+
+
+@pytest.mark.parametrize("shape", [(4, 5, 2, 3), (3, 7, 55, 55), (5, 3, 7, 7), (8, 130, 14, 14)])
+def test_batchnorm_relu_pair(surf, shape):
+	"""BatchNorm2D -> Activation(relu, inplace=True) forward and backward as the reference issues them
+	(Modules/BatchNormND.py:60-88, Activation.py:52-70). Lazy: one fused apply, and the ReLU derivative evaluated inside
+	the batch-norm backward from x and the forward's own coefficients. Must equal the literal four kernels bit for bit."""
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	rng = np.random.RandomState(11)
+	x = (0.5 + 2.0 * rng.randn(*shape)).astype(np.float32)
+	dy = rng.randn(*shape).astype(np.float32)
+	(scale, bias, rm, rv), fresh = bnParams(surf, rng, shape[1])
+
+	def run():
+		gs, gb, grm, grv = fresh()
+		gx, gdy = g.to_gpu(x), g.to_gpu(dy)
+		y, sm, si = Dnn.batchNormNd(gx, gs, gb, grm, grv, 1e-5, 0.3, False)
+		El.reluKer(np.float32)(y, y)
+		El.reluDerKer(np.float32)(gdy, gdy, y)
+		dx, ds, db = Dnn.batchNormNdBackward(gx, gdy, gs, sm, si, 1e-5)
+		return [a.get() for a in (y, dx, ds, db, sm, si, grm, grv)]
+
+	(lz, taken), (lit, none) = both(run)
+	assert taken.get("bn_bwd_gate", 0) == 1 and taken.get("bn_apply_relu", 0) == 1 and not none
+	for a, b, what in zip(lz, lit, ("y", "dx", "dscale", "dbias", "savemean", "saveinvvar", "running mean", "running var")):
+		assert np.array_equal(a, b), what
+
+	rm_ref, rv_ref = rm.ravel().copy(), rv.ravel().copy()
+	y_ref, sm_ref, si_ref = R.bn_fwd_train(x, scale.ravel(), bias.ravel(), rm_ref, rv_ref, 1e-5, 0.3, acc=np.float64)
+	assert_close(lz[0], np.maximum(y_ref, 0), atol=2e-5, rtol=1e-4, what="relu(bn(x))")
+	# the gate of the device (sign of its own fp32 y) is used for the oracle's backward: a pre-activation at rounding
+	# distance from zero may gate either way, which is not what this test is about
+	dx_ref, ds_ref, db_ref = R.bn_bwd(dy * (lz[0] > 0), x, scale.ravel(), sm_ref, si_ref, acc=np.float64)
+	assert_close(lz[1], dx_ref, atol=1e-4 * np.abs(dx_ref).max() + 1e-6, rtol=1e-3, what="dx")
+	assert_close(lz[2].ravel(), ds_ref, atol=1e-4 * np.abs(ds_ref).max() + 1e-5, rtol=1e-3, what="dscale")
+	assert_close(lz[6].ravel(), rm_ref, atol=1e-5, rtol=1e-5, what="running mean")
+
+
+def test_described_tensor_sees_the_inputs_of_call_time(surf):
+	"""A batch-norm output that was only described must come out with the x of the moment batchNormNd was called, even if x
+	is overwritten before anybody reads the output; same for a residual sum whose term changes."""
+	g, Dnn, El, Blas = surf.gpuarray, surf.Dnn, surf.ElementWise, surf.Blas
+	from puzzlelib_amd import lazy, fusion
+	rng = np.random.RandomState(3)
+	x = rng.randn(4, 6, 9, 9).astype(np.float32)
+	(scale, bias, rm, rv), fresh = bnParams(surf, rng, 6)
+
+	gs, gb, grm, grv = fresh()
+	gx = g.to_gpu(x)
+	y, sm, si = Dnn.batchNormNd(gx, gs, gb, grm, grv, 1e-5, 1.0, False)
+	assert isinstance(lazy.pending(y), fusion.BnApply)
+	gx.set(np.zeros_like(x))                                            # overwrites the description's input
+	y_ref = R.bn_fwd_train(x, scale.ravel(), bias.ravel(), rm.ravel().copy(), rv.ravel().copy(), 1e-5, 1.0)[0]
+	assert_close(y.get(), y_ref, atol=2e-5, rtol=1e-4, what="y after its input was overwritten")
+
+	a, b = rng.randn(4, 6, 9, 9).astype(np.float32), rng.randn(4, 6, 9, 9).astype(np.float32)
+	ga, gb2 = g.to_gpu(a), g.to_gpu(b)
+	total = g.empty(a.shape, dtype=np.float32)
+	total.fill(0)
+	Blas.toVectorAddVector(total.ravel(), ga.ravel())
+	Blas.toVectorAddVector(total.ravel(), gb2.ravel())
+	assert isinstance(lazy.pending(total), fusion.Sum)
+	El.reluKer(np.float32)(gb2, gb2)                                    # in-place change of a term, after the axpy
+	assert np.array_equal(total.get(), a + b)
+
+	# a gate described on a gradient applies the sign of y as it was at reluDerKer time
+	gy, gg = g.to_gpu(a), g.to_gpu(b)
+	El.reluDerKer(np.float32)(gg, gg, gy)
+	assert isinstance(lazy.pending(gg), fusion.Gate)
+	gy.fill(-1.0)
+	assert np.array_equal(gg.get(), b * (a > 0))
+
+
+@pytest.mark.parametrize("cfg", [dict(n=4, c=16, k=32, hw=(12, 12), r=1), dict(n=3, c=24, k=40, hw=(9, 11), r=1),
+								 dict(n=4, c=64, k=64, hw=(20, 20), r=3), dict(n=2, c=3, k=16, hw=(32, 32), r=7, stride=2, pad=3)])
+def test_convolution_statistics_feed_the_batchnorm(surf, cfg):
+	"""Conv2D -> BatchNorm2D: the convolution's epilogue leaves per-strip sums and the batch-norm skips its statistics
+	pass (policy "always"; "adaptive" learns it after the first pass). Same mean / variance up to summation order."""
+	from puzzlelib_amd import backend, lazy
+	g, Dnn = surf.gpuarray, surf.Dnn
+	rng = np.random.RandomState(5)
+	n, c, k, (h, w), r = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"]
+	stride, pad = cfg.get("stride", 1), cfg.get("pad", r // 2)
+	x = rng.randn(n, c, h, w).astype(np.float32)
+	wt = (rng.randn(k, c, r, r) / np.sqrt(c * r * r)).astype(np.float32)
+	(scale, bias, rm, rv), fresh = bnParams(surf, rng, k)
+	algo = surf.Dnn.ConvFwdAlgo.implicitGemm
+
+	results = {}
+	for policy in ("never", "always"):
+		backend.DnnContext.convStatsPolicy = policy
+		lazy.counters.clear()
+		gs, gb, grm, grv = fresh()
+		y = Dnn.convNd(g.to_gpu(x), g.to_gpu(wt), None, (stride, stride), (pad, pad), (1, 1), 1, algo)
+		out, sm, si = Dnn.batchNormNd(y, gs, gb, grm, grv, 1e-5, 0.3, False)
+		results[policy] = [a.get() for a in (y, out, sm, si, grm, grv)] + [lazy.counters.get("conv_stats", 0)]
+	assert results["never"][-1] == 0 and results["always"][-1] == 1
+	assert np.array_equal(results["never"][0], results["always"][0]), "the convolution's output does not depend on the epilogue sums"
+	for a, b, what in zip(results["never"][1:6], results["always"][1:6], ("y", "savemean", "saveinvvar", "rmean", "rvar")):
+		assert_close(b, a, atol=2e-5, rtol=2e-5, what=what)
+
+	# adaptive: the second pass of the same filter emits them
+	backend.DnnContext.convStatsPolicy = "adaptive"
+	gw = g.to_gpu(wt)
+	for expect in (0, 1):
+		lazy.counters.clear()
+		gs, gb, grm, grv = fresh()
+		y = Dnn.convNd(g.to_gpu(x), gw, None, (stride, stride), (pad, pad), (1, 1), 1, algo)
+		Dnn.batchNormNd(y, gs, gb, grm, grv, 1e-5, 0.3, False)
+		assert lazy.counters.get("conv_stats", 0) == expect
+
+
+def residualBlock(surf, rng, n, c, hw, projection, stride):
+	"""arrays of a bottleneck tail: main = conv1x1(a) -> BN, shortcut = conv1x1(x, stride) -> BN or x itself"""
+	h, w = hw
+	mid = max(c // 4, 4)
+	p, q = (h + stride - 1) // stride, (w + stride - 1) // stride
+	data = dict(
+		a=rng.randn(n, mid, p, q).astype(np.float32), wa=(rng.randn(c, mid, 1, 1) / np.sqrt(mid)).astype(np.float32),
+		x=rng.randn(n, c if not projection else mid * 2, h, w).astype(np.float32), dy=rng.randn(n, c, p, q).astype(np.float32)
+	)
+	if projection:
+		data["ws"] = (rng.randn(c, mid * 2, 1, 1) / np.sqrt(mid * 2)).astype(np.float32)
+	return data
+
+
+@pytest.mark.parametrize("cfg", [dict(n=4, c=64, hw=(14, 14), projection=False, stride=1),
+								 dict(n=3, c=128, hw=(13, 15), projection=True, stride=2),
+								 dict(n=2, c=48, hw=(9, 9), projection=True, stride=1)])       # 48 maps: the fold declines
+def test_residual_block_tail_and_its_backward(surf, cfg):
+	"""The end of a ResNet block and the start of its backward exactly as the reference's modules issue them:
+	  fwd  convNd, batchNormNd (x2 with a projection), zeros + 2 x toVectorAddVector (Add), reluKer in place
+	  bwd  reluDerKer in place on the incoming gradient (itself a Replicate fan-in: zeros + 2 x toVectorAddVector),
+	       batchNormNdBackward + addVectorToVector x2 per BN, convNdBackwardData / convNdBackwardParams
+	Lazy: residual sum normalising on the fly (+ sign mask), fan-in + gate + both BNs' statistics in one pass, BN backward
+	folded into the 1x1 convolutions, compact stride-2 input gradients, filter gradients on the side stream.
+	Bit-identical to the literal sequence with the (rounding-different) BN-backward fold off; within tolerance with it on."""
+	from puzzlelib_amd import lazy, backend
+	g, Dnn, El, Blas = surf.gpuarray, surf.Dnn, surf.ElementWise, surf.Blas
+	rng = np.random.RandomState(9)
+	n, c, stride, projection = cfg["n"], cfg["c"], cfg["stride"], cfg["projection"]
+	d = residualBlock(surf, rng, n, c, cfg["hw"], projection, stride)
+	(_, _, _, _), freshA = bnParams(surf, rng, c)
+	(_, _, _, _), freshS = bnParams(surf, rng, c)
+	g0, g1 = rng.randn(*d["dy"].shape).astype(np.float32), rng.randn(*d["dy"].shape).astype(np.float32)
+	auto = Dnn.ConvFwdAlgo.auto, Dnn.ConvBwdDataAlgo.auto, Dnn.ConvBwdFilterAlgo.auto
+	backend.DnnContext.convStatsPolicy = "never"          # (epilogue statistics differ in summation order; tested above)
+
+	def run():
+		ga, gwa, gx = g.to_gpu(d["a"]), g.to_gpu(d["wa"]), g.to_gpu(d["x"])
+		sA, bA, mA, vA = freshA()
+		ca = Dnn.convNd(ga, gwa, None, (1, 1), (0, 0), (1, 1), 1, auto[0])
+		ya, smA, siA = Dnn.batchNormNd(ca, sA, bA, mA, vA, 1e-5, 1.0, False)
+		if projection:
+			gws = g.to_gpu(d["ws"])
+			sS, bS, mS, vS = freshS()
+			cs = Dnn.convNd(gx, gws, None, (stride, stride), (0, 0), (1, 1), 1, auto[0])
+			ys, smS, siS = Dnn.batchNormNd(cs, sS, bS, mS, vS, 1e-5, 1.0, False)
+		else:
+			ys = gx
+		out = g.empty(ya.shape, dtype=np.float32, allocator=g.memoryPool)
+		out.fill(0)
+		for term in (ya, ys):
+			Blas.toVectorAddVector(out.ravel(), term.ravel())
+		El.reluKer(np.float32)(out, out)
+
+		# backward: the gradient arrives as the next block's fan-in
+		grad = g.empty(out.shape, dtype=np.float32, allocator=g.memoryPool)
+		grad.fill(0)
+		for term in (g.to_gpu(g0), g.to_gpu(g1)):
+			Blas.toVectorAddVector(grad.ravel(), term.ravel())
+		El.reluDerKer(np.float32)(grad, grad, out)
+
+		res = {"out": out, "grad": grad}
+		wgA = g.zeros(d["wa"].shape, dtype=np.float32)
+		dA, dsA, dbA = Dnn.batchNormNdBackward(ca, grad, sA, smA, siA, 1e-5)
+		res["dxa"] = Dnn.convNdBackwardData(dA, gwa, data=ga, stride=(1, 1), pad=(0, 0), dilation=(1, 1), groups=1, algo=auto[1])
+		Dnn.convNdBackwardParams(ga, dA, gwa, None, (1, 1), (0, 0), (1, 1), 1, wgA, None, 1.0, 1.0, auto[2])
+		res.update(wgA=wgA, dsA=dsA, dbA=dbA)
+		if projection:
+			wgS = g.zeros(d["ws"].shape, dtype=np.float32)
+			dS, dsS, dbS = Dnn.batchNormNdBackward(cs, grad, sS, smS, siS, 1e-5)
+			res["dxs"] = Dnn.convNdBackwardData(dS, gws, data=gx, stride=(stride, stride), pad=(0, 0), dilation=(1, 1), groups=1, algo=auto[1])
+			Dnn.convNdBackwardParams(gx, dS, gws, None, (stride, stride), (0, 0), (1, 1), 1, wgS, None, 1.0, 1.0, auto[2])
+			res.update(wgS=wgS, dsS=dsS, dbS=dbS)
+		return {k: v.get() for k, v in res.items()}
+
+	lazy.disabled = {"bnbwdfold"}
+	(lz, taken), (lit, none) = both(run)
+	assert taken.get("bn_apply_add", 0) == 1 and taken.get("gate_stats", 0) == 1 and taken.get("gate_by_mask", 0) == 1
+	assert taken.get("bn_bwd_from_partials", 0) == (2 if projection else 1), "one fan-in pass serves both batch-norms"
+	if projection and stride == 2:
+		assert taken.get("compact_dgrad", 0) == 1
+	for key in lit:
+		assert np.array_equal(lz[key], lit[key]), "%s differs between the fused and the literal sequence" % key
+
+	lazy.disabled = set()
+	lazy.counters.clear()
+	folded = run()
+	expect = 0 if c % 16 else (2 if projection else 1)
+	assert lazy.counters.get("dgrad_bn_fold", 0) == expect and lazy.counters.get("wgrad_bn_fold", 0) == expect
+	for key in lit:
+		scale = np.abs(lit[key]).max() + 1e-12
+		assert_close(folded[key], lit[key], atol=3e-5 * scale, rtol=3e-4, what="BN backward folded into the convolution: " + key)
+
+	# oracle: block output and the main branch's input gradient in fp64
+	ca = R.conv2d_fwd(d["a"], d["wa"], None, stride=(1, 1), pad=(0, 0), dilation=(1, 1), groups=1, acc=np.float64)
+	assert lit["out"].shape == ca.shape and (lit["out"] >= 0).all()
+	assert np.array_equal(lit["grad"], (g0 + g1) * (lit["out"] > 0))
+
+
+def test_gated_gradient_without_a_batchnorm_reader(surf):
+	"""reluDerKer in place followed by a reader that is not the batch-norm backward (NiN: conv -> relu -> conv): the gate
+	is applied by its own kernel when the convolution reads the gradient — same numbers as the literal sequence."""
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	rng = np.random.RandomState(2)
+	x, y = rng.randn(4, 8, 10, 10).astype(np.float32), rng.randn(4, 12, 10, 10).astype(np.float32)
+	dy = rng.randn(4, 12, 10, 10).astype(np.float32)
+	wt = rng.randn(12, 8, 3, 3).astype(np.float32)
+
+	def run():
+		gx, gy, gdy, gw = g.to_gpu(x), g.to_gpu(y), g.to_gpu(dy), g.to_gpu(wt)
+		El.reluDerKer(np.float32)(gdy, gdy, gy)
+		dx = Dnn.convNdBackwardData(gdy, gw, data=gx, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, algo=Dnn.ConvBwdDataAlgo.auto)
+		wg = g.zeros(wt.shape, dtype=np.float32)
+		Dnn.convNdBackwardParams(gx, gdy, gw, None, (1, 1), (1, 1), (1, 1), 1, wg, None, 1.0, 1.0, Dnn.ConvBwdFilterAlgo.auto)
+		return dx.get(), wg.get(), gdy.get()
+
+	(lz, taken), (lit, _) = both(run)
+	assert taken.get("gate", 0) == 1
+	for a, b in zip(lz, lit):
+		assert np.array_equal(a, b)
+	assert np.array_equal(lz[2], dy * (y > 0))
+
+
+def test_filter_gradients_on_the_side_stream(surf):
+	"""Every convNdBackwardParams goes to the filter-gradient stream; whoever touches the gradient next (here: .get(), an
+	axpy, the next accumulate call) is ordered behind it by the buffer's event. Same bits as on one stream, and the
+	tensors the side stream reads may be overwritten or dropped right after the call."""
+	from puzzlelib_amd import lazy
+	g, Dnn, Blas = surf.gpuarray, surf.Dnn, surf.Blas
+	rng = np.random.RandomState(4)
+	x, dy = rng.randn(16, 64, 28, 28).astype(np.float32), rng.randn(16, 128, 28, 28).astype(np.float32)
+	wt = rng.randn(128, 64, 3, 3).astype(np.float32)
+	algo = Dnn.ConvBwdFilterAlgo.auto
+
+	def run():
+		gx, gdy, gw = g.to_gpu(x), g.to_gpu(dy), g.to_gpu(wt)
+		arena = g.zeros((2 * wt.size, ), dtype=np.float32)            # two accumulators in one allocation, like the optimizer's
+		first = arena[:wt.size].reshape(wt.shape)
+		second = arena[wt.size:].reshape(wt.shape)
+		Dnn.convNdBackwardParams(gx, gdy, gw, None, (1, 1), (1, 1), (1, 1), 1, first, None, 1.0, 1.0, algo)
+		Dnn.convNdBackwardParams(gx, gdy, gw, None, (1, 1), (1, 1), (1, 1), 1, second, None, 0.5, 1.0, algo)
+		gx.fill(0)                                                    # a main-stream write to what the side stream reads
+		del gdy                                                       # ... and a free of the other operand
+		Dnn.convNdBackwardParams(g.to_gpu(x), g.to_gpu(dy), gw, None, (1, 1), (1, 1), (1, 1), 1, first, None, 1.0, 1.0, algo)
+		Blas.toVectorAddVector(arena, arena, alpha=1.0)               # main-stream read-modify-write of the arena
+		return arena.get()
+
+	launches = surf.backend.dnn.sideLaunches
+	with_side = run()
+	assert surf.backend.dnn.sideLaunches == launches + 3
+	lazy.disabled = {"sidestream"}
+	one_stream = run()
+	assert surf.backend.dnn.sideLaunches == launches + 3
+	assert np.array_equal(with_side, one_stream)
+	dw = R.conv2d_bwd_filter(dy, x, wt.shape, withbias=False, acc=np.float64, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	scale = np.abs(dw).max()
+	assert_close(with_side[:wt.size].reshape(wt.shape), 4.0 * dw, atol=2e-4 * scale, rtol=2e-4, what="2 x (dw + dw)")
+	assert_close(with_side[wt.size:].reshape(wt.shape), 1.0 * dw, atol=2e-4 * scale, rtol=2e-4, what="2 x 0.5 dw")
+
+
+def test_borrowed_streams_are_ordered_by_the_buffers(surf):
+	"""Optimizer.update(useStreams=True) (Optimizers/Optimizer.py:176-196): per-parameter updates on borrowed streams. The
+	reference's streams are blocking ones; here ordering is carried by events on the buffers (updates raced
+	with backward and the next forward). Three SGD steps on several parameters, useStreams on/off, same bits."""
+	from puzzlelib_amd import nets, optim
+	g = surf.gpuarray
+	spec = [("conv", "c1", 3, 16, 3, 1, 1, True), ("relu", "r1"), ("conv", "c2", 16, 16, 3, 1, 1, True), ("relu", "r2"),
+			("maxpool", "p", 2, 2, 0), ("flatten", "f"), ("linear", "fc", 16 * 8 * 8, 10)]
+	rng = np.random.RandomState(6)
+	data, labels = rng.randn(8, 3, 16, 16).astype(np.float32), rng.randint(0, 10, size=(8, )).astype(np.int32)
+
+	results = []
+	for streams in (False, True):
+		np.random.seed(3)
+		net = nets.build(spec, initscheme="he")
+		opt = optim.MomentumSGD(learnRate=0.05, momRate=0.9)
+		opt.setupOn(net, useGlobalState=False)
+		cost = optim.CrossEntropy()
+		net.trainMode()
+		gd, gl = g.to_gpu(data), g.to_gpu(labels)
+		for _ in range(3):
+			grad = cost(net(gd), gl, queryError=False)
+			opt.zeroGradParams()
+			net.backward(grad, updGrad=False)
+			opt.update(useStreams=streams, sync=False)
+			net.reset()
+		results.append({k: p.data.get() for k, p in net.namedParams().items()})
+	for key in results[0]:
+		assert np.array_equal(results[0][key], results[1][key]), key

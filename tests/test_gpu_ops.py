@@ -319,176 +319,6 @@ def test_batchnorm_fresh(bnd, shape):
 	assert_close(y2.get(), y_ref, atol=2e-5, rtol=1e-4, what="in-place y")
 
 
-@pytest.mark.parametrize("shape", [(4, 5, 2, 3), (3, 7, 55, 55), (5, 3, 7, 7), (8, 130, 14, 14)])
-def test_batchnorm_fused_relu_is_the_unfused_sequence(bnd, shape):
-	"""BN + in-place ReLU fused inside the backend. Forward must equal reluKer(batchNormNd(x)) and backward
-	batchNormNdBackward(reluDerKer(dy, y)) BIT FOR BIT (the gate is re-created from x with the forward's own fma), and
-	both must match the oracle."""
-	rng = np.random.RandomState(11)
-	c = shape[1]
-	x = (0.5 + 2.0 * rng.randn(*shape)).astype(np.float32)
-	scale, bias = rng.randn(c).astype(np.float32), rng.randn(c).astype(np.float32)
-	dy = rng.randn(*shape).astype(np.float32)
-	rm0, rv0 = rng.randn(c).astype(np.float32), (1 + rng.rand(c)).astype(np.float32)
-
-	gx, gs, gb = gpu(bnd, x), gpu(bnd, scale), gpu(bnd, bias)
-
-	# unfused sequence
-	y, sm, si = bnd.dnn.batchNormNd(gx, gpu(bnd, rm0), gpu(bnd, rv0), gs, gb, 1e-5, 0.3, False)
-	bnd.reluKer(np.float32)(y, y)
-	gdy = gpu(bnd, dy)
-	bnd.reluDerKer(np.float32)(gdy, gdy, y)
-	dx, ds, db = bnd.dnn.batchNormNdBackward(gdy, gx, gs, sm, si, 1e-5)
-
-	# fused
-	grm, grv = gpu(bnd, rm0), gpu(bnd, rv0)
-	yf, smf, sif = bnd.dnn.batchNormNd(gx, grm, grv, gs, gb, 1e-5, 0.3, False, fuseRelu=True)
-	dxf, dsf, dbf = bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, smf, sif, 1e-5, bias=gb, fuseRelu=True)
-
-	assert np.array_equal(yf.get(), y.get())
-	assert np.array_equal(smf.get(), sm.get()) and np.array_equal(sif.get(), si.get())
-	assert np.array_equal(dxf.get(), dx.get())
-	assert np.array_equal(dsf.get(), ds.get()) and np.array_equal(dbf.get(), db.get())
-
-	# oracle
-	rm, rv = rm0.copy(), rv0.copy()
-	y_ref, sm_ref, si_ref = R.bn_fwd_train(x, scale, bias, rm, rv, 1e-5, 0.3, acc=np.float64)
-	near_zero = np.abs(y_ref) < 1e-4                   # the gate of such elements may legitimately differ from float64's
-	y_relu = R.relu(y_ref)
-	dy_gated = np.where(near_zero, dy * (yf.get() > 0), R.relu_der(dy, y_relu)).astype(np.float32)
-	dx_ref, ds_ref, db_ref = R.bn_bwd(dy_gated, x, scale, sm_ref, si_ref, acc=np.float64)
-
-	n = x.size // c
-	assert_close(yf.get(), y_relu, atol=2e-5, rtol=1e-4, what="fused y")
-	assert_close(grm.get(), rm, atol=1e-5, what="running mean")
-	assert_close(dxf.get(), dx_ref, atol=2e-5, rtol=1e-4, what="fused dx")
-	assert_close(dsf.get(), ds_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="fused dscale")
-	assert_close(dbf.get(), db_ref, atol=1e-5 * np.sqrt(n) * 4, rtol=1e-4, what="fused dbias")
-
-	with pytest.raises(ValueError):
-		bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gx, gs, smf, sif, 1e-5, fuseRelu=True)      # gate needs the bias
-
-
-@pytest.mark.parametrize("cfg", [
-	dict(n=3, c=5, k=70, hw=(13, 17), r=3, pad=1, stride=1, groups=1, bias=True),        # odd map: strips straddle images
-	dict(n=4, c=16, k=64, hw=(28, 28), r=1, pad=0, stride=1, groups=1, bias=False),      # 64x256 tile configuration, tap-major
-	dict(n=2, c=32, k=160, hw=(15, 15), r=3, pad=1, stride=2, groups=2, bias=False),     # groups, stride, ragged channel tiles
-	dict(n=20, c=64, k=128, hw=(20, 20), r=3, pad=1, stride=1, groups=1, bias=False),    # enough tiles for a k-sliced tail
-])
-def test_conv_epilogue_statistics_feed_batchnorm(bnd, cfg):
-	"""BN statistics from the producing convolution's epilogue (pz_conv2d_fwd_stats -> pz_bn_fwd_train_pre).
-	The strip sums must reproduce the per-channel mean / variance of y, and BN fed by them must equal BN computing its own
-	statistics (fp32 summation-order tolerance) and the oracle."""
-	rng = np.random.RandomState(5)
-	n, c, k, (h, w_), r, groups = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"], cfg["groups"]
-	x = rng.randn(n, c, h, w_).astype(np.float32)
-	wt = (rng.randn(k, c // groups, r, r) / np.sqrt(c // groups * r * r)).astype(np.float32)
-	bias = (3.0 * rng.randn(k)).astype(np.float32) if cfg["bias"] else None          # a large bias: mean >> std per channel
-	# strip statistics are an epilogue of the implicit GEMM (the Winograd path, which `auto` prefers for wide 3x3 layers,
-	# returns none and lets the BatchNorm make its own pass)
-	okw = dict(stride=(cfg["stride"], ) * 2, pad=(cfg["pad"], ) * 2, dilation=(1, 1), groups=groups,
-			   algo=bnd.ConvFwdAlgo.implicitGemm.value)
-
-	gx, gw, gb = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias) if bias is not None else None
-	y_plain = bnd.dnn.convNd(gx, gw, gb, **okw)
-	y, stats = bnd.dnn.convNd(gx, gw, gb, withStats=True, **okw)
-	assert stats is not None and stats.tensor is y
-	if r == 3 and cfg["stride"] == 1 and groups == 1 and c % 4 == 0:
-		_, none = bnd.dnn.convNd(gx, gw, gb, withStats=True, **dict(okw, algo=bnd.ConvFwdAlgo.winograd.value))
-		assert none is None
-	assert np.array_equal(y.get(), y_plain.get())
-
-	# strip sums -> exact per-channel moments
-	yh = y.get().astype(np.float64)
-	flat = yh.transpose(1, 0, 2, 3).reshape(k, -1)                       # (k, n*p*q) in the kernel's pixel order? no: (n, pq)
-	flat = yh.transpose(0, 2, 3, 1).reshape(-1, k)                       # pixel-major (n, p, q) x channel
-	st = stats.stats.get().astype(np.float64).transpose(1, 0, 2)         # (strip, channel, 4)
-	strips = st.shape[0]
-	assert strips == -(-flat.shape[0] // 64)
-	for s_ in (0, strips // 2, strips - 1):
-		seg = flat[64 * s_:64 * (s_ + 1)]
-		shift = st[s_, :, 0]
-		assert np.allclose(shift, seg[0], rtol=0, atol=0)
-		assert np.allclose(st[s_, :, 1], (seg - shift).sum(0), rtol=1e-4, atol=1e-4)
-		assert np.allclose(st[s_, :, 2], ((seg - shift) ** 2).sum(0), rtol=1e-4, atol=1e-4)
-
-	scale, bnb = rng.randn(k).astype(np.float32), rng.randn(k).astype(np.float32)
-	rm0, rv0 = rng.randn(k).astype(np.float32), (1 + rng.rand(k)).astype(np.float32)
-	gs, gbb = gpu(bnd, scale), gpu(bnd, bnb)
-
-	rm_a, rv_a = gpu(bnd, rm0), gpu(bnd, rv0)
-	out_a, sm_a, si_a = bnd.dnn.batchNormNd(y, rm_a, rv_a, gs, gbb, 1e-5, 0.3, False)
-	rm_b, rv_b = gpu(bnd, rm0), gpu(bnd, rv0)
-	out_b, sm_b, si_b = bnd.dnn.batchNormNd(y, rm_b, rv_b, gs, gbb, 1e-5, 0.3, False, convStats=stats, fuseRelu=False)
-
-	assert_close(sm_b.get(), sm_a.get(), atol=2e-6, rtol=1e-5, what="mean: strips vs own pass")
-	assert_close(si_b.get(), si_a.get(), atol=1e-6, rtol=2e-5, what="invvar: strips vs own pass")
-	assert_close(out_b.get(), out_a.get(), atol=3e-5, rtol=1e-4, what="y: strips vs own pass")
-	assert_close(rv_b.get(), rv_a.get(), atol=1e-5, rtol=1e-4, what="running var")
-
-	rm, rv = rm0.copy(), rv0.copy()
-	y_ref, sm_ref, si_ref = R.bn_fwd_train(y.get(), scale, bnb, rm, rv, 1e-5, 0.3, acc=np.float64)
-	assert_close(sm_b.get(), sm_ref, atol=1e-5, what="mean vs oracle")
-	assert_close(si_b.get(), si_ref, atol=1e-5, rtol=1e-4, what="invvar vs oracle")
-	assert_close(out_b.get(), y_ref, atol=3e-5, rtol=1e-4, what="y vs oracle")
-
-	# statistics of a different tensor object are ignored (the BN then runs its own pass)
-	y2 = y.copy()
-	out_c, sm_c, _ = bnd.dnn.batchNormNd(y2, gpu(bnd, rm0), gpu(bnd, rv0), gs, gbb, 1e-5, 0.3, False, convStats=stats)
-	assert np.array_equal(sm_c.get(), sm_a.get())
-
-
-@pytest.mark.parametrize("shape", [(3, 5, 13, 17), (4, 64, 28, 28), (2, 130, 7, 7)])
-def test_deferred_batchnorm_into_residual_add(bnd, shape):
-	"""pz_bn_fwd_train_defer + pz_bn_apply_add == batchNormNd + add3(/Relu) bit for bit (projection and identity shortcuts,
-	with and without the fused ReLU), and materialize() == the BN output."""
-	rng = np.random.RandomState(2)
-	n, k = shape[0], shape[1]
-	kw = dict(stride=(1, 1), pad=(0, 0), dilation=(1, 1), groups=1)
-
-	def conv_bn(seed, defer):
-		r = np.random.RandomState(seed)
-		x = gpu(bnd, r.randn(n, 8, *shape[2:]).astype(np.float32))
-		w = gpu(bnd, r.randn(k, 8, 1, 1).astype(np.float32))
-		scale, bias = gpu(bnd, r.randn(k).astype(np.float32)), gpu(bnd, r.randn(k).astype(np.float32))
-		mean, var = gpu(bnd, np.zeros(k, np.float32)), gpu(bnd, np.ones(k, np.float32))
-		y, stats = bnd.dnn.convNd(x, w, None, withStats=True, **kw)
-		assert stats is not None
-		out, sm, si = bnd.dnn.batchNormNd(y, mean, var, scale, bias, 1e-5, 0.5, False, convStats=stats, defer=defer)
-		return out, sm, si, mean, var
-
-	a_l, sm_l, si_l, rm_l, rv_l = conv_bn(1, True)
-	a_m, sm_m, si_m, rm_m, rv_m = conv_bn(1, False)
-	b_l, *_ = conv_bn(2, True)
-	b_m, *_ = conv_bn(2, False)
-	assert type(a_l).__name__ == "DeferredBN" and a_l.shape == a_m.shape
-	for got, want in ((sm_l, sm_m), (si_l, si_m), (rm_l, rm_m), (rv_l, rv_m)):
-		assert np.array_equal(got.get(), want.get())
-	assert np.array_equal(a_l.materialize().get(), a_m.get())
-
-	plain = gpu(bnd, rng.randn(*a_m.shape).astype(np.float32))             # identity shortcut
-	out = bnd.GPUArray.empty(a_m.shape, dtype=np.float32)
-	for second_l, second_m in ((b_l, b_m), (plain, plain)):
-		bnd.add3Ker(out, a_m, second_m)
-		assert np.array_equal(bnd.dnn.bnApplyAdd(a_l, second_l, relu=False).get(), out.get())
-		bnd.add3ReluKer(out, a_m, second_m)
-		assert np.array_equal(bnd.dnn.bnApplyAdd(a_l, second_l, relu=True).get(), out.get())
-
-
-@pytest.mark.parametrize("n", [1, 5, 1024, 4 * 3025 + 3])
-def test_fused_residual_kernels(bnd, n):
-	rng = np.random.RandomState(n)
-	a, b, y = (rng.randn(n).astype(np.float32) for _ in range(3))
-	ga, gb_, gy = gpu(bnd, a), gpu(bnd, b), gpu(bnd, y)
-
-	out = bnd.GPUArray.empty((n, ), dtype=np.float32)
-	bnd.add3ReluKer(out, ga, gb_)
-	assert np.array_equal(out.get(), R.relu(a + b))
-
-	bnd.add3GateKer(out, ga, gb_, gy)
-	assert np.array_equal(out.get(), R.relu_der(a + b, y))
-
-
 # ------------------------------------------------------------------------------------------------ pooling
 @pytest.mark.parametrize("name", ["p0", "p1", "p2"])
 def test_pool_golden(bnd, ops, name):
@@ -720,43 +550,40 @@ def test_deconvolution_passes(bnd, cfg):
 
 
 @pytest.mark.parametrize("groups", [1, 2])
-def test_deconv2d_module(bnd, groups):
-	"""Modules/Deconv2D.py unittest shape: a Deconv2D step equals the transposed convolution of the oracle, is the adjoint
-	of Conv2D with the same filter, and accumulates parameter gradients like every other module."""
-	from puzzlelib_amd import nn
+def test_deconv_layer(bnd, groups):
+	"""Modules/Deconv2D.py unittest shape through the executor: a deconv layer's step equals the transposed convolution of
+	the oracle, is the adjoint of the convolution with the same filter, and accumulates parameter gradients."""
+	from puzzlelib_amd import nets
 	rng = np.random.RandomState(21)
 	n, inmaps, outmaps, h, w_ = 3, 8, 6, 6, 5
 
 	np.random.seed(5)
-	mod = nn.Deconv2D(inmaps, outmaps, 3, stride=2, pad=1, postpad=1, groups=groups, useBias=groups == 1)
-	assert mod.W.shape == (inmaps, outmaps // groups, 3, 3)
-	wt = mod.W.get()
-	bound_ = np.sqrt(3.0 / (inmaps * 9))                      # factorTranspose: fan-in counts the stored dim 0
-	assert np.abs(wt).max() <= bound_ + 1e-6
+	net = nets.build([("deconv", "up", inmaps, outmaps, 3, 2, 1, groups == 1, dict(postpad=1, groups=groups))])
+	layer = net.layers[0]
+	wt = layer.params["W"].data.get()
+	assert wt.shape == (inmaps, outmaps // groups, 3, 3)
+	assert np.abs(wt).max() <= np.sqrt(3.0 / (inmaps * 9)) + 1e-6        # fan-in counts the stored dim 0 (Module.py:471)
 
 	x = rng.randn(n, inmaps, h, w_).astype(np.float32)
-	y = mod(gpu(bnd, x))
-	assert y.shape == mod.dataShapeFrom(x.shape) == (n, outmaps, 2 * h, 2 * w_)
-	assert mod.gradShapeFrom(y.shape) == x.shape
+	net.trainMode()
+	y = net(gpu(bnd, x))
+	assert y.shape == (n, outmaps, 2 * h, 2 * w_)
 
 	kw = dict(stride=(2, 2), pad=(1, 1), dilation=(1, 1), groups=groups)
 	y_ref = R.conv2d_bwd_data(x, wt, y.shape, acc=np.float64, **kw)
-	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="Deconv2D data")
+	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="deconv data")
 
 	dy = rng.randn(*y.shape).astype(np.float32)
-	mod.backward(gpu(bnd, dy))
-	assert_close(mod.grad.get(), R.conv2d_fwd(dy, wt, None, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what="Deconv2D grad")
-	# adjoint identity <deconv(x), dy> == <x, conv(dy)>
-	lhs, rhs = float((y_ref.astype(np.float64) * dy).sum()), float((x.astype(np.float64) * mod.grad.get()).sum())
-	assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+	net.zeroGradParams()
+	dx = net.backward(gpu(bnd, dy))
+	assert_close(dx.get(), R.conv2d_fwd(dy, wt, None, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what="deconv grad")
+	lhs, rhs = float((y_ref.astype(np.float64) * dy).sum()), float((x.astype(np.float64) * dx.get()).sum())
+	assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))                     # <deconv(x), dy> == <x, conv(dy)>
 
 	dw_ref = R.conv2d_bwd_filter(dy, x, wt.shape, withbias=False, acc=np.float64, **kw)
-	assert_close(mod.vars["W"].grad.get(), dw_ref, atol=2e-4, rtol=1e-4, what="Deconv2D filter gradient")
+	assert_close(layer.params["W"].grad.get(), dw_ref, atol=2e-4, rtol=1e-4, what="deconv filter gradient")
 	if groups == 1:
-		assert_close(mod.vars["b"].grad.get().ravel(), dy.sum(axis=(0, 2, 3)), atol=1e-4, rtol=1e-4, what="Deconv2D bias gradient")
-
-	with pytest.raises(nn.ModuleError, match="Postpad"):
-		nn.Deconv2D(4, 4, 3, stride=2, postpad=2)
+		assert_close(layer.params["b"].grad.get().ravel(), dy.sum(axis=(0, 2, 3)), atol=1e-4, rtol=1e-4, what="deconv bias gradient")
 
 
 @pytest.mark.parametrize("cfg", [
@@ -825,15 +652,16 @@ def test_winograd_convolution(bnd, cfg):
 def test_optimize_for_shape_enumerates_kernel_families(bnd):
 	"""Modules/ConvND.py:52-61 optimizeForShape over convNdbenchmark (Hip/Wrappers/MIOpen.py:465-519): every family that
 	serves the layer is timed — for a wide 3x3 layer implicit GEMM, Winograd and direct — the fastest within the memory
-	limit is installed, and the module still computes the convolution."""
-	from puzzlelib_amd import nn
+	limit is installed, and the layer still computes the convolution."""
+	from puzzlelib_amd import nets
 	from puzzlelib_amd.surface import bound
 	Dnn = bound().Dnn
 	rng = np.random.RandomState(3)
 
 	np.random.seed(2)
-	conv = nn.Conv2D(64, 64, 3, pad=1, useBias=False)
-	fwd, bwdFilter, bwdData = Dnn.convNdbenchmark((8, 64, 20, 20), conv.W.shape, conv.stride, conv.pad, conv.dilation, 1, transpose=False)
+	net = nets.build([("conv", "c", 64, 64, 3, 1, 1, False)])
+	layer = net.layers[0]
+	fwd, bwdFilter, bwdData = Dnn.convNdbenchmark((8, 64, 20, 20), (64, 64, 3, 3), (1, 1), (1, 1), (1, 1), 1, transpose=False)
 	for res in (fwd, bwdFilter, bwdData):
 		assert sorted(r.algo.value for r in res) == [1, 3, 5]
 		assert all(r.time > 0 for r in res) and [r.time for r in res] == sorted(r.time for r in res)
@@ -842,103 +670,9 @@ def test_optimize_for_shape_enumerates_kernel_families(bnd):
 	pointwise = Dnn.convNdbenchmark((8, 64, 20, 20), (32, 64, 1, 1), (1, 1), (0, 0), (1, 1), 1, transpose=False)
 	assert sorted(r.algo.value for r in pointwise[0]) == [1, 5]       # Winograd does not serve a 1x1 layer
 
-	conv.optimizeForShape((8, 64, 20, 20))
-	assert conv.fwdAlgo.value in (3, 5) and conv.bwdDataAlgo.value in (3, 5) and conv.bwdFilterAlgo.value in (3, 5)
+	net.optimizeForShape((8, 64, 20, 20))
+	assert all(a.value in (3, 5) for a in layer.cfg["algos"])
 	x = rng.randn(8, 64, 20, 20).astype(np.float32)
-	y = conv(gpu(bnd, x))
-	y_ref = R.conv2d_fwd(x, conv.W.get(), None, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, acc=np.float64)
+	y = net(gpu(bnd, x))
+	y_ref = R.conv2d_fwd(x, layer.params["W"].data.get(), None, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, acc=np.float64)
 	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="convolution after optimizeForShape")
-
-
-@pytest.mark.parametrize("cfg", [dict(n=3, c=16, k=32, hw=(9, 7), two=False), dict(n=2, c=24, k=16, hw=(8, 10), two=True),
-								 dict(n=4, c=64, k=32, hw=(55, 55), two=False)])
-def test_compact_stride2_gradients_through_the_fan_in(bnd, cfg):
-	"""Backend-internal pair convNdBackwardData(compact=True) -> bnGateStats (pz_bn_gate_stats_up2): the input gradients of
-	two stride-2 pointwise convolutions stay (n, c, ceil(h/2), ceil(w/2)); the fan-in expands them on the fly. Everything
-	must equal, bit for bit, the dense route (zero-filled gradients through pz_bn_gate_stats), and the handle must
-	zero-fill correctly for any other consumer."""
-	from puzzlelib_amd import backend
-	rng = np.random.RandomState(31)
-	n, c, k, (h, w_) = cfg["n"], cfg["c"], cfg["k"], cfg["hw"]
-	p, q = (h + 1) // 2, (w_ + 1) // 2
-	x = gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32))
-	w0, w1 = [gpu(bnd, (rng.randn(k, c, 1, 1) / np.sqrt(c)).astype(np.float32)) for _ in range(2)]
-	dy0, dy1 = [gpu(bnd, rng.randn(n, k, p, q).astype(np.float32)) for _ in range(2)]
-	kw = dict(stride=(2, 2), pad=(0, 0), dilation=(1, 1), groups=1)
-
-	dense = [bnd.dnn.convNdBackwardData(dy, wt, data=x, **kw) for dy, wt in ((dy0, w0), (dy1, w1))]
-	lazy = [bnd.dnn.convNdBackwardData(dy, wt, data=x, compact=True, **kw) for dy, wt in ((dy0, w0), (dy1, w1))]
-	assert all(isinstance(g, backend.StridedGrad) and g.compact.shape == (n, c, p, q) and g.shape == x.shape for g in lazy)
-	for a, b in zip(dense, lazy):
-		assert np.array_equal(a.get(), b.get()), "the compact gradient zero-fills to the dense one"
-		full = a.get()
-		assert not full[:, :, 1::2, :].any() and not full[:, :, :, 1::2].any()
-
-	# a 3x3 or padded convolution keeps the dense form
-	w3 = gpu(bnd, rng.randn(k, c, 3, 3).astype(np.float32))
-	dy3 = gpu(bnd, rng.randn(n, k, (h - 1) // 2 + 1, (w_ - 1) // 2 + 1).astype(np.float32))
-	assert not isinstance(bnd.dnn.convNdBackwardData(dy3, w3, data=x, stride=(2, 2), pad=(1, 1), compact=True), backend.StridedGrad)
-
-	out = gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32))                       # the ReLU output that gates the sum
-	targets = [(gpu(bnd, rng.randn(n, c, h, w_).astype(np.float32)), gpu(bnd, rng.randn(c).astype(np.float32)))
-			   for _ in range(2 if cfg["two"] else 1)]
-	g_dense, parts_dense = bnd.dnn.bnGateStats(dense[0], dense[1], out, targets)
-	g_lazy, parts_lazy = bnd.dnn.bnGateStats(lazy[0], lazy[1], out, targets)
-	assert np.array_equal(g_dense.get(), g_lazy.get())
-	# the partial sums are consumed by the BatchNorm backward: same parameter gradients and input gradient, bit for bit
-	scale, invvar = gpu(bnd, rng.randn(c).astype(np.float32)), gpu(bnd, (0.5 + rng.rand(c)).astype(np.float32))
-	for (xt, mean), pa, pb in zip(targets, parts_dense, parts_lazy):
-		ra = bnd.dnn.batchNormNdBackward(g_dense, xt, scale, mean, invvar, 1e-5, partials=pa)
-		rb = bnd.dnn.batchNormNdBackward(g_lazy, xt, scale, mean, invvar, 1e-5, partials=pb)
-		for a, b in zip(ra, rb):
-			assert np.array_equal(a.get(), b.get())
-
-	ref = (dense[0].get() + dense[1].get()) * (out.get() > 0)
-	assert np.array_equal(g_lazy.get(), ref)
-
-	# one compact, one dense operand: the handle is zero-filled
-	g_mixed, _ = bnd.dnn.bnGateStats(lazy[0], dense[1], out, targets)
-	assert np.array_equal(g_mixed.get(), ref)
-
-
-@pytest.mark.parametrize("shape", [(3, 16, 9, 7), (2, 8, 4, 4), (4, 64, 55, 55), (5, 3, 1, 1)])
-def test_relu_sign_mask_gates_the_fan_in(bnd, shape):
-	"""pz_bn_apply_add_mask -> pz_bn_gate_stats(mask=): the residual Add's kernel leaves (out > 0) as one bit per element
-	(a byte per 4 consecutive elements of a plane, then a byte per trailing element), and the fan-in gates with it instead
-	of reading `out` back. Layout, and bit-identity with the y-gated kernel for dense and compact gradients."""
-	from puzzlelib_amd import backend
-	rng = np.random.RandomState(17)
-	n, c, h, w_ = shape
-	hw = h * w_
-	x1, x2 = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
-	coef = rng.randn(c, 2).astype(np.float32)
-	first = backend.DeferredBN(gpu(bnd, x1), gpu(bnd, coef.ravel()), bnd.dnn)
-
-	out, mask = bnd.dnn.bnApplyAdd(first, gpu(bnd, x2), relu=True, withMask=True)
-	plain = bnd.dnn.bnApplyAdd(first, gpu(bnd, x2), relu=True)
-	assert np.array_equal(out.get(), plain.get()) and mask.tensor is out
-
-	pos = out.get().reshape(n * c, hw) > 0
-	stride = hw // 4 + 3
-	bits = mask.bits.get().reshape(n * c, stride)
-	n4 = hw // 4
-	expect = np.zeros((n * c, n4), np.uint8)
-	for e in range(4):
-		expect |= (pos[:, e:4 * n4:4].astype(np.uint8) << e)
-	assert np.array_equal(bits[:, :n4], expect)
-	assert np.array_equal(bits[:, n4:n4 + hw % 4], pos[:, 4 * n4:].astype(np.uint8))
-
-	g0, g1 = gpu(bnd, rng.randn(*shape).astype(np.float32)), gpu(bnd, rng.randn(*shape).astype(np.float32))
-	targets = [(gpu(bnd, rng.randn(*shape).astype(np.float32)), gpu(bnd, rng.randn(c).astype(np.float32)))]
-	ga, pa = bnd.dnn.bnGateStats(g0, g1, out, targets)
-	gb, pb = bnd.dnn.bnGateStats(g0, g1, out, targets, mask=mask)
-	assert np.array_equal(ga.get(), gb.get())
-	scale, invvar = gpu(bnd, rng.randn(c).astype(np.float32)), gpu(bnd, (0.5 + rng.rand(c)).astype(np.float32))
-	ra = bnd.dnn.batchNormNdBackward(ga, targets[0][0], scale, targets[0][1], invvar, 1e-5, partials=pa[0])
-	rb = bnd.dnn.batchNormNdBackward(gb, targets[0][0], scale, targets[0][1], invvar, 1e-5, partials=pb[0])
-	assert all(np.array_equal(a.get(), b.get()) for a, b in zip(ra, rb))
-
-	# a mask of some other tensor is ignored (the gate falls back to reading y)
-	other = gpu(bnd, out.get())
-	gc, _ = bnd.dnn.bnGateStats(g0, g1, other, targets, mask=mask)
-	assert np.array_equal(gc.get(), ga.get())

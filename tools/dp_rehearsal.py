@@ -1,11 +1,11 @@
 """Data-parallel rehearsal on ONE device: N ranks (python -m torch.distributed.run --nproc-per-node N) all bound to
 device PUZZLE_MI355_DEVICE train the mini-ResNet on THE SAME batch through the full data-parallel path (parameter
 broadcast, overlapped bucketed gradient exchange, 1/N scaling). RCCL refuses two ranks on one device, so the exchange
-runs on the host-staged gloo fallback — everything around the transport (hooks, buckets, events, ordering) is the code
+runs on the host-staged TCP fallback — everything around the transport (hooks, buckets, events, ordering) is the code
 the multi-GPU run uses. With identical shards the mean gradient equals the single-process gradient bit for bit
 ((g + g) / 2 is exact), so rank 0's parameters must equal a single-process run's: tests/test_gpu_boundary.py checks that.
 
-    python tools/dp_rehearsal.py OUT.npz            (single process)      or under torch.distributed.run"""
+    python tools/dp_rehearsal.py OUT.npz            (single process)      or with RANK / WORLD_SIZE / MASTER_* set per rank"""
 import os, sys
 import numpy as np
 
@@ -31,7 +31,7 @@ rank = int(os.environ.get("RANK", "0"))
 np.random.seed(7 + 100 * rank)                              # different initial parameters per rank: the broadcast must fix that
 net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
 if rank == 0:
-	for name, var in nets.namedVariables(net).items():
+	for name, var in net.namedParams().items():
 		var.data.set(golden["init_" + name])
 
 optimizer = optim.Adam(alpha=1e-3, nodeinfo=nodeinfo)
@@ -46,5 +46,5 @@ for _ in range(3):
 
 if rank == 0:
 	np.savez(out, transport=np.array(getattr(nodeinfo, "transport", "single")),
-			 **{name: var.data.get() for name, var in nets.namedVariables(net).items()})
+			 **{name: var.data.get() for name, var in net.namedParams().items()})
 grid.barrier()
