@@ -141,15 +141,22 @@ def streamHandle(stream):
 class Buffer:
 	"""A span of device memory. `parent` is the MemoryPool (or None for a raw allocation) for an owning buffer and
 	the sliced Buffer for a view — the same convention the reference uses (Cuda/GPUArray.py:146-154)."""
-	__slots__ = ["ptr", "size", "parent", "owner", "root", "lz", "__weakref__"]
+	__slots__ = ["ptr", "size", "parent", "owner", "base", "lz", "__weakref__"]
 
 
 	def __init__(self, ptr, size, parent=None, owner=False):
 		self.ptr, self.size, self.parent, self.owner = ptr, size, parent, owner
 		# `root`: the allocation this span lies in (itself unless it is a view); `lz`: that allocation's lazy state
 		# (puzzlelib_amd/lazy.py — pending contents, dependents, foreign-stream events), None for most buffers
-		self.root = parent.root if isinstance(parent, Buffer) else self
+		# (an allocation must not point at itself: a reference cycle would keep device memory until the next gc run)
+		self.base = parent.root if isinstance(parent, Buffer) else None
 		self.lz = None
+
+
+	@property
+	def root(self):
+		base = self.base
+		return self if base is None else base
 
 
 	@classmethod

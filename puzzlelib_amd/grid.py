@@ -259,10 +259,17 @@ class RcclNodeInfo(NodeInfo):
 			reason = str(e)
 
 		if self.vote(reason is None):
+			# every rank enters the collective; a refusal (e.g. two ranks on one device) comes back as an error on all of them
 			handle = ctypes.c_void_p()
-			lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
-			self.comm, self.commStream = handle.value, driver.Stream()
-			return
+			try:
+				lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+			except lib.HipError as e:
+				reason = str(e)
+			if self.vote(reason is None):
+				self.comm, self.commStream = handle.value, driver.Stream()
+				return
+			if reason is None:
+				lib.pz_comm_destroy(handle.value)
 
 		if self.gridsize == 1:
 			raise lib.CommError(reason)

@@ -183,6 +183,31 @@ def fused_step_counts():
 	print("fused step: %d launches against %d with the lazy layer off" % (fusedCalls, literalCalls))
 
 
+def no_leaks_without_gc():
+	"""device memory is returned by reference counting alone: after a step and reset() no activation buffer survives
+	(a cycle through a buffer would keep gigabytes until the collector happens to run)"""
+	import gc
+	from puzzlelib_amd import driver
+	g = bound().gpuarray
+	spec = nets.resnet_spec(stages=((32, 1), (64, 2)), classes=10, stem=16, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+	trainer, _ = trainerFor(net, 4)
+	data, labels = g.to_gpu(np.zeros((4, 3, 64, 64), np.float32)), g.to_gpu(np.zeros((4, ), np.int32))
+	gc.collect()
+	gc.disable()
+	try:
+		live = []
+		for _ in range(3):
+			trainer.step([data, labels])
+			net.reset()
+			live.append(sum(1 for o in gc.get_objects() if isinstance(o, driver.Buffer) and o.owner))
+	finally:
+		gc.enable()
+	assert live[0] == live[1] == live[2], "owning buffers alive after each step: %s" % live
+	print("no leaks: %d owning buffers alive between steps" % live[0])
+
+
 # ------------------------------------------------------------------------------------------------ data-parallel planning
 def dp_bucket_progress():
 	"""the real ResNet-50 arena, in the order the optimizer lays it out: as backward reports layers, all-reduce buckets

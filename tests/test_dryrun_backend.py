@@ -39,5 +39,9 @@ def test_fused_paths_taken_and_switchable():
 	run("fused_step_counts")
 
 
+def test_buffers_are_freed_by_reference_counting():
+	run("no_leaks_without_gc")
+
+
 def test_gradient_buckets_leave_progressively_for_resnet50():
 	run("dp_bucket_progress")
