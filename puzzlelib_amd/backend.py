@@ -732,6 +732,7 @@ class DnnContext:
 			waiting = lazy.pending(grad, fusion.Sum)
 			if waiting is not None and waiting.gate is not None:
 				targets = [(data, savemean)]
+				waiting.gate.rptr                            # (a gate tensor that is itself still described gets written now)
 				for other in (lazy.fact(waiting.gate, "bnterms") or ()):
 					saved = lazy.fact(other, "bnsaved")
 					if saved is not None and not lazy.sameBuffer(other, data) and other.shape == data.shape and len(targets) < 2:

@@ -136,6 +136,7 @@ class Sum(Thunk):
 		"""the sign mask of the gate tensor, if the kernel that produced it left one"""
 		if self.gate is None or not lazy.on("mask"):
 			return None
+		self.gate.rptr                                       # (a gate tensor that is itself still described gets written now)
 		bits = lazy.fact(self.gate, "relumask")
 		return bits if bits is not None and self.gate.shape == out.shape else None
 

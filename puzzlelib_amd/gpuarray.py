@@ -68,7 +68,7 @@ def viewStridesForReshape(oldshape, oldstrides, newshape):
 
 
 class GPUArray:
-	__slots__ = ["shape", "strides", "dtype", "gpudata", "size", "ndim", "nbytes", "contiguous", "__weakref__"]
+	__slots__ = ["shape", "_strides", "dtype", "gpudata", "size", "ndim", "nbytes", "contiguous", "__weakref__"]
 
 	defaultAllocator = None        # set by the backend: its memory pool
 	debugFill = os.environ.get("PUZZLE_MI355_DEBUG_ALLOC", "0") == "1"     # setupDebugAllocator (Cuda/Utils.py:97-114)
@@ -79,16 +79,19 @@ class GPUArray:
 			shape = (int(shape), )
 
 		self.shape = tuple(int(d) for d in shape)
-		self.dtype = np.dtype(dtype)
+		self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
 		self.ndim = len(self.shape)
 		self.size = prod(self.shape)
 		self.nbytes = self.size * self.dtype.itemsize
 
-		cstrides = contiguousStrides(self.shape, self.dtype.itemsize)
-		self.strides = cstrides if strides is None else tuple(int(s) for s in strides)
-		self.contiguous = self.size <= 1 or all(
-			s == cs for s, cs, d in zip(self.strides, cstrides, self.shape) if d != 1
-		)
+		if strides is None:                      # dense: the strides are derived on demand (most arrays never need them)
+			self._strides, self.contiguous = None, True
+		else:
+			cstrides = contiguousStrides(self.shape, self.dtype.itemsize)
+			self._strides = tuple(int(s) for s in strides)
+			self.contiguous = self.size <= 1 or all(
+				s == cs for s, cs, d in zip(self._strides, cstrides, self.shape) if d != 1
+			)
 
 		if gpudata is None:
 			allocator = GPUArray.defaultAllocator if allocator is None else allocator
@@ -105,6 +108,22 @@ class GPUArray:
 
 
 	# ------------------------------------------------------------------ properties
+	@classmethod
+	def dense(cls, shape, dtype, gpudata, size):
+		"""a contiguous array over existing memory, arguments already normalised (the hot path of reshape / ravel)"""
+		self = object.__new__(cls)
+		self.shape, self.dtype, self.gpudata, self.size = shape, dtype, gpudata, size
+		self.ndim, self.nbytes, self._strides, self.contiguous = len(shape), size * dtype.itemsize, None, True
+		return self
+
+
+	@property
+	def strides(self):
+		if self._strides is None:
+			self._strides = contiguousStrides(self.shape, self.dtype.itemsize)
+		return self._strides
+
+
 	# Device addresses are handed out behind the lazy-buffer barriers (puzzlelib_amd/lazy.py): `rptr` for reading, `wptr`
 	# for partial or read-modify-write access, `optr` when the whole array is about to be overwritten, `ptr` (the
 	# reference attribute, Array.c:1462-1512) when the use is not known = read + write.
@@ -281,7 +300,7 @@ class GPUArray:
 			raise ValueError("cannot reshape array of size %d into shape %s" % (self.size, shape))
 
 		if self.contiguous:
-			return GPUArray(shape, self.dtype, gpudata=self.gpudata)
+			return GPUArray.dense(shape, self.dtype, self.gpudata, self.size)
 
 		strides = viewStridesForReshape(self.shape, self.strides, shape)
 		if strides is None:
@@ -291,6 +310,8 @@ class GPUArray:
 
 
 	def ravel(self):
+		if self.contiguous:
+			return GPUArray.dense((self.size, ), self.dtype, self.gpudata, self.size)
 		return self.reshape(self.size)
 
 

@@ -68,7 +68,8 @@ def test_batchnorm_relu_pair(surf, shape):
 		return [a.get() for a in (y, dx, ds, db, sm, si, grm, grv)]
 
 	(lz, taken), (lit, none) = both(run)
-	assert taken.get("bn_bwd_gate", 0) == 1 and taken.get("bn_apply_relu", 0) == 1 and not none
+	assert taken.get("bn_bwd_gate", 0) == 1 and taken.get("bn_apply_relu", 0) == 1
+	assert none == {"bn_apply": 1}, "with the layer off the normalisation is written at once and nothing else is deferred"
 	for a, b, what in zip(lz, lit, ("y", "dx", "dscale", "dbias", "savemean", "saveinvvar", "running mean", "running var")):
 		assert np.array_equal(a, b), what
 
@@ -173,7 +174,7 @@ def residualBlock(surf, rng, n, c, hw, projection, stride):
 
 @pytest.mark.parametrize("cfg", [dict(n=4, c=64, hw=(14, 14), projection=False, stride=1),
 								 dict(n=3, c=128, hw=(13, 15), projection=True, stride=2),
-								 dict(n=2, c=48, hw=(9, 9), projection=True, stride=1)])       # 48 maps: the fold declines
+								 dict(n=2, c=40, hw=(9, 9), projection=True, stride=1)])       # 40 maps: the fold declines
 def test_residual_block_tail_and_its_backward(surf, cfg):
 	"""The end of a ResNet block and the start of its backward exactly as the reference's modules issue them:
 	  fwd  convNd, batchNormNd (x2 with a projection), zeros + 2 x toVectorAddVector (Add), reluKer in place
@@ -311,7 +312,7 @@ def test_filter_gradients_on_the_side_stream(surf):
 	one_stream = run()
 	assert surf.backend.dnn.sideLaunches == launches + 3
 	assert np.array_equal(with_side, one_stream)
-	dw = R.conv2d_bwd_filter(dy, x, wt.shape, withbias=False, acc=np.float64, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
+	dw = R.conv2d_bwd_filter(x, dy, wt.shape, withbias=False, acc=np.float64, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1)
 	scale = np.abs(dw).max()
 	assert_close(with_side[:wt.size].reshape(wt.shape), 4.0 * dw, atol=2e-4 * scale, rtol=2e-4, what="2 x (dw + dw)")
 	assert_close(with_side[wt.size:].reshape(wt.shape), 1.0 * dw, atol=2e-4 * scale, rtol=2e-4, what="2 x 0.5 dw")

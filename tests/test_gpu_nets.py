@@ -204,7 +204,7 @@ def test_lazy_fusion_is_bit_identical_to_the_literal_sequence_and_matches_oracle
 	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 7), ("bn_bwd_gate", 7), ("gate_stats", 1), ("gate_stats_up2", 1),
 				   ("compact_dgrad", 2), ("gate_by_mask", 2), ("bn_bwd_from_partials", 4)):
 		assert taken.get(key, 0) == n, "%s taken %d times, expected %d: %s" % (key, taken.get(key, 0), n, taken)
-	assert not results["literal"]["taken"], "with the layer off nothing is deferred"
+	assert set(results["literal"]["taken"]) <= {"bn_apply"}, "with the layer off nothing is deferred"
 	assert results[("bnadd", )]["taken"].get("bn_apply_add", 0) == 0 and results[("up2", )]["taken"].get("compact_dgrad", 0) == 0
 	assert results[("mask", )]["taken"].get("gate_by_mask", 0) == 0
 
@@ -225,8 +225,8 @@ def test_lazy_fusion_is_bit_identical_to_the_literal_sequence_and_matches_oracle
 def test_batchnorm_backward_folded_into_the_convolution(bnd, planes):
 	"""Conv2D -> BatchNorm2D backward with the BN's input gradient only described and evaluated inside the 1x1
 	convolution's backward-data / backward-filter gathers (pz_conv2d_bwd_*_bn): gradients equal the unfolded path to fp32
-	rounding and the oracle to the usual tolerances. planes 6: 24 / 48 maps, not a multiple of 16 -> the convolution
-	declines and the description is written out by pz_bn_bwd_apply_coef (same numbers)."""
+	rounding and the oracle to the usual tolerances. planes 6: the 24-map layers are not a multiple of 16 -> their
+	convolution declines and the description is written out by pz_bn_bwd_apply_coef (same numbers)."""
 	from puzzlelib_amd import lazy, nets
 
 	spec = miniSpec(planes, stem=16)
@@ -243,7 +243,8 @@ def test_batchnorm_backward_folded_into_the_convolution(bnd, planes):
 	if planes == 16:
 		assert folded["taken"].get("dgrad_bn_fold", 0) == 4 and folded["taken"].get("wgrad_bn_fold", 0) == 4
 	else:
-		assert folded["taken"].get("dgrad_bn_fold", 0) == 0 and folded["taken"].get("bn_bwd_apply", 0) >= 3
+		# stage 2's 48 maps are a multiple of 16 (folded), stage 1's 24 are not (written out)
+		assert folded["taken"].get("dgrad_bn_fold", 0) == 2 and folded["taken"].get("bn_bwd_apply", 0) == 2
 	for name in plain["grads"]:
 		scale = np.abs(plain["grads"][name]).max() + 1e-12
 		assert_close(folded["grads"][name], plain["grads"][name], atol=3e-5 * scale, rtol=3e-4, what="grad " + name)
