@@ -40,6 +40,11 @@ size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q);
 int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float *dy, float *dw, float alpha, float beta,
                void *workspace, hipStream_t st);
 
+// direct backward-data for stride-2 convolutions with <= 4 input maps (thin.hip): the stem layer
+bool thin_dgrad_eligible(const pz_conv_desc *d, int P, int Q);
+size_t thin_dgrad_workspace_bytes(const pz_conv_desc *d);
+int thin_dgrad(const pz_conv_desc *d, int P, int Q, const float *dy, const float *w, float *dx, void *workspace, hipStream_t st);
+
 }  // namespace pz
 
 #define PZ_REQUIRE(cond, ...)                                   \

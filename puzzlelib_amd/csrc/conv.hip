@@ -1348,7 +1348,8 @@ int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(used != nullptr && which >= PZ_CONV_FWD && which <= PZ_CONV_BWD_FILTER, "pz_conv2d_algo_used: bad arguments");
-	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || (which == PZ_CONV_BWD_DATA && !dgrad_uses_igemm(d)))
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || (which == PZ_CONV_BWD_DATA && !dgrad_uses_igemm(d)) ||
+	    (which == PZ_CONV_BWD_DATA && algo == PZ_CONV_ALGO_AUTO && pz::thin_dgrad_eligible(d, P, Q)))
 		*used = PZ_CONV_ALGO_DIRECT;
 	else
 		*used = uses_winograd(d, which, P, Q, algo) ? PZ_CONV_ALGO_WINOGRAD : PZ_CONV_ALGO_IMPLICIT_GEMM;
@@ -1375,6 +1376,10 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 		*nbytes = p.wp_bytes + p.tab_bytes + p.slab_bytes;
 
 	} else if (which == PZ_CONV_BWD_DATA) {
+		if (algo == PZ_CONV_ALGO_AUTO && pz::thin_dgrad_eligible(d, P, Q)) {
+			*nbytes = align256(pz::thin_dgrad_workspace_bytes(d));
+			return PZ_OK;
+		}
 		if (!dgrad_uses_igemm(d)) return PZ_OK;
 		DgradClass cls[16];
 		bool nz;
@@ -1520,6 +1525,13 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
 		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, workspace, st);
+	}
+
+	// a handful of input maps behind a stride-2 filter (the network's first layer): the dedicated vector-ALU kernel
+	if (algo == PZ_CONV_ALGO_AUTO && bnx == nullptr && pz::thin_dgrad_eligible(d, P, Q)) {
+		const size_t need = pz::thin_dgrad_workspace_bytes(d);
+		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		return pz::thin_dgrad(d, P, Q, dy, w, dx, workspace, st);
 	}
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !dgrad_uses_igemm(d) || !igemm_eligible(d, P, Q)) {

@@ -1,0 +1,191 @@
+// Backward-data of a stride-2 convolution with very few input maps — the stem of an ImageNet network (3 maps, 7x7 / 2,
+// Models/Nets/ResNet.py:88): dx has 3 channels, so as an implicit GEMM its M side fills 3 of 64 tile rows (the 128x128 /
+// 64x256 MFMA tiles of conv.hip spend 9.5 ms on 60 GFLOP of useful work at batch 256). This is the direct form, shaped
+// for the vector ALU instead:
+//
+//   dx[n, c, 2i+a, 2j+b] = sum_k sum_{dr, ds} dy[n, k, i + dmin + dr, j + dmin + ds] * w[k, c, r(a, dr), s(b, ds)]
+//   r(a, dr) = a + pad - 2*(dr + dmin)         (the filter taps that reach output row parity a from input row i + dmin + dr)
+//
+// One thread owns one coarse pixel (i, j) of one image = the 2 x 2 x C outputs that share one WR x WS window of dy
+// (4 x 4 for 7x7 / pad 3). Per reduction channel k it loads the window once (16 loads, lanes along j: coalesced; the
+// 4x overlap between neighbouring threads is served by L1/L2) and issues one fma per (output, valid tap) — 147 for the
+// stem — whose weight operand is WAVE-UNIFORM: the packed filter is indexed by k and compile-time constants only, so
+// the compiler fetches it with scalar loads and the fma takes it from an SGPR. No LDS, no barrier, 2 x 2 x C accumulators.
+// Taps that do not exist for a parity (a = 0 meets 3 filter rows, a = 1 meets 4) are skipped at compile time.
+// Work: 2*N*P*Q*K*C*R*S FLOP on the VALU (78 TFLOP/s of plain fp32 fma on 256 CUs); dy is read once from HBM.
+#include "common.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0xfffffff0u;
+
+// d = (a + pad - r) / 2 over the valid (a, r) pairs: the window of input rows an output row pair touches
+constexpr int win_min(int R, int pad) {
+	int m = 1 << 20;
+	for (int a = 0; a < 2; ++a)
+		for (int r = 0; r < R; ++r)
+			if (((a + pad - r) & 1) == 0) m = (a + pad - r) / 2 < m ? (a + pad - r) / 2 : m;
+	return m;
+}
+
+constexpr int win_max(int R, int pad) {
+	int m = -(1 << 20);
+	for (int a = 0; a < 2; ++a)
+		for (int r = 0; r < R; ++r)
+			if (((a + pad - r) & 1) == 0) m = (a + pad - r) / 2 > m ? (a + pad - r) / 2 : m;
+	return m;
+}
+
+template <int R, int PAD>
+struct Win {
+	static constexpr int lo = win_min(R, PAD), hi = win_max(R, PAD), size = hi - lo + 1;
+	static constexpr int tap(int a, int d) { return a + PAD - 2 * (d + lo); }                 // filter index, may be out of range
+	static constexpr bool valid(int a, int d) { return tap(a, d) >= 0 && tap(a, d) < R; }
+};
+
+// wpk[k][dr][ds][a][b][c] = w[k][c][r(a, dr)][s(b, ds)], zero where the tap does not exist
+template <int C, int R, int S, int PH, int PW>
+__global__ void __launch_bounds__(256) thin_pack_kernel(const float *__restrict__ w, float *__restrict__ wpk, int K) {
+	using WH = Win<R, PH>;
+	using WW = Win<S, PW>;
+	const int per_k = WH::size * WW::size * 4 * C;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= K * per_k) return;
+	int t = idx;
+	const int c = t % C;
+	t /= C;
+	const int b = t & 1, a = (t >> 1) & 1;
+	t >>= 2;
+	const int ds = t % WW::size;
+	t /= WW::size;
+	const int dr = t % WH::size, k = t / WH::size;
+	const int r = a + PH - 2 * (dr + WH::lo), s = b + PW - 2 * (ds + WW::lo);
+	wpk[idx] = (r >= 0 && r < R && s >= 0 && s < S) ? w[((k * C + c) * R + r) * S + s] : 0.f;
+}
+
+template <int C, int R, int S, int PH, int PW>
+__global__ void __launch_bounds__(256) thin_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ wpk,
+                                                          float *__restrict__ dx, int K, int P, int Q, int H, int W, int Hc,
+                                                          int Wc, unsigned dy_bytes) {
+	using WH = Win<R, PH>;
+	using WW = Win<S, PW>;
+	constexpr int WR = WH::size, WS = WW::size;
+
+	const int cell = blockIdx.x * 256 + threadIdx.x;           // coarse pixel inside the image, row-major: lanes along j
+	const int n = blockIdx.y;
+	const bool live = cell < Hc * Wc;
+	const int i = cell / Wc, j = cell - i * Wc;
+
+	// byte offsets of the window inside one (n, k) plane of dy; outside the map (or a dead thread) -> the hardware returns 0
+	unsigned woff[WR][WS];
+#pragma unroll
+	for (int dr = 0; dr < WR; ++dr)
+#pragma unroll
+		for (int ds = 0; ds < WS; ++ds) {
+			const int p = i + WH::lo + dr, q = j + WW::lo + ds;
+			woff[dr][ds] = (live && (unsigned)p < (unsigned)P && (unsigned)q < (unsigned)Q) ? (unsigned)(p * Q + q) * 4u : kOOB;
+		}
+
+	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, dy_bytes, 0x00020000);
+	const unsigned plane = (unsigned)(P * Q) * 4u;
+	unsigned soff = (unsigned)n * (unsigned)K * plane;          // scalar: start of this image's first plane
+
+	float acc[2][2][C];
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int b = 0; b < 2; ++b)
+#pragma unroll
+			for (int c = 0; c < C; ++c) acc[a][b][c] = 0.f;
+
+	constexpr int per_k = WR * WS * 4 * C;
+	for (int k = 0; k < K; ++k, soff += plane) {
+		float v[WR][WS];
+#pragma unroll
+		for (int dr = 0; dr < WR; ++dr)
+#pragma unroll
+			for (int ds = 0; ds < WS; ++ds)
+				v[dr][ds] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, woff[dr][ds], soff, 0));
+
+		const float *wk = wpk + (size_t)k * per_k;              // wave-uniform: scalar loads
+#pragma unroll
+		for (int dr = 0; dr < WR; ++dr)
+#pragma unroll
+			for (int ds = 0; ds < WS; ++ds)
+#pragma unroll
+				for (int a = 0; a < 2; ++a)
+#pragma unroll
+					for (int b = 0; b < 2; ++b)
+						if (WH::valid(a, dr) && WW::valid(b, ds)) {
+#pragma unroll
+							for (int c = 0; c < C; ++c)
+								acc[a][b][c] = __builtin_fmaf(v[dr][ds], wk[((dr * WS + ds) * 4 + a * 2 + b) * C + c], acc[a][b][c]);
+						}
+	}
+
+	if (!live) return;
+#pragma unroll
+	for (int c = 0; c < C; ++c)
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			const int h = 2 * i + a, x0 = 2 * j;
+			if (h >= H) continue;
+			float *row = dx + (((size_t)n * C + c) * H + h) * W + x0;
+			if (x0 + 1 < W) {
+				typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+				*reinterpret_cast<f2u *>(row) = f2u{acc[a][0][c], acc[a][1][c]};
+			} else if (x0 < W) {
+				row[0] = acc[a][0][c];
+			}
+		}
+}
+
+// the shapes instantiated: (C, R, S, pad_h, pad_w)
+template <int C, int R, int S, int PH, int PW>
+bool thin_match(const pz_conv_desc *d) {
+	return d->c == C && d->r == R && d->s == S && d->pad_h == PH && d->pad_w == PW;
+}
+
+template <int C, int R, int S, int PH, int PW>
+int thin_launch(const pz_conv_desc *d, int P, int Q, const float *dy, const float *w, float *dx, void *workspace, hipStream_t st) {
+	float *wpk = (float *)workspace;
+	const int per_k = Win<R, PH>::size * Win<S, PW>::size * 4 * C;
+	thin_pack_kernel<C, R, S, PH, PW><<<pz::ceil_div((long)d->k * per_k, 256), 256, 0, st>>>(w, wpk, d->k);
+	PZ_LAUNCH_CHECK();
+	const int Hc = (d->h + 1) / 2, Wc = (d->w + 1) / 2;
+	dim3 grid(pz::ceil_div((long)Hc * Wc, 256), d->n);
+	thin_dgrad_kernel<C, R, S, PH, PW><<<grid, 256, 0, st>>>(dy, wpk, dx, d->k, P, Q, d->h, d->w, Hc, Wc,
+	                                                           (unsigned)((size_t)d->n * d->k * P * Q * 4));
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+}  // namespace
+
+namespace pz {
+
+#define PZ_THIN_SHAPES(X) X(3, 7, 7, 3, 3) X(3, 3, 3, 1, 1) X(1, 7, 7, 3, 3) X(3, 5, 5, 2, 2) X(4, 7, 7, 3, 3) X(1, 3, 3, 1, 1)
+
+bool thin_dgrad_eligible(const pz_conv_desc *d, int P, int Q) {
+	if (d->stride_h != 2 || d->stride_w != 2 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
+	if ((size_t)d->n * d->k * P * Q * 4 >= 0xfffffff0ull || d->n > 65535) return false;
+#define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return true;
+	PZ_THIN_SHAPES(X)
+#undef X
+	return false;
+}
+
+size_t thin_dgrad_workspace_bytes(const pz_conv_desc *d) {
+	// window <= ceil(R/2)+1 per axis, 2x2 parities, C channels
+	return (size_t)d->k * ((d->r + 1) / 2 + 1) * ((d->s + 1) / 2 + 1) * 4 * d->c * sizeof(float);
+}
+
+int thin_dgrad(const pz_conv_desc *d, int P, int Q, const float *dy, const float *w, float *dx, void *workspace, hipStream_t st) {
+#define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return thin_launch<C, R, S, PH, PW>(d, P, Q, dy, w, dx, workspace, st);
+	PZ_THIN_SHAPES(X)
+#undef X
+	pz::set_error("thin_dgrad: shape not instantiated");
+	return PZ_ERR_INVALID;
+}
+
+}  // namespace pz

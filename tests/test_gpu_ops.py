@@ -676,3 +676,40 @@ def test_optimize_for_shape_enumerates_kernel_families(bnd):
 	y = net(gpu(bnd, x))
 	y_ref = R.conv2d_fwd(x, layer.params["W"].data.get(), None, stride=(1, 1), pad=(1, 1), dilation=(1, 1), groups=1, acc=np.float64)
 	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="convolution after optimizeForShape")
+
+
+@pytest.mark.parametrize("cfg", [
+	dict(n=3, c=3, k=16, hw=(32, 32), r=7, pad=3),        # the ImageNet stem geometry (Models/Nets/ResNet.py:88), small
+	dict(n=2, c=3, k=8, hw=(23, 37), r=7, pad=3),         # odd maps: the last coarse row / column has one output pixel
+	dict(n=2, c=3, k=5, hw=(9, 10), r=3, pad=1),
+	dict(n=1, c=1, k=4, hw=(12, 12), r=7, pad=3),
+	dict(n=2, c=3, k=6, hw=(16, 15), r=5, pad=2),
+	dict(n=2, c=4, k=7, hw=(14, 14), r=7, pad=3),
+	dict(n=4, c=3, k=64, hw=(64, 64), r=7, pad=3),        # more coarse pixels than one workgroup, 64 reduction channels
+])
+def test_thin_backward_data_of_the_stem(bnd, cfg):
+	"""Stride-2 convolutions with <= 4 input maps: `auto` backward-data runs the dedicated direct kernel (csrc/thin.hip,
+	reported as family `direct`); it must match the fp64 oracle and the implicit GEMM it replaces."""
+	rng = np.random.RandomState(17)
+	n, c, k, (h, w_), r, pad = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"], cfg["pad"]
+	kw = dict(stride=(2, 2), pad=(pad, pad), dilation=(1, 1), groups=1)
+	x = rng.randn(n, c, h, w_).astype(np.float32)
+	wt = rng.randn(k, c, r, r).astype(np.float32)
+	y_ref = R.conv2d_fwd(x, wt, None, acc=np.float64, **kw)
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	gx, gw, gdy = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, dy)
+
+	desc = bnd.dnn.convDesc(x.shape, wt.shape, (2, 2), (pad, pad), (1, 1), 1)
+	assert bnd.dnn.convAlgoUsed(desc, lib_bwd_data(), -1) == 1 and bnd.dnn.convAlgoUsed(desc, lib_bwd_data(), 5) == 5
+
+	dx_ref = R.conv2d_bwd_data(dy, wt, x.shape, acc=np.float64, **kw)
+	scale = np.abs(dx_ref).max()
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, data=gx, **kw).get()
+	assert_close(dx, dx_ref, atol=1e-5 * scale, rtol=1e-4, what="thin backward-data vs oracle")
+	dx_ig = bnd.dnn.convNdBackwardData(gdy, gw, data=gx, algo=bnd.ConvBwdDataAlgo.implicitGemm.value, **kw).get()
+	assert_close(dx, dx_ig, atol=1e-5 * scale, rtol=1e-4, what="thin backward-data vs implicit GEMM")
+
+
+def lib_bwd_data():
+	from puzzlelib_amd import lib
+	return lib.CONV_BWD_DATA
