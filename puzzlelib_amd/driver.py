@@ -200,9 +200,9 @@ class Buffer:
 		if root.lz is not None:
 			from puzzlelib_amd import lazy
 			if write:
-				lazy.writeBarrier(root, whole and self.size == root.size)
+				lazy.writeBarrier(root, self, whole and self.size == root.size)
 			else:
-				lazy.readBarrier(root)
+				lazy.readBarrier(root, self)
 		return self.ptr
 
 

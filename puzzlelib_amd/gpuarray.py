@@ -132,7 +132,7 @@ class GPUArray:
 		buf = self.gpudata
 		root = buf.root
 		if root.lz is not None:
-			lazy.readBarrier(root)
+			lazy.readBarrier(root, buf)
 		return buf.ptr
 
 
@@ -141,7 +141,7 @@ class GPUArray:
 		buf = self.gpudata
 		root = buf.root
 		if root.lz is not None:
-			lazy.writeBarrier(root)
+			lazy.writeBarrier(root, buf)
 		return buf.ptr
 
 
@@ -150,7 +150,7 @@ class GPUArray:
 		buf = self.gpudata
 		root = buf.root
 		if root.lz is not None:
-			lazy.writeBarrier(root, self.contiguous and buf.ptr == root.ptr and self.nbytes == root.size)
+			lazy.writeBarrier(root, buf, self.contiguous and buf.ptr == root.ptr and self.nbytes == root.size)
 		return buf.ptr
 
 
@@ -164,9 +164,9 @@ class GPUArray:
 		root = buf.root
 		if root.lz is not None:
 			if write:
-				lazy.writeBarrier(root, False, stream)
+				lazy.writeBarrier(root, buf, False, stream)
 			else:
-				lazy.readBarrier(root, stream)
+				lazy.readBarrier(root, buf, stream)
 		return buf.ptr
 
 

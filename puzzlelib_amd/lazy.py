@@ -45,16 +45,18 @@ def on(pattern):
 
 
 class State:
-	__slots__ = ("thunk", "deps", "meta", "wev", "rev")
+	"""thunk: pending contents; deps: weak references to allocations whose thunk / facts derive from this one's contents;
+	meta: facts about the contents; wev / rev: [(event, stream, lo, hi)] — byte ranges a foreign stream still writes / reads"""
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base")
 
-	def __init__(self):
-		self.thunk, self.deps, self.meta, self.wev, self.rev = None, None, None, None, None
+	def __init__(self, base):
+		self.thunk, self.deps, self.meta, self.wev, self.rev, self.base = None, None, None, None, None, base
 
 
 def stateOf(root):
 	lz = root.lz
 	if lz is None:
-		lz = root.lz = State()
+		lz = root.lz = State(root.ptr)
 	return lz
 
 
@@ -137,27 +139,37 @@ def settle(root):
 			depend(src, root)
 
 
-def waitEvents(lz, read, stream=None):
-	"""Cross-stream ordering: before the accessing stream reads (writes) the buffer, foreign writes (and reads) finish."""
+def waitEvents(lz, read, stream, buf):
+	"""Cross-stream ordering: before the accessing stream reads (writes) the bytes of `buf`, foreign writes (and reads) of
+	overlapping bytes finish. Events are kept per byte range of the allocation: the optimizer's flat gradient arena is one
+	allocation in which the filter-gradient stream and the main stream write different parameters' blocks side by side."""
+	lo = buf.ptr - lz.base
+	hi = lo + buf.size
 	for name in (("wev", ) if read else ("wev", "rev")):
-		pair = getattr(lz, name)
-		if pair is not None:
-			event, owner = pair
-			if owner is not stream:
-				lib.pz_stream_wait_event(None if stream is None else stream.handle, event.handle)
-				if stream is None:
-					setattr(lz, name, None)
+		entries = getattr(lz, name)
+		if not entries:
+			continue
+		keep = []
+		for entry in entries:
+			event, owner, elo, ehi = entry
+			if owner is stream or ehi <= lo or elo >= hi:
+				keep.append(entry)
+				continue
+			lib.pz_stream_wait_event(None if stream is None else stream.handle, event.handle)
+			if stream is not None:
+				keep.append(entry)              # only the main stream's wait retires the entry (everything later follows it)
+		setattr(lz, name, keep or None)
 
 
-def readBarrier(root, stream=None):
+def readBarrier(root, buf=None, stream=None):
 	lz = root.lz
 	if lz.thunk is not None:
 		settle(root)
 	if lz.wev is not None:
-		waitEvents(lz, True, stream)
+		waitEvents(lz, True, stream, root if buf is None else buf)
 
 
-def writeBarrier(root, whole=False, stream=None):
+def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
 	if lz.thunk is not None:
 		if whole:
@@ -174,7 +186,7 @@ def writeBarrier(root, whole=False, stream=None):
 				other.lz.meta = None
 	lz.meta = None
 	if lz.wev is not None or lz.rev is not None:
-		waitEvents(lz, False, stream)
+		waitEvents(lz, False, stream, root if buf is None else buf)
 
 
 # ---------------------------------------------------------------------------------------------- foreign streams
@@ -210,10 +222,16 @@ def foreignEnd(stream, ready, reads=(), writes=(), keep=()):
 	from puzzlelib_amd.driver import Event
 	done = Event()
 	done.record(stream)
-	for ary in writes:
-		stateOf(ary.gpudata.root).wev = (done, stream)
-	for ary in reads:
-		stateOf(ary.gpudata.root).rev = (done, stream)
+	for name, arrays in (("wev", writes), ("rev", reads)):
+		for ary in arrays:
+			buf = ary.gpudata
+			lz = stateOf(buf.root)
+			lo = buf.ptr - lz.base
+			entries = getattr(lz, name) or []
+			# a later event of the same stream over the same bytes supersedes the earlier one
+			entries = [e for e in entries if not (e[1] is stream and e[2] >= lo and e[3] <= lo + buf.size)]
+			entries.append((done, stream, lo, lo + buf.size))
+			setattr(lz, name, entries)
 	held.append((done, (ready, tuple(reads), tuple(writes), tuple(keep))))
 	return done
 
@@ -250,5 +268,5 @@ def rawRead(ary):
 	only foreign-stream writes are waited for."""
 	lz = ary.gpudata.root.lz
 	if lz is not None and lz.wev is not None:
-		waitEvents(lz, True)
+		waitEvents(lz, True, None, ary.gpudata)
 	return ary.gpudata.ptr

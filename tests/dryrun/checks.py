@@ -150,6 +150,18 @@ def lazy_barriers():
 	p.get()
 	after = len([n for n, _ in lib.trace if n == "pz_stream_wait_event"])
 	assert after == before + 1 and p.gpudata.root.lz.wev is None
+
+	# (9) ... and only for the bytes it wrote: a neighbour block of the same allocation (the optimizer's arena holds every
+	# gradient) is touched by the main stream without waiting
+	arena = g.to_gpu(np.zeros(256, f32))
+	left, right = arena[:128], arena[128:]
+	surf.ElementWise.toVectorAddVectorKer(f32)(left, g.to_gpu(np.zeros(128, f32)), 1.0, stream=stream)
+	waits = lambda: len([n for n, _ in lib.trace if n == "pz_stream_wait_event"])
+	before = waits()
+	surf.ElementWise.toVectorAddVectorKer(f32)(right, g.to_gpu(np.zeros(128, f32)), 1.0)
+	assert waits() == before, "a write next to the foreign stream's bytes must not wait for it"
+	surf.ElementWise.toVectorAddVectorKer(f32)(arena, g.to_gpu(np.zeros(256, f32)), 1.0)
+	assert waits() == before + 1 and arena.gpudata.root.lz.wev is None
 	print("lazy barriers: OK")
 
 
