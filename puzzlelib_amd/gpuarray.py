@@ -360,7 +360,9 @@ class GPUArray:
 		shape.extend(self.shape[len(item):])
 		strides.extend(self.strides[len(item):])
 
-		return GPUArray(tuple(shape), self.dtype, gpudata=self.gpudata[offset:], strides=tuple(strides))
+		# the view's buffer spans exactly the bytes it can touch (lazy.py orders foreign streams per byte range)
+		extent = self.dtype.itemsize + sum((d - 1) * st for d, st in zip(shape, strides)) if all(d > 0 for d in shape) else 0
+		return GPUArray(tuple(shape), self.dtype, gpudata=self.gpudata[offset:offset + extent], strides=tuple(strides))
 
 
 	def __setitem__(self, key, value):
