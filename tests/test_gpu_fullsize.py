@@ -259,3 +259,173 @@ def test_resnet_3x3_layers_winograd_agrees_with_implicit_gemm(bnd, shape):
 	dwdiff = bnd.GPUArray.empty(wt.shape, dtype=np.float32)
 	assert max_abs(w3, w5, dwdiff) < 3e-5 * max(1.0, float(w5.max().get()))
 	assert np.array_equal(bnd.dnn.convNdBackwardParams(x, dy, wt, algo=3, **kw).get(), w3.get())
+
+
+# ================================================================================================ config 4 at full size
+# every 1x1 convolution shape of the reference's ResNet-50 (Models/Nets/ResNet.py:23-121, 55x55 stage-2 maps) and the
+# 7x7/2 stem at batch 256: (C, H, W) -> (K, size, stride, pad)
+R50_POINTWISE_AND_STEM = [
+	((3, 224, 224), (64, 7, 2, 3)), ((64, 55, 55), (64, 1, 1, 0)), ((64, 55, 55), (256, 1, 1, 0)), ((256, 55, 55), (64, 1, 1, 0)),
+	((256, 55, 55), (128, 1, 2, 0)), ((128, 28, 28), (512, 1, 1, 0)), ((256, 55, 55), (512, 1, 2, 0)), ((512, 28, 28), (128, 1, 1, 0)),
+	((512, 28, 28), (256, 1, 2, 0)), ((256, 14, 14), (1024, 1, 1, 0)), ((512, 28, 28), (1024, 1, 2, 0)), ((1024, 14, 14), (256, 1, 1, 0)),
+	((1024, 14, 14), (512, 1, 2, 0)), ((512, 7, 7), (2048, 1, 1, 0)), ((1024, 14, 14), (2048, 1, 2, 0)), ((2048, 7, 7), (512, 1, 1, 0)),
+]
+
+
+def max_abs_diff(bnd, a, b):
+	d = bnd.GPUArray.empty(a.shape, dtype=np.float32)
+	bnd.addKer(np.float32)(d, a, 1.0, b, -1.0)
+	return max(float(d.max().get()), -float(d.min().get()))
+
+
+@pytest.mark.parametrize("layer", R50_POINTWISE_AND_STEM, ids=lambda l: "%dx%dx%d_to_%d_k%d_s%d" % (l[0] + l[1][:3]))
+def test_resnet50_pointwise_and_stem_layers_full_size(bnd, layer):
+	"""All three passes of every 1x1 layer and of the stem at batch 256, as the training step runs them — `auto` kernels,
+	the batch-norm backward folded into the backward gathers (pz_conv2d_bwd_{data,filter}_bn), compact stride-2 input
+	gradients, the dedicated stem backward-data — through size-independent properties (the adjoint identities) and fp64
+	oracle checks on single images."""
+	from puzzlelib_amd import lazy, fusion
+	from puzzlelib_amd.surface import bound
+	surf = bound()
+	Dnn, dot, G = surf.Dnn, bnd.blas.dot, bnd.GPUArray
+	lazy.enabled, lazy.disabled = True, set()
+	(c, h, w), (k, size, stride, pad) = layer
+	n = 256
+	okw = dict(stride=(stride, stride), pad=(pad, pad), dilation=(1, 1), groups=1)
+	algos = Dnn.ConvFwdAlgo.auto, Dnn.ConvBwdDataAlgo.auto, Dnn.ConvBwdFilterAlgo.auto
+
+	x = dev_randn(bnd, (n, c, h, w), 21)
+	wt = gpu(bnd, (np.random.RandomState(22).randn(k, c, size, size) / np.sqrt(c * size * size)).astype(np.float32))
+	y = Dnn.convNd(x, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, algos[0])
+	p, q = y.shape[2:]
+	dy = dev_randn(bnd, (n, k, p, q), 23)
+
+	# adjoint identities at full size: <dy, conv(x; w)> == <bwd_data(dy; w), x> == <w, bwd_filter(x, dy)>
+	lhs = dot(dy.ravel(), y.ravel())
+	dx = Dnn.convNdBackwardData(dy, wt, x, okw["stride"], okw["pad"], okw["dilation"], 1, algos[1])
+	if stride == 2 and size == 1:
+		assert isinstance(lazy.pending(dx), fusion.Up2), "stride-2 pointwise layers keep their input gradient compact"
+	mid = dot(dx.ravel(), x.ravel())
+	dw = G.zeros(wt.shape, dtype=np.float32)
+	Dnn.convNdBackwardParams(x, dy, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dw, None, 1.0, 1.0, algos[2])
+	rhs = dot(dw.ravel(), wt.ravel())
+	scale = abs(lhs) + np.sqrt(float(dy.size))
+	assert abs(lhs - mid) < 3e-4 * scale, "backward-data is not the adjoint of forward: %r vs %r" % (lhs, mid)
+	assert abs(lhs - rhs) < 3e-4 * scale, "backward-filter is not the adjoint of forward: %r vs %r" % (lhs, rhs)
+
+	# fp64 oracle on the first and the last image
+	wh = wt.get()
+	for img in (0, n - 1):
+		xi, dyi = x[img:img + 1].get(), dy[img:img + 1].get()
+		ref = R.conv2d_fwd(xi, wh, None, acc=np.float64, **okw)
+		assert_close(y[img:img + 1].get(), ref, atol=2e-4, rtol=2e-4, what="forward, image %d" % img)
+		ref = R.conv2d_bwd_data(dyi, wh, xi.shape, acc=np.float64, **okw)
+		assert_close(dx[img:img + 1].get(), ref, atol=2e-4, rtol=2e-4, what="backward-data, image %d" % img)
+	sub = 2
+	dws = G.zeros(wt.shape, dtype=np.float32)
+	Dnn.convNdBackwardParams(x[:sub], dy[:sub], wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dws, None, 1.0, 1.0, algos[2])
+	ref = R.conv2d_bwd_filter(x[:sub].get(), dy[:sub].get(), wh.shape, withbias=False, acc=np.float64, **okw)
+	assert_close(dws.get(), ref, atol=1e-4 * np.sqrt(sub * p * q), rtol=2e-4, what="backward-filter, %d images" % sub)
+
+	if size != 1:
+		return
+
+	# the batch-norm behind this layer, backward: its input gradient is only described (A*dy + B*y + C per channel) and the
+	# convolution's backward kernels evaluate it while gathering. Against the written-out form (same coefficients).
+	rng = np.random.RandomState(24)
+	coef = gpu(bnd, np.stack([1.0 + 0.1 * rng.randn(k), 0.05 * rng.randn(k), 0.01 * rng.randn(k), np.zeros(k)], axis=1).astype(np.float32))
+	desc = bnd.dnn.convDesc((n, c, h, w), wt.shape, stride, pad, 1, 1)
+	assert bnd.dnn.bnFoldSupported(desc, -1) == (k % 16 == 0)
+
+	def described():
+		g = G.empty(dy.shape, dtype=np.float32)
+		lazy.attach(g, fusion.BnBwdApply(dy, y, coef))
+		return g
+
+	written = described()
+	written.rptr                                                       # pz_bn_bwd_apply_coef
+	lazy.counters.clear()
+	dx_fold = Dnn.convNdBackwardData(described(), wt, x, okw["stride"], okw["pad"], okw["dilation"], 1, algos[1])
+	dx_plain = Dnn.convNdBackwardData(written, wt, x, okw["stride"], okw["pad"], okw["dilation"], 1, algos[1])
+	dw_fold, dw_plain = G.zeros(wt.shape, dtype=np.float32), G.zeros(wt.shape, dtype=np.float32)
+	Dnn.convNdBackwardParams(x, described(), wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dw_fold, None, 1.0, 1.0, algos[2])
+	Dnn.convNdBackwardParams(x, written, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dw_plain, None, 1.0, 1.0, algos[2])
+	assert lazy.counters.get("dgrad_bn_fold", 0) == 1 and lazy.counters.get("wgrad_bn_fold", 0) == 1
+	top = max(float(dx_plain.max().get()), -float(dx_plain.min().get()))
+	assert max_abs_diff(bnd, dx_fold, dx_plain) < 3e-5 * top + 1e-6, "backward-data with the batch-norm folded in"
+	topw = max(float(dw_plain.max().get()), -float(dw_plain.min().get()))
+	assert max_abs_diff(bnd, dw_fold, dw_plain) < 1e-4 * topw + 1e-5, "backward-filter with the batch-norm folded in"
+
+
+def test_resnet50_b256_step_fused_equals_literal_and_matches_oracle(bnd):
+	"""Config 4 itself: loadResNet("50", actInplace=True) at batch 256, forward + cross-entropy + backward, (1) under the
+	lazy-buffer layer and (2) with it off (every reference call launches its own kernels), plus (3) with the batch-norm
+	backward fold on. (1) and (2) must agree bit for bit in logits, loss and every parameter gradient (compared on the
+	device); (3) to fp32 rounding; the logits of two images against the CPU oracle (evaluation mode, running statistics)."""
+	import cpu_net as N
+	from puzzlelib_amd import nets, optim, lazy, backend
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	backend.DnnContext.convStatsPolicy = "never"          # (epilogue statistics differ in summation order from the BN's own pass)
+
+	np.random.seed(1234)
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="he")
+	net.layers.pop()                                       # the trailing SoftMax: training runs on raw scores
+	optimizer = optim.Adam(alpha=1e-3)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = optim.CrossEntropy()
+	rng = np.random.RandomState(1234)
+	data = gpuarray.to_gpu(rng.randn(256, 3, 224, 224).astype(np.float32))
+	labels = gpuarray.to_gpu(rng.randint(0, 1000, size=(256, )).astype(np.int32))
+	net.trainMode()
+
+	def passOnce():
+		for layer in net.walk():                           # same running statistics / momentum factor on every pass
+			if layer.kind == "bn":
+				layer.cfg["passes"] = 0
+				layer.attrs["mean"].fill(0.0)
+				layer.attrs["var"].fill(1.0)
+		lazy.counters.clear()
+		logits = net(data)
+		grad = cost(logits, labels, queryError=False)
+		optimizer.zeroGradParams()
+		net.backward(grad, updGrad=False)
+		out = (logits.copy(), float(cost.devErr.get()), optimizer.grads.ary.copy(), dict(lazy.counters))
+		net.reset()
+		return out
+
+	try:
+		lazy.disabled = {"bnbwdfold"}
+		fused = passOnce()
+		lazy.enabled = False
+		literal = passOnce()
+		lazy.enabled, lazy.disabled = True, set()
+		folded = passOnce()
+	finally:
+		lazy.enabled, lazy.disabled = True, set()
+		backend.DnnContext.convStatsPolicy = "adaptive"
+
+	taken = fused[3]
+	assert taken.get("bn_apply_add", 0) == 16 and taken.get("bn_bwd_gate", 0) == 33 and taken.get("gate_stats", 0) == 12
+	assert taken.get("gate_stats_up2", 0) == 3 and taken.get("compact_dgrad", 0) == 6 and taken.get("bn_bwd_from_partials", 0) == 19
+	assert folded[3].get("dgrad_bn_fold", 0) == 19 and folded[3].get("wgrad_bn_fold", 0) == 19
+
+	assert fused[1] == literal[1], "loss: %r fused, %r literal" % (fused[1], literal[1])
+	assert max_abs_diff(bnd, fused[0], literal[0]) == 0.0, "logits differ between the fused and the literal call sequence"
+	assert max_abs_diff(bnd, fused[2], literal[2]) == 0.0, "parameter gradients differ between fused and literal"
+
+	top = max(float(literal[2].max().get()), -float(literal[2].min().get()))
+	assert folded[1] == literal[1]
+	assert max_abs_diff(bnd, folded[2], literal[2]) < 2e-3 * top, "gradients with the batch-norm backward folded into the convolutions"
+	assert np.isfinite(fused[1]) and 6.0 < fused[1] / 256 < 9.0, "cross-entropy of a random-init 1000-class net"
+
+	# oracle spot check: two images, evaluation mode (running statistics as initialised), CPU restatement of the network
+	net.evalMode()
+	dev = net(data[:2]).get()
+	spec = nets.resnet50_spec(softmax=False)
+	params = {name: p.data.get() for name, p in net.namedParams().items()}
+	attrs = {name: a.get() for name, a in net.namedAttrs().items()}
+	cnet = N.CpuNet(spec, params, attrs)
+	cnet.train = False
+	ref = cnet.forward(data[:2].get())
+	assert_close(dev, ref, atol=2e-3 * np.abs(ref).max() + 1e-4, rtol=2e-3, what="ResNet-50 logits vs oracle, 2 images")
