@@ -137,6 +137,13 @@ int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double to
  *      C[M,N] = alpha*op(A)*op(B) + beta*C, lda/ldb/ldc = row pitches in elements.                    */
 int pz_gemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda,
             const float *b, int ldb, float beta, float *c, int ldc, pz_stream_t stream);
+/* the same with scratch for a split along K (small outputs with long reductions — the 256 x 1000 x 2048 classifier —
+ * would otherwise run on a handful of the 256 CUs); partial tiles are added in a fixed order, no atomics.
+ * Batched GEMM (BlasContext.gemmBatched, CuBlas.c:308-312, both group formats) is a loop of these calls over the
+ * groups: lda / ldb / ldc express the "bgp" layout directly.                                                      */
+int pz_gemm_workspace_bytes(int m, int n, int k, size_t *nbytes);
+int pz_gemm_ws(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda, const float *b, int ldb,
+               float beta, float *c, int ldc, void *workspace, size_t ws_bytes, pz_stream_t stream);
 
 /* ---- batch normalisation (spatial): replaces DnnContext.batchNormNd / batchNormNdBackward
  *      (Hip/Wrappers/MIOpen.py:634-688). x viewed as (n, c, hw). running stats updated in place:

@@ -113,6 +113,8 @@ _PROTOS = {
 	"pz_conv_profile_collect": [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_longlong)],
 
 	"pz_gemm": [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float, P, c_int, P],
+	"pz_gemm_workspace_bytes": [c_int, c_int, c_int, POINTER(c_size_t)],
+	"pz_gemm_ws": [c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float, P, c_int, P, c_size_t, P],
 
 	"pz_bn_workspace_bytes": [c_int, c_int, c_int, POINTER(c_size_t)],
 	"pz_bn_fwd_train": [P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_float, P, c_size_t, P],
@@ -215,7 +217,7 @@ def _bind(name, argtypes):
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
-	"pz_pool2d_out_shape", "pz_conv_profile_enable", "pz_conv_profile_collect"
+	"pz_pool2d_out_shape", "pz_conv_profile_enable", "pz_conv_profile_collect", "pz_gemm_workspace_bytes"
 }
 _fake = {"next": 0x7000_0000_0000}
 

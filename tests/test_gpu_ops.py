@@ -713,3 +713,54 @@ def test_thin_backward_data_of_the_stem(bnd, cfg):
 def lib_bwd_data():
 	from puzzlelib_amd import lib
 	return lib.CONV_BWD_DATA
+
+
+@pytest.mark.parametrize("shape", [(256, 2048, 1000), (64, 800, 1024), (130, 70, 190), (5, 3, 7), (300, 4097, 65), (129, 16, 129)])
+def test_gemm_tiles_split_k_and_unaligned_operands(bnd, shape):
+	"""The MFMA GEMM over its tile shapes (64 / 128 on either side), the split along K for small outputs with long
+	reductions (deterministic: slabs added in order), operands whose rows are not 16-byte multiples (4-byte loader), all
+	three layouts with the alpha / beta epilogue, against an fp64 product."""
+	m, k, n = shape
+	rng = np.random.RandomState(m + k + n)
+	a, b = rng.randn(m, k).astype(np.float32), rng.randn(k, n).astype(np.float32)
+	c0 = rng.randn(m, n).astype(np.float32)
+	ref = a.astype(np.float64) @ b.astype(np.float64)
+	tol = dict(atol=2e-6 * np.sqrt(k) * 8, rtol=1e-5)
+
+	for ta, tb in ((False, False), (False, True), (True, False)):
+		ga = gpu(bnd, a.T.copy() if ta else a)
+		gb = gpu(bnd, b.T.copy() if tb else b)
+		out = bnd.blas.gemm(ga, gb, None, ta, tb, 1.0, 0.0, bnd.memoryPool)
+		assert_close(out.get(), ref, what="gemm %s%s" % ("T" if ta else "N", "T" if tb else "N"), **tol)
+		again = bnd.blas.gemm(ga, gb, None, ta, tb, 1.0, 0.0, bnd.memoryPool)
+		assert np.array_equal(out.get(), again.get()), "run-to-run identical (split-K slabs are added in a fixed order)"
+		acc = gpu(bnd, c0)
+		bnd.blas.gemm(ga, gb, acc, ta, tb, 0.5, -2.0, bnd.memoryPool)
+		assert_close(acc.get(), 0.5 * ref - 2.0 * c0, what="alpha / beta epilogue", **tol)
+
+
+def test_gemm_batched_group_formats(bnd):
+	"""BlasContext.gemmBatched in the reference's three layout combinations and transposes
+	(Cuda/Wrappers/CuBlas.py:50-176: gbpGbpTest, gbpBgpTest, bgpGbpTest, bgpBgpTest shapes)."""
+	gbp, bgp = bnd.GroupFormat.gbp.value, bnd.GroupFormat.bgp.value
+	rng = np.random.RandomState(0)
+	groups = 3
+
+	def grouped(t, fmt):                       # -> list of the per-group matrices of a host tensor
+		return [t[i] for i in range(groups)] if fmt == gbp else [t[:, i, :] for i in range(groups)]
+
+	def stack(mats, fmt):
+		return np.stack(mats, axis=0 if fmt == gbp else 1)
+
+	for fa, fb, fo in ((gbp, gbp, gbp), (gbp, bgp, bgp), (bgp, gbp, bgp), (bgp, bgp, bgp)):
+		for ta, tb in ((False, False), (True, False), (False, True)):
+			m, k, n = 4, 7, 5
+			As = [rng.randn(*((k, m) if ta else (m, k))).astype(np.float32) for _ in range(groups)]
+			Bs = [rng.randn(*((n, k) if tb else (k, n))).astype(np.float32) for _ in range(groups)]
+			A, B = gpu(bnd, stack(As, fa)), gpu(bnd, stack(Bs, fb))
+			out = bnd.blas.gemmBatched(A, B, formatA=fa, formatB=fb, formatOut=fo, transpA=ta, transpB=tb)
+			want = stack([(x.T if ta else x) @ (y.T if tb else y) for x, y in zip(As, Bs)], fo)
+			assert_close(out.get(), want, atol=1e-5, rtol=1e-5, what="gemmBatched %s %s %s %s%s" % (fa, fb, fo, ta, tb))
+	acc = gpu(bnd, np.ones((groups, 4, 5), np.float32))
+	bnd.blas.gemmBatched(gpu(bnd, stack(As, gbp)), gpu(bnd, stack(Bs, gbp)), gbp, gbp, gbp, False, True, 2.0, 3.0, acc)
+	assert_close(acc.get(), 3.0 + 2.0 * stack([x @ y.T for x, y in zip(As, Bs)], gbp), atol=1e-5, rtol=1e-5, what="alpha / beta")
