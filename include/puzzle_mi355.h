@@ -351,6 +351,32 @@ int pz_rng_fill_u32(pz_rng_t rng, uint32_t *out, size_t count, pz_stream_t strea
 int pz_rng_fill_uniform(pz_rng_t rng, float *out, size_t count, pz_stream_t stream);           /* (0, 1] */
 int pz_rng_fill_normal(pz_rng_t rng, float *out, size_t count, float mean, float stddev, pz_stream_t stream);
 
+/* ---- beside the ResNet / NiN / LeNet path -------------------------------------------------------------
+ * mask pooling: PoolModule.maxpool2d / maxpool2dBackward / maxunpool2d / maxunpool2dBackward (Cuda/Kernels/Pool.py:7-114);
+ * mask[n, c, p, q] = flat index h*W + w of the maximum inside the (n, c) input plane, -1 for an empty window            */
+int pz_maskpool2d_fwd(const pz_pool_desc *d, const float *x, float *y, int32_t *mask, pz_stream_t stream);
+int pz_maskpool2d_bwd(const pz_pool_desc *d, const float *dy, const int32_t *mask, float *dx, pz_stream_t stream);
+int pz_maxunpool2d_fwd(const float *x, const int32_t *mask, float *y, size_t planes, size_t in_plane, size_t out_plane,
+                       pz_stream_t stream);
+int pz_maxunpool2d_bwd(const float *dy, const int32_t *mask, float *dx, size_t planes, size_t in_plane, size_t out_plane,
+                       pz_stream_t stream);
+/* local response normalisation: DnnContext.lrn / lrnBackward (Hip/Wrappers/MIOpen.py:691-751); cross = 0: N x N window
+ * inside a map (LRNMode.map), 1: N neighbouring maps (LRNMode.cross); `scale` (same shape as x) is the training-mode
+ * workspace the backward reads, NULL in inference                                                                     */
+int pz_lrn_fwd(const float *x, float *y, float *scale, int n, int c, int h, int w, int size, float alpha, float beta, float k,
+               int cross, pz_stream_t stream);
+int pz_lrn_bwd(const float *x, const float *dy, const float *scale, float *dx, int n, int c, int h, int w, int size,
+               float alpha, float beta, float k, int cross, pz_stream_t stream);
+/* SVM cost (CostModule.svm, Cuda/Kernels/Costs.py:109-130,250-276): gradient per score and the per-element error terms
+ * (the caller sums them with pz_asum — they are non-negative — instead of the reference's atomicAdd)                */
+int pz_svm_cost(const float *scores, const int32_t *labels, int samples, int cases, int spatial, int squared, float *grad,
+                float *terms, pz_stream_t stream);
+/* MatModule.matvec / argmin (Cuda/Kernels/MatVec.py:231-345) */
+int pz_matvec(const float *mat, const float *vec, float *out, int z, int h, int w, int axis, float alpha, float beta,
+              pz_stream_t stream);
+int pz_argmin_rows(const float *t, int rows, int cols, int32_t *out, pz_stream_t stream);
+int pz_argmin_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_t stream);
+
 /* ---- data-parallel exchange: replaces NodeInfo.{sumTensor,broadcastBuffer} (Grid.py:54-63,103-157: IPC star)
  *      with RCCL collectives over xGMI. One communicator per process (one process per GPU).             */
 #define PZ_COMM_ID_BYTES 128

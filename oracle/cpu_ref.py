@@ -584,3 +584,140 @@ def grad_mean_allreduce(grads):
 	for g in grads[1:]:
 		acc = acc + g * F(1.0 / n)
 	return acc
+
+
+# --------------------------------------------------------------------------------------------------
+# operators beside the ResNet / NiN / LeNet path — host formulas of the reference's own unit tests
+# --------------------------------------------------------------------------------------------------
+
+def maskpool2d_fwd(x, size, stride, pad):
+	"""Cuda/Kernels/Pool.py:9-46 maxpool2d kernel (and its host check :229-262): window maximum and the flat index
+	h*W + w of the FIRST maximum inside the input plane (strict >), -1 for an empty window."""
+	n, c, h, w = x.shape
+	(fh, fw), (sh, sw), (ph, pw) = pair(size), pair(stride), pair(pad)
+	oh, ow = (h - fh + 2 * ph) // sh + 1, (w - fw + 2 * pw) // sw + 1
+	y = np.full((n, c, oh, ow), np.finfo(np.float32).min, np.float32)
+	mask = np.full((n, c, oh, ow), -1, np.int32)
+	for p in range(oh):
+		for q in range(ow):
+			h0, w0 = max(p * sh - ph, 0), max(q * sw - pw, 0)
+			h1, w1 = min(p * sh - ph + fh, h), min(q * sw - pw + fw, w)
+			if h1 <= h0 or w1 <= w0:
+				continue
+			win = x[:, :, h0:h1, w0:w1].reshape(n, c, -1)
+			arg = win.argmax(axis=2)                              # first maximum
+			y[:, :, p, q] = np.take_along_axis(win, arg[..., None], axis=2)[..., 0]
+			mask[:, :, p, q] = (h0 + arg // (w1 - w0)) * w + (w0 + arg % (w1 - w0))
+	return y, mask
+
+
+def maskpool2d_bwd(dy, mask, inshape):
+	"""Cuda/Kernels/Pool.py:66-97: every pooled gradient goes to the element its mask names."""
+	n, c, h, w = inshape
+	dx = np.zeros((n, c, h * w), np.float64)
+	flat_dy, flat_m = dy.reshape(n, c, -1), mask.reshape(n, c, -1)
+	for i in range(n):
+		for j in range(c):
+			ok = flat_m[i, j] >= 0
+			np.add.at(dx[i, j], flat_m[i, j][ok], flat_dy[i, j][ok])
+	return dx.reshape(inshape).astype(np.float32)
+
+
+def maxunpool2d_fwd(x, mask, outshape):
+	"""Cuda/Kernels/Pool.py:48-63"""
+	n, c = x.shape[:2]
+	y = np.zeros((n, c, outshape[2] * outshape[3]), np.float32)
+	for i in range(n):
+		for j in range(c):
+			ok = mask[i, j].ravel() >= 0
+			y[i, j][mask[i, j].ravel()[ok]] = x[i, j].ravel()[ok]
+	return y.reshape(n, c, outshape[2], outshape[3])
+
+
+def maxunpool2d_bwd(dy, mask):
+	"""Cuda/Kernels/Pool.py:99-114"""
+	n, c = dy.shape[:2]
+	flat = dy.reshape(n, c, -1)
+	safe = np.maximum(mask.reshape(n, c, -1), 0)
+	return (np.take_along_axis(flat, safe, axis=2) * (mask.reshape(n, c, -1) >= 0)).reshape(mask.shape).astype(np.float32)
+
+
+def lrn_norms(x, N, alpha, K, cross):
+	"""normaliser of mapLRN2dTest / crossMapLRN2dTest (Cuda/Wrappers/CuDnnNorm.py:183-262)"""
+	n, c, h, w = x.shape
+	behind = (N - 1) // 2
+	ahead = N - behind
+	sq = x.astype(np.float64) ** 2
+	s = np.empty(x.shape, np.float64)
+	if cross:
+		for ch in range(c):
+			s[:, ch] = K + sq[:, max(0, ch - behind):min(c, ch + ahead)].sum(axis=1) * alpha / N
+	else:
+		for y in range(h):
+			for xx in range(w):
+				win = sq[:, :, max(0, y - behind):min(h, y + ahead), max(0, xx - behind):min(w, xx + ahead)]
+				s[:, :, y, xx] = K + win.sum(axis=(2, 3)) * alpha / N ** 2
+	return s
+
+
+def lrn_fwd(x, N=5, alpha=1e-4, beta=0.75, K=2.0, cross=False):
+	return (x / lrn_norms(x, N, alpha, K, cross) ** beta).astype(np.float32)
+
+
+def lrn_bwd(x, dy, N=5, alpha=1e-4, beta=0.75, K=2.0, cross=False):
+	n, c, h, w = x.shape
+	behind = (N - 1) // 2
+	ahead = N - behind
+	s = lrn_norms(x, N, alpha, K, cross)
+	t = dy.astype(np.float64) * x / s ** (beta + 1)
+	acc = np.empty(x.shape, np.float64)
+	if cross:
+		for ch in range(c):
+			acc[:, ch] = t[:, max(0, ch - behind):min(c, ch + ahead)].sum(axis=1)
+		coef = 2.0 * alpha * beta / N
+	else:
+		for y in range(h):
+			for xx in range(w):
+				acc[:, :, y, xx] = t[:, :, max(0, y - behind):min(h, y + ahead), max(0, xx - behind):min(w, xx + ahead)].sum(axis=(2, 3))
+		coef = 2.0 * alpha * beta / N ** 2
+	return (dy / s ** beta - coef * x * acc).astype(np.float32)
+
+
+def matvec(mat, vec, axis):
+	"""Cuda/Kernels/MatVec.py:430-447 host check: per leading index, mat @ vec (axis 1) or mat.T @ vec (axis 0)"""
+	m, v = mat.astype(np.float64), vec.astype(np.float64)
+	return (np.einsum("...ij,...j->...i", m, v) if axis == 1 else np.einsum("...ij,...i->...j", m, v)).astype(np.float32)
+
+
+def svm_cost(scores, labels, mode):
+	"""Cuda/Kernels/Costs.py:109-130 + svmTest :327-350: (summed error, gradient)"""
+	n, c = scores.shape[:2]
+	spatial = int(np.prod(scores.shape[2:]))
+	s = scores.reshape(n, c, spatial).astype(np.float64)
+	cls = 2.0 * (labels.reshape(n, 1, spatial) == np.arange(c).reshape(1, c, 1)) - 1.0
+	margin = np.maximum(0.0, 1.0 - s * cls)
+	if mode == "l1":
+		grad = np.where(s * cls < 1.0, cls / c / n, 0.0)
+		err = margin.sum() / c / spatial
+	else:
+		grad = 2.0 * cls * margin / c / n
+		err = (margin ** 2).sum() / c / spatial
+	return np.float32(err), grad.reshape(scores.shape).astype(np.float32)
+
+
+def conv3d_fwd(x, w, bias, stride, pad, dilation):
+	"""Direct 3-d cross-correlation in fp64 (Modules/Conv3D.py over Dnn.convNd; groups = 1)."""
+	n, c, D, H, W = x.shape
+	k, _, T, R, S = w.shape
+	(sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = stride, pad, dilation
+	xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (pd, pd), (ph, ph), (pw, pw)))
+	Do, Ho, Wo = (D + 2 * pd - dd * (T - 1) - 1) // sd + 1, (H + 2 * ph - dh * (R - 1) - 1) // sh + 1, (W + 2 * pw - dw * (S - 1) - 1) // sw + 1
+	y = np.zeros((n, k, Do, Ho, Wo), np.float64)
+	for t in range(T):
+		for r in range(R):
+			for s in range(S):
+				win = xp[:, :, t * dd:t * dd + (Do - 1) * sd + 1:sd, r * dh:r * dh + (Ho - 1) * sh + 1:sh, s * dw:s * dw + (Wo - 1) * sw + 1:sw]
+				y += np.einsum("ncdhw,kc->nkdhw", win, w[:, :, t, r, s].astype(np.float64))
+	if bias is not None:
+		y += bias.reshape(1, -1, 1, 1, 1)
+	return y

@@ -17,7 +17,7 @@ import numpy as np
 from puzzlelib_amd import lib, driver, lazy, fusion
 from puzzlelib_amd.lib import HipError, ConvDesc, PoolDesc
 from puzzlelib_amd.driver import streamHandle
-from puzzlelib_amd.gpuarray import GPUArray, prod, eltwise
+from puzzlelib_amd.gpuarray import GPUArray, prod, eltwise, contiguousStrides
 
 
 # ---------------------------------------------------------------------------------------------- enums
@@ -809,21 +809,138 @@ class DnnContext:
 		return out, scalegrad, bgrad
 
 
-	def lrn(self, *args, **kwargs):
-		raise NotImplementedError("LRN is outside the implemented operator path")
+	def lrn(self, data, N=5, alpha=1e-4, beta=0.75, K=2.0, mode=LRNMode.map.value, test=False, out=None, allocator=None):
+		"""Hip/Wrappers/MIOpen.py:708-731. Training mode returns (out, workspace): the workspace holds the normaliser
+		s = K + alpha/|window| * sum x^2 per element, which the backward reads."""
+		assert data.ndim == 4
+		requireF32(data, out)
+		out = GPUArray.empty(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
+		workspace = None if test else GPUArray.empty(data.shape, dtype=np.float32, allocator=allocator)
+		n, c, h, w = data.shape
+		lib.pz_lrn_fwd(
+			data.rptr, out.optr, None if workspace is None else workspace.optr, n, c, h, w, N, alpha, beta, K,
+			int(mode == LRNMode.cross.value), None
+		)
+		return out if test else (out, workspace)
 
 
-	lrnBackward = lrn
+	def lrnBackward(self, grad, indata, outdata, workspace, N=5, alpha=1e-4, beta=0.75, K=2.0, mode=LRNMode.map.value,
+					out=None, allocator=None):
+		"""Hip/Wrappers/MIOpen.py:734-751"""
+		requireF32(grad, indata, out)
+		mode = mode.value if isinstance(mode, Enum) else mode
+		if workspace is None:                   # (a forward pass in inference mode keeps no normaliser: recompute it)
+			_, workspace = self.lrn(indata, N, alpha, beta, K, mode, False, None, allocator)
+		out = GPUArray.empty(grad.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
+		n, c, h, w = indata.shape
+		lib.pz_lrn_bwd(
+			indata.rptr, grad.rptr, workspace.rptr, out.optr, n, c, h, w, N, alpha, beta, K, int(mode == LRNMode.cross.value), None
+		)
+		return out
 
 
 class conv3d:
-	"""3-D convolutions (Modules/Conv3D.py) on the 2-D core — not implemented yet."""
+	"""3-D convolutions (Modules/Conv3D.py through the same Dnn.convNd* entries) on the 2-D MFMA core: the depth taps are
+	unfolded into channels — xu[(n, d), (c, t), h, w] = x[n, c, d*sd + t*dd - pd, h, w] (zero outside), T strided copies
+	— after which all three passes are the 2-D passes with filters (K, C*T, R, S) = the 5-d filter tensor reshaped:
+	forward = conv2d(xu) transposed to (N, K, D', P, Q); backward-filter = the 2-D filter gradient, already in 5-d
+	order; backward-data = the 2-D backward-data folded back over the taps."""
 
 	@staticmethod
-	def forward(*args):
-		raise NotImplementedError("3-D convolution is not implemented on this backend")
+	def triple(v):
+		return (int(v), ) * 3 if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
 
-	backwardData = backwardParams = forward
+
+	@staticmethod
+	def taps(D, Dout, T, sd, pd, dd):
+		"""per depth tap t: (first output depth, count, first input depth) of the in-range part"""
+		for t in range(T):
+			d0 = max(0, -((t * dd - pd) // sd))                    # smallest d with d*sd + t*dd - pd >= 0
+			d1 = min(Dout - 1, (D - 1 + pd - t * dd) // sd)
+			if d1 >= d0:
+				yield t, d0, d1 - d0 + 1, d0 * sd + t * dd - pd
+
+
+	@classmethod
+	def unfold(cls, data, T, Dout, sd, pd, dd, allocator):
+		n, c, D, h, w = data.shape
+		xu = GPUArray.zeros((n, Dout, c, T, h, w), dtype=data.dtype, allocator=allocator)
+		sN, sD, sC, sT, sH, sW = xu.strides
+		for t, d0, count, z0 in cls.taps(D, Dout, T, sd, pd, dd):
+			src = data[:, :, z0:z0 + (count - 1) * sd + 1:sd]
+			dst = MemModule.viewLike(xu, (n, c, count, h, w), (sN, sC, sD, sH, sW), d0 * sD + t * sT)
+			dst.stridedCopyFrom(src)
+		return xu.reshape(n * Dout, c * T, h, w)
+
+
+	@classmethod
+	def geometry(cls, dshape, Wshape, stride, pad, dilation):
+		(sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = cls.triple(stride), cls.triple(pad), cls.triple(dilation)
+		T = Wshape[2]
+		Dout = (dshape[2] + 2 * pd - dd * (T - 1) - 1) // sd + 1
+		return (sd, pd, dd, T, Dout), dict(stride=(sh, sw), pad=(ph, pw), dilation=(dh, dw))
+
+
+	@classmethod
+	def forward(cls, dnn, data, W, bias, stride, pad, dilation, groups, algo, out, allocator):
+		(sd, pd, dd, T, Dout), kw = cls.geometry(data.shape, W.shape, stride, pad, dilation)
+		n, k = data.shape[0], W.shape[0]
+		xu = cls.unfold(data, T, Dout, sd, pd, dd, allocator)
+		W2 = W.reshape(k, W.shape[1] * T, W.shape[3], W.shape[4])
+		y2 = dnn.convNd(xu, W2, bias, groups=groups, algo=algo, allocator=allocator, **kw)
+		y5 = y2.reshape(n, Dout, k, y2.shape[2], y2.shape[3])
+		return dnn.backend.memmod.transpose(y5, (0, 2, 1, 3, 4), out=out, allocator=allocator)
+
+
+	@classmethod
+	def backwardData(cls, dnn, grad, W, bias, data, stride, pad, dilation, postpad, groups, algo, out, allocator):
+		if data is None or bias is not None:
+			raise NotImplementedError("3-d deconvolution forward is not implemented on this backend")
+		(sd, pd, dd, T, Dout), kw = cls.geometry(data.shape, W.shape, stride, pad, dilation)
+		n, c, D, h, w = data.shape
+		k = W.shape[0]
+		memmod = dnn.backend.memmod
+		g2 = memmod.transpose(grad, (0, 2, 1, 3, 4), allocator=allocator).reshape(n * Dout, k, grad.shape[3], grad.shape[4])
+		W2 = W.reshape(k, W.shape[1] * T, W.shape[3], W.shape[4])
+		dxu = dnn.convNdBackwardData(
+			g2, W2, None, cls.Shape((n * Dout, c * T, h, w)), groups=groups, algo=algo, allocator=allocator, **kw
+		)
+		dx = GPUArray.zeros(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
+		if out is not None:
+			out.fill(0)
+		sN, sD, sC, sT, sH, sW = contiguousStrides((n, Dout, c, T, h, w), 4)
+		for t, d0, count, z0 in cls.taps(D, Dout, T, sd, pd, dd):
+			part = GPUArray.zeros(data.shape, dtype=data.dtype, allocator=allocator)
+			src = MemModule.viewLike(dxu, (n, c, count, h, w), (sN, sC, sD, sH, sW), d0 * sD + t * sT)
+			part[:, :, z0:z0 + (count - 1) * sd + 1:sd].stridedCopyFrom(src)
+			dnn.backend.toVectorAddVectorKer(np.float32)(dx.ravel(), part.ravel(), 1.0)
+		return dx
+
+
+	class Shape:
+		"""stands in for the `data` argument of convNdBackwardData where only its shape is read"""
+		def __init__(self, shape):
+			self.shape, self.ndim = tuple(shape), len(shape)
+
+
+	@classmethod
+	def backwardParams(cls, dnn, data, grad, W, stride, pad, dilation, groups, withbias, deconv, wgrad, bgrad, scale, momentum,
+					   algo, allocator):
+		if deconv:
+			raise NotImplementedError("3-d deconvolution is not implemented on this backend")
+		(sd, pd, dd, T, Dout), kw = cls.geometry(data.shape, W.shape, stride, pad, dilation)
+		n, k = data.shape[0], W.shape[0]
+		xu = cls.unfold(data, T, Dout, sd, pd, dd, allocator)
+		g2 = dnn.backend.memmod.transpose(grad, (0, 2, 1, 3, 4), allocator=allocator).reshape(n * Dout, k, grad.shape[3], grad.shape[4])
+		shape2 = (k, W.shape[1] * T, W.shape[3], W.shape[4])
+		res = dnn.convNdBackwardParams(
+			xu, g2, W.reshape(shape2), groups=groups, withbias=withbias, deconv=False,
+			wgrad=None if wgrad is None else wgrad.reshape(shape2), bgrad=bgrad, scale=scale, momentum=momentum, algo=algo,
+			allocator=allocator, **kw
+		)
+		if withbias:
+			return (wgrad if wgrad is not None else res[0].reshape(W.shape)), res[1]
+		return wgrad if wgrad is not None else res.reshape(W.shape)
 
 
 # ---------------------------------------------------------------------------------------------- matrix-vector module
@@ -869,11 +986,33 @@ class MatModule:
 
 
 	def argmin(self, tensor, axis=0, allocator=None):
-		raise NotImplementedError("argmin is not on the implemented operator path")
+		requireF32(tensor)
+		assert 0 <= axis < tensor.ndim
+
+		idx = GPUArray.empty(tensor.shape[:axis] + tensor.shape[axis + 1:], dtype=np.int32, allocator=allocator)
+		if axis == tensor.ndim - 1:
+			lib.pz_argmin_rows(tensor.rptr, prod(tensor.shape[:-1]), tensor.shape[-1], idx.optr, None)
+		else:
+			z, h, w = prod(tensor.shape[:axis]), tensor.shape[axis], prod(tensor.shape[axis + 1:])
+			lib.pz_argmin_cols(tensor.rptr, z, h, w, idx.optr, None)
+		return idx
 
 
-	def matvec(self, *args, **kwargs):
-		raise NotImplementedError("matvec (GroupLinear) is outside the implemented operator path")
+	def matvec(self, mat, vec, axis=0, out=None, alpha=1.0, beta=0.0, allocator=None):
+		"""Cuda/Kernels/MatVec.py:302-345: per leading index z, out[z] = alpha * mat[z] @ vec[z] (axis 1: over the last
+		axis) or alpha * mat[z].T @ vec[z] (axis 0) + beta * out[z]."""
+		requireF32(mat, vec, out)
+		assert vec.ndim == mat.ndim - 1 and 0 <= axis < 2
+		h, w = mat.shape[-2:]
+		assert vec.dimAt(-1) == (w if axis == 1 else h)
+
+		oshape = mat.shape[:-1] if axis == 1 else mat.shape[:-2] + (w, )
+		if out is None:
+			out = GPUArray.zeros(oshape, dtype=mat.dtype, allocator=allocator)
+		else:
+			assert out.shape == oshape
+		lib.pz_matvec(mat.rptr, vec.rptr, out.wptr, prod(mat.shape[:-2]), h, w, axis, alpha, beta, None)
+		return out
 
 
 	def addVecToMat(self, vec, mat, axis=0, out=None, allocator=None, tiled=False):
@@ -952,8 +1091,20 @@ class CostModule:
 		return error, grad
 
 
-	def svm(self, *args, **kwargs):
-		raise NotImplementedError("SVM cost is outside the implemented operator path")
+	def svm(self, scores, labels, mode, error=None, allocator=None):
+		"""Cuda/Kernels/Costs.py:250-276 (mode "l1" | "l2")"""
+		assert scores.dtype == np.float32 and labels.dtype == np.int32 and mode in ("l1", "l2")
+		requireF32(scores)
+		n, c = scores.shape[:2]
+		spatial = prod(scores.shape[2:])
+
+		grad = GPUArray.empty(scores.shape, dtype=np.float32, allocator=allocator)
+		if error is None:
+			error = GPUArray.empty((), dtype=np.float32, allocator=allocator)
+		terms = GPUArray.empty((scores.size, ), dtype=np.float32, allocator=allocator)
+		lib.pz_svm_cost(scores.rptr, labels.rptr, n, c, spatial, int(mode == "l2"), grad.optr, terms.optr, None)
+		lib.pz_asum(terms.rptr, terms.size, error.optr, None)
+		return error, grad
 
 
 class MemModule:
@@ -1042,6 +1193,63 @@ class MemModule:
 			gr.stridedCopyFrom(self.viewLike(grad, gr.shape, grad.strides, offset + self.centred(grad, gr)))
 			offset += grad.strideAt(1) * gr.dimAt(1)
 		return ingrads
+
+
+class PoolModule:
+	"""maxpool2d / maxpool2dBackward / maxunpool2d / maxunpool2dBackward with index masks — Cuda/Kernels/Pool.py:117-213
+	(MaxPool2D(useMask=True), MaxUnpool2D)."""
+
+	def __init__(self, backend):
+		self.backend = backend
+
+
+	@staticmethod
+	def desc(shape, size, stride, pad):
+		(fh, fw), (sh, sw), (ph, pw) = pair(size), pair(stride), pair(pad)
+		n, c, h, w = shape
+		return PoolDesc(n, c, h, w, fh, fw, sh, sw, ph, pw, PoolMode.max.value)
+
+
+	def maxpool2d(self, data, size, stride, pad, allocator=None):
+		assert data.dtype == np.float32 and data.ndim == 4
+		requireF32(data)
+		desc = self.desc(data.shape, size, stride, pad)
+		p, q = c_int(0), c_int(0)
+		lib.pz_pool2d_out_shape(byref(desc), byref(p), byref(q))
+		shape = data.shape[:2] + (p.value, q.value)
+		outdata = GPUArray.empty(shape, dtype=np.float32, allocator=allocator)
+		mask = GPUArray.empty(shape, dtype=np.int32, allocator=allocator)
+		lib.pz_maskpool2d_fwd(byref(desc), data.rptr, outdata.optr, mask.optr, None)
+		return outdata, mask
+
+
+	def maxpool2dBackward(self, grad, origshape, mask, size, stride, pad, allocator=None):
+		assert grad.dtype == np.float32 and mask.dtype == np.int32
+		requireF32(grad)
+		desc = self.desc(tuple(grad.shape[:2]) + tuple(origshape[2:]), size, stride, pad)
+		ingrad = GPUArray.empty(tuple(grad.shape[:2]) + tuple(origshape[2:]), dtype=np.float32, allocator=allocator)
+		lib.pz_maskpool2d_bwd(byref(desc), grad.rptr, mask.rptr, ingrad.optr, None)
+		return ingrad
+
+
+	def maxunpool2d(self, data, origshape, mask, allocator=None):
+		assert data.dtype == np.float32 and mask.dtype == np.int32
+		requireF32(data)
+		n, c, inh, inw = data.shape
+		outh, outw = origshape[2], origshape[3]
+		outdata = GPUArray.empty((n, c, outh, outw), dtype=np.float32, allocator=allocator)
+		lib.pz_maxunpool2d_fwd(data.rptr, mask.rptr, outdata.optr, n * c, inh * inw, outh * outw, None)
+		return outdata
+
+
+	def maxunpool2dBackward(self, grad, poolshape, mask, allocator=None):
+		assert grad.dtype == np.float32 and mask.dtype == np.int32
+		requireF32(grad)
+		n, c, outh, outw = grad.shape
+		inh, inw = poolshape[2], poolshape[3]
+		ingrad = GPUArray.empty((n, c, inh, inw), dtype=np.float32, allocator=allocator)
+		lib.pz_maxunpool2d_bwd(grad.rptr, mask.rptr, ingrad.optr, n * c, inh * inw, outh * outw, None)
+		return ingrad
 
 
 class StubModule:
@@ -1363,7 +1571,8 @@ class Mi355Backend:
 		self.getAccuracyKernel = self.costmod.getAccuracyKernel
 
 		self.memmod = MemModule(self)
-		for name in ("ctcmod", "embedmod", "padmod", "poolmod", "prelumod", "upsamplemod"):
+		self.poolmod = PoolModule(self)
+		for name in ("ctcmod", "embedmod", "padmod", "prelumod", "upsamplemod"):
 			setattr(self, name, StubModule(name))
 
 		K = memoizedKernel

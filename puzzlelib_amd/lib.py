@@ -144,6 +144,17 @@ _PROTOS = {
 	"pz_pool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
 	"pz_pool2d_bwd": [POINTER(PoolDesc), P, P, P, P, P, P],
 
+	"pz_maskpool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
+	"pz_maskpool2d_bwd": [POINTER(PoolDesc), P, P, P, P],
+	"pz_maxunpool2d_fwd": [P, P, P, c_size_t, c_size_t, c_size_t, P],
+	"pz_maxunpool2d_bwd": [P, P, P, c_size_t, c_size_t, c_size_t, P],
+	"pz_lrn_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, P],
+	"pz_lrn_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, P],
+	"pz_svm_cost": [P, P, c_int, c_int, c_int, c_int, P, P, P],
+	"pz_matvec": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
+	"pz_argmin_rows": [P, c_int, c_int, P, P],
+	"pz_argmin_cols": [P, c_int, c_int, c_int, P, P],
+
 	"pz_softmax_fwd": [P, P, c_int, c_int, c_int, P],
 	"pz_softmax_bwd": [P, P, P, c_int, c_int, c_int, P],
 	"pz_cross_entropy": [P, P, P, c_int, c_int, c_int, P, P, P, c_size_t, P],

@@ -764,3 +764,181 @@ def test_gemm_batched_group_formats(bnd):
 	acc = gpu(bnd, np.ones((groups, 4, 5), np.float32))
 	bnd.blas.gemmBatched(gpu(bnd, stack(As, gbp)), gpu(bnd, stack(Bs, gbp)), gbp, gbp, gbp, False, True, 2.0, 3.0, acc)
 	assert_close(acc.get(), 3.0 + 2.0 * stack([x @ y.T for x, y in zip(As, Bs)], gbp), atol=1e-5, rtol=1e-5, what="alpha / beta")
+
+
+# ------------------------------------------------------------------------------------------------ beside the hot path (f3)
+@pytest.mark.parametrize("cfg", [dict(shape=(10, 4, 6, 6), size=2, stride=2, pad=0), dict(shape=(3, 5, 9, 11), size=3, stride=2, pad=1),
+								 dict(shape=(2, 3, 7, 7), size=(3, 2), stride=(1, 2), pad=(1, 0))])
+def test_mask_pooling_and_unpooling(bnd, cfg):
+	"""poolmod (Cuda/Kernels/Pool.py:117-213, host checks :229-328): index-mask max pooling, its backward, unpooling and
+	its backward — bit-exact values and indices."""
+	rng = np.random.RandomState(0)
+	x = rng.randn(*cfg["shape"]).astype(np.float32)
+	kw = dict(size=R.pair(cfg["size"]), stride=R.pair(cfg["stride"]), pad=R.pair(cfg["pad"]))
+	y_ref, mask_ref = R.maskpool2d_fwd(x, **kw)
+
+	gx = gpu(bnd, x)
+	y, mask = bnd.poolmod.maxpool2d(gx, allocator=bnd.memoryPool, **kw)
+	assert mask.dtype == np.int32 and np.array_equal(y.get(), y_ref) and np.array_equal(mask.get(), mask_ref)
+
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	dx = bnd.poolmod.maxpool2dBackward(gpu(bnd, dy), x.shape, mask, **kw)
+	assert_close(dx.get(), R.maskpool2d_bwd(dy, mask_ref, x.shape), atol=1e-6, what="mask pooling backward")
+
+	up = bnd.poolmod.maxunpool2d(y, x.shape, mask)
+	assert np.array_equal(up.get(), R.maxunpool2d_fwd(y_ref, mask_ref, x.shape))
+	g = rng.randn(*x.shape).astype(np.float32)
+	back = bnd.poolmod.maxunpool2dBackward(gpu(bnd, g), y_ref.shape, mask)
+	assert np.array_equal(back.get(), R.maxunpool2d_bwd(g, mask_ref))
+
+
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("shape", [(2, 2, 9, 10), (2, 10, 2, 3), (3, 7, 5, 5)])
+def test_local_response_normalisation(bnd, shape, cross):
+	"""dnn.lrn / lrnBackward (Hip/Wrappers/MIOpen.py:691-751) against the host formulas of mapLRN2dTest /
+	crossMapLRN2dTest (Cuda/Wrappers/CuDnnNorm.py:183-262), with those tests' parameters and AlexNet-style ones."""
+	rng = np.random.RandomState(1)
+	x, dy = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
+	mode = (bnd.LRNMode.cross if cross else bnd.LRNMode.map).value
+	for N, alpha, beta, K in ((5, 1.0, 0.5, 2.0), (3, 1e-4, 0.75, 2.0), (4, 0.3, 0.6, 1.0)):
+		gx = gpu(bnd, x)
+		y, ws = bnd.dnn.lrn(gx, N, alpha, beta, K, mode, False, allocator=bnd.memoryPool)
+		assert_close(y.get(), R.lrn_fwd(x, N, alpha, beta, K, cross), atol=1e-5, rtol=1e-5, what="lrn forward")
+		assert np.array_equal(bnd.dnn.lrn(gx, N, alpha, beta, K, mode, True).get(), y.get())
+		dx = bnd.dnn.lrnBackward(gpu(bnd, dy), gx, y, ws, N, alpha, beta, K, mode)
+		assert_close(dx.get(), R.lrn_bwd(x, dy, N, alpha, beta, K, cross), atol=2e-5, rtol=1e-4, what="lrn backward")
+
+
+def test_matvec_argmin_svm(bnd):
+	"""MatModule.matvec / argmin (Cuda/Kernels/MatVec.py:231-345, host checks :430-455) and CostModule.svm
+	(Cuda/Kernels/Costs.py:250-276, svmTest :327-350)."""
+	rng = np.random.RandomState(2)
+	a = rng.randn(8, 32, 64).astype(np.float32)
+	v, w = rng.randn(8, 64).astype(np.float32), rng.randn(8, 32).astype(np.float32)
+	ga = gpu(bnd, a)
+	assert_close(bnd.matmod.matvec(ga, gpu(bnd, v), axis=1).get(), R.matvec(a, v, 1), atol=1e-4, rtol=1e-4, what="matvec rows")
+	assert_close(bnd.matmod.matvec(ga, gpu(bnd, w), axis=0).get(), R.matvec(a, w, 0), atol=1e-4, rtol=1e-4, what="matvec cols")
+	out = gpu(bnd, np.ones((8, 32), np.float32))
+	bnd.matmod.matvec(ga, gpu(bnd, v), axis=1, out=out, alpha=0.5, beta=2.0)
+	assert_close(out.get(), 2.0 + 0.5 * R.matvec(a, v, 1), atol=1e-4, rtol=1e-4, what="matvec alpha / beta")
+	assert_close(bnd.matmod.matvec(gpu(bnd, a[0]), gpu(bnd, v[0]), axis=1).get(), a[0] @ v[0], atol=1e-4, rtol=1e-4, what="2-d matvec")
+
+	t = rng.normal(scale=16.0, size=(9, 33, 65)).astype(np.float32)
+	gt = gpu(bnd, t)
+	for axis in (1, 2):
+		assert np.array_equal(bnd.matmod.argmin(gt, axis=axis).get(), np.argmin(t, axis=axis))
+		assert np.array_equal(bnd.matmod.argmax(gt, axis=axis).get(), np.argmax(t, axis=axis))
+
+	for shape in ((20, 4), (6, 5, 3, 2)):
+		scores = rng.randn(*shape).astype(np.float32)
+		labels = rng.randint(0, shape[1], size=(shape[0], ) + shape[2:]).astype(np.int32)
+		for mode in ("l1", "l2"):
+			err, grad = bnd.costmod.svm(gpu(bnd, scores), gpu(bnd, labels), mode=mode)
+			err_ref, grad_ref = R.svm_cost(scores, labels, mode)
+			assert np.isclose(float(err.get()), err_ref, rtol=1e-5) and np.allclose(grad.get(), grad_ref, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(6, 5, 4, 3), (16, 3, 7, 7), (8, 10), (4, 6, 5)])
+def test_batchnorm_per_activation_mode(bnd, shape):
+	"""BatchNormMode.perActivation (Hip/Wrappers/MIOpen.py:634-688 honours `mode`): statistics per (c, h, w) position over
+	the batch only; the oracle is the spatial formula on the tensor seen as (n, c*h*w, 1, 1)."""
+	rng = np.random.RandomState(4)
+	x, dy = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
+	feat = int(np.prod(shape[1:]))
+	scale, bias = rng.randn(feat).astype(np.float32), rng.randn(feat).astype(np.float32)
+	rm, rv = np.zeros(feat, np.float32), np.ones(feat, np.float32)
+	mode = bnd.BatchNormMode.perActivation.value
+
+	grm, grv = gpu(bnd, rm), gpu(bnd, rv)
+	y, sm, si = bnd.dnn.batchNormNd(gpu(bnd, x), grm, grv, gpu(bnd, scale), gpu(bnd, bias), 1e-5, 0.5, False, mode)
+	flat = x.reshape(shape[0], feat, 1, 1)
+	y_ref, sm_ref, si_ref = R.bn_fwd_train(flat, scale, bias, rm, rv, 1e-5, 0.5, acc=np.float64)
+	assert y.shape == x.shape
+	assert_close(y.get().reshape(flat.shape), y_ref, atol=2e-5, rtol=1e-4, what="per-activation y")
+	assert_close(sm.get(), sm_ref, atol=1e-5, rtol=1e-5, what="saved mean")
+	assert_close(grm.get(), rm, atol=1e-5, rtol=1e-5, what="running mean")
+
+	dx, ds, db = bnd.dnn.batchNormNdBackward(gpu(bnd, dy), gpu(bnd, x), gpu(bnd, scale), sm, si, 1e-5, mode)
+	dx_ref, ds_ref, db_ref = R.bn_bwd(dy.reshape(flat.shape), flat, scale, sm_ref, si_ref, acc=np.float64)
+	assert_close(dx.get().reshape(flat.shape), dx_ref, atol=1e-4, rtol=1e-3, what="per-activation dx")
+	assert_close(ds.get(), ds_ref, atol=1e-4, rtol=1e-3, what="dscale")
+
+	inf = bnd.dnn.batchNormNd(gpu(bnd, x), gpu(bnd, rm), gpu(bnd, rv), gpu(bnd, scale), gpu(bnd, bias), 1e-5, 0, True, mode)
+	assert_close(inf.get().reshape(flat.shape), R.bn_fwd_infer(flat, scale, bias, rm, rv, 1e-5), atol=2e-5, rtol=1e-4, what="inference")
+
+
+def test_gelu_forward_and_derivative(bnd):
+	"""geluKer / geluDerKer (Cuda/Kernels/ElementWise.py gelu, the tanh-free erf form) against the oracle."""
+	rng = np.random.RandomState(6)
+	x = (3.0 * rng.randn(4097)).astype(np.float32)
+	g = rng.randn(4097).astype(np.float32)
+	gx, out = gpu(bnd, x), bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	bnd.geluKer(np.float32)(out, gx)
+	assert_close(out.get(), R.gelu(x), atol=1e-5, rtol=1e-5, what="gelu")
+	dx = bnd.GPUArray.empty(x.shape, dtype=np.float32)
+	bnd.geluDerKer(np.float32)(dx, gpu(bnd, g), gx)
+	assert_close(dx.get(), R.gelu_der(g, x), atol=1e-5, rtol=1e-5, what="gelu derivative")
+
+
+@pytest.mark.parametrize("cfg", [dict(n=3, c=4, k=6, w=17, r=3, stride=1, pad=1, dil=1), dict(n=2, c=5, k=3, w=20, r=5, stride=2, pad=2, dil=1),
+								 dict(n=2, c=3, k=4, w=15, r=3, stride=1, pad=2, dil=2)])
+def test_conv1d_through_the_2d_core(bnd, cfg):
+	"""Modules/Conv1D.py hands (n, c, w) tensors and 1-tuples to Dnn.convNd*: lifted to (n, c, 1, w) inside the backend."""
+	rng = np.random.RandomState(8)
+	n, c, k, w_, r = cfg["n"], cfg["c"], cfg["k"], cfg["w"], cfg["r"]
+	st, pad, dil = (cfg["stride"], ), (cfg["pad"], ), (cfg["dil"], )
+	x, wt = rng.randn(n, c, w_).astype(np.float32), rng.randn(k, c, r).astype(np.float32)
+	b = rng.randn(k).astype(np.float32)
+	kw2 = dict(stride=(1, st[0]), pad=(0, pad[0]), dilation=(1, dil[0]), groups=1)
+	y_ref = R.conv2d_fwd(x[:, :, None], wt[:, :, None], b, acc=np.float64, **kw2)[:, :, 0]
+
+	gx, gw = gpu(bnd, x), gpu(bnd, wt)
+	y = bnd.dnn.convNd(gx, gw, gpu(bnd, b), st, pad, dil, 1)
+	assert y.shape == y_ref.shape
+	assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what="conv1d forward")
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	dx = bnd.dnn.convNdBackwardData(gpu(bnd, dy), gw, None, gx, st, pad, dil, None, 1)
+	dx_ref = R.conv2d_bwd_data(dy[:, :, None], wt[:, :, None], x[:, :, None].shape, acc=np.float64, **kw2)[:, :, 0]
+	assert_close(dx.get(), dx_ref, atol=1e-4, rtol=1e-4, what="conv1d backward data")
+	dw, db = bnd.dnn.convNdBackwardParams(gx, gpu(bnd, dy), gw, st, pad, dil, 1, True)
+	dw_ref, db_ref = R.conv2d_bwd_filter(x[:, :, None], dy[:, :, None], wt[:, :, None].shape, withbias=True, acc=np.float64, **kw2)
+	assert dw.shape == wt.shape
+	assert_close(dw.get(), dw_ref[:, :, 0], atol=1e-4, rtol=1e-4, what="conv1d filter gradient")
+	assert_close(db.get(), db_ref, atol=1e-4, rtol=1e-4, what="conv1d bias gradient")
+
+
+@pytest.mark.parametrize("cfg", [dict(n=2, c=3, k=4, dhw=(6, 7, 8), trs=(3, 3, 3), stride=(1, 1, 1), pad=(1, 1, 1), dil=(1, 1, 1)),
+								 dict(n=2, c=4, k=5, dhw=(7, 6, 9), trs=(3, 2, 3), stride=(2, 1, 2), pad=(1, 0, 1), dil=(1, 1, 1)),
+								 dict(n=1, c=2, k=3, dhw=(8, 5, 5), trs=(2, 3, 3), stride=(1, 1, 1), pad=(2, 1, 1), dil=(2, 1, 1))])
+def test_conv3d_on_the_2d_core(bnd, cfg):
+	"""Modules/Conv3D.py through Dnn.convNd*: depth taps unfolded into channels, the 2-D MFMA kernels do the arithmetic.
+	Forward against a direct fp64 3-d correlation; the two backward passes through the adjoint identities and (filter
+	gradient) a finite contraction check."""
+	rng = np.random.RandomState(9)
+	n, c, k = cfg["n"], cfg["c"], cfg["k"]
+	x = rng.randn(n, c, *cfg["dhw"]).astype(np.float32)
+	wt = rng.randn(k, c, *cfg["trs"]).astype(np.float32)
+	b = rng.randn(k).astype(np.float32)
+	st, pad, dil = cfg["stride"], cfg["pad"], cfg["dil"]
+	y_ref = R.conv3d_fwd(x, wt, b, st, pad, dil)
+
+	gx, gw = gpu(bnd, x), gpu(bnd, wt)
+	y = bnd.dnn.convNd(gx, gw, gpu(bnd, b), st, pad, dil, 1)
+	assert y.shape == y_ref.shape
+	assert_close(y.get(), y_ref, atol=2e-4, rtol=1e-4, what="conv3d forward")
+
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	gdy = gpu(bnd, dy)
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, None, gx, st, pad, dil, None, 1)
+	dw, db = bnd.dnn.convNdBackwardParams(gx, gdy, gw, st, pad, dil, 1, True)
+	assert dx.shape == x.shape and dw.shape == wt.shape
+	lin = R.conv3d_fwd(x, wt, None, st, pad, dil)                       # <dy, conv(x; w)> is linear in x and in w
+	lhs = float((dy.astype(np.float64) * lin).sum())
+	assert abs(lhs - float((dx.get().astype(np.float64) * x).sum())) < 1e-3 * (abs(lhs) + 10), "backward-data is the adjoint in x"
+	assert abs(lhs - float((dw.get().astype(np.float64) * wt).sum())) < 1e-3 * (abs(lhs) + 10), "backward-filter is the adjoint in w"
+	assert_close(db.get(), dy.sum(axis=(0, 2, 3, 4)), atol=1e-3, rtol=1e-4, what="conv3d bias gradient")
+	# element-wise check of the gradients against finite directional probes: d/dx <dy, conv(x)> in the direction e_i
+	probe = np.zeros_like(x)
+	idx = (0, c - 1, cfg["dhw"][0] // 2, 1, 2)
+	probe[idx] = 1.0
+	assert np.isclose(dx.get()[idx], float((dy * R.conv3d_fwd(probe, wt, None, st, pad, dil)).sum()), rtol=1e-3, atol=1e-3)
