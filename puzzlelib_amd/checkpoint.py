@@ -1,0 +1,98 @@
+"""
+Checkpoints of the stand-alone harness: a network's parameters and attributes (and, optionally, an optimizer's state) to
+a file and back.
+
+The reference stores a module tree in HDF5 (Modules/Module.py:179-283): group `params` holds the tensors under running
+indices, group `links` maps "<module path>.<param>" to an index (so tied variables are stored once), group `attrs` holds
+"<module path>.<attr>" (batch-norm running statistics). The same three-part structure is kept here — `params/<idx>`,
+`links/<layer>.<param>` -> idx, `attrs/<layer>.<attr>`, plus `optimizer/...` and `meta/...` — in a numpy .npz container
+(h5py is not part of this image); with h5py importable, `format="hdf5"` writes the identical structure as HDF5 groups and
+datasets. `layer` is the spec's layer name (= the reference's module name for the shipped networks).
+
+What a round trip must restore for training to continue bit for bit: parameters, running mean / variance, the batch-norm
+layers' pass counters (their momentum factor is 1/passes until it reaches minFactor, Modules/BatchNormND.py:55-58), the
+optimizer's step count and state tensors.
+"""
+import json
+
+import numpy as np
+
+
+def collect(net, optimizer=None):
+	"""-> {path: ndarray} with the structure described above"""
+	out, index = {}, {}
+	for name, param in net.namedParams().items():
+		key = id(param)
+		if key not in index:
+			index[key] = len(index)
+			out["params/%d" % index[key]] = param.data.get()
+		out["links/" + name] = np.array(index[key], dtype=np.int64)
+	for name, attr in net.namedAttrs().items():
+		out["attrs/" + name] = attr.get()
+
+	meta = {"name": net.name, "bn_passes": {l.name: l.cfg["passes"] for l in net.walk() if l.kind == "bn"}}
+	if optimizer is not None:
+		meta["optimizer"] = {"rule": optimizer.rule, "t": optimizer.t, "flat": optimizer.params is not None}
+		if optimizer.params is not None:
+			meta["optimizer"]["order"] = list(optimizer.params.blocks.keys())
+		for idx, (target, state) in enumerate(optimizer.targets):
+			for key, tensor in state.items():
+				out["optimizer/%d/%s" % (idx, key)] = tensor.get()
+	out["meta/json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+	return out
+
+
+def save(net, path, optimizer=None, format="npz"):
+	tensors = collect(net, optimizer)
+	if format == "npz":
+		np.savez(path, **{k.replace("/", "|"): v for k, v in tensors.items()})
+	elif format == "hdf5":
+		import h5py
+		with h5py.File(path, "w") as hdf:
+			for key, value in tensors.items():
+				hdf.create_dataset(key, data=value)
+	else:
+		raise ValueError(format)
+
+
+def read(path):
+	if str(path).endswith((".hdf", ".hdf5", ".h5")):
+		import h5py
+		out = {}
+		with h5py.File(path, "r") as hdf:
+			hdf.visititems(lambda name, obj: out.__setitem__(name, np.array(obj)) if hasattr(obj, "shape") else None)
+		return out
+	with np.load(path) as z:
+		return {k.replace("|", "/"): z[k] for k in z.files}
+
+
+def load(net, path, optimizer=None):
+	"""Restores `net` (and `optimizer`, which must already be set up on it the same way) from a checkpoint."""
+	tensors = read(path)
+	meta = json.loads(bytes(tensors["meta/json"]).decode())
+
+	for name, param in net.namedParams().items():
+		key = "links/" + name
+		if key not in tensors:
+			raise KeyError("checkpoint %s has no parameter %s" % (path, name))
+		value = tensors["params/%d" % int(tensors[key])]
+		if value.shape != param.data.shape:
+			raise ValueError("parameter %s: checkpoint shape %s, network shape %s" % (name, value.shape, param.data.shape))
+		param.data.set(value.astype(np.float32, casting="safe", copy=False))
+	for name, attr in net.namedAttrs().items():
+		attr.set(tensors["attrs/" + name].astype(np.float32, casting="safe", copy=False))
+	for layer in net.walk():
+		if layer.kind == "bn":
+			layer.cfg["passes"] = int(meta["bn_passes"].get(layer.name, 0))
+
+	if optimizer is not None:
+		saved = meta.get("optimizer")
+		if saved is None or saved["rule"] != optimizer.rule or saved["flat"] != (optimizer.params is not None):
+			raise ValueError("checkpoint %s holds no matching optimizer state" % path)
+		if saved["flat"] and saved["order"] != list(optimizer.params.blocks.keys()):
+			raise ValueError("the flat arena is laid out differently from the checkpoint's")
+		optimizer.t = int(saved["t"])
+		for idx, (target, state) in enumerate(optimizer.targets):
+			for key, tensor in state.items():
+				tensor.set(tensors["optimizer/%d/%s" % (idx, key)])
+	return meta

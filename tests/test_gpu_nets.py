@@ -396,3 +396,51 @@ def test_nin_step_matches_oracle(bnd):
 	for name, p in net.namedParams().items():
 		ref = cnet.params[name]
 		assert_close(p.data.get(), ref, atol=5e-3 * (np.abs(ref).max() + 1e-8), rtol=5e-3, what="NiN param after the step " + name)
+
+
+def test_checkpoint_round_trip_continues_bit_for_bit(bnd, mini_golden, tmp_path):
+	"""Modules/Module.py:179-283 save / load (params + links + attrs) in the harness's container, plus optimizer state: train
+	2 steps, save, restore into a freshly built network + optimizer, train 2 more — equal to 4 uninterrupted steps bit for
+	bit (parameters, running statistics, Adam moments, batch-norm momentum schedule)."""
+	from puzzlelib_amd import nets, optim, checkpoint, backend
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	spec = miniSpec()
+	data, labels = gpuarray.to_gpu(mini_golden["data"]), gpuarray.to_gpu(mini_golden["labels"])
+	# (the adaptive policy switches a convolution's epilogue statistics on after its first pass — run-time state that is
+	# not part of a checkpoint and moves results by summation order only; pinned so that both runs round identically)
+	backend.DnnContext.convStatsPolicy = "always"
+
+	def fresh(seed):
+		np.random.seed(seed)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		opt = optim.Adam(alpha=1e-3)
+		opt.setupOn(net, useGlobalState=True)
+		return net, opt, optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=4)
+
+	net, opt, trainer = fresh(7)
+	for _ in range(2):
+		trainer.train(data, labels, random=False)
+	path = str(tmp_path / "mini.npz")
+	checkpoint.save(net, path, optimizer=opt)
+	for _ in range(2):
+		trainer.train(data, labels, random=False)
+	straight = {k: p.data.get() for k, p in net.namedParams().items()}
+	straight.update({k: a.get() for k, a in net.namedAttrs().items()})
+
+	tensors = checkpoint.read(path)
+	assert "links/conv1.W" in tensors and "attrs/bn_conv1.mean" in tensors and "optimizer/0/mg" in tensors
+	assert tensors["params/%d" % int(tensors["links/conv1.W"])].shape == (8, 3, 7, 7)
+
+	net2, opt2, trainer2 = fresh(99)                                     # different initial values: everything must come from the file
+	meta = checkpoint.load(net2, path, optimizer=opt2)
+	assert meta["optimizer"]["t"] == 2 and opt2.t == 2
+	for _ in range(2):
+		trainer2.train(data, labels, random=False)
+	resumed = {k: p.data.get() for k, p in net2.namedParams().items()}
+	resumed.update({k: a.get() for k, a in net2.namedAttrs().items()})
+	for key in straight:
+		assert np.array_equal(straight[key], resumed[key]), key
+
+	with pytest.raises(ValueError):
+		checkpoint.load(net2, path, optimizer=optim.MomentumSGD())
