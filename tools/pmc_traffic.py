@@ -1,12 +1,14 @@
-"""gpurun_out/pmc_bench/summary.json (tools/pmc_bench.sh) -> profiles/r01_hbm_traffic.json: HBM bytes per launch of every
+"""gpurun_out/pmc_bench/summary.json (tools/pmc_bench.sh) -> profiles/r02_hbm_traffic.json: HBM bytes per launch of every
 kernel of the bench, with the gfx950 corrections MI355X_MICROARCH.md prescribes, checked against the calibration streams
 of tools/pmc_calibrate.py (known byte counts).
 
-    python tools/pmc_traffic.py [gpurun_out/pmc_bench] [profiles/r01_hbm_traffic.json]
+    python tools/pmc_traffic.py [gpurun_out/pmc_bench] [profiles/r02_hbm_traffic.json]
 """
 import json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from puzzlelib_amd import lib            # (loads without a device) — the summary records which build it was taken from
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_bench")
 dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
 
@@ -46,8 +48,9 @@ steps = max([v["dispatches"] for k, v in kernels.items() if "OpAdam" in k] or [4
 total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kernels.values())
 out = {
 	"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 1 "
-			  "--no-cpu-baseline`, tools/pmc_bench.sh -> tools/pmc_traffic.py",
+			  "--no-cpu-baseline --no-extras`, tools/pmc_bench.sh -> tools/pmc_traffic.py",
 	"units": "counters are KiB; bytes = KiB*1024",
+	"build_id": lib.buildId(),
 	"calibration": {
 		"note": "tools/pmc_calibrate.py: 1 GiB-per-operand streams. FETCH_SIZE reads exactly 1/2 of the bytes of "
 				"16-B-per-lane streaming reads -> FETCH is doubled; WRITE_SIZE is exact",
