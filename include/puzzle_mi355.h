@@ -340,6 +340,11 @@ enum pz_eltwise_op {
 
 int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *scalars, int nscalars,
                int64_t start, int64_t stop, int64_t step, pz_stream_t stream);
+/* up to PZ_MULTI_ADD_MAX independent small `out = alpha*x + beta*y` (addKer, Cuda/Kernels/ElementWise.py:1017-1045) in one
+ * launch, one workgroup per job: the per-layer parameter-gradient accumulates of BatchNormND.accGradParams              */
+#define PZ_MULTI_ADD_MAX 96
+int pz_multi_add(int njobs, float *const *out, const float *const *x, const float *const *y, const float *alpha,
+                 const float *beta, const unsigned *n, pz_stream_t stream);
 int pz_cast_i32_f32(float *out, const int32_t *in, size_t count, pz_stream_t stream);
 int pz_cast_f32_i32(int32_t *out, const float *in, size_t count, pz_stream_t stream);
 

@@ -197,7 +197,43 @@ int launch(const EltArgs &a, int nptrs, int nscalars, int need_scalars, bool den
 
 }  // namespace
 
+// Many small `out = alpha*x + beta*y` in one launch (one workgroup per job): the 106 BatchNorm parameter-gradient
+// accumulates of a ResNet-50 step (Modules/BatchNormND.py:86-92: two addVectorToVector per layer) as two launches instead
+// of 106. Same expression, same file, same contraction as OpAdd.
+struct MultiAddJob {
+	float *out;
+	const float *x, *y;
+	float alpha, beta;
+	unsigned n, pad;
+};
+struct MultiAddArgs {
+	MultiAddJob job[PZ_MULTI_ADD_MAX];
+};
+
+__global__ void __launch_bounds__(256) multi_add_kernel(MultiAddArgs a) {
+	const MultiAddJob j = a.job[blockIdx.x];
+	for (unsigned i = threadIdx.x; i < j.n; i += 256) {
+		float v[3] = {0.f, j.x[i], j.y[i]};
+		const float s[2] = {j.alpha, j.beta};
+		v[0] = v[1] * s[0] + v[2] * s[1];
+		j.out[i] = v[0];
+	}
+}
+
 extern "C" {
+
+int pz_multi_add(int njobs, float *const *out, const float *const *x, const float *const *y, const float *alpha,
+                 const float *beta, const unsigned *n, pz_stream_t stream) {
+	PZ_REQUIRE(njobs >= 1 && njobs <= PZ_MULTI_ADD_MAX && out && x && y && alpha && beta && n, "pz_multi_add: bad arguments");
+	MultiAddArgs a{};
+	for (int i = 0; i < njobs; ++i) {
+		PZ_REQUIRE(out[i] && x[i] && y[i], "pz_multi_add: job %d has a null operand", i);
+		a.job[i] = MultiAddJob{out[i], x[i], y[i], alpha[i], beta[i], n[i], 0u};
+	}
+	multi_add_kernel<<<njobs, 256, 0, pz::as_stream(stream)>>>(a);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
 
 int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *scalars, int nscalars, int64_t start,
                int64_t stop, int64_t step, pz_stream_t stream) {

@@ -340,8 +340,9 @@ class HipReduceOps:
 	def markReady(self):
 		"""'final up to here' = an event on the compute stream plus one behind the filter-gradient stream, where the
 		gradients of this bucket were accumulated (DnnContext.filterGradStream)"""
-		from puzzlelib_amd import driver
+		from puzzlelib_amd import driver, lazy
 		from puzzlelib_amd.surface import bound
+		lazy.flushSmall()                             # queued small accumulates into the arena are part of "final"
 		event = driver.Event()
 		event.record(None)
 		return (event, bound().backend.dnn.sideEvent())

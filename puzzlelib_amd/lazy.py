@@ -47,10 +47,11 @@ def on(pattern):
 class State:
 	"""thunk: pending contents; deps: weak references to allocations whose thunk / facts derive from this one's contents;
 	meta: facts about the contents; wev / rev: [(event, stream, lo, hi)] — byte ranges a foreign stream still writes / reads"""
-	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base")
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small")
 
 	def __init__(self, base):
 		self.thunk, self.deps, self.meta, self.wev, self.rev, self.base = None, None, None, None, None, base
+		self.small = None         # [(lo, hi, written)] byte ranges that queued small adds (deferAdd) will write / read
 
 
 def stateOf(root):
@@ -163,6 +164,8 @@ def waitEvents(lz, read, stream, buf):
 
 def readBarrier(root, buf=None, stream=None):
 	lz = root.lz
+	if lz.small is not None:
+		touchSmall(lz, root if buf is None else buf, False)
 	if lz.thunk is not None:
 		settle(root)
 	if lz.wev is not None:
@@ -171,6 +174,8 @@ def readBarrier(root, buf=None, stream=None):
 
 def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
+	if lz.small is not None:
+		touchSmall(lz, root if buf is None else buf, True)
 	if lz.thunk is not None:
 		if whole:
 			lz.thunk = None
@@ -187,6 +192,62 @@ def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz.meta = None
 	if lz.wev is not None or lz.rev is not None:
 		waitEvents(lz, False, stream, root if buf is None else buf)
+
+
+# ---------------------------------------------------------------------------------------------- queued small adds
+# `out = alpha*x + beta*y` on a few hundred elements is all launch latency; a training step issues dozens of them back to
+# back (two per BatchNorm layer: Modules/BatchNormND.py:86-92). They are queued and run as ONE launch (pz_multi_add) as
+# soon as anybody touches bytes one of them writes, or writes bytes one of them reads — the barriers below check the byte
+# ranges — or when the queue is full. Operands are settled when the job is queued, so the launch itself needs no barrier.
+smallQueue = []          # (out, x, y, alpha, beta) in call order
+smallRoots = []          # allocations that carry ranges of queued jobs
+
+
+def deferAdd(out, x, y, alpha, beta):
+	ptrs = (out.wptr, x.rptr, y.rptr)                      # settles descriptions, waits for foreign streams — now
+	for ary, written in ((out, True), (x, False), (y, False)):
+		buf = ary.gpudata
+		root = buf.root
+		lz = stateOf(root)
+		if lz.small is None:
+			lz.small = []
+			smallRoots.append(root)
+		lo = buf.ptr - lz.base
+		lz.small.append((lo, lo + buf.size, written))
+	smallQueue.append((out, x, y, float(alpha), float(beta), ptrs))
+	count("small_add_queued")
+	if len(smallQueue) >= lib.MULTI_ADD_MAX:
+		flushSmall()
+
+
+def touchSmall(lz, buf, write):
+	lo = buf.ptr - lz.base
+	hi = lo + buf.size
+	for slo, shi, written in lz.small:
+		if slo < hi and lo < shi and (write or written):
+			flushSmall()
+			return
+
+
+def flushSmall():
+	global smallQueue, smallRoots
+	if not smallQueue:
+		return
+	jobs, smallQueue = smallQueue, []
+	for root in smallRoots:
+		if root.lz is not None:
+			root.lz.small = None
+	smallRoots = []
+
+	import ctypes
+	n = len(jobs)
+	P = ctypes.c_void_p * n
+	outs, xs, ys = P(*[j[5][0] for j in jobs]), P(*[j[5][1] for j in jobs]), P(*[j[5][2] for j in jobs])
+	alphas = (ctypes.c_float * n)(*[j[3] for j in jobs])
+	betas = (ctypes.c_float * n)(*[j[4] for j in jobs])
+	sizes = (ctypes.c_uint32 * n)(*[j[0].size for j in jobs])
+	lib.pz_multi_add(n, outs, xs, ys, alphas, betas, sizes, None)
+	count("small_add_launches")
 
 
 # ---------------------------------------------------------------------------------------------- foreign streams

@@ -171,6 +171,7 @@ _PROTOS = {
 	"pz_asum": [P, c_size_t, P, P],
 
 	"pz_eltwise": [c_int, c_size_t, PP, c_int, POINTER(c_float), c_int, c_int64, c_int64, c_int64, P],
+	"pz_multi_add": [c_int, PP, PP, PP, POINTER(c_float), POINTER(c_float), POINTER(c_uint32), P],
 	"pz_cast_i32_f32": [P, P, c_size_t, P],
 	"pz_cast_f32_i32": [P, P, c_size_t, P],
 
@@ -327,6 +328,7 @@ def sourceId():
 	return digest.hexdigest()[:16]
 
 COMM_ID_BYTES = 128
+MULTI_ADD_MAX = 96
 
 # element-wise op ids (enum pz_eltwise_op)
 (
