@@ -315,6 +315,8 @@ class DnnContext:
 		if nd == 3:
 			return conv3d.forward(self, data, W, bias, stride, pad, dilation, groups, algo, out, allocator)
 		requireF32(data, W, bias, out)
+		if lazy.held:
+			lazy.prune()             # tensors the filter-gradient stream has finished with go back to the pool
 
 		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
 		p, q = c_int(0), c_int(0)
