@@ -250,6 +250,7 @@ class DnnContext:
 	def __init__(self, backend):
 		self.backend = backend
 		self.statsWanted = set()
+		self.geometry = {}
 		self.sideStream = None
 		self.sideLaunches = 0
 
@@ -286,6 +287,24 @@ class DnnContext:
 		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
 
 
+	def convGeometry(self, desc, which, algo):
+		"""(P, Q, workspace bytes, statistics strips) of a convolution pass — host-side queries of the library, asked once
+		per (geometry, pass, algo): small networks are bound by the host's call rate (NiN: ~120 launches in 3 ms)."""
+		key = (which, algo) + tuple(getattr(desc, name) for name, _ in ConvDesc._fields_)
+		hit = self.geometry.get(key)
+		if hit is None:
+			p, q, size, strips = c_int(0), c_int(0), c_size_t(0), c_int(0)
+			lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
+			lib.pz_conv2d_workspace_bytes(byref(desc), which, algo, byref(size))
+			if which == lib.CONV_FWD:
+				lib.pz_conv2d_fwd_stats_strips(byref(desc), algo, byref(strips))
+			fold = c_int(0)
+			if which != lib.CONV_FWD:
+				lib.pz_conv2d_bn_fold_supported(byref(desc), algo, byref(fold))
+			hit = self.geometry[key] = (p.value, q.value, size.value, strips.value, bool(fold.value))
+		return hit
+
+
 	# ---- 1-D / 3-D convolutions on the 2-D core (Modules/ConvND.py:14-95 passes nd-tuples straight through)
 	@staticmethod
 	def lift(ary, nd):
@@ -319,33 +338,27 @@ class DnnContext:
 			lazy.prune()             # tensors the filter-gradient stream has finished with go back to the pool
 
 		desc = self.convDesc(data.shape, W.shape, stride, pad, dilation, groups)
-		p, q = c_int(0), c_int(0)
-		lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
-		outshape = (data.shape[0], W.shape[0], p.value, q.value)
+		algo = toAlgoId(algo)
+		p, q, wsbytes, nstrips, _ = self.convGeometry(desc, lib.CONV_FWD, algo)
+		outshape = (data.shape[0], W.shape[0], p, q)
 
 		given = out is not None
 		out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator) if out is None else out
 		if out.shape != outshape:
 			raise ValueError("conv output has shape %s, expected %s" % (out.shape, outshape))
 
-		algo = toAlgoId(algo)
-		size = c_size_t(0)
-		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_FWD, algo, byref(size))
-		ws = self.workspace(size.value, allocator)
+		ws = self.workspace(wsbytes, allocator)
 
 		key = W.gpudata.ptr
 		policy = DnnContext.convStatsPolicy
 		want = lazy.on("convstats") and not given and (policy == "always" or (policy == "adaptive" and key in self.statsWanted))
-		strips = c_int(0)
-		if want:
-			lib.pz_conv2d_fwd_stats_strips(byref(desc), algo, byref(strips))
 
-		if strips.value == 0:
-			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), size.value, None)
+		if not want or nstrips == 0:
+			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), wsbytes, None)
 		else:
-			stats = GPUArray.empty((W.shape[0], strips.value, 4), dtype=np.float32, allocator=allocator)
+			stats = GPUArray.empty((W.shape[0], nstrips, 4), dtype=np.float32, allocator=allocator)
 			lib.pz_conv2d_fwd_stats(
-				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), size.value, None
+				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), wsbytes, None
 			)
 			lazy.setFact(out, "convstats", stats)
 			lazy.count("conv_stats")
@@ -415,27 +428,23 @@ class DnnContext:
 			)
 
 		desc = self.convDesc(inshape, W.shape, stride, pad, dilation, groups)
-		p, q = c_int(0), c_int(0)
-		lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
-		if (p.value, q.value) != grad.shape[2:]:
-			raise ValueError("gradient maps %s do not match the convolution geometry %s" % (grad.shape[2:], (p.value, q.value)))
+		algo = toAlgoId(algo)
+		p, q, wsbytes, _, foldable = self.convGeometry(desc, lib.CONV_BWD_DATA, algo)
+		if (p, q) != grad.shape[2:]:
+			raise ValueError("gradient maps %s do not match the convolution geometry %s" % (grad.shape[2:], (p, q)))
 
 		out = GPUArray.empty(inshape, dtype=grad.dtype, allocator=allocator) if out is None else out
-
-		algo = toAlgoId(algo)
-		size = c_size_t(0)
-		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_DATA, algo, byref(size))
-		ws = self.workspace(size.value, allocator)
+		ws = self.workspace(wsbytes, allocator)
 
 		# the gradient is the un-written input gradient of a BatchNorm (fusion.BnBwdApply): evaluate it while gathering
 		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
-		if bn is not None and self.bnFoldSupported(desc, algo):
+		if bn is not None and foldable:
 			lib.pz_conv2d_bwd_data_bn(
-				byref(desc), bn.dy.rptr, bn.x.rptr, fusion.raw(bn.coef), W.rptr, out.optr, algo, rptrOf(ws), size.value, None
+				byref(desc), bn.dy.rptr, bn.x.rptr, fusion.raw(bn.coef), W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None
 			)
 			lazy.count("dgrad_bn_fold")
 		else:
-			lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), size.value, None)
+			lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None)
 
 		if bias is not None:           # deconvolution forward: bias over the produced maps, rows of the (n*maps, pixels) view
 			assert bias.size == out.shape[1]
@@ -505,9 +514,8 @@ class DnnContext:
 		wgrad = GPUArray.empty(W.shape, dtype=W.dtype, allocator=allocator) if wgrad is None else wgrad
 
 		algo = toAlgoId(algo)
-		size = c_size_t(0)
-		lib.pz_conv2d_workspace_bytes(byref(desc), lib.CONV_BWD_FILTER, algo, byref(size))
-		ws = self.workspace(size.value, allocator)
+		_, _, wsbytes, _, foldable = self.convGeometry(desc, lib.CONV_BWD_FILTER, algo)
+		ws = self.workspace(wsbytes, allocator)
 
 		bg = None
 		if withbias:
@@ -515,7 +523,7 @@ class DnnContext:
 
 		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
 		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
-		folded = bn is not None and not withbias and self.bnFoldSupported(desc, algo)
+		folded = bn is not None and not withbias and foldable
 
 		side = self.filterGradStream() if (not withbias or fused) else None
 		st = side.handle if side is not None else None
@@ -535,13 +543,13 @@ class DnnContext:
 		if folded:
 			lib.pz_conv2d_bwd_filter_bn(
 				byref(desc), rptrs[0], rptrs[1], rptrs[2], fusion.raw(bn.coef), wptrs[0], wcoef[0], wcoef[1], algo,
-				rptrOf(ws), size.value, st
+				rptrOf(ws), wsbytes, st
 			)
 			lazy.count("wgrad_bn_fold")
 		else:
 			lib.pz_conv2d_bwd_filter(
 				byref(desc), rptrs[0], rptrs[1], wptrs[0], wptrs[1] if fused else None, wcoef[0], wcoef[1], algo,
-				rptrOf(ws), size.value, st
+				rptrOf(ws), wsbytes, st
 			)
 
 		if side is not None:
@@ -677,9 +685,12 @@ class DnnContext:
 
 
 	def bnWorkspace(self, n, c, hw, allocator):
-		size = c_size_t(0)
-		lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
-		return GPUArray.empty((size.value, ), dtype=np.uint8, allocator=allocator), size.value
+		nbytes = self.geometry.get(("bn", n, c, hw))
+		if nbytes is None:
+			size = c_size_t(0)
+			lib.pz_bn_workspace_bytes(n, c, hw, byref(size))
+			nbytes = self.geometry[("bn", n, c, hw)] = size.value
+		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator), nbytes
 
 
 	@staticmethod

@@ -252,6 +252,12 @@ def flushSmall():
 
 # ---------------------------------------------------------------------------------------------- foreign streams
 held = deque()           # (event, objects) kept alive until the event has passed: memory a foreign stream still uses
+spare = []               # events ready for reuse (creating / destroying one per launch is two library calls too many)
+
+
+def newEvent():
+	from puzzlelib_amd.driver import Event
+	return spare.pop() if spare else Event()
 
 
 def prune(block=False):
@@ -264,14 +270,17 @@ def prune(block=False):
 			lib.pz_event_query(event.handle, lib.byref(done))
 			if not done.value:
 				break
-		held.popleft()
+		_, objects = held.popleft()
+		if len(spare) < 256:
+			# (a buffer may still list `event` as a past write: waiting for its next recording instead only waits longer)
+			spare.append(event)
+			spare.append(objects[0])              # the launch's `ready` event
 
 
 def foreignBegin(stream):
 	"""Everything issued on the main stream so far happens before what `stream` is given next."""
-	from puzzlelib_amd.driver import Event
 	prune()
-	ready = Event()
+	ready = newEvent()
 	ready.record(None)
 	stream.waitEvent(ready)
 	return ready
@@ -280,8 +289,7 @@ def foreignBegin(stream):
 def foreignEnd(stream, ready, reads=(), writes=(), keep=()):
 	"""Marks the buffers a foreign-stream launch touched with its completion event; the main stream waits for it when (and
 	only when) it touches them; the memory stays referenced until the event has passed."""
-	from puzzlelib_amd.driver import Event
-	done = Event()
+	done = newEvent()
 	done.record(stream)
 	for name, arrays in (("wev", writes), ("rev", reads)):
 		for ary in arrays:
