@@ -102,6 +102,15 @@ def spawnRanks(args):
 	sys.exit(max(codes))
 
 
+def oomEvents(lib):
+	"""allocations that found the device full (e.g. while the driver still reclaims a previous process's memory): each one
+	stalls the step it happens in — a non-zero count explains an outlier"""
+	import ctypes
+	count = ctypes.c_long(0)
+	lib.pz_pool_oom_events(ctypes.byref(count))
+	return count.value
+
+
 def timeSteps(step, n, lib, grid):
 	lib.pz_device_sync()
 	grid.barrier()
@@ -365,6 +374,7 @@ def main():
 		"pct_executed_note": "FLOP the matrix pipe actually executes per step: the 3x3 layers' Winograd kernels do 1/2.25 of "
 							 "their direct-convolution share; conv1's input gradient is executed and counted here",
 		"final_loss": loss,
+		"pool_out_of_memory_events": oomEvents(lib),
 		"backend_fusion_counts_total": fusion_counts,
 		"roofline": {
 			"kernel": FAMILY[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

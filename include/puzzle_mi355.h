@@ -58,6 +58,7 @@ int pz_pool_alloc(pz_pool_t pool, size_t nbytes, void **ptr);
 int pz_pool_release(pz_pool_t pool, void *ptr);
 int pz_pool_free_held(pz_pool_t pool);
 int pz_pool_stats(pz_pool_t pool, size_t *held_bytes, size_t *live_bytes, size_t *n_held, size_t *n_live);
+int pz_pool_oom_events(long *count);     /* how often an allocation hit "out of memory" (and waited / trimmed) in this process */
 int pz_host_alloc_pinned(void **h_ptr, size_t nbytes);
 int pz_host_free_pinned(void *h_ptr);
 
