@@ -230,7 +230,7 @@ def _bind(name, argtypes):
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
-	"pz_pool2d_out_shape", "pz_pool_oom_events", "pz_conv_profile_enable", "pz_conv_profile_collect", "pz_gemm_workspace_bytes"
+	"pz_pool2d_out_shape", "pz_pool_oom_events", "pz_gemm_workspace_bytes"
 }
 _fake = {"next": 0x7000_0000_0000}
 
