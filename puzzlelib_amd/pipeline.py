@@ -144,5 +144,7 @@ class HostStager:
 	def release(ticket):
 		"""Call after the last kernel reading the macro-batch was launched."""
 		slot, _ = ticket
+		from puzzlelib_amd import lazy
+		lazy.joinAll()                          # kernels on the filter-gradient stream may still read the macro-batch (conv1)
 		slot.consumed.record(None)
 		slot.everConsumed = True
