@@ -302,6 +302,12 @@ def main():
 		net.reset()
 		extras = sideConfigs(gpuarray, lib, optim, nets, bnd)
 
+	if nodeinfo is not None:                    # leave together: no rank tears its communicator down under a peer's collective
+		lib.pz_device_sync()
+		grid.barrier()
+		nodeinfo.close()
+		grid.barrier()
+
 	if rank != 0:
 		return
 
