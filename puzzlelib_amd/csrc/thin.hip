@@ -15,6 +15,10 @@
 // Work: 2*N*P*Q*K*C*R*S FLOP on the VALU (78 TFLOP/s of plain fp32 fma on 256 CUs); dy is read once from HBM.
 #include "common.h"
 
+#ifndef PZ_THIN_UNROLL
+#define PZ_THIN_UNROLL 2           // reduction channels in flight per thread: the window loads of two channels overlap
+#endif
+
 namespace {
 
 constexpr unsigned kOOB = 0xfffffff0u;
@@ -99,6 +103,7 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(const float *__restrict
 			for (int c = 0; c < C; ++c) acc[a][b][c] = 0.f;
 
 	constexpr int per_k = WR * WS * 4 * C;
+#pragma unroll PZ_THIN_UNROLL
 	for (int k = 0; k < K; ++k, soff += plane) {
 		float v[WR][WS];
 #pragma unroll
