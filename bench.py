@@ -111,6 +111,14 @@ def oomEvents(lib):
 	return count.value
 
 
+def driverAllocs(lib):
+	"""(pool misses served by hipMalloc, host seconds inside them) so far in this process"""
+	import ctypes
+	count, secs = ctypes.c_long(0), ctypes.c_double(0.0)
+	lib.pz_pool_driver_allocs(ctypes.byref(count), ctypes.byref(secs))
+	return count.value, secs.value
+
+
 def timeSteps(step, n, lib, grid):
 	lib.pz_device_sync()
 	grid.barrier()
@@ -236,12 +244,15 @@ def main():
 	grid.barrier()
 	lib.pz_conv_profile_enable(1)
 
+	allocs0 = driverAllocs(lib)
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
 		step()
+	issued = time.perf_counter() - t0
 	lib.pz_device_sync()
 	grid.barrier()
 	elapsed = time.perf_counter() - t0
+	allocs1 = driverAllocs(lib)
 
 	lib.pz_conv_profile_enable(0)
 	ms = (ctypes.c_double * NFAM)()
@@ -381,6 +392,12 @@ def main():
 							 "their direct-convolution share; conv1's input gradient is executed and counted here",
 		"final_loss": loss,
 		"pool_out_of_memory_events": oomEvents(lib),
+		"timed_region_host": {
+			"issue_ms_per_step": issued / args.steps * 1e3,
+			"driver_allocations": allocs1[0] - allocs0[0], "driver_allocation_ms": (allocs1[1] - allocs0[1]) * 1e3,
+			"note": "host time to issue the timed steps (no device wait inside), and pool misses that went to hipMalloc during "
+					"them: an outlier step time with normal kernel times shows up here",
+		},
 		"backend_fusion_counts_total": fusion_counts,
 		"roofline": {
 			"kernel": FAMILY[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -58,6 +58,7 @@ int pz_pool_alloc(pz_pool_t pool, size_t nbytes, void **ptr);
 int pz_pool_release(pz_pool_t pool, void *ptr);
 int pz_pool_free_held(pz_pool_t pool);
 int pz_pool_stats(pz_pool_t pool, size_t *held_bytes, size_t *live_bytes, size_t *n_held, size_t *n_live);
+int pz_pool_driver_allocs(long *count, double *seconds);   /* pool misses served by hipMalloc in this process, and the host time they took */
 int pz_pool_oom_events(long *count);     /* how often an allocation hit "out of memory" (and waited / trimmed) in this process */
 int pz_host_alloc_pinned(void **h_ptr, size_t nbytes);
 int pz_host_free_pinned(void *h_ptr);
@@ -122,6 +123,16 @@ int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, f
  * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue.         */
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
                          float alpha, float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
+/* How the matrix pipe multiplies the fp32 operands of the MFMA convolution / GEMM kernels (the counterpart of the
+ * reference's per-context math switches — cudnnSetConvolutionMathType in Cuda/Source/Libs/CuDnn.c, MIOpen picks its fp32
+ * solver itself): 0 = v_mfma_f32_32x32x2_f32; 6 or 9 = each fp32 operand is split exactly into three bf16 terms
+ * (8 + 8 + 8 significand bits) and the product is the sum of 6 / 9 exact bf16 partial products accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate on gfx950). 9 terms: a*b exactly; 6 terms: the three terms below
+ * 2^-23 |a||b| are left out. Inputs, outputs and accumulation stay fp32 in every mode. Process-wide; set it before
+ * querying workspace sizes (the packed-filter part of a workspace is 1.5x larger in the split modes).                */
+int pz_conv_math_set(int products);
+int pz_conv_math_get(int *products);
 
 /* Launch-level profiling of the convolution kernels (bench.py's roofline leg; the analogue of the reference's
  * Driver timing hooks, Cuda/GPUBackend.py:332-368): while enabled, every MFMA convolution launch is bracketed by

@@ -247,12 +247,29 @@ class DnnContext:
 	# (keyed by the filter's address); "always" / "never" pin it (tests).
 	convStatsPolicy = os.environ.get("PUZZLE_MI355_CONV_STATS", "adaptive")
 
+	# How the MFMA kernels multiply fp32 operands (include/puzzle_mi355.h, pz_conv_math_set): "f32" = the fp32 MFMA;
+	# "split6" / "split9" = exact 3-way bf16 split of every operand, 6 / 9 bf16 partial products, fp32 accumulation
+	MATH = {"f32": 0, "split6": 6, "split9": 9}
+	convMathDefault = os.environ.get("PUZZLE_MI355_MATH", "f32")
+
 	def __init__(self, backend):
 		self.backend = backend
 		self.statsWanted = set()
 		self.geometry = {}
 		self.sideStream = None
 		self.sideLaunches = 0
+		self.convMath = None
+		self.setConvMath(self.convMathDefault)
+
+
+	def setConvMath(self, name):
+		"""process-wide; workspace sizes depend on it, so the geometry cache starts over"""
+		if name not in self.MATH:
+			raise ValueError("PUZZLE_MI355_MATH / setConvMath: %r is not one of %s" % (name, sorted(self.MATH)))
+		lib.pz_conv_math_set(self.MATH[name])
+		self.geometry.clear()
+		self.convMath = name
+		return self
 
 
 	def enableTensorOps(self, _):

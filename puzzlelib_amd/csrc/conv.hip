@@ -19,6 +19,7 @@
 // Replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams — Hip/Wrappers/MIOpen.py:333-462.
 #include "common.h"
 
+#include <type_traits>
 #include <vector>
 
 // ablation switches for kernel experiments (tools/ablate.sh builds variant libraries); 0 = the shipped kernel
@@ -55,6 +56,17 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace pz {
+// How the matrix pipe multiplies fp32 operands (pz_conv_math_set): 0 = v_mfma_f32_32x32x2_f32; 6 / 9 = every fp32 operand
+// is split EXACTLY into three bf16 terms (24 significand bits = 8 + 8 + 8) when it is staged in LDS and the product runs as
+// 6 / 9 v_mfma_f32_32x32x16_bf16 partial products with fp32 accumulation (gfx950 issues bf16 MFMA FLOP at 16x the fp32
+// rate). Every partial product is exact in fp32; 9 terms reproduce a*b exactly, 6 leave out the three terms below
+// 2^-23 |a||b| — see DESIGN.md section 3.1e and tools/probes/split_probe.hip for the measured error next to the f32 MFMA.
+int g_conv_math = 0;
+int conv_math() { return g_conv_math; }
+}  // namespace pz
 
 namespace {
 
@@ -100,6 +112,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 	const int q = nblk / pz::kNumXCD, r = nblk % pz::kNumXCD;
 	const int xcd = bid % pz::kNumXCD, idx = bid / pz::kNumXCD;
 	return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- exact 3-way bf16 split of fp32 values: hi = RN_bf16(v), mid = RN_bf16(v - hi), lo = v - hi - mid. The two
+// subtractions are exact and lo fits 8 significand bits, so v == hi + mid + lo exactly, with |mid| <= 2^-8 |v| and
+// |lo| <= 2^-16 |v| (round-to-nearest keeps the terms small and their signs unbiased). Eight values -> three 16-byte
+// cells of 8 bf16 each, the operand fragment of one lane of v_mfma_f32_32x32x16_bf16. v_cvt_pk_bf16_f32 converts a pair.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3_cells(const float (&v)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+#pragma unroll
+	for (int q = 0; q < 4; ++q) {
+		const float a0 = v[2 * q], a1 = v[2 * q + 1];
+		const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a0, a1}, bf16x2));
+		const float r0 = a0 - __builtin_bit_cast(float, h << 16), r1 = a1 - __builtin_bit_cast(float, h & 0xffff0000u);
+		const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+		const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+		const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){s0, s1}, bf16x2));
+		hi[q] = h, mid[q] = m, lo[q] = l;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -160,6 +192,53 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
 				e = make_int2((ch * a.in_h * a.in_w + rr * a.dil_h * a.in_w + ss * a.dil_w) * 4, rs);
 			}
 			a.tab[kr] = e;
+		}
+	}
+}
+
+// The same filters for the split kernels (tap-major orders only): pre-split into bf16 terms and laid out as the 16-byte
+// operand cells the kernel copies straight into LDS — wp16[g][k-tile][term 0..2][k half 0..1][m] = 8 bf16 of row m at
+// k = 16 kt + 8 half + 0..7 (6 bytes per filter element instead of 4).
+__global__ void __launch_bounds__(256) pack_filter_split_kernel(PackArgs a) {
+	const int nkt = a.kred_pad / 16;
+	const long total = (long)a.groups * nkt * 2 * a.mpad;
+	const int RS = a.mode == 0 ? a.R * a.S : a.Rc * a.Sc;
+	const int Sx = a.mode == 0 ? a.S : a.Sc;
+	u32x4 *wp16 = reinterpret_cast<u32x4 *>(a.wp);
+
+	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+		const int m = (int)(i % a.mpad);
+		long t = i / a.mpad;
+		const int half = (int)(t & 1);
+		t >>= 1;
+		const int kt = (int)(t % nkt), g = (int)(t / nkt);
+
+		float v[8];
+#pragma unroll
+		for (int e = 0; e < 8; ++e) {
+			const int kr = kt * 16 + half * 8 + e;
+			v[e] = 0.f;
+			if (m < a.M && kr < a.kred) {
+				const int ch = kr % a.chans, rs = kr / a.chans;
+				const int rr = rs / Sx, ss = rs - rr * Sx;
+				if (a.mode == 0) {
+					v[e] = a.w[(((long)(g * a.Kg + m) * a.Cg + ch) * a.R + rr) * a.S + ss];
+				} else {
+					const int r = a.a_h + a.st_h * (a.Rc - 1 - rr), s = a.a_w + a.st_w * (a.Sc - 1 - ss);
+					v[e] = a.w[(((long)(g * a.Kg + ch) * a.Cg + m) * a.R + r) * a.S + s];
+				}
+			}
+		}
+		u32x4 hi, mid, lo;
+		split3_cells(v, hi, mid, lo);
+		const long cell = (((long)g * nkt + kt) * 6 + half) * a.mpad + m;
+		wp16[cell] = hi, wp16[cell + 2 * a.mpad] = mid, wp16[cell + 4 * a.mpad] = lo;
+
+		if (g == 0 && m == 0 && half == 0) {
+			const int kr = kt * 16;
+			const int ch = kr % a.chans, rs = kr / a.chans;
+			const int rr = rs / Sx, ss = rs - rr * Sx;
+			reinterpret_cast<int4 *>(a.tab)[kt] = make_int4((rr * a.dil_h * a.in_w + ss * a.dil_w) * 4, rs, ch * a.in_h * a.in_w * 4, 0);
 		}
 	}
 }
@@ -569,6 +648,244 @@ igemm_conv_kernel(IgemmArgs a) {
 		}
 	} else {
 		// partial accumulators of a tail slice: slab[(tail tile, slice)][register][thread] — coalesced 256-B rows
+		float *slab = a.slabs + ((size_t)(blockIdx.x - a.full_tiles) + (size_t)g * (gridDim.x - a.full_tiles)) * (BM * BN);
+#pragma unroll
+		for (int i = 0; i < TM; ++i)
+#pragma unroll
+			for (int j = 0; j < TN; ++j)
+#pragma unroll
+				for (int r = 0; r < 16; ++r) slab[((i * TN + j) * 16 + r) * NT + tid] = acc[i][j][r];
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same implicit GEMM on the bf16 matrix pipe: fp32 operands split exactly into three bf16 terms
+// ------------------------------------------------------------------------------------------------
+// Tap-major problems only (reduction channels in whole k-tiles). A k-tile of 16 is ONE v_mfma_f32_32x32x16_bf16 per
+// (partial product, 32x32 tile): LDS holds 16-byte cells [term][k half][row] = the 8 k-values one lane feeds, read back
+// with ds_read_b128 (12 reads for 6 * TM * TN MFMAs per wave). The filters arrive pre-split (pack_filter_split_kernel) and
+// are copied; the thread that gathers pixel column jb for k half kb0 holds exactly one cell's 8 values, splits them in
+// registers (split3_cells) and writes three cells — no transposition anywhere.
+// Pipeline: a k-tile's MFMAs last a third of the fp32 kernel's, so the gathers run TWO k-tiles ahead (two register
+// sets, the loop is unrolled by two so that they stay static): step t issues the gathers of tile t+2 and the filter
+// cells of tile t+1, runs the MFMAs of tile t out of LDS buffer t&1 and — in their shadow — splits tile t+1 into
+// buffer (t+1)&1. One barrier per k-tile.
+template <int BM, int BN, int WM, int WN, bool BNX, int NPROD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BM == 128 ? 3 : 2, 8)))
+igemm_split_kernel(IgemmArgs a) {
+	constexpr int BK = 16, NT = 256;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+	static_assert(NPROD == 6 || NPROD == 9, "6 or 9 partial products");
+
+	constexpr int kCells = 2 * 6 * (BM + BN);
+	static_assert(kCells * 4 >= WM * WN * kEpiFloatsPerWave, "epilogue scratch does not fit the operand tiles");
+	__shared__ u32x4 smem16[kCells];
+	u32x4(*As16)[6][BM] = reinterpret_cast<u32x4(*)[6][BM]>(smem16);                 // [buf][term * 2 + k half][row]
+	u32x4(*Bs16)[6][BN] = reinterpret_cast<u32x4(*)[6][BN]>(smem16 + 2 * 6 * BM);
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave / WN, wn = wave % WN;
+	const int g = blockIdx.z;
+
+	int L, kslice = -1;
+	if ((int)blockIdx.x < a.full_tiles) {
+		L = xcd_remap(blockIdx.x, a.full_tiles);
+	} else {
+		const int t = blockIdx.x - a.full_tiles;
+		L = a.full_tiles + t / a.tail_splits;
+		kslice = t % a.tail_splits;
+	}
+	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+
+	// ---- B (gathered pixels): this thread owns pixel column jb and NB consecutive reduction channels of every k-tile
+	constexpr int NB = BK * BN / NT, CB = NB / 8;           // 8 (one cell) or 16 (two cells)
+	static_assert(NB % 8 == 0, "a thread gathers whole operand cells");
+	const int jb = tid % BN;
+	const int kb0 = __builtin_amdgcn_readfirstlane(tid / BN);
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, a.wp_bytes, 0x00020000);
+
+	const int pix = tn * BN + jb;
+	unsigned long long tapmask = 0;
+	unsigned base_bytes = 0;
+	if (pix < a.npix) {
+		const int pq_sz = a.Pv * a.Qv;
+		const int n_img = pix / pq_sz;
+		const int pq = pix - n_img * pq_sz;
+		const int pp = pq / a.Qv, qq = pq - pp * a.Qv;
+		const int h0 = pp * a.vs_h - a.pad_h, w0 = qq * a.vs_w - a.pad_w;
+		for (int r = 0; r < a.R; ++r)
+			for (int t = 0; t < a.S; ++t) {
+				const bool ok = (unsigned)(h0 + r * a.dil_h) < (unsigned)a.H && (unsigned)(w0 + t * a.dil_w) < (unsigned)a.W;
+				tapmask |= (unsigned long long)ok << (r * a.S + t);
+			}
+		base_bytes = (unsigned)((((long)n_img * a.C_total + (long)g * a.Cg) * a.H + h0) * a.W + w0) * 4u;
+	}
+	const unsigned mask_lo = (unsigned)tapmask, mask_hi = (unsigned)(tapmask >> 32);
+	const unsigned hw4 = (unsigned)(a.H * a.W) * 4u;
+	const unsigned row_off = (unsigned)(kb0 * NB) * hw4;
+
+	// ---- A (pre-split filters): the 6 * BM cells of a k-tile in LDS order, cell f = (term * 2 + half) * BM + row
+	constexpr int NA = (6 * BM + NT - 1) / NT;
+	unsigned voffA[NA];
+#pragma unroll
+	for (int i = 0; i < NA; ++i) {
+		const int f = tid + i * NT;
+		voffA[i] = f < 6 * BM ? (unsigned)(((long)g * (a.kred_pad / BK) * 6 + f / BM) * a.mpad + tm * BM + f % BM) * 16u : kOOB;
+	}
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+	u32x4 ra[NA];
+	float rb[2][NB];
+	float rb2[2][BNX ? NB : 1];
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	const int nk_all = a.kred_pad / BK;
+	int kt0 = 0, kt1 = nk_all;
+	if (kslice >= 0) {
+		kt0 = (int)((long)nk_all * kslice / a.tail_splits);
+		kt1 = (int)((long)nk_all * (kslice + 1) / a.tail_splits);
+	}
+	const int kt_last = kt1 - 1;
+
+	auto issue_a = [&](int kt) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i)
+			ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[i], (unsigned)(kt * 6 * a.mpad) * 16u, 0));
+	};
+	auto issue_b = [&](int kt, float (&dst)[NB], float (&dst2)[BNX ? NB : 1]) {
+		const int4 t = reinterpret_cast<const int4 *>(a.tab)[kt];
+		const unsigned word = t.y < 32 ? mask_lo : mask_hi;
+		const unsigned voff = (word >> (t.y & 31)) & 1u ? base_bytes + (unsigned)t.x : kOOB;
+		const unsigned soff = (unsigned)t.z + row_off;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			dst[i] = buf_load_f32(xr, voff, soff + (unsigned)i * hw4);
+			if constexpr (BNX) dst2[i] = buf_load_f32(x2r, voff, soff + (unsigned)i * hw4);
+		}
+	};
+	auto store_a = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const int f = tid + i * NT;
+			if (6 * BM % NT == 0 || f < 6 * BM) (&As16[buf][0][0])[f] = ra[i];
+		}
+	};
+	// tile kt's gathers (BNX: through the BatchNorm backward of their channels) -> three terms -> LDS buffer buf
+	auto split_b = [&](int kt, const float (&src)[NB], const float (&src2)[BNX ? NB : 1], int buf) {
+		const int ch0 = g * a.Cg + (kt * BK) % a.Cg + kb0 * NB;       // BNX: channels of this thread's cells (wave-uniform)
+#pragma unroll
+		for (int c = 0; c < CB; ++c) {
+			float v[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				const int i = c * 8 + e;
+				if constexpr (BNX) {
+					const float4 co = a.xcoef[ch0 + i];
+					v[e] = __builtin_fmaf(co.x, src[i], __builtin_fmaf(co.y, src2[i], co.z));
+				} else {
+					v[e] = src[i];
+				}
+			}
+			u32x4 hi, mid, lo;
+#if PZ_ABL & 8          // ablation: no split arithmetic (timing only)
+			for (int q = 0; q < 4; ++q) hi[q] = __builtin_bit_cast(unsigned, v[q]), mid[q] = __builtin_bit_cast(unsigned, v[4 + q]), lo[q] = hi[q] ^ mid[q];
+#else
+			split3_cells(v, hi, mid, lo);
+#endif
+			const int half = kb0 * CB + c;
+#if PZ_ABL & 16         // ablation: one LDS store instead of three (timing only)
+			Bs16[buf][half][jb] = hi ^ mid ^ lo;
+#else
+			Bs16[buf][half][jb] = hi, Bs16[buf][2 + half][jb] = mid, Bs16[buf][4 + half][jb] = lo;
+#endif
+		}
+	};
+	auto mma_tile = [&](int buf) {
+		bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+		for (int t = 0; t < 3; ++t) {
+#pragma unroll
+			for (int i = 0; i < TM; ++i) fa[i][t] = __builtin_bit_cast(bf16x8, As16[buf][2 * t + lhi][wm * (32 * TM) + i * 32 + l31]);
+#pragma unroll
+			for (int j = 0; j < TN; ++j) fb[j][t] = __builtin_bit_cast(bf16x8, Bs16[buf][2 * t + lhi][wn * (32 * TN) + j * 32 + l31]);
+		}
+		// term orders 0 (hi*hi), 1, 2 (, 3, 4): the large terms' fragments are the first to arrive
+#pragma unroll
+		for (int order = 0; order <= (NPROD == 9 ? 4 : 2); ++order)
+#pragma unroll
+			for (int ta = 0; ta < 3; ++ta) {
+				const int tb = order - ta;
+				if (tb < 0 || tb > 2) continue;
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+#pragma unroll
+					for (int jj = 0; jj < TN; ++jj)
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[jj][tb], acc[i][jj], 0, 0, 0);
+			}
+	};
+	// one k-tile; SET = (kt - kt0) & 1 names the LDS buffer it computes from and the register set it refills
+	// (BNX gathers two tensors: with two sets in flight the kernel would not fit three waves per SIMD — it keeps one,
+	// filled at the start of a step and split at its end)
+	constexpr int AHEAD = BNX ? 1 : 2;
+	auto step = [&](auto set_tag, int kt) {
+		constexpr int SET = decltype(set_tag)::value;
+		constexpr int FILL = AHEAD == 2 ? SET : 0, DRAIN = AHEAD == 2 ? SET ^ 1 : 0;
+		const int kt_a = min(kt + 1, kt_last), kt_b = min(kt + AHEAD, kt_last);
+#if !(PZ_ABL & 1)
+#if !(PZ_ABL & 32)      // ablation: no filter loads / stores
+		issue_a(kt_a);
+#endif
+		issue_b(kt_b, rb[FILL], rb2[FILL]);
+#endif
+		mma_tile(SET);
+#if !(PZ_ABL & 1)
+		split_b(kt_a, rb[DRAIN], rb2[DRAIN], SET ^ 1);
+#if !(PZ_ABL & 32)
+		store_a(SET ^ 1);
+#endif
+#endif
+#if !(PZ_ABL & 2)
+		__syncthreads();
+#endif
+	};
+
+	issue_a(kt0);
+	issue_b(kt0, rb[0], rb2[0]);
+	if constexpr (AHEAD == 2) issue_b(min(kt0 + 1, kt_last), rb[1], rb2[1]);
+	split_b(kt0, rb[0], rb2[0], 0);
+	store_a(0);
+	__syncthreads();
+
+	int kt = kt0;
+	for (; kt + 1 < kt1; kt += 2) {
+		step(std::integral_constant<int, 0>{}, kt);
+		step(std::integral_constant<int, 1>{}, kt + 1);
+	}
+	if (kt < kt1) step(std::integral_constant<int, 0>{}, kt);
+
+	float *scratch = reinterpret_cast<float *>(smem16);
+	if (kslice < 0) {
+#if PZ_ABL & 256
+		a.y[(size_t)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15];
+		return;
+#endif
+		if (a.contig)         // (the last step's barrier: every wave is done reading the operand tiles)
+			igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, scratch);
+		else
+			igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+	} else {
 		float *slab = a.slabs + ((size_t)(blockIdx.x - a.full_tiles) + (size_t)g * (gridDim.x - a.full_tiles)) * (BM * BN);
 #pragma unroll
 		for (int i = 0; i < TM; ++i)
@@ -1137,11 +1454,14 @@ struct FwdPlan {
 	int bm, bn;                 // tile
 	int tiles_m, tiles_n, mpad, kred, kred_pad;
 	int full_tiles, tail_splits, blocks;     // tail balancing (see IgemmArgs)
+	int split;                               // 0, or the number of bf16 partial products (pz::g_conv_math) of a tap-major problem
 	size_t wp_bytes, tab_bytes, slab_bytes;
 };
 
-FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
+// chans = reduction channels per tap (the tap-major order needs them in whole k-tiles)
+FwdPlan plan_igemm(int M, int kred, long npix, int groups, int chans) {
 	FwdPlan p;
+	p.split = chans % 16 == 0 ? pz::g_conv_math : 0;
 	// 64 x 256 tiles when 64-row tiles pad the channel axis less than 128-row ones (M <= 64, 160, 192, 320, ...)
 	const bool narrow = M <= 64 || pz::ceil_div(M, 64) * 64 < pz::ceil_div(M, 128) * 128;
 	p.bm = narrow ? 64 : 128;
@@ -1155,7 +1475,7 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups) {
 	p.mpad = p.tiles_m * p.bm;
 	p.kred = kred;
 	p.kred_pad = pz::ceil_div(kred, 16) * 16;
-	p.wp_bytes = align256((size_t)groups * p.kred_pad * p.mpad * sizeof(float));
+	p.wp_bytes = align256((size_t)groups * p.kred_pad * p.mpad * (p.split ? 6 : 4));
 	p.tab_bytes = align256((size_t)p.kred_pad * sizeof(int2));
 
 	// The matrix pipes bound the kernel, so a launch takes ceil(tiles / #CU) tile-times: a last round that fills only
@@ -1209,12 +1529,26 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 		// profile bracket = the MFMA kernel alone (what rocprofv3 lists under its name); all of the launch's algorithmic
 		// FLOP are its work — the slab reduce of a k-sliced last round only adds
 		ProfScope prof(st, BM == 64 ? 1 : 0, flops);
+		if constexpr (WM * WN == 4) {
+			if (p.split) {
+				if (p.split == 6 && a.x2)
+					igemm_split_kernel<BM, BN, WM, WN, true, 6><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+				else if (p.split == 6)
+					igemm_split_kernel<BM, BN, WM, WN, false, 6><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+				else if (a.x2)
+					igemm_split_kernel<BM, BN, WM, WN, true, 9><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+				else
+					igemm_split_kernel<BM, BN, WM, WN, false, 9><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+				goto launched;
+			}
+		}
 		if (a.x2)
 			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else if (a.tapmajor)
 			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else
 			igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+	launched:;
 	}
 	if (p.tail_splits > 1)
 		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 64 * WM * WN, 0, st>>>(a);
@@ -1320,6 +1654,18 @@ bool uses_winograd(const pz_conv_desc *d, int which, int P, int Q, int algo) {
 
 extern "C" {
 
+int pz_conv_math_set(int products) {
+	PZ_REQUIRE(products == 0 || products == 6 || products == 9, "pz_conv_math_set: %d is not one of 0 (f32 MFMA), 6, 9 (bf16 partial products)", products);
+	pz::g_conv_math = products;
+	return PZ_OK;
+}
+
+int pz_conv_math_get(int *products) {
+	PZ_REQUIRE(products != nullptr, "pz_conv_math_get: null output");
+	*products = pz::g_conv_math;
+	return PZ_OK;
+}
+
 int pz_conv_profile_enable(int on) {
 	g_prof_on = on != 0;
 	return PZ_OK;
@@ -1372,7 +1718,7 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
 	if (which == PZ_CONV_FWD) {
-		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups);
+		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups, Cg);
 		*nbytes = p.wp_bytes + p.tab_bytes + p.slab_bytes;
 
 	} else if (which == PZ_CONV_BWD_DATA) {
@@ -1386,7 +1732,7 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 		const int nc = dgrad_classes(d, cls, &nz);
 		size_t total = 0;
 		for (int i = 0; i < nc; ++i) {
-			FwdPlan p = plan_igemm(Cg, Kg * cls[i].Rc * cls[i].Sc, (long)d->n * cls[i].Pv * cls[i].Qv, d->groups);
+			FwdPlan p = plan_igemm(Cg, Kg * cls[i].Rc * cls[i].Sc, (long)d->n * cls[i].Pv * cls[i].Qv, d->groups, Kg);
 			total += p.wp_bytes + p.tab_bytes + p.slab_bytes;
 		}
 		*nbytes = total;
@@ -1444,7 +1790,7 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
-	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups);
+	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups, Cg);
 
 	float *wp = (float *)workspace;
 	int2 *tab = (int2 *)((char *)workspace + p.wp_bytes);
@@ -1457,7 +1803,10 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = d->h, pa.in_w = d->w;
 	pa.tapmajor = Cg % 16 == 0, pa.chans = Cg;
 	const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
-	pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
+	if (p.split)
+		pack_filter_split_kernel<<<pz::stream_grid(ptotal / 8, 256), 256, 0, st>>>(pa);
+	else
+		pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
 	PZ_LAUNCH_CHECK();
 
 	IgemmArgs a{};
@@ -1468,7 +1817,7 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	a.vs_h = d->stride_h, a.vs_w = d->stride_w, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
 	a.R = d->r, a.S = d->s, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
 	a.x_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
-	a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
+	a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * (p.split ? 6 : 4));
 	a.y_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tapmajor = pa.tapmajor;
@@ -1560,7 +1909,7 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 	char *wsp = (char *)workspace;
 	for (int i = 0; i < nc; ++i) {
 		const DgradClass &c = cls[i];
-		FwdPlan p = plan_igemm(Cg, Kg * c.Rc * c.Sc, (long)d->n * c.Pv * c.Qv, d->groups);
+		FwdPlan p = plan_igemm(Cg, Kg * c.Rc * c.Sc, (long)d->n * c.Pv * c.Qv, d->groups, Kg);
 
 		float *wp = (float *)wsp;
 		wsp += p.wp_bytes;
@@ -1577,7 +1926,10 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = P, pa.in_w = Q;
 		pa.tapmajor = Kg % 16 == 0, pa.chans = Kg;
 		const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
-		pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
+		if (p.split)
+			pack_filter_split_kernel<<<pz::stream_grid(ptotal / 8, 256), 256, 0, st>>>(pa);
+		else
+			pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
 		PZ_LAUNCH_CHECK();
 
 		IgemmArgs a{};
@@ -1588,7 +1940,7 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		a.vs_h = 1, a.vs_w = 1, a.pad_h = c.pad_h, a.pad_w = c.pad_w;
 		a.R = c.Rc, a.S = c.Sc, a.dil_h = d->dil_h, a.dil_w = d->dil_w;
 		a.x_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
-		a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * 4);
+		a.wp_bytes = (unsigned)((size_t)d->groups * p.kred_pad * p.mpad * (p.split ? 6 : 4));
 		a.y_bytes = (unsigned)((size_t)d->n * d->c * d->h * d->w * 4);
 		a.OC_total = d->c, a.OH = d->h, a.OW = d->w;
 		a.os_h = d->stride_h, a.os_w = d->stride_w, a.oo_h = c.oo_h, a.oo_w = c.oo_w;

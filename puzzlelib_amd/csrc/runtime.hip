@@ -165,6 +165,14 @@ int pz_pool_destroy(pz_pool_t pool) {
 }
 
 static long g_pool_oom_events = 0;
+static long g_pool_driver_allocs = 0;          // pool misses: blocks fetched from the driver
+static double g_pool_driver_seconds = 0.0;     // host time spent inside those hipMalloc calls
+
+int pz_pool_driver_allocs(long *count, double *seconds) {
+	if (count) *count = g_pool_driver_allocs;
+	if (seconds) *seconds = g_pool_driver_seconds;
+	return PZ_OK;
+}
 
 int pz_pool_oom_events(long *count) {
 	PZ_REQUIRE(count != nullptr, "pz_pool_oom_events: null output");
@@ -187,7 +195,10 @@ int pz_pool_alloc(pz_pool_t pool, size_t nbytes, void **ptr) {
 		pool->held_bytes -= cls;
 		pool->n_held -= 1;
 	} else {
+		const auto t0 = std::chrono::steady_clock::now();
 		hipError_t e = hipMalloc(ptr, cls);
+		g_pool_driver_allocs += 1;
+		g_pool_driver_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 		if (e == hipErrorOutOfMemory) {
 			g_pool_oom_events += 1;
 			(void)hipGetLastError();

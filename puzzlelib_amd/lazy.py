@@ -253,6 +253,11 @@ def flushSmall():
 # ---------------------------------------------------------------------------------------------- foreign streams
 held = deque()           # (event, objects) kept alive until the event has passed: memory a foreign stream still uses
 spare = []               # events ready for reuse (creating / destroying one per launch is two library calls too many)
+# The host issues a step faster than the device runs it, and what a foreign-stream launch reads (activations, gradients,
+# its workspace) stays allocated until the device has passed it: without a bound the footprint grows with the host's
+# lead and differs from step to step, so the pool keeps missing (measured: 60-70 hipMalloc calls, 25-30 ms of host time,
+# per ResNet-50 step). The host therefore waits once more than this many foreign launches are outstanding.
+maxHeld = int(os.environ.get("PUZZLE_MI355_MAX_FOREIGN", "12"))
 
 
 def newEvent():
@@ -302,6 +307,9 @@ def foreignEnd(stream, ready, reads=(), writes=(), keep=()):
 			entries.append((done, stream, lo, lo + buf.size))
 			setattr(lz, name, entries)
 	held.append((done, (ready, tuple(reads), tuple(writes), tuple(keep))))
+	if len(held) > maxHeld:
+		held[0][0].synchronize()
+		prune()
 	return done
 
 

@@ -80,6 +80,7 @@ _PROTOS = {
 	"pz_pool_free_held": [P],
 	"pz_pool_stats": [P, POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t), POINTER(c_size_t)],
 	"pz_pool_oom_events": [POINTER(ctypes.c_long)],
+	"pz_pool_driver_allocs": [POINTER(ctypes.c_long), POINTER(ctypes.c_double)],
 	"pz_host_alloc_pinned": [PP, c_size_t],
 	"pz_host_free_pinned": [P],
 
@@ -110,6 +111,8 @@ _PROTOS = {
 	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 
 	"pz_conv2d_algo_used": [POINTER(ConvDesc), c_int, c_int, POINTER(c_int)],
+	"pz_conv_math_set": [c_int],
+	"pz_conv_math_get": [POINTER(c_int)],
 	"pz_conv_profile_enable": [c_int],
 	"pz_conv_profile_collect": [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_longlong)],
 
@@ -230,7 +233,7 @@ def _bind(name, argtypes):
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
-	"pz_pool2d_out_shape", "pz_pool_oom_events", "pz_gemm_workspace_bytes"
+	"pz_pool2d_out_shape", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get"
 }
 _fake = {"next": 0x7000_0000_0000}
 

@@ -14,15 +14,16 @@ PASS=${PASS:-fwd}
 if [ "$1" = "build" ]; then
 	[ -n "$ONLY" ] && { build $ONLY $FLAGS; exit 0; }
 	build base
-	build noload -DPZ_ABL=9
-	build noload_nobar -DPZ_ABL=27
-	build loadonly -DPZ_ABL=32
-	build storeonly -DPZ_ABL=64
-	build nearloads -DPZ_ABL=128
+	build noload -DPZ_ABL=1
+	build nosplit -DPZ_ABL=8
+	build onestore -DPZ_ABL=16
+	build nosplit_onestore -DPZ_ABL=24
+	build nofilter -DPZ_ABL=32
+	build noslp -fno-slp-vectorize
 	ls -la puzzlelib_amd/variants/*.so
 else
-	for v in ${VARIANTS:-base noload noload_nobar loadonly storeonly nearloads}; do
-		for layer in 2 6 12; do
+	for v in ${VARIANTS:-base noload nosplit onestore nosplit_onestore nofilter noslp}; do
+		for layer in ${LAYERS:-3 12 14}; do
 			echo "== $v layer $layer"
 			PUZZLE_MI355_LIB=$PWD/puzzlelib_amd/variants/lib_$v.so python tools/conv_census.py --only $layer --passes $PASS --reps 5 | sed -n 2p
 		done
