@@ -1273,6 +1273,233 @@ wgrad_conv_kernel(WgradArgs a) {
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward-filter of pointwise (1x1, stride 1, pad 0) convolutions on the bf16 matrix pipe (split operands)
+// ------------------------------------------------------------------------------------------------
+// dw[k][c] = sum over (image, pixel) dy[n][k][pix] * x[n][c][pix]: both operands are rows of contiguous pixels, and the
+// reduction index is the pixel — exactly the k axis of a v_mfma_f32_32x32x16_bf16 fragment (8 consecutive k per lane). An
+// image plane is walked in CELLS of 8 consecutive pixels (the last cell of a plane is masked in operand B); a thread loads
+// one cell (2 x 16 bytes) of one row per operand, splits it into three bf16 cells (split3_cells) and parks them in LDS as
+// [term][cell of the k-step][row]; a k-step is 2 cells = 16 pixels = one MFMA per (partial product, 32x32 tile).
+// Split along the reduction like wgrad_conv_kernel (slabs + wgrad_reduce_kernel); a.steps_* count k-steps of 2 cells,
+// a.npix = cells in the tensor, a.Q4 = cells per plane (magic_q4 its multiply-high reciprocal).
+#ifndef PZ_WGS_BNX_AHEAD
+#define PZ_WGS_BNX_AHEAD 2
+#endif
+template <int BM, int BN, int WM, int WN, bool BNX, int NPROD>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BNX && PZ_WGS_BNX_AHEAD == 2 ? 2 : 3, 8)))
+wgrad_split_kernel(WgradArgs a) {
+	constexpr int NT = 256;
+	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+	static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+	constexpr int NA = (BM + 127) / 128, NB = (BN + 127) / 128;        // cells per thread and operand
+
+	// [buf][term][cell][row]; the row pitch of BM + 2 cells spreads the (2 rows x 2 cells) x 2 a group of 8 lanes writes
+	__shared__ u32x4 As16[2][3][2][BM + 2];
+	__shared__ u32x4 Bs16[2][3][2][BN + 2];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave / WN, wn = wave % WN;
+	const int g = blockIdx.z;
+
+	const int ntiles = a.tiles_m * a.tiles_n;
+	const int B = xcd_remap(blockIdx.x, gridDim.x);
+	const int split = B / ntiles, L = B - split * ntiles;
+	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+
+	const int cell = tid & 1, row0 = tid >> 1;
+	const int PQ = a.P * a.Q;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)a.dy, 0, a.dy_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t bnr = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.bnx : a.dy), 0, a.dy_bytes, 0x00020000);
+
+	// rows of this thread (fixed for the whole kernel): byte offsets of (row, pixel 0) inside image 0, or out of range
+	unsigned rowA[NA], rowB[NB];
+	float4 bnc[BNX ? NA : 1];
+#pragma unroll
+	for (int i = 0; i < NA; ++i) {
+		const int r = row0 + 128 * i, m = tm * BM + r;
+		rowA[i] = (r < BM && m < a.Kg) ? (unsigned)(g * a.Kg + m) * (unsigned)PQ * 4u : kOOB;
+		if constexpr (BNX) bnc[i] = a.bncoef[g * a.Kg + min(m, a.Kg - 1)];
+	}
+#pragma unroll
+	for (int i = 0; i < NB; ++i) {
+		const int r = row0 + 128 * i, c = tn * BN + r;
+		rowB[i] = (r < BN && c < a.Cg) ? (unsigned)(g * a.Cg + c) * (unsigned)PQ * 4u : kOOB;
+	}
+
+	f32x16 acc[TM][TN];
+#pragma unroll
+	for (int i = 0; i < TM; ++i)
+#pragma unroll
+		for (int j = 0; j < TN; ++j)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+	constexpr int AHEAD = BNX ? PZ_WGS_BNX_AHEAD : 2;
+	f32x4 ra[AHEAD][NA][2], rb[AHEAD][NB][2], ra2[AHEAD][BNX ? NA : 1][2];
+	int nvalid[AHEAD];            // real pixels in this thread's cell of the step a set holds (0..8)
+	const int l31 = lane & 31, lhi = lane >> 5;
+
+	// global loads of k-step `step` into register set `set`
+	auto issue = [&](int step, int set) {
+		const unsigned u = (unsigned)(step * 2 + cell);
+		unsigned img_dy = kOOB, img_x = kOOB;
+		nvalid[set] = 0;
+		if (u < (unsigned)a.npix) {
+			const unsigned n_img = a.Q4 == 1u ? u : __umulhi(u, a.magic_q4), c = u - n_img * a.Q4;
+			const unsigned pix = c * 8u;
+			nvalid[set] = min(8, PQ - (int)pix);
+			img_dy = (n_img * (unsigned)a.K_total * (unsigned)PQ + pix) * 4u;
+			img_x = (n_img * (unsigned)a.C_total * (unsigned)PQ + pix) * 4u;
+		}
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			const unsigned off = (img_dy != kOOB && rowA[i] != kOOB) ? img_dy + rowA[i] : kOOB;
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				ra[set][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyr, off, 16 * h, 0));
+				if constexpr (BNX) ra2[set][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bnr, off, 16 * h, 0));
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const unsigned off = (img_x != kOOB && rowB[i] != kOOB) ? img_x + rowB[i] : kOOB;
+#pragma unroll
+			for (int h = 0; h < 2; ++h) rb[set][i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 16 * h, 0));
+		}
+	};
+
+	// register set -> three bf16 terms -> LDS buffer
+	auto park = [&](int set, int buf) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) {
+			float v[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				v[e] = ra[set][i][e >> 2][e & 3];
+				if constexpr (BNX) v[e] = __builtin_fmaf(bnc[i].x, v[e], __builtin_fmaf(bnc[i].y, (float)ra2[set][i][e >> 2][e & 3], bnc[i].z));
+			}
+			u32x4 hi, mid, lo;
+#if PZ_ABL & 2048       // ablation: no split arithmetic
+			for (int q = 0; q < 4; ++q) hi[q] = __builtin_bit_cast(unsigned, v[q]), mid[q] = __builtin_bit_cast(unsigned, v[4 + q]), lo[q] = hi[q] ^ mid[q];
+#else
+			split3_cells(v, hi, mid, lo);
+#endif
+			const int r = row0 + 128 * i;
+#if PZ_ABL & 1024       // ablation: one LDS store per cell
+			if (BM % 128 == 0 || r < BM) As16[buf][0][cell][r] = hi ^ mid ^ lo;
+#else
+			if (BM % 128 == 0 || r < BM) As16[buf][0][cell][r] = hi, As16[buf][1][cell][r] = mid, As16[buf][2][cell][r] = lo;
+#endif
+		}
+		// the last cell of an image plane is shorter than 8 pixels: its tail reads the next plane (or nothing) and is
+		// zeroed in operand B. Rare (one k-step in PQ/16), so the masking sits behind a wave-uniform test.
+		const bool ragged = __builtin_amdgcn_ballot_w64(nvalid[set] < 8) != 0ull;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			float v[8];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) v[e] = rb[set][i][e >> 2][e & 3];
+			if (ragged) {
+#pragma unroll
+				for (int e = 0; e < 8; ++e) v[e] = e < nvalid[set] ? v[e] : 0.f;
+			}
+			u32x4 hi, mid, lo;
+			split3_cells(v, hi, mid, lo);
+			const int r = row0 + 128 * i;
+			if (BN % 128 == 0 || r < BN) Bs16[buf][0][cell][r] = hi, Bs16[buf][1][cell][r] = mid, Bs16[buf][2][cell][r] = lo;
+		}
+	};
+
+	auto mma_step = [&](int buf) {
+		bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+		for (int t = 0; t < 3; ++t) {
+#pragma unroll
+			for (int i = 0; i < TM; ++i) fa[i][t] = __builtin_bit_cast(bf16x8, As16[buf][t][lhi][wm * (32 * TM) + i * 32 + l31]);
+#pragma unroll
+			for (int j = 0; j < TN; ++j) fb[j][t] = __builtin_bit_cast(bf16x8, Bs16[buf][t][lhi][wn * (32 * TN) + j * 32 + l31]);
+		}
+#pragma unroll
+		for (int order = 0; order <= (NPROD == 9 ? 4 : 2); ++order)
+#pragma unroll
+			for (int ta = 0; ta < 3; ++ta) {
+				const int tb = order - ta;
+				if (tb < 0 || tb > 2) continue;
+#pragma unroll
+				for (int i = 0; i < TM; ++i)
+#pragma unroll
+					for (int jj = 0; jj < TN; ++jj)
+#if PZ_ABL & 512        // ablation: no MFMA (a VALU op keeps the fragments alive)
+						acc[i][jj][0] += (float)fa[i][ta][0] * (float)fb[jj][tb][0];
+#elif PZ_ABL & 8192     // ablation: fp32 MFMAs of the same count / twice the pipe time in place of the bf16 ones
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)fa[i][ta][0], (float)fb[jj][tb][0], acc[i][jj], 0, 0, 0);
+#elif PZ_ABL & 16384    // ablation: the small bf16 MFMA shape
+						{
+							typedef float f32x4_ __attribute__((ext_vector_type(4)));
+							f32x4_ t4 = {acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]};
+							t4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ta], fb[jj][tb], t4, 0, 0, 0);
+							acc[i][jj][0] = t4[0], acc[i][jj][1] = t4[1], acc[i][jj][2] = t4[2], acc[i][jj][3] = t4[3];
+						}
+#else
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[jj][tb], acc[i][jj], 0, 0, 0);
+#endif
+			}
+	};
+
+	const int s_begin = split * a.steps_per_split;
+	const int s_end = min(s_begin + a.steps_per_split, a.steps_total);
+
+	// steps past s_end address cells beyond this split's range: they are loaded (harmless, the next split's data or
+	// nothing) but never multiplied
+	auto step_fn = [&](auto par_tag, int step) {
+		constexpr int PAR = decltype(par_tag)::value;
+		constexpr int FILL = AHEAD == 2 ? PAR : 0, DRAIN = AHEAD == 2 ? PAR ^ 1 : 0;
+		issue(step + AHEAD, FILL);
+		mma_step(PAR);
+		park(DRAIN, PAR ^ 1);
+		__syncthreads();
+	};
+
+	if (s_begin < s_end) {
+		issue(s_begin, 0);
+		if constexpr (AHEAD == 2) issue(s_begin + 1, 1);
+		park(0, 0);
+		__syncthreads();
+		int step = s_begin;
+		for (; step + 1 < s_end; step += 2) {
+			step_fn(std::integral_constant<int, 0>{}, step);
+			step_fn(std::integral_constant<int, 1>{}, step + 1);
+		}
+		if (step < s_end) step_fn(std::integral_constant<int, 0>{}, step);
+	}
+
+	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
+#pragma unroll
+	for (int j = 0; j < TN; ++j) {
+		const int col = tn * BN + wn * (32 * TN) + j * 32 + l31;
+		if (col >= a.ncrs) continue;
+#pragma unroll
+		for (int i = 0; i < TM; ++i) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				const int m = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+				if (m < a.Kg) {
+					float *o = outb + (size_t)m * a.ncrs + col;
+					const float v = acc[i][j][r];
+					if (a.direct)
+						*o = (a.beta == 0.f ? 0.f : a.beta * *o) + a.alpha * v;
+					else
+						*o = v;
+				}
+			}
+		}
+	}
+}
+
 // dw = beta*dw + alpha * sum_s slab[s]   (fixed summation order -> deterministic). 16 bytes per lane and four slabs in
 // flight per step: the launch is latency-, not bandwidth-bound (tens of MB), so independent wide loads are what counts.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
@@ -1641,6 +1868,38 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	return p;
 }
 
+// Which backward-filter problems take wgrad_split_kernel in a split math mode: pointwise, unit stride, and at least 128
+// channels on both sides — with 64 the layer is bound by HBM (55x55 maps), and the fp32 kernel's 128-byte row pieces move
+// the bytes faster than the split kernel's 64-byte ones (measured 0.30 vs 0.36-0.39 ms on the three stage-2 shapes).
+bool wgrad_split_eligible(const pz_conv_desc *d) {
+	return pz::g_conv_math != 0 && d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1 &&
+	       d->k / d->groups >= 128 && d->c / d->groups >= 128;
+}
+
+// k-steps of 2 cells = 16 pixels of an image plane
+WgradPlan plan_wgrad_split(const pz_conv_desc *d, int P, int Q) {
+	WgradPlan p;
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	p.ncrs = Cg;
+	p.bm = p.bn = 128;
+	p.tiles_m = pz::ceil_div(Kg, p.bm);
+	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
+	p.ncrs_pad = p.tiles_n * p.bn;
+	const long cells = (long)d->n * pz::ceil_div(P * Q, 8);
+	p.steps_total = (int)pz::ceil_div(cells, 2);
+
+	const int tiles = p.tiles_m * p.tiles_n * d->groups;
+	int splits = 3 * pz::kNumCU / tiles;                           // three workgroups fit a CU (LDS, registers): one balanced round
+	const int max_by_work = p.steps_total / 16 > 0 ? p.steps_total / 16 : 1;   // >= 16 k-steps (256 pixels) per split
+	if (splits > max_by_work) splits = max_by_work;
+	if (splits < 1) splits = 1;
+	p.steps_per_split = pz::ceil_div(p.steps_total, splits);
+	p.splits = pz::ceil_div(p.steps_total, p.steps_per_split);
+	p.tab_bytes = 0;
+	p.slab_elems = (size_t)d->groups * Kg * p.ncrs;
+	return p;
+}
+
 // the Winograd F(2x2, 3x3) path (wino.hip) serves the 3x3 / stride-1 forward and backward-data passes: always when asked
 // for by name, and by default from 32 channels on either side (1.6-1.8x the implicit GEMM on every 3x3 layer of the
 // ResNet-50 census, tools/wino_check.py; below that the 64-channel workgroup block is mostly padding)
@@ -1738,7 +1997,7 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 		*nbytes = total;
 
 	} else if (which == PZ_CONV_BWD_FILTER) {
-		WgradPlan p = plan_wgrad(d, P, Q);
+		WgradPlan p = wgrad_split_eligible(d) ? plan_wgrad_split(d, P, Q) : plan_wgrad(d, P, Q);
 		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0) +
 		          align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float));       // bias-gradient partials
 
@@ -2013,15 +2272,18 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 		return pz::wino_wgrad(d, P, Q, x, dy, dw, alpha, beta, workspace, st);
 	}
 
-	WgradPlan p = plan_wgrad(d, P, Q);
+	const bool split_math = wgrad_split_eligible(d);
+	WgradPlan p = split_math ? plan_wgrad_split(d, P, Q) : plan_wgrad(d, P, Q);
 	const size_t need = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0);   // (+ bias partials, optional)
-	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_filter: workspace %zu < required %zu bytes", ws_bytes, need);
+	PZ_REQUIRE((workspace != nullptr || need == 0) && ws_bytes >= need, "pz_conv2d_bwd_filter: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	int2 *tab = (int2 *)workspace;
 	float *slabs = (float *)((char *)workspace + p.tab_bytes);
 
-	build_tab_kernel<<<pz::ceil_div(p.ncrs_pad, 256), 256, 0, st>>>(tab, p.ncrs, p.ncrs_pad, d->r, d->s, d->dil_h, d->dil_w, d->h, d->w);
-	PZ_LAUNCH_CHECK();
+	if (!split_math) {
+		build_tab_kernel<<<pz::ceil_div(p.ncrs_pad, 256), 256, 0, st>>>(tab, p.ncrs, p.ncrs_pad, d->r, d->s, d->dil_h, d->dil_w, d->h, d->w);
+		PZ_LAUNCH_CHECK();
+	}
 
 	WgradArgs a{};
 	a.x = x, a.dy = dy, a.tab = tab;
@@ -2044,7 +2306,20 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	a.bnx = bnx, a.bncoef = reinterpret_cast<const float4 *>(bncoef);
 
 	dim3 grid(p.tiles_m * p.tiles_n * p.splits, 1, d->groups);
-	{
+	if (split_math) {
+		// cells of 8 pixels of an image plane instead of runs of 4 pixels of a row
+		const unsigned cpp = (unsigned)pz::ceil_div(P * Q, 8);
+		a.npix = (int)(d->n * cpp), a.Q4 = cpp;
+		a.magic_q4 = (unsigned)((((unsigned long long)1 << 32) + cpp - 1) / cpp);
+		ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg);
+#define PZ_WGRAD_SPLIT(BM_, BN_, WM_, WN_) \
+		(pz::g_conv_math == 6 ? (a.bnx ? wgrad_split_kernel<BM_, BN_, WM_, WN_, true, 6><<<grid, 256, 0, st>>>(a)   \
+		                               : wgrad_split_kernel<BM_, BN_, WM_, WN_, false, 6><<<grid, 256, 0, st>>>(a)) \
+		                      : (a.bnx ? wgrad_split_kernel<BM_, BN_, WM_, WN_, true, 9><<<grid, 256, 0, st>>>(a)   \
+		                               : wgrad_split_kernel<BM_, BN_, WM_, WN_, false, 9><<<grid, 256, 0, st>>>(a)))
+		PZ_WGRAD_SPLIT(128, 128, 2, 2);          // wgrad_split_eligible: both sides fill 128-row tiles
+#undef PZ_WGRAD_SPLIT
+	} else {
 	ProfScope prof(st, 2, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
 	const bool unit_w = d->stride_w == 1;
 	const bool pointwise = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && unit_w;

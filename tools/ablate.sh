@@ -14,6 +14,9 @@ PASS=${PASS:-fwd}
 if [ "$1" = "build" ]; then
 	[ -n "$ONLY" ] && { build $ONLY $FLAGS; exit 0; }
 	build base
+	build wg_nomfma -DPZ_ABL=512
+	build wg_onestore -DPZ_ABL=1024
+	build wg_nosplit -DPZ_ABL=2048
 	build noload -DPZ_ABL=1
 	build nosplit -DPZ_ABL=8
 	build onestore -DPZ_ABL=16
