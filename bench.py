@@ -308,6 +308,29 @@ def main():
 													   "means to, Containers/Sequential.py:215-218 is unreachable)"},
 		}
 
+	# the same steps with the MFMA kernels in a split math mode (backend.DnnContext.MATH; off by default: `value` is
+	# the fp32-MFMA path unless PUZZLE_MI355_MATH says otherwise)
+	mathModes = None
+	if not args.no_extras:
+		current = bnd.dnn.convMath
+		mathModes = {"value_measured_with": current}
+		for mode in ("f32", "split6", "split9"):
+			if mode == current:
+				continue
+			bnd.dnn.setConvMath(mode)
+			step(); step()
+			t_mode = timeSteps(step, n, lib, grid) / n
+			mathModes[mode] = {"images_per_sec": world * args.batch / t_mode, "ms_per_step": t_mode * 1e3}
+		bnd.dnn.setConvMath(current)
+		step()
+		mathModes["what"] = (
+			"f32 = v_mfma_f32_32x32x2_f32. split6 / split9 = every fp32 operand of the 1x1 convolutions (forward, backward-data, "
+			"backward-filter of >= 128-channel layers) split exactly into three bf16 terms, 6 / 9 partial products on "
+			"v_mfma_f32_32x32x16_bf16, fp32 accumulation; inputs, outputs and every other kernel unchanged; error against "
+			"float64 equal to the fp32 MFMA's (tools/probes/split_probe.hip, tools/split_wgrad_check.py, DESIGN.md 3.1e). "
+			"Split modes run on one stream (no filter-gradient overlap)."
+		)
+
 	extras = None
 	if rank == 0 and world == 1 and not args.no_extras and args.batch == BATCH:
 		net.reset()
@@ -370,7 +393,7 @@ def main():
 		"metric": "images/sec fwd+bwd+Adam ResNet-50 224x224 fp32 b256 per GPU", "value": images_per_sec,
 		"unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
 		"ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-		"dtype": "f32", "data": "synthetic",
+		"dtype": "f32", "data": "synthetic", "math": bnd.dnn.convMath,
 		"config": {
 			"workload": "ResNet-50 (PuzzleLib variant, 55x55 stage 2) synthetic ImageNet 224x224 fp32, batch %d per GPU, "
 						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True), reference-literal "
@@ -413,6 +436,8 @@ def main():
 	}
 	if dropin is not None:
 		result["dropin"] = dropin
+	if mathModes is not None:
+		result["math_modes"] = mathModes
 	if extras is not None:
 		result["configs"] = extras
 
