@@ -479,10 +479,10 @@ class DnnContext:
 	# the optimizer, `.get()`, the all-reduce or the next step's zero fill wait for it when they touch the gradient arena,
 	# and the tensors the side stream reads stay referenced (and guarded against overwrites) until the event has passed.
 	def filterGradStream(self):
-		# Split modes run everything on ONE stream: a kernel issuing v_mfma_*_bf16 next to another of this library's kernels
-		# on the same CUs made the latter's packed-fp32 code (v_pk_*_f32 from the SLP pass) return wrong sums in a few
-		# workgroups per launch — reproducible with tools/concurrency_check.py, not with fp32 MFMAs in the same kernel, not
-		# on an idle chip. Until that is understood, nothing of ours overlaps in these modes.
+		# The split modes run everything on ONE stream: on gfx950 a packed-fp32 instruction whose low lane reads the high
+		# half of a source (v_pk_mul_f32 ... op_sel:[0,1] — hipcc's SLP pass emits them all over the BatchNorm / element-wise
+		# kernels) returns a wrong low lane while another wave of the SIMD executes a bf16 MFMA
+		# (tools/probes/pk_forms_probe.hip): no kernel of this library may overlap a split kernel.
 		if not lazy.on("sidestream") or self.convMath != "f32":
 			return None
 		if self.sideStream is None:

@@ -18,6 +18,8 @@
 #ifndef PZ_THIN_UNROLL
 #define PZ_THIN_UNROLL 2           // reduction channels in flight per thread: the window loads of two channels overlap
 #endif
+#define PZ_PRAGMA_(x) _Pragma(#x)
+#define PZ_UNROLL(n) PZ_PRAGMA_(unroll n)      // (a macro inside a plain #pragma does not survive -save-temps)
 
 namespace {
 
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(const float *__restrict
 			for (int c = 0; c < C; ++c) acc[a][b][c] = 0.f;
 
 	constexpr int per_k = WR * WS * 4 * C;
-#pragma unroll PZ_THIN_UNROLL
+PZ_UNROLL(PZ_THIN_UNROLL)
 	for (int k = 0; k < K; ++k, soff += plane) {
 		float v[WR][WS];
 #pragma unroll

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 			const f32x2 t01 = slice == 4 ? tA[0] : tB[0], t23 = slice == 4 ? tA[1] : tB[1];
 			f32x2 v01, v23;                               // (t0 - t2, t1 + t2), (t2 - t1, t1 - t3)
 			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
-			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+			v23[0] = t23[0] - t01[1], v23[1] = t01[1] - t23[1];      // (scalar: a packed op whose LOW lane reads a HIGH half is not safe)
 			float *dst = stg + vdst + (slice - 4) * 4 * (TB * BC);
 			dst[0 * (TB * BC)] = v01[0];
 			dst[1 * (TB * BC)] = v01[1];
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 				const f32x2 t01 = sl == 4 ? tA[0] : tB[0], t23 = sl == 4 ? tA[1] : tB[1];
 				f32x2 v01, v23;
 				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
-				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				v23[0] = t23[0] - t01[1], v23[1] = t01[1] - t23[1];      // (scalar: a packed op whose LOW lane reads a HIGH half is not safe)
 				float *dst = stg + vdst + (sl - 4) * 4 * (TB * BC);
 				dst[0 * (TB * BC)] = v01[0];
 				dst[1 * (TB * BC)] = v01[1];
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
 				}
 				f32x2 v01, v23;                               // (t0 - t2, t1 + t2), (t2 - t1, t1 - t3)
 				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
-				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				v23[0] = t23[0] - t01[1], v23[1] = t01[1] - t23[1];      // (scalar: a packed op whose LOW lane reads a HIGH half is not safe)
 				float *dst = stg + vdst + i * 64;
 				dst[0 * 128] = v01[0];
 				dst[1 * 128] = v01[1];
@@ -994,7 +994,7 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_kernel(WinoWgradArgs a) {
 			const f32x2 t01 = slice == 4 ? tA[0] : tB[0], t23 = slice == 4 ? tA[1] : tB[1];
 			f32x2 v01, v23;
 			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
-			asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+			v23[0] = t23[0] - t01[1], v23[1] = t01[1] - t23[1];      // (scalar: a packed op whose LOW lane reads a HIGH half is not safe)
 			float *dst = stg + vdst + (slice - 4) * 4 * (2 * CB * 2);
 			dst[0 * (2 * CB * 2)] = v01[0];
 			dst[1 * (2 * CB * 2)] = v01[1];
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(256, 2) wino_wgrad_kernel(WinoWgradArgs a) {
 			const int i = slice - 4;
 			const f32x2 row = i == 0 ? sz[0] : i == 1 ? zr1 : i == 2 ? zr2 : sz[1];
 			f32x2 mid;
-			asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(mid) : "v"(row));
+			mid[0] = row[0] + row[1], mid[1] = row[0] - row[1];             // (scalar, see above)
 			float *dst = stg + zdst + i * 4 * (2 * KB * 2);
 			dst[0 * (2 * KB * 2)] = row[0];
 			dst[1 * (2 * KB * 2)] = mid[0];
@@ -1262,7 +1262,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 				const f32x2 t01 = w == 4 ? tA[0] : tB[0], t23 = w == 4 ? tA[1] : tB[1];
 				f32x2 v01, v23;
 				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(t01), "v"(t23));
-				asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(t23), "v"(t01));
+				v23[0] = t23[0] - t01[1], v23[1] = t01[1] - t23[1];      // (scalar: a packed op whose LOW lane reads a HIGH half is not safe)
 				float *dst = stg + vdst + (w - 4) * 4 * (2 * CB * 2);
 				dst[0 * (2 * CB * 2)] = v01[0];
 				dst[1 * (2 * CB * 2)] = v01[1];
@@ -1280,7 +1280,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 				const int i = w - 2;                     // row (a, b) of A dY -> (a, a + b, a - b, [-]b)
 				const f32x2 row = i == 0 ? sz[0] : i == 1 ? zr1 : i == 2 ? zr2 : sz[1];
 				f32x2 mid;
-				asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(mid) : "v"(row));
+				mid[0] = row[0] + row[1], mid[1] = row[0] - row[1];             // (scalar, see above)
 				float *dst = stg + zdst + i * 4 * (2 * KB * 2);
 				dst[0 * (2 * KB * 2)] = row[0];
 				dst[1 * (2 * KB * 2)] = mid[0];

@@ -327,7 +327,7 @@ def sourceId():
 	if not files or not os.path.exists(header):
 		return None
 	digest = hashlib.sha256()
-	for path in files + [header]:
+	for path in files + [header, os.path.join(here, "Makefile")]:
 		digest.update(open(path, "rb").read())
 	return digest.hexdigest()[:16]
 

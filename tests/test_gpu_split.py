@@ -137,6 +137,3 @@ def test_math_switch(bnd, dnn):
 		dnn.setConvMath("bf16")
 	with pytest.raises(Exception):
 		lib.pz_conv_math_set(7)
-	# the split modes keep every launch on the main stream (see DnnContext.filterGradStream)
-	dnn.setConvMath("split6")
-	assert dnn.filterGradStream() is None
