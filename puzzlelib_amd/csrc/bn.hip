@@ -188,6 +188,30 @@ __device__ __forceinline__ float bn_act(float x, float a, float b) {
 	return RELU ? (y > 0.f ? y : 0.f) : y;
 }
 
+// Deferred apply: what the BatchNorm forward derives per channel from {mean, var} without touching the tensor — saved
+// statistics, running statistics and the affine coefficients coef[ch] = {a, b} of y = a*x + b, which the consumer
+// (bn_apply_add_kernel) applies while it reads x anyway. Called from the kernels that produce {mean, var}, so that it
+// costs no launch of its own. `coef == nullptr`: nothing to do.
+struct BnFinal {
+	const float *scale, *bias;
+	float *run_mean, *run_var, *save_mean, *save_invvar, *coef;
+	float eps, factor;
+	double cnt;
+};
+
+__device__ __forceinline__ void bn_finalize_one(const BnFinal &f, int ch, float mean, float var_f) {
+	const double var = (double)var_f;
+	const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+	f.save_mean[ch] = mean;
+	f.save_invvar[ch] = rstd;
+	const double unbiased = f.cnt > 1.0 ? var * f.cnt / (f.cnt - 1.0) : var;
+	f.run_mean[ch] = (1.f - f.factor) * f.run_mean[ch] + f.factor * mean;
+	f.run_var[ch] = (1.f - f.factor) * f.run_var[ch] + f.factor * (float)unbiased;
+	float a, b;
+	bn_affine(rstd, mean, f.scale[ch], f.bias[ch], a, b);
+	f.coef[2 * ch] = a, f.coef[2 * ch + 1] = b;
+}
+
 // ---- statistics from the producing convolution's strip sums: stats[ch*strips + strip] = {shift, s1, s2, -} over
 // `strip_px` consecutive pixels of the flattened (n, hw) axis. One workgroup per channel folds them, in fp64 and about the
 // common reference R = the channel's first shift, into S = sum(v - R) and Q = sum((v - R)^2):
@@ -198,7 +222,8 @@ __device__ __forceinline__ float bn_act(float x, float a, float b) {
 // stem): the strips of a channel are then cut into `parts` segments (blockIdx.y) whose {S, Q} go to `partial`, and
 // bn_merge_finish_kernel adds them in order.
 __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__restrict__ stats, int strips, int strip_px, long total_px,
-                                                               int c, float *__restrict__ pre, int parts, double *__restrict__ partial) {
+                                                               int c, float *__restrict__ pre, int parts, double *__restrict__ partial,
+                                                               BnFinal fin) {
 	__shared__ double sh_s[256], sh_q[256];
 	const int ch = blockIdx.x, t = threadIdx.x;
 	const float4 *mine = stats + (size_t)ch * strips;
@@ -228,21 +253,26 @@ __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__re
 		}
 		const double n = (double)total_px, m = sh_s[0] / n;
 		const double var = sh_q[0] / n - m * m;
-		pre[2 * ch + 0] = (float)(R + m);
-		pre[2 * ch + 1] = (float)(var > 0.0 ? var : 0.0);
+		const float mean_f = (float)(R + m), var_f = (float)(var > 0.0 ? var : 0.0);
+		pre[2 * ch + 0] = mean_f;
+		pre[2 * ch + 1] = var_f;
+		if (fin.coef) bn_finalize_one(fin, ch, mean_f, var_f);
 	}
 }
 
 __global__ void __launch_bounds__(256) bn_merge_finish_kernel(const float4 *__restrict__ stats, int strips, long total_px, int c,
-                                                               float *__restrict__ pre, int parts, const double *__restrict__ partial) {
+                                                               float *__restrict__ pre, int parts, const double *__restrict__ partial,
+                                                               BnFinal fin) {
 	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
 	if (ch >= c) return;
 	double S = 0.0, Q = 0.0;
 	for (int p = 0; p < parts; ++p) S += partial[((size_t)ch * parts + p) * 2 + 0], Q += partial[((size_t)ch * parts + p) * 2 + 1];
 	const double R = (double)stats[(size_t)ch * strips].x, n = (double)total_px, m = S / n;
 	const double var = Q / n - m * m;
-	pre[2 * ch + 0] = (float)(R + m);
-	pre[2 * ch + 1] = (float)(var > 0.0 ? var : 0.0);
+	const float mean_f = (float)(R + m), var_f = (float)(var > 0.0 ? var : 0.0);
+	pre[2 * ch + 0] = mean_f;
+	pre[2 * ch + 1] = var_f;
+	if (fin.coef) bn_finalize_one(fin, ch, mean_f, var_f);
 }
 
 // launches the strip merge; `scratch` (after the 2*c floats of `pre`) must hold c * parts * 2 doubles
@@ -251,39 +281,15 @@ inline int bn_merge_parts(int c) {
 	return parts < 1 ? 1 : (parts > 16 ? 16 : parts);
 }
 
-inline void bn_merge_strips(const float *stats, int strips, long total_px, int c, float *pre, double *scratch, hipStream_t st) {
+inline void bn_merge_strips(const float *stats, int strips, long total_px, int c, float *pre, double *scratch, hipStream_t st,
+                            const BnFinal &fin = BnFinal{}) {
 	int parts = bn_merge_parts(c);
 	if (strips < 4 * 256 * parts) parts = 1;          // not worth a second launch
 	bn_merge_strips_kernel<<<dim3(c, parts), 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, PZ_CONV_STATS_STRIP,
-	                                                       total_px, c, pre, parts, scratch);
+	                                                       total_px, c, pre, parts, scratch, parts > 1 ? BnFinal{} : fin);
 	if (parts > 1)
 		bn_merge_finish_kernel<<<(c + 255) / 256, 256, 0, st>>>(reinterpret_cast<const float4 *>(stats), strips, total_px, c, pre,
-		                                                        parts, scratch);
-}
-
-// Deferred apply: per channel, what bn_apply_train_kernel<.., PRE> derives from {mean, var} — saved statistics, running
-// statistics, and the affine coefficients coef[ch] = {a, b} of y = a*x + b — without touching the tensor. The consumer
-// (bn_apply_add_kernel) applies them while it reads x anyway.
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float *__restrict__ pre, int c, double cnt,
-                                                           const float *__restrict__ scale, const float *__restrict__ bias,
-                                                           float *__restrict__ run_mean, float *__restrict__ run_var,
-                                                           float *__restrict__ save_mean, float *__restrict__ save_invvar,
-                                                           float eps, float factor, float *__restrict__ coef) {
-	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-	if (ch >= c) return;
-	const float mean = pre[2 * ch];
-	const double var = (double)pre[2 * ch + 1];
-	const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-
-	save_mean[ch] = mean;
-	save_invvar[ch] = rstd;
-	const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-	run_mean[ch] = (1.f - factor) * run_mean[ch] + factor * mean;
-	run_var[ch] = (1.f - factor) * run_var[ch] + factor * (float)unbiased;
-
-	float a, b;
-	bn_affine(rstd, mean, scale[ch], bias[ch], a, b);
-	coef[2 * ch] = a, coef[2 * ch + 1] = b;
+		                                                        parts, scratch, fin);
 }
 
 // out = act( (a1*x1 + b1) + (AFF2 ? a2*x2 + b2 : x2) )   /   out = a1*x1 + b1 when x2 == nullptr
@@ -730,27 +736,36 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
 
 	float *pre = (float *)workspace;
 	hipStream_t st = pz::as_stream(stream);
-	bn_merge_strips(stats, strips, total_px, c, pre, reinterpret_cast<double *>(pre + 2 * c + (2 * c) % 2), st);
-	PZ_LAUNCH_CHECK();
-	bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(pre, c, (double)total_px, scale, bias, run_mean, run_var, save_mean,
-	                                                    save_invvar, epsilon, factor, coef);
+	// {mean, var} -> saved / running statistics and coefficients in the merge's last kernel (no launch of its own)
+	const BnFinal fin{scale, bias, run_mean, run_var, save_mean, save_invvar, coef, epsilon, factor, (double)total_px};
+	bn_merge_strips(stats, strips, total_px, c, pre, reinterpret_cast<double *>(pre + 2 * c + (2 * c) % 2), st, fin);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
 
-// Per channel {mean, var} from the statistics pass's merged shifted sums (what bn_apply_train_kernel<.., false> derives
-// in every workgroup): pre[2ch] = mean, pre[2ch+1] = var — the input format of bn_finalize_kernel.
-__global__ void __launch_bounds__(256) bn_parts_to_pre_kernel(const float *__restrict__ part, const float *__restrict__ shift, int c,
-                                                               double cnt, float *__restrict__ pre) {
-	const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// Statistics pass's partial sums of one channel per wave -> merged totals (bn_reduce_parts_kernel's arithmetic) -> {mean,
+// var} about the channel's shift -> saved / running statistics and coefficients (bn_finalize_one), all in one launch
+__global__ void __launch_bounds__(256) bn_reduce_finalize_kernel(float *__restrict__ buf, int splits, int c, const float *__restrict__ shift,
+                                                                  BnFinal fin) {
+	const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (ch >= c) return;
-	double S1, S2;
-	bn_merge(part, ch, S1, S2);
-	const double m1 = S1 / cnt;
-	double var = S2 / cnt - m1 * m1;
-	var = var > 0.0 ? var : 0.0;
-	pre[2 * ch] = (float)((double)shift[ch] + m1);
-	pre[2 * ch + 1] = (float)var;
+	const float *part = buf + bn_parts_offset_floats(c);
+	double a = 0.0, b = 0.0;
+	for (int i = lane; i < splits; i += 64) {
+		a += (double)part[((size_t)ch * splits + i) * 2 + 0];
+		b += (double)part[((size_t)ch * splits + i) * 2 + 1];
+	}
+#pragma unroll
+	for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);
+	if (lane == 0) {
+		double *merged = reinterpret_cast<double *>(buf);
+		merged[2 * ch] = a, merged[2 * ch + 1] = b;
+		const double m1 = a / fin.cnt;
+		double var = b / fin.cnt - m1 * m1;
+		var = var > 0.0 ? var : 0.0;
+		const float mean_f = (float)((double)shift[ch] + m1), var_f = (float)var;
+		bn_finalize_one(fin, ch, mean_f, var_f);
+	}
 }
 
 // Training-mode forward without the normalisation pass: statistics (from the producing convolution's strip sums when
@@ -773,13 +788,9 @@ int pz_bn_fwd_train_coef(const float *x, int n, int c, int hw, const float *scal
 	hipStream_t st = pz::as_stream(stream);
 	bn_stats_kernel<<<dim3(c, gc.splits), 256, 0, st>>>(x, gc, part, shift);
 	PZ_LAUNCH_CHECK();
-	bn_reduce_parts(part, gc.splits, c, st);
-	// {mean, var} overwrite the per-workgroup partials, dead once bn_reduce_parts has folded them into the merged totals
-	float *pre = part + bn_parts_offset_floats(c);
-	bn_parts_to_pre_kernel<<<(c + 255) / 256, 256, 0, st>>>(part, shift, c, (double)n * hw, pre);
-	PZ_LAUNCH_CHECK();
-	bn_finalize_kernel<<<(c + 255) / 256, 256, 0, st>>>(pre, c, (double)n * hw, scale, bias, run_mean, run_var, save_mean,
-	                                                    save_invvar, epsilon, factor, coef);
+	// partial sums -> merged totals -> {mean, var} -> saved / running statistics and coefficients: one launch, one wave per channel
+	const BnFinal fin{scale, bias, run_mean, run_var, save_mean, save_invvar, coef, epsilon, factor, (double)n * hw};
+	bn_reduce_finalize_kernel<<<(c + 3) / 4, 256, 0, st>>>(part, gc.splits, c, shift, fin);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

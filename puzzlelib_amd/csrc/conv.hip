@@ -19,6 +19,9 @@
 // Replaces DnnContext.convNd / convNdBackwardData / convNdBackwardParams — Hip/Wrappers/MIOpen.py:333-462.
 #include "common.h"
 
+#include <array>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -257,6 +260,25 @@ __global__ void __launch_bounds__(256) build_tab_kernel(int2 *tab, int n, int np
 	tab[j] = e;
 }
 
+// host side: one table per (device, geometry), kept for the life of the process (a few KB each). The first request
+// builds it on the caller's stream and waits for it, so that later launches on any stream find it complete.
+static int2 *cached_wgrad_tab(int n, int npad, int R, int S, int dil_h, int dil_w, int in_h, int in_w, hipStream_t st) {
+	static std::mutex mu;
+	static std::map<std::array<int, 9>, int2 *> cache;
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	const std::array<int, 9> key{dev, n, npad, R, S, dil_h, dil_w, in_h, in_w};
+	std::lock_guard<std::mutex> lock(mu);
+	auto it = cache.find(key);
+	if (it != cache.end()) return it->second;
+	int2 *tab = nullptr;
+	if (hipMalloc(&tab, (size_t)npad * sizeof(int2)) != hipSuccess) return nullptr;
+	build_tab_kernel<<<pz::ceil_div(npad, 256), 256, 0, st>>>(tab, n, npad, R, S, dil_h, dil_w, in_h, in_w);
+	if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+	cache.emplace(key, tab);
+	return tab;
+}
+
 // ------------------------------------------------------------------------------------------------
 // implicit-GEMM forward / backward-data kernel
 // ------------------------------------------------------------------------------------------------
@@ -295,7 +317,7 @@ struct IgemmArgs {
 // get the out-of-range offset and are dropped by the hardware.
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int tn, int g, int wm, int wn, int lane,
-                                                 f32x16 (&acc)[TM][TN]) {
+                                                 f32x16 (&acc)[TM][TN], int only_i = -1) {
 	const int l31 = lane & 31, lhi = lane >> 5;
 	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
 	const unsigned plane_bytes = (unsigned)(a.OH * a.OW) * 4u;
@@ -317,6 +339,7 @@ __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int
 
 #pragma unroll
 		for (int i = 0; i < TM; ++i) {
+			if (only_i >= 0 && i != only_i) continue;      // (the slab reduce gives each sub-tile row a workgroup of its own)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) {
 				const int ms = tm * BM + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2);     // wave-uniform row (lane half adds 4)
@@ -342,7 +365,7 @@ constexpr int kEpiFloatsPerWave = 32 * kEpiStride;
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm, int tn, int g, int wm, int wn, int wave, int lane,
-                                                     f32x16 (&acc)[TM][TN], float *smem) {
+                                                     f32x16 (&acc)[TM][TN], float *smem, int only_i = -1) {
 	const int l31 = lane & 31, lhi = lane >> 5;
 	const int rr = lane >> 3, c4 = lane & 7;
 	float *scr = smem + wave * kEpiFloatsPerWave;
@@ -352,6 +375,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 
 #pragma unroll
 	for (int i = 0; i < TM; ++i) {
+		if (only_i >= 0 && i != only_i) continue;
 		const int row_base = tm * BM + wm * (32 * TM) + i * 32;      // first channel row of this sub-tile row
 		float st_shift[4], st_s1[4], st_s2[4];
 #pragma unroll
@@ -522,7 +546,8 @@ igemm_conv_kernel(IgemmArgs a) {
 	// load issue can sit in the shadow of one k2-step's MFMAs (the matrix pipe is busy 4 x 64 cycles per k2-step)
 	auto load_tab = [&](int kt) {
 		if constexpr (TAPMAJOR) {
-			const int4 t = reinterpret_cast<const int4 *>(a.tab)[kt];
+			// no table: a pointwise filter (one tap at offset 0, k-tile kt starts at channel 16 kt)
+			const int4 t = a.tab ? reinterpret_cast<const int4 *>(a.tab)[kt] : make_int4(0, 0, (int)((unsigned)(kt * BK) * hw4), 0);
 			const unsigned word = t.y < 32 ? mask_lo : mask_hi;
 			voff_tile = (word >> (t.y & 31)) & 1u ? base_bytes + (unsigned)t.x : kOOB;
 			soff_tile = (unsigned)t.z + row_off;
@@ -896,42 +921,62 @@ igemm_split_kernel(IgemmArgs a) {
 	}
 }
 
-// sums the k-slices of one tail tile (fixed order) and writes it out like a whole tile
+// sums the k-slices of one tail tile (fixed order) and writes it out like a whole tile. One single-wave workgroup per
+// (tail tile, wave of the producing workgroup, 32-row sub-tile row): the slab rows of a wave are 256 contiguous bytes per
+// accumulator register. The slices are summed in order, but their loads are issued kGroup slices at a time (one workgroup
+// per tile walking the slices one by one was a chain of `splits` dependent memory latencies: 28 us per launch where the
+// data is 16 MB).
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN) igemm_tail_reduce_kernel(IgemmArgs a) {
+__global__ void __launch_bounds__(64) igemm_tail_reduce_kernel(IgemmArgs a) {
 	constexpr int NT = 64 * WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	constexpr int kGroup = 256 / (TN * 16);             // slices in flight (<= 256 registers)
+	const int lane = threadIdx.x;
+	const int isel = blockIdx.x % TM, wave = (blockIdx.x / TM) % (WM * WN), tile = blockIdx.x / (TM * WM * WN);
 	const int wm = wave / WN, wn = wave % WN;
 	const int g = blockIdx.z;
+	const int tid = wave * 64 + lane;          // the thread of the producing workgroup whose accumulators this lane sums
 
 	const int ntail = a.tiles_m * a.tiles_n - a.full_tiles;
-	const int L = a.full_tiles + blockIdx.x;
+	const int L = a.full_tiles + tile;
 	const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+	const float *slab0 = a.slabs + ((size_t)tile * a.tail_splits + (size_t)g * ntail * a.tail_splits) * (BM * BN);
 
 	f32x16 acc[TM][TN];
 #pragma unroll
-	for (int i = 0; i < TM; ++i)
+	for (int i = 0; i < TM; ++i) {
+		if (i != isel) continue;
 #pragma unroll
 		for (int j = 0; j < TN; ++j)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-	for (int sl = 0; sl < a.tail_splits; ++sl) {
-		const float *slab = a.slabs + ((size_t)(blockIdx.x * a.tail_splits + sl) + (size_t)g * ntail * a.tail_splits) * (BM * BN);
+		for (int sl0 = 0; sl0 < a.tail_splits; sl0 += kGroup) {
+			float part[kGroup][TN][16];
 #pragma unroll
-		for (int i = 0; i < TM; ++i)
+			for (int q = 0; q < kGroup; ++q) {
+				const int sl = min(sl0 + q, a.tail_splits - 1);              // clamped: the surplus loads are not added
+				const float *slab = slab0 + (size_t)sl * (BM * BN);
 #pragma unroll
-			for (int j = 0; j < TN; ++j)
+				for (int j = 0; j < TN; ++j)
 #pragma unroll
-				for (int r = 0; r < 16; ++r) acc[i][j][r] += slab[((i * TN + j) * 16 + r) * NT + tid];
+					for (int r = 0; r < 16; ++r) part[q][j][r] = slab[((i * TN + j) * 16 + r) * NT + tid];
+			}
+#pragma unroll
+			for (int q = 0; q < kGroup; ++q)
+				if (sl0 + q < a.tail_splits) {
+#pragma unroll
+					for (int j = 0; j < TN; ++j)
+#pragma unroll
+						for (int r = 0; r < 16; ++r) acc[i][j][r] += part[q][j][r];
+				}
+		}
 	}
 
 	if (a.contig) {
-		__shared__ __attribute__((aligned(16))) float smem[WM * WN * kEpiFloatsPerWave];
-		igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, smem);
+		__shared__ __attribute__((aligned(16))) float smem[kEpiFloatsPerWave];
+		igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, 0, lane, acc, smem, isel);
 	} else {
-		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc);
+		igemm_store_tile<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, lane, acc, isel);
 	}
 }
 
@@ -1721,7 +1766,8 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups, int chans) {
 		}
 		// ... and the slab reduce is a launch of its own (~20 us): a k-tile takes ~1 us of a CU, so the round has to get
 		// PZ_TAIL_MIN_GAIN k-tile-times shorter to pay for it
-		if ((1.0 - best_cost) * nk < PZ_TAIL_MIN_GAIN) best = 1;
+		static const int min_gain = getenv("PZ_TAIL_MIN_GAIN_RT") ? atoi(getenv("PZ_TAIL_MIN_GAIN_RT")) : PZ_TAIL_MIN_GAIN;      // experiment
+		if ((1.0 - best_cost) * nk < min_gain) best = 1;
 		if (best > 1) p.full_tiles = tiles - rem, p.tail_splits = best;
 	}
 	const int ntail = tiles - p.full_tiles;
@@ -1751,7 +1797,7 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
-	constexpr int lds_pad = 0;
+	static const int lds_pad = getenv("PZ_IG_LDS_PAD") ? atoi(getenv("PZ_IG_LDS_PAD")) : 0;      // experiment: dynamic LDS bytes = fewer resident workgroups per CU
 	{
 		// profile bracket = the MFMA kernel alone (what rocprofv3 lists under its name); all of the launch's algorithmic
 		// FLOP are its work — the slab reduce of a k-sliced last round only adds
@@ -1778,7 +1824,7 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 	launched:;
 	}
 	if (p.tail_splits > 1)
-		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3(a.tiles_m * a.tiles_n - p.full_tiles, 1, groups), 64 * WM * WN, 0, st>>>(a);
+		igemm_tail_reduce_kernel<BM, BN, WM, WN><<<dim3((a.tiles_m * a.tiles_n - p.full_tiles) * (WM * WN) * (BM / WM / 32), 1, groups), 64, 0, st>>>(a);
 }
 
 void run_igemm(const FwdPlan &p, IgemmArgs a, float *slabs, int groups, hipStream_t st, double flops) {
@@ -2184,8 +2230,13 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		pa.a_h = c.a_h, pa.a_w = c.a_w, pa.st_h = d->stride_h, pa.st_w = d->stride_w, pa.Rc = c.Rc, pa.Sc = c.Sc;
 		pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = P, pa.in_w = Q;
 		pa.tapmajor = Kg % 16 == 0, pa.chans = Kg;
+		// A pointwise filter (K, C, 1, 1) already IS the packed operand [kred = k][m = c] of its backward-data GEMM when
+		// neither axis needs padding: the kernel reads the filter tensor itself and derives the k-table (no pack launch)
+		const bool as_is = d->r == 1 && d->s == 1 && d->groups == 1 && pa.tapmajor && !p.split && p.mpad == Cg && p.kred_pad == p.kred;
 		const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
-		if (p.split)
+		if (as_is)
+			wp = const_cast<float *>(w), tab = nullptr;
+		else if (p.split)
 			pack_filter_split_kernel<<<pz::stream_grid(ptotal / 8, 256), 256, 0, st>>>(pa);
 		else
 			pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
@@ -2281,8 +2332,10 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	float *slabs = (float *)((char *)workspace + p.tab_bytes);
 
 	if (!split_math) {
-		build_tab_kernel<<<pz::ceil_div(p.ncrs_pad, 256), 256, 0, st>>>(tab, p.ncrs, p.ncrs_pad, d->r, d->s, d->dil_h, d->dil_w, d->h, d->w);
-		PZ_LAUNCH_CHECK();
+		// the gather table depends on the geometry alone: built once per (device, geometry) into memory the library keeps,
+		// not once per call into the workspace (37 launches of ~4 us per ResNet-50 step in front of the main kernels)
+		tab = cached_wgrad_tab(p.ncrs, p.ncrs_pad, d->r, d->s, d->dil_h, d->dil_w, d->h, d->w, st);
+		PZ_REQUIRE(tab != nullptr, "pz_conv2d_bwd_filter: gather table allocation failed");
 	}
 
 	WgradArgs a{};
