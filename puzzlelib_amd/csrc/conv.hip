@@ -1545,33 +1545,61 @@ wgrad_split_kernel(WgradArgs a) {
 	}
 }
 
-// dw = beta*dw + alpha * sum_s slab[s]   (fixed summation order -> deterministic). 16 bytes per lane and four slabs in
-// flight per step: the launch is latency-, not bandwidth-bound (tens of MB), so independent wide loads are what counts.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
-                                                            int splits, float alpha, float beta) {
+// dw = beta*dw + alpha * (slab 0 + slab 1 + ...), deterministic. A workgroup owns 64 consecutive 16-byte elements; its W
+// waves each sum a contiguous range of the slabs (in order, eight loads in flight) and wave 0 adds the W range sums in
+// order. W follows the split count (small filters have up to 512 slabs: one thread walking them was a chain of 128
+// dependent memory round trips), W = 1 is the plain in-order sum.
+template <int W>
+__global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
+                                                              int splits, float alpha, float beta) {
 	typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+	__shared__ f4 sh[W > 1 ? W : 1][64];
 	const size_t n4 = n >> 2;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-		f4 s = {0.f, 0.f, 0.f, 0.f};
-		int k = 0;
-		for (; k + 4 <= splits; k += 4) {
-			const f4 a = *reinterpret_cast<const f4 *>(slabs + (size_t)k * n + 4 * i);
-			const f4 b = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 1) * n + 4 * i);
-			const f4 c = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 2) * n + 4 * i);
-			const f4 d = *reinterpret_cast<const f4 *>(slabs + (size_t)(k + 3) * n + 4 * i);
-			s = (((s + a) + b) + c) + d;              // same order as the scalar loop
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const size_t i = (size_t)blockIdx.x * 64 + lane;
+	const int per = (splits + W - 1) / W, k0 = w * per, k1 = min(k0 + per, splits);
+
+	f4 s = {0.f, 0.f, 0.f, 0.f};
+	if (i < n4) {
+		for (int k = k0; k < k1; k += 8) {
+			f4 v[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f4 *>(slabs + (size_t)min(k + q, k1 - 1) * n + 4 * i);
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+				if (k + q < k1) s += v[q];
 		}
-		for (; k < splits; ++k) s += *reinterpret_cast<const f4 *>(slabs + (size_t)k * n + 4 * i);
+	}
+	if (W > 1) {
+		sh[w][lane] = s;
+		__syncthreads();
+		if (w != 0) return;
+		s = sh[0][lane];
+#pragma unroll
+		for (int q = 1; q < W; ++q) s += sh[q][lane];
+	}
+	if (i < n4) {
 		f4 *o = reinterpret_cast<f4 *>(dw + 4 * i);
 		const f4 old = beta == 0.f ? f4{0.f, 0.f, 0.f, 0.f} : *o;
 		*o = (beta == 0.f ? f4{0.f, 0.f, 0.f, 0.f} : beta * old) + alpha * s;
 	}
 	// the n % 4 trailing elements
-	for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-		float s = 0.f;
-		for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
-		dw[i] = (beta == 0.f ? 0.f : beta * dw[i]) + alpha * s;
+	if (blockIdx.x == 0 && w == 0 && (n4 << 2) + lane < n) {
+		const size_t t = (n4 << 2) + lane;
+		float r = 0.f;
+		for (int k = 0; k < splits; ++k) r += slabs[(size_t)k * n + t];
+		dw[t] = (beta == 0.f ? 0.f : beta * dw[t]) + alpha * r;
 	}
+}
+
+inline void launch_wgrad_reduce(float *dw, const float *slabs, size_t n, int splits, float alpha, float beta, hipStream_t st) {
+	const int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
+	if (splits >= 128)
+		wgrad_reduce_kernel<16><<<blocks, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta);
+	else if (splits >= 32)
+		wgrad_reduce_kernel<4><<<blocks, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta);
+	else
+		wgrad_reduce_kernel<1><<<blocks, 64, 0, st>>>(dw, slabs, n, splits, alpha, beta);
 }
 
 // db[k] = beta*db[k] + alpha * sum_{n,pq} dy[n,k,pq], two deterministic stages: workgroup (k, s) sums the images
@@ -2397,7 +2425,7 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	PZ_LAUNCH_CHECK();
 
 	if (!a.direct) {
-		wgrad_reduce_kernel<<<pz::stream_grid((p.slab_elems >> 2) + 1, 256), 256, 0, st>>>(dw, slabs, p.slab_elems, p.splits, alpha, beta);
+		launch_wgrad_reduce(dw, slabs, p.slab_elems, p.splits, alpha, beta, st);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;

@@ -55,7 +55,7 @@ loop(float *out, int ktiles, const float *src, unsigned plane, unsigned planes, 
 	auto load_part = [&](int kt, int buf, int j) {
 		const unsigned soffA = ((unsigned)(kt * BK) % kfilt) * BM * 4u;
 		const unsigned soffB = (((unsigned)(kt * BK) % planes) + kb0 * 8 + j) * plane;
-		if (MODE == 1) {
+		if (MODE == 1 || MODE == 4) {
 			if (j < 2) ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[j], soffA, 0));
 			rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voffB, soffB, 0));
 		} else if (MODE >= 2) {
@@ -64,7 +64,7 @@ loop(float *out, int ktiles, const float *src, unsigned plane, unsigned planes, 
 		}
 	};
 	auto store_tile = [&](int buf) {
-		if (MODE == 1) {
+		if (MODE == 1 || MODE == 4) {
 			for (int i = 0; i < 2; ++i) {
 				const int f = tid + i * 256;
 				*reinterpret_cast<f32x4 *>(&As[buf][f / 32][(f % 32) * 4]) = ra[i];
@@ -95,6 +95,10 @@ loop(float *out, int ktiles, const float *src, unsigned plane, unsigned planes, 
 		}
 	};
 
+	if (MODE == 4) {           // staggered start: a pseudo-random delay of up to ~one k-tile so that co-resident workgroups run out of phase
+		const int n = (int)((blockIdx.x * 2654435761u) >> 28);
+		for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(6);
+	}
 	if (MODE == 3) {
 		// three-stage ring, loads two k-tiles ahead: at the end of tile kt only the loads of tile kt+1 (issued a whole
 		// tile earlier) have to have landed -> vmcnt(10) leaves the 10 loads of tile kt+2 in flight
@@ -216,9 +220,9 @@ int main() {
 			};
 			const float m1 = timeit([&] { loop<1, false><<<nb, 256>>>(out, kt, src, plane, planes, filt, kfilt); });
 			const float m2 = timeit([&] { loop<2, false><<<nb, 256>>>(out, kt, src, plane, planes, filt, kfilt); });
-			const float m3 = timeit([&] { loop<3, false><<<nb, 256>>>(out, kt, src, plane, planes, filt, kfilt); });
+			const float m3 = timeit([&] { loop<4, false><<<nb, 256>>>(out, kt, src, plane, planes, filt, kfilt); });
 			const double gf = (double)nb * kt * 2.0 * BM * BN * BK / 1e9;
-			printf("%5d blocks (%5.2f per CU) x %3d k-tiles: production %7.3f ms %6.1f TF | LDS-direct %7.3f ms %6.1f TF | 3-stage ring %7.3f ms %6.1f TF\n",
+			printf("%5d blocks (%5.2f per CU) x %3d k-tiles: production %7.3f ms %6.1f TF | LDS-direct %7.3f ms %6.1f TF | staggered start %7.3f ms %6.1f TF\n",
 			       nb, nb / 256.0, kt, m1, gf / m1, m2, gf / m2, m3, gf / m3);
 		}
 	}
