@@ -399,7 +399,8 @@ def main():
 						"fwd+CE+zeroGrad+bwd+Adam, random-init (he) weights, loadResNet(actInplace=True), reference-literal "
 						"call sequence (conv1 input gradient computed as the reference does)" % args.batch,
 			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
-			"grad_allreduce": "none" if world == 1 else (
+			"grad_allreduce": "none" if nodeinfo is None else (
+				"single-rank rehearsal (PUZZLE_MI355_FORCE_COMM=1): " if world == 1 else "") + (
 				"RCCL sum + 1/N, 25 MB buckets in reverse execution order, overlapped with backward"
 				if nodeinfo.transport == "rccl" else
 				"FALLBACK: host-staged all-reduce over TCP (RCCL communicator could not be created)"

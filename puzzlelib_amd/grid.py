@@ -27,6 +27,27 @@ import numpy as np
 
 
 # ---------------------------------------------------------------------------------------------- host-side group (TCP star)
+class stdoutToStderr:
+	"""librccl prints a version banner with printf on the first communicator: it sits in the C library's stdout buffer
+	and comes out when the process exits — behind whatever the program printed last (bench.py's one JSON line must stay
+	the last line of stdout). Inside this block file descriptor 1 is descriptor 2, and the C buffers are flushed on both
+	sides of it."""
+
+	def __enter__(self):
+		import ctypes
+		self.libc = ctypes.CDLL(None)
+		sys.stdout.flush()
+		self.libc.fflush(None)
+		self.saved = os.dup(1)
+		os.dup2(2, 1)
+
+	def __exit__(self, *exc):
+		self.libc.fflush(None)
+		os.dup2(self.saved, 1)
+		os.close(self.saved)
+		return False
+
+
 class HostGroup:
 	"""Rank 0 listens on (MASTER_ADDR, port) and keeps one connection per peer. Collectives are a gather to rank 0
 	followed by a scatter of the result: bytes broadcast, float64 reductions, float32 array sums (the fallback gradient
@@ -262,7 +283,8 @@ class RcclNodeInfo(NodeInfo):
 			# every rank enters the collective; a refusal (e.g. two ranks on one device) comes back as an error on all of them
 			handle = ctypes.c_void_p()
 			try:
-				lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
+				with stdoutToStderr():
+					lib.pz_comm_init_rank(ctypes.byref(handle), self.gridsize, self.uniqueId, self.index)
 			except lib.HipError as e:
 				reason = str(e)
 			if self.vote(reason is None):
@@ -429,8 +451,11 @@ def nodeFromEnv(bucketBytes=25 << 20):
 	torch.distributed.run or by bench.py's own launcher). Returns None for a single-process run."""
 	global hostGroup
 	world = int(os.environ.get("WORLD_SIZE", "1"))
-	if world == 1:
+	# PUZZLE_MI355_FORCE_COMM=1: a single process still gets a communicator (one rank) — the whole exchange path (RCCL
+	# bring-up, buckets on the communication stream, event joins, 1/N scale) then runs on the one GPU a test box has
+	if world == 1 and os.environ.get("PUZZLE_MI355_FORCE_COMM", "0") != "1":
 		return None
+	os.environ.setdefault("RANK", "0")
 
 	rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
 	# PUZZLE_MI355_DEVICE pins every rank to one device: a single-GPU rehearsal of the multi-process path (RCCL itself
