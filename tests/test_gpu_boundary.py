@@ -222,3 +222,13 @@ def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
 	for name in a.files:
 		if name != "transport":
 			assert np.array_equal(a[name], b[name]), "parameter %s differs between 1 and 2 ranks" % name
+
+	# ... and one rank with a real RCCL communicator (PUZZLE_MI355_FORCE_COMM=1): the same hooks, buckets and event joins, the
+	# all-reduces issued through librccl on the communication stream — RCCL must be the transport, the result unchanged
+	solo = str(tmp_path / "solo.npz")
+	subprocess.run([sys.executable, script, solo], check=True, env=dict(env, PUZZLE_MI355_FORCE_COMM="1"), timeout=600)
+	c = np.load(solo)
+	assert str(c["transport"]) == "rccl"
+	for name in a.files:
+		if name != "transport":
+			assert np.array_equal(a[name], c[name]), "parameter %s differs with a one-rank RCCL communicator" % name
