@@ -1924,6 +1924,10 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	p.bm = (Kg <= 64 || pz::ceil_div(Kg, 64) * 64 < pz::ceil_div(Kg, 128) * 128) ? 64 : 128;
 	// the narrower column tile when it pads less (conv1: 147 columns = 3 x 64 rather than 2 x 128)
 	p.bn = (p.ncrs <= 64 || pz::ceil_div(p.ncrs, 64) * 64 < pz::ceil_div(p.ncrs, 128) * 128) ? 64 : 128;
+	// the stem (64 x 147 filter gradient, strided gather): one 64 x 192 tile per workgroup — the dy runs are fetched once
+	// instead of once per 64-column tile, and a wave's 32 x 96 share does 3 MFMAs per 4 fragment reads instead of 1 per 2
+	if (p.bm == 64 && Kg <= 64 && p.ncrs > 128 && p.ncrs <= 192 && d->stride_w > 1 && d->r * d->s > 1 && PZ_WG_RUNS == 8 && PZ_WG_WAVES == 4)
+		p.bn = 192;      // (not a pointwise filter: those may arrive with a BatchNorm fold, which this instantiation does not carry)
 	p.tiles_m = pz::ceil_div(Kg, p.bm);
 	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
 	p.ncrs_pad = p.tiles_n * p.bn;
@@ -2418,6 +2422,7 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128, 2, 2);
 	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64, 2, 2);
 	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128, 2, 2);
+	else if (p.bm == 64 && p.bn == 192) wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a);      // plan_wgrad: strided gathers only
 #endif
 	else PZ_WGRAD_LAUNCH(64, 64, 2, 2);
 #undef PZ_WGRAD_LAUNCH
