@@ -1792,10 +1792,9 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups, int chans) {
 			const double cost = (double)pz::ceil_div((long)rem * sp, pz::kNumCU) / sp;
 			if (cost < best_cost - 1e-9) best_cost = cost, best = sp;
 		}
-		// ... and the slab reduce is a launch of its own (~20 us): a k-tile takes ~1 us of a CU, so the round has to get
-		// PZ_TAIL_MIN_GAIN k-tile-times shorter to pay for it
-		static const int min_gain = getenv("PZ_TAIL_MIN_GAIN_RT") ? atoi(getenv("PZ_TAIL_MIN_GAIN_RT")) : PZ_TAIL_MIN_GAIN;      // experiment
-		if ((1.0 - best_cost) * nk < min_gain) best = 1;
+		// ... and the slab reduce is a launch of its own (~12 us): a k-tile takes ~1 us of a CU, so the round has to get
+		// PZ_TAIL_MIN_GAIN k-tile-times shorter to pay for it (thresholds 8 ... 40 measured within 0.1 ms per ResNet-50 step)
+		if ((1.0 - best_cost) * nk < PZ_TAIL_MIN_GAIN) best = 1;
 		if (best > 1) p.full_tiles = tiles - rem, p.tail_splits = best;
 	}
 	const int ntail = tiles - p.full_tiles;
@@ -1825,7 +1824,7 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
-	static const int lds_pad = getenv("PZ_IG_LDS_PAD") ? atoi(getenv("PZ_IG_LDS_PAD")) : 0;      // experiment: dynamic LDS bytes = fewer resident workgroups per CU
+	constexpr int lds_pad = 0;
 	{
 		// profile bracket = the MFMA kernel alone (what rocprofv3 lists under its name); all of the launch's algorithmic
 		// FLOP are its work — the slab reduce of a k-sliced last round only adds

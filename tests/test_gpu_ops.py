@@ -147,6 +147,14 @@ FRESH = [
 	dict(n=2, c=16, h=28, w=28, k=40, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
 	dict(n=4, c=16, h=7, w=9, k=24, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
 	dict(n=2, c=150, h=14, w=13, k=16, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	# filter gradient = 135 elements (not a multiple of 4) summed from 37 / 512 slabs: the 4- and 16-wave slab reduces
+	dict(n=8, c=3, h=33, w=33, k=5, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
+	dict(n=32, c=3, h=64, w=64, k=5, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
+	# pointwise with both channel counts in whole tiles: backward-data reads the filter tensor as its packed operand
+	dict(n=3, c=128, h=9, w=11, k=64, r=1, s=1, stride=1, pad=0, dil=1, groups=1),
+	dict(n=2, c=64, h=10, w=10, k=256, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	# the stem's filter gradient (64 x 147) on the 64 x 192 tile, here with fewer than 64 output maps and an odd map
+	dict(n=3, c=3, h=45, w=39, k=48, r=7, s=7, stride=2, pad=3, dil=1, groups=1),
 ]
 
 
