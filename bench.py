@@ -245,10 +245,12 @@ def main():
 	lib.pz_conv_profile_enable(1)
 
 	allocs0 = driverAllocs(lib)
+	side0 = bnd.dnn.sideLaunches
 	t0 = time.perf_counter()
 	for _ in range(args.steps):
 		step()
 	issued = time.perf_counter() - t0
+	side_launches = bnd.dnn.sideLaunches - side0
 	lib.pz_device_sync()
 	grid.barrier()
 	elapsed = time.perf_counter() - t0
@@ -265,11 +267,12 @@ def main():
 	loss = float(cost.getMeanError())
 	fusion_counts = dict(lazy.counters)
 
-	# Kernel roofline. In the timed region the filter-gradient launches of every layer run on a second stream next to the
-	# backward-data chain: the step gets shorter, but two kernels then share the CUs and a launch's event-to-event time
-	# contains its neighbour's work. A kernel's own rate is therefore taken from ROOF_STEPS more steps of the same loop
-	# with that stream off (same kernels, same launches, one at a time); the timed-region figures are reported next to it.
-	concurrent = lazy.on("sidestream")
+	# Kernel roofline. When the backend put filter-gradient launches on its second stream during the timed region (its
+	# policy does so for networks of short kernels, backend.DnnContext.filterGradStream — not for this one at batch 256),
+	# two kernels shared the CUs and a launch's event-to-event time contains its neighbour's work: a kernel's own rate is
+	# then taken from ROOF_STEPS more steps of the same loop with that stream off (same kernels, same launches, one at a
+	# time) and the timed-region figures are reported next to it. Otherwise the timed region itself is the measurement.
+	concurrent = side_launches > 0
 	if concurrent:
 		lazy.disabled.add("sidestream")
 		step()
@@ -419,6 +422,7 @@ def main():
 		"timed_region_host": {
 			"issue_ms_per_step": issued / args.steps * 1e3,
 			"driver_allocations": allocs1[0] - allocs0[0], "driver_allocation_ms": (allocs1[1] - allocs0[1]) * 1e3,
+			"side_stream_launches_per_step": side_launches / args.steps,
 			"note": "host time to issue the timed steps (no device wait inside), and pool misses that went to hipMalloc during "
 					"them: an outlier step time with normal kernel times shows up here",
 		},

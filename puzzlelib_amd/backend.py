@@ -251,6 +251,8 @@ class DnnContext:
 	# "split6" / "split9" = exact 3-way bf16 split of every operand, 6 / 9 bf16 partial products, fp32 accumulation
 	MATH = {"f32": 0, "split6": 6, "split9": 9}
 	convMathDefault = os.environ.get("PUZZLE_MI355_MATH", "f32")
+	sideStreamMaxGflop = float(os.environ.get("PUZZLE_MI355_SIDE_MAX_GFLOP", "15"))      # mean GFLOP per filter-gradient launch
+	sideWorkMean = 0.0
 
 	def __init__(self, backend):
 		self.backend = backend
@@ -478,12 +480,21 @@ class DnnContext:
 	# join the streams explicitly: the launch leaves its completion event on the buffers it touched (lazy.foreignEnd) —
 	# the optimizer, `.get()`, the all-reduce or the next step's zero fill wait for it when they touch the gradient arena,
 	# and the tensors the side stream reads stay referenced (and guarded against overwrites) until the event has passed.
-	def filterGradStream(self):
+	def filterGradStream(self, gflop=0.0):
 		# The split modes run everything on ONE stream: on gfx950 a packed-fp32 instruction whose low lane reads the high
 		# half of a source (v_pk_mul_f32 ... op_sel:[0,1] — hipcc's SLP pass emits them all over the BatchNorm / element-wise
 		# kernels) returns a wrong low lane while another wave of the SIMD executes a bf16 MFMA
 		# (tools/probes/pk_forms_probe.hip): no kernel of this library may overlap a split kernel.
 		if not lazy.on("sidestream") or self.convMath != "f32":
+			return None
+		# A second queue pays while the launches are short (it hides launch latency and fills partial rounds: NiN at batch
+		# 128, 3.28 -> 3.08 ms per step). Long kernels from two queues only share the CUs, and share them badly: a
+		# filter-gradient launch next to its layer's backward-data launch or next to a BatchNorm pass takes 20-60 % of the
+		# shorter kernel LONGER than the two in sequence (tools/pair_overlap.py, profiles/r02_pair_overlap.txt; ResNet-50 at
+		# batch 256: 61.9 -> 61.3 ms on one stream, and the host is not held back by the bound on outstanding side launches).
+		# The decision follows the running mean of the filter-gradient work per launch, so a network stays on one side of it.
+		self.sideWorkMean += 0.1 * (gflop - self.sideWorkMean)
+		if self.sideWorkMean > self.sideStreamMaxGflop:
 			return None
 		if self.sideStream is None:
 			self.sideStream = driver.Stream()
@@ -546,7 +557,8 @@ class DnnContext:
 		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
 		folded = bn is not None and not withbias and foldable
 
-		side = self.filterGradStream() if (not withbias or fused) else None
+		gflop = 2e-9 * prod(grad.shape) * prod(W.shape[1:])
+		side = self.filterGradStream(gflop) if (not withbias or fused) else None
 		st = side.handle if side is not None else None
 		reads = [data, bn.dy, bn.x] if folded else [data, grad]
 		writes = [wgrad] + ([bg] if fused else [])

@@ -305,6 +305,7 @@ def test_filter_gradients_on_the_side_stream(surf):
 		Blas.toVectorAddVector(arena, arena, alpha=1.0)               # main-stream read-modify-write of the arena
 		return arena.get()
 
+	surf.backend.dnn.sideWorkMean = 0.0           # (full-size tests before this one may have moved the policy to one stream)
 	launches = surf.backend.dnn.sideLaunches
 	with_side = run()
 	# (the split math modes keep everything on one stream: backend.DnnContext.filterGradStream)
