@@ -6,17 +6,17 @@
 //   dx[n, c, 2i+a, 2j+b] = sum_k sum_{dr, ds} dy[n, k, i + dmin + dr, j + dmin + ds] * w[k, c, r(a, dr), s(b, ds)]
 //   r(a, dr) = a + pad - 2*(dr + dmin)         (the filter taps that reach output row parity a from input row i + dmin + dr)
 //
-// One thread owns one coarse pixel (i, j) of one image = the 2 x 2 x C outputs that share one WR x WS window of dy
-// (4 x 4 for 7x7 / pad 3). Per reduction channel k it loads the window once (16 loads, lanes along j: coalesced; the
-// 4x overlap between neighbouring threads is served by L1/L2) and issues one fma per (output, valid tap) — 147 for the
-// stem — whose weight operand is WAVE-UNIFORM: the packed filter is indexed by k and compile-time constants only, so
+// A coarse pixel (i, j) of one image = the 2 x 2 x C outputs that share one WR x WS window of dy (4 x 4 for 7x7 / pad 3).
+// One thread owns kThinCells vertically adjacent coarse pixels; per reduction channel k it loads their joint window once
+// (5 x 4 loads for 2 cells, lanes along j: coalesced) and issues one fma per (output, valid tap) — 147 per cell for the stem, the two
+// column parities of an output row as one v_pk_fma_f32 — whose weight operand is WAVE-UNIFORM: the packed filter is indexed by k and compile-time constants only, so
 // the compiler fetches it with scalar loads and the fma takes it from an SGPR. No LDS, no barrier, 2 x 2 x C accumulators.
 // Taps that do not exist for a parity (a = 0 meets 3 filter rows, a = 1 meets 4) are skipped at compile time.
 // Work: 2*N*P*Q*K*C*R*S FLOP on the VALU (78 TFLOP/s of plain fp32 fma on 256 CUs); dy is read once from HBM.
 #include "common.h"
 
 #ifndef PZ_THIN_UNROLL
-#define PZ_THIN_UNROLL 2           // reduction channels in flight per thread: the window loads of two channels overlap
+#define PZ_THIN_UNROLL 1           // reduction channels unrolled per thread (2 with two-cell threads: registers, 0.83 -> 0.99 ms)
 #endif
 #define PZ_PRAGMA_(x) _Pragma(#x)
 #define PZ_UNROLL(n) PZ_PRAGMA_(unroll n)      // (a macro inside a plain #pragma does not survive -save-temps)
@@ -49,7 +49,9 @@ struct Win {
 	static constexpr bool valid(int a, int d) { return tap(a, d) >= 0 && tap(a, d) < R; }
 };
 
-// wpk[k][dr][ds][a][b][c] = w[k][c][r(a, dr)][s(b, ds)], zero where the tap does not exist
+// wpk[k][dr][ds][a][c][b] = w[k][c][r(a, dr)][s(b, ds)], zero where the tap does not exist. The column parity b is the
+// fastest axis: the two outputs (2i+a, 2j) and (2i+a, 2j+1) of a channel take one v_pk_fma_f32 whose weight pair is an
+// aligned SGPR pair
 template <int C, int R, int S, int PH, int PW>
 __global__ void __launch_bounds__(256) thin_pack_kernel(const float *__restrict__ w, float *__restrict__ wpk, int K) {
 	using WH = Win<R, PH>;
@@ -58,10 +60,12 @@ __global__ void __launch_bounds__(256) thin_pack_kernel(const float *__restrict_
 	const int idx = blockIdx.x * 256 + threadIdx.x;
 	if (idx >= K * per_k) return;
 	int t = idx;
+	const int b = t & 1;
+	t >>= 1;
 	const int c = t % C;
 	t /= C;
-	const int b = t & 1, a = (t >> 1) & 1;
-	t >>= 2;
+	const int a = t & 1;
+	t >>= 1;
 	const int ds = t % WW::size;
 	t /= WW::size;
 	const int dr = t % WH::size, k = t / WH::size;
@@ -69,23 +73,33 @@ __global__ void __launch_bounds__(256) thin_pack_kernel(const float *__restrict_
 	wpk[idx] = (r >= 0 && r < R && s >= 0 && s < S) ? w[((k * C + c) * R + r) * S + s] : 0.f;
 }
 
+// NC vertically adjacent coarse pixels per thread: their windows overlap in WR - 1 rows, so WR + NC - 1 rows of WS
+// columns are loaded for NC cells (10 loads per cell and reduction channel with NC = 2 instead of 16), every load still
+// 256 contiguous bytes per wave (lanes along j). The kernel is bound by those 4-byte gathers next to its fmas: without
+// them it takes 0.68 instead of 1.01 ms on the stem. Measured on the stem (ms): NC = 1: 1.01, 2: 0.83, 3: 0.86, 4: 0.87,
+// 6: 0.85, 8: 0.89; cells side by side in a row instead (lane stride 16 B: four times the cache lines per load): 1.6.
+#ifndef PZ_THIN_CELLS
+#define PZ_THIN_CELLS 2
+#endif
+constexpr int kThinCells = PZ_THIN_CELLS;
+
 template <int C, int R, int S, int PH, int PW>
 __global__ void __launch_bounds__(256) thin_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ wpk,
-                                                          float *__restrict__ dx, int K, int P, int Q, int H, int W, int Hc,
+                                                          float *__restrict__ dx, int K, int P, int Q, int H, int W, int Hg,
                                                           int Wc, unsigned dy_bytes) {
 	using WH = Win<R, PH>;
 	using WW = Win<S, PW>;
-	constexpr int WR = WH::size, WS = WW::size;
+	constexpr int WR = WH::size, WS = WW::size, NC = kThinCells, WROWS = WR + NC - 1;
 
-	const int cell = blockIdx.x * 256 + threadIdx.x;           // coarse pixel inside the image, row-major: lanes along j
+	const int grp = blockIdx.x * 256 + threadIdx.x;            // (group of NC coarse rows, coarse column), row-major: lanes along j
 	const int n = blockIdx.y;
-	const bool live = cell < Hc * Wc;
-	const int i = cell / Wc, j = cell - i * Wc;
+	const bool live = grp < Hg * Wc;
+	const int ig = grp / Wc, j = grp - ig * Wc, i = ig * NC;    // first coarse row of the group
 
 	// byte offsets of the window inside one (n, k) plane of dy; outside the map (or a dead thread) -> the hardware returns 0
-	unsigned woff[WR][WS];
+	unsigned woff[WROWS][WS];
 #pragma unroll
-	for (int dr = 0; dr < WR; ++dr)
+	for (int dr = 0; dr < WROWS; ++dr)
 #pragma unroll
 		for (int ds = 0; ds < WS; ++ds) {
 			const int p = i + WH::lo + dr, q = j + WW::lo + ds;
@@ -96,55 +110,73 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(const float *__restrict
 	const unsigned plane = (unsigned)(P * Q) * 4u;
 	unsigned soff = (unsigned)n * (unsigned)K * plane;          // scalar: start of this image's first plane
 
-	float acc[2][2][C];
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	f32x2 acc[NC][2][C];                                       // [cell][row parity a][channel] = the column pair (b = 0, 1)
 #pragma unroll
-	for (int a = 0; a < 2; ++a)
+	for (int e = 0; e < NC; ++e)
 #pragma unroll
-		for (int b = 0; b < 2; ++b)
+		for (int a = 0; a < 2; ++a)
 #pragma unroll
-			for (int c = 0; c < C; ++c) acc[a][b][c] = 0.f;
+			for (int c = 0; c < C; ++c) acc[e][a][c] = f32x2{0.f, 0.f};
 
 	constexpr int per_k = WR * WS * 4 * C;
 PZ_UNROLL(PZ_THIN_UNROLL)
 	for (int k = 0; k < K; ++k, soff += plane) {
-		float v[WR][WS];
+		float v[WROWS][WS];
 #pragma unroll
-		for (int dr = 0; dr < WR; ++dr)
+		for (int dr = 0; dr < WROWS; ++dr)
 #pragma unroll
 			for (int ds = 0; ds < WS; ++ds)
+#ifdef PZ_THIN_ABL      // timing only: no window loads
+				v[dr][ds] = __builtin_bit_cast(float, woff[dr][ds] + soff);
+#else
 				v[dr][ds] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, woff[dr][ds], soff, 0));
+#endif
 
-		const float *wk = wpk + (size_t)k * per_k;              // wave-uniform: scalar loads
+		const f32x2 *wk = reinterpret_cast<const f32x2 *>(wpk + (size_t)k * per_k);      // wave-uniform: scalar loads
 #pragma unroll
 		for (int dr = 0; dr < WR; ++dr)
 #pragma unroll
 			for (int ds = 0; ds < WS; ++ds)
 #pragma unroll
 				for (int a = 0; a < 2; ++a)
+					if (WH::valid(a, dr)) {
 #pragma unroll
-					for (int b = 0; b < 2; ++b)
-						if (WH::valid(a, dr) && WW::valid(b, ds)) {
+						for (int c = 0; c < C; ++c) {
+							const f32x2 w2 = wk[((dr * WS + ds) * 2 + a) * C + c];
 #pragma unroll
-							for (int c = 0; c < C; ++c)
-								acc[a][b][c] = __builtin_fmaf(v[dr][ds], wk[((dr * WS + ds) * 4 + a * 2 + b) * C + c], acc[a][b][c]);
+							for (int e = 0; e < NC; ++e) {
+								const float x = v[dr + e][ds];
+								// a tap that exists for one column parity only is a scalar fma on that half: no 0 * dy term
+								// enters the other sum (it would turn a non-finite dy into NaNs the convolution does not produce)
+								if (WW::valid(0, ds) && WW::valid(1, ds))
+									acc[e][a][c] = __builtin_elementwise_fma(f32x2{x, x}, w2, acc[e][a][c]);
+								else if (WW::valid(0, ds))
+									acc[e][a][c][0] = __builtin_fmaf(x, w2[0], acc[e][a][c][0]);
+								else if (WW::valid(1, ds))
+									acc[e][a][c][1] = __builtin_fmaf(x, w2[1], acc[e][a][c][1]);
+							}
 						}
+					}
 	}
 
 	if (!live) return;
+	typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+	const int x0 = 2 * j;
 #pragma unroll
 	for (int c = 0; c < C; ++c)
 #pragma unroll
-		for (int a = 0; a < 2; ++a) {
-			const int h = 2 * i + a, x0 = 2 * j;
-			if (h >= H) continue;
-			float *row = dx + (((size_t)n * C + c) * H + h) * W + x0;
-			if (x0 + 1 < W) {
-				typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-				*reinterpret_cast<f2u *>(row) = f2u{acc[a][0][c], acc[a][1][c]};
-			} else if (x0 < W) {
-				row[0] = acc[a][0][c];
+		for (int e = 0; e < NC; ++e)
+#pragma unroll
+			for (int a = 0; a < 2; ++a) {
+				const int h = 2 * (i + e) + a;
+				if (h >= H) continue;
+				float *row = dx + (((size_t)n * C + c) * H + h) * W + x0;
+				if (x0 + 1 < W)
+					*reinterpret_cast<f2u *>(row) = acc[e][a][c];
+				else if (x0 < W)
+					row[0] = acc[e][a][c][0];
 			}
-		}
 }
 
 // the shapes instantiated: (C, R, S, pad_h, pad_w)
@@ -159,9 +191,9 @@ int thin_launch(const pz_conv_desc *d, int P, int Q, const float *dy, const floa
 	const int per_k = Win<R, PH>::size * Win<S, PW>::size * 4 * C;
 	thin_pack_kernel<C, R, S, PH, PW><<<pz::ceil_div((long)d->k * per_k, 256), 256, 0, st>>>(w, wpk, d->k);
 	PZ_LAUNCH_CHECK();
-	const int Hc = (d->h + 1) / 2, Wc = (d->w + 1) / 2;
-	dim3 grid(pz::ceil_div((long)Hc * Wc, 256), d->n);
-	thin_dgrad_kernel<C, R, S, PH, PW><<<grid, 256, 0, st>>>(dy, wpk, dx, d->k, P, Q, d->h, d->w, Hc, Wc,
+	const int Hg = pz::ceil_div((d->h + 1) / 2, kThinCells), Wc = (d->w + 1) / 2;      // groups of coarse rows, coarse columns
+	dim3 grid(pz::ceil_div((long)Hg * Wc, 256), d->n);
+	thin_dgrad_kernel<C, R, S, PH, PW><<<grid, 256, 0, st>>>(dy, wpk, dx, d->k, P, Q, d->h, d->w, Hg, Wc,
 	                                                           (unsigned)((size_t)d->n * d->k * P * Q * 4));
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
