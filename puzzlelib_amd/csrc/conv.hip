@@ -418,7 +418,13 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 
 				const unsigned chan_off = (unsigned)(g * a.M + ch) * (unsigned)PQ;
 				if (whole) {
+#if PZ_ABL & 4096       // ablation: epilogue transposes through LDS but every store is dropped (timing only)
+					const unsigned off = kOOB + 0u * (unsigned)n_img * chan_off * pq;
+#elif PZ_ABL & 32768    // ablation: every store of the epilogue goes to the first 1 MB of y (L2-resident: no HBM write stream)
+					const unsigned off = row_ok ? ((((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u) & 0xffff0u : kOOB;
+#else
 					const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u : kOOB;
+#endif
 					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, 0);
 				} else {
 					auto store_one = [&](int e, float val) {

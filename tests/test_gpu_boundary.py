@@ -232,3 +232,25 @@ def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
 	for name in a.files:
 		if name != "transport":
 			assert np.array_equal(a[name], c[name]), "parameter %s differs with a one-rank RCCL communicator" % name
+
+
+@pytest.mark.gpu
+def test_bench_json_is_the_last_stdout_line_with_a_communicator_up(bnd):
+	"""librccl prints a version banner with printf when the first communicator is created; it used to leave the process
+	behind bench.py's JSON line. The driver reads the LAST line of stdout."""
+	import json, subprocess, sys
+	from conftest import ROOT
+
+	env = dict(os.environ, PUZZLE_MI355_FORCE_COMM="1")
+	for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+		env.pop(key, None)
+	res = subprocess.run(
+		[sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+		env=env, capture_output=True, text=True, timeout=900
+	)
+	assert res.returncode == 0, res.stderr[-3000:]
+	lines = [l for l in res.stdout.splitlines() if l.strip()]
+	line = json.loads(lines[-1])
+	assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+	assert line["config"]["grad_allreduce"].startswith("single-rank rehearsal")
+	assert "RCCL version" not in res.stdout
