@@ -279,6 +279,14 @@ typedef struct pz_pool_desc {
 
 int pz_pool2d_out_shape(const pz_pool_desc *d, int *p, int *q);
 int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *index_ws, pz_stream_t stream);
+/* Max pooling over a batch normalisation that was only described (the lazy-buffer layer, puzzlelib_amd/lazy.py): reads the
+ * BN's INPUT x and applies y = a*x + b per channel (coef = (c, 2) pairs from pz_bn_fwd_train_coef), optionally through
+ * ReLU, while it stages the rows — the normalised tensor between Modules/BatchNorm2D.py, Modules/Activation.py (in place)
+ * and Modules/MaxPool2D.py (the ResNet stem, Models/Nets/ResNet.py:88-96) is never written. Bit-identical to pz_bn_apply_add
+ * followed by pz_pool2d_fwd. Only for the geometries pz_pool2d_fwd_bn_supported reports (max pooling, band kernel). */
+int pz_pool2d_fwd_bn_supported(const pz_pool_desc *d, int *supported);
+int pz_pool2d_fwd_bn(const pz_pool_desc *d, const float *x, const float *coef, int relu, float *y, uint8_t *index_ws,
+                     pz_stream_t stream);
 /* x/y are only read for max pooling when index_ws == NULL (arg-max recomputed, first maximum wins) */
 int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const float *y, const uint8_t *index_ws,
                   float *dx, pz_stream_t stream);

@@ -260,6 +260,7 @@ class DnnContext:
 		self.geometry = {}
 		self.sideStream = None
 		self.sideLaunches = 0
+		self.poolBnCache = {}
 		self.convMath = None
 		self.setConvMath(self.convMathDefault)
 
@@ -664,9 +665,28 @@ class DnnContext:
 			workspace = GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
 
 		index = workspace.optr if (workspace is not None and mode == PoolMode.max.value) else None
-		lib.pz_pool2d_fwd(byref(desc), data.rptr, out.optr, index, None)
+
+		# max pooling over a BatchNorm(+ReLU) that is still only described (the ResNet stem): the band kernel normalises the
+		# rows while it stages them, and the normalised tensor is never written — nobody else reads it (the pooling's
+		# backward works from the arg-max bytes, the BatchNorm's from its own input)
+		bn = lazy.pending(data, fusion.BnApply) if (lazy.on("bnpool") and mode == PoolMode.max.value) else None
+		if bn is not None and bn.x.shape == data.shape and self.poolFusesBn(desc):
+			lib.pz_pool2d_fwd_bn(byref(desc), bn.x.rptr, fusion.raw(bn.coef), int(bn.relu), out.optr, index, None)
+			lazy.count("bn_pool")
+		else:
+			lib.pz_pool2d_fwd(byref(desc), data.rptr, out.optr, index, None)
 
 		return out if test else (out, workspace)
+
+
+	def poolFusesBn(self, desc):
+		key = tuple(getattr(desc, f) for f, _ in desc._fields_)
+		known = self.poolBnCache.get(key)
+		if known is None:
+			flag = c_int(0)
+			lib.pz_pool2d_fwd_bn_supported(byref(desc), byref(flag))
+			known = self.poolBnCache[key] = bool(flag.value)
+		return known
 
 
 	def poolNdBackward(self, grad, indata, outdata, workspace, size=2, stride=2, pad=0, mode=PoolMode.max.value,
@@ -684,7 +704,11 @@ class DnnContext:
 		out = GPUArray.empty(indata.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
 
 		index = workspace.rptr if (workspace is not None and mode == PoolMode.max.value) else None
-		lib.pz_pool2d_bwd(byref(desc), grad.rptr, indata.rptr, outdata.rptr, index, out.optr, None)
+		# with the arg-max bytes the kernel reads neither tensor: not asking for their addresses leaves a described input
+		# (a BatchNorm the forward pooling normalised on the fly) unwritten
+		xptr = indata.rptr if index is None else None
+		yptr = outdata.rptr if index is None else None
+		lib.pz_pool2d_bwd(byref(desc), grad.rptr, xptr, yptr, index, out.optr, None)
 		return out
 
 

@@ -147,9 +147,13 @@ constexpr int kPoolBandFloats = 3584;           // 14 KB
 constexpr int kPoolFwdBand = 8;                 // output rows per workgroup (forward)
 constexpr int kPoolBwdBand = 16;                // input rows per workgroup (backward)
 
+// `coef` != nullptr: the input is a batch normalisation that was only described — the band is normalised while it is
+// staged, v = fma(x, a[ch], b[ch]) and the fused ReLU's (v > 0 ? v : 0), exactly what pz_bn_apply_add would have written
+// (same fma, same select), and the normalised tensor never exists in memory
 template <int SZ, int ST>
 __global__ void __launch_bounds__(256) maxpool_fwd_lds_kernel(pz_pool_desc d, PoolGeom g, const float *__restrict__ x,
-                                                               float *__restrict__ y, uint8_t *__restrict__ idx) {
+                                                               float *__restrict__ y, uint8_t *__restrict__ idx,
+                                                               const float *__restrict__ coef = nullptr, int relu = 0) {
 	__shared__ __attribute__((aligned(16))) float rows[kPoolBandFloats];
 	const int HW = d.h * d.w, PQ = g.P * g.Q;
 	const int p0 = blockIdx.y * kPoolFwdBand, p1 = min(p0 + kPoolFwdBand, g.P);
@@ -159,8 +163,22 @@ __global__ void __launch_bounds__(256) maxpool_fwd_lds_kernel(pz_pool_desc d, Po
 
 	typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 	typedef float f4a __attribute__((ext_vector_type(4), may_alias));
-	for (int i = threadIdx.x; i < (count >> 2); i += 256) *reinterpret_cast<f4a *>(&rows[4 * i]) = *reinterpret_cast<const f4u *>(img + 4 * i);
-	for (int i = (count & ~3) + threadIdx.x; i < count; i += 256) rows[i] = img[i];
+	if (coef) {
+		const int ch = (int)(blockIdx.x % (unsigned)d.c);
+		const float a = coef[2 * ch], b = coef[2 * ch + 1];
+		auto act = [&](float u) {
+			const float v = __builtin_fmaf(u, a, b);
+			return relu ? (v > 0.f ? v : 0.f) : v;
+		};
+		for (int i = threadIdx.x; i < (count >> 2); i += 256) {
+			const f4u u = *reinterpret_cast<const f4u *>(img + 4 * i);
+			*reinterpret_cast<f4a *>(&rows[4 * i]) = f4a{act(u[0]), act(u[1]), act(u[2]), act(u[3])};
+		}
+		for (int i = (count & ~3) + threadIdx.x; i < count; i += 256) rows[i] = act(img[i]);
+	} else {
+		for (int i = threadIdx.x; i < (count >> 2); i += 256) *reinterpret_cast<f4a *>(&rows[4 * i]) = *reinterpret_cast<const f4u *>(img + 4 * i);
+		for (int i = (count & ~3) + threadIdx.x; i < count; i += 256) rows[i] = img[i];
+	}
 	__syncthreads();
 
 	for (int i = threadIdx.x; i < (p1 - p0) * g.Q; i += 256) {
@@ -330,6 +348,34 @@ int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *inde
 	} else {
 		pool_fwd_kernel<2, 0, 0><<<blocks, 256, 0, st>>>(*d, g, x, y, index_ws);
 	}
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+static bool pool_fwd_bn_ok(const pz_pool_desc *d, int Q, const PoolGeom &g) {
+	return d->mode == 0 && pool_lds_window(d) && pool_lds_fits(d, Q, true) && g.planes < 65536u * 32768u;
+}
+
+int pz_pool2d_fwd_bn_supported(const pz_pool_desc *d, int *supported) {
+	int P, Q;
+	if (int rc = pool_check(d, &P, &Q)) return rc;
+	PZ_REQUIRE(supported != nullptr, "pz_pool2d_fwd_bn_supported: null output");
+	*supported = pool_fwd_bn_ok(d, Q, pool_geom(d, P, Q, (size_t)P * Q)) ? 1 : 0;
+	return PZ_OK;
+}
+
+int pz_pool2d_fwd_bn(const pz_pool_desc *d, const float *x, const float *coef, int relu, float *y, uint8_t *index_ws,
+                     pz_stream_t stream) {
+	int P, Q;
+	if (int rc = pool_check(d, &P, &Q)) return rc;
+	PZ_REQUIRE(x && coef && y, "pz_pool2d_fwd_bn: null tensor");
+	const PoolGeom g = pool_geom(d, P, Q, (size_t)P * Q);
+	PZ_REQUIRE(pool_fwd_bn_ok(d, Q, g), "pz_pool2d_fwd_bn: this pooling does not run on the band kernel (pz_pool2d_fwd_bn_supported)");
+	hipStream_t st = pz::as_stream(stream);
+	const dim3 grid(g.planes, (P + kPoolFwdBand - 1) / kPoolFwdBand);
+	if (d->size_h == 3 && d->stride_h == 2) maxpool_fwd_lds_kernel<3, 2><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws, coef, relu);
+	else if (d->size_h == 2) maxpool_fwd_lds_kernel<2, 2><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws, coef, relu);
+	else maxpool_fwd_lds_kernel<3, 1><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws, coef, relu);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

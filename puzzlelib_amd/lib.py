@@ -146,6 +146,8 @@ _PROTOS = {
 
 	"pz_pool2d_out_shape": [POINTER(PoolDesc), POINTER(c_int), POINTER(c_int)],
 	"pz_pool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
+	"pz_pool2d_fwd_bn_supported": [POINTER(PoolDesc), POINTER(c_int)],
+	"pz_pool2d_fwd_bn": [POINTER(PoolDesc), P, P, c_int, P, P, P],
 	"pz_pool2d_bwd": [POINTER(PoolDesc), P, P, P, P, P, P],
 
 	"pz_maskpool2d_fwd": [POINTER(PoolDesc), P, P, P, P],
@@ -233,7 +235,7 @@ def _bind(name, argtypes):
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
-	"pz_pool2d_out_shape", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get"
+	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get"
 }
 _fake = {"next": 0x7000_0000_0000}
 

@@ -350,3 +350,47 @@ def test_borrowed_streams_are_ordered_by_the_buffers(surf):
 		results.append({k: p.data.get() for k, p in net.namedParams().items()})
 	for key in results[0]:
 		assert np.array_equal(results[0][key], results[1][key]), key
+
+
+@pytest.mark.parametrize("shape,size,stride,pad", [((5, 7, 21, 19), 3, 2, 0), ((3, 4, 16, 16), 2, 2, 0), ((2, 6, 13, 13), 3, 1, 1),
+												   ((2, 64, 112, 112), 3, 2, 0)])
+def test_max_pooling_normalises_a_described_batchnorm_on_the_fly(surf, shape, size, stride, pad):
+	"""BatchNorm -> in-place ReLU -> MaxPool (the ResNet stem, Models/Nets/ResNet.py:88-96): the pooling reads the BN's
+	input and applies the affine pair + ReLU while staging its rows; output and arg-max bytes equal the unfused sequence
+	bit for bit, the normalised tensor is never written, and the backward pooling does not need it either."""
+	from puzzlelib_amd import lazy
+	g, Dnn, f32 = surf.gpuarray, surf.Dnn, np.float32
+	rng = np.random.RandomState(11)
+	x = rng.randn(*shape).astype(f32)
+	c = shape[1]
+	sc, bi = (1.0 + 0.2 * rng.randn(1, c, 1, 1)).astype(f32), (0.3 * rng.randn(1, c, 1, 1)).astype(f32)
+	dy = None
+
+	def run():
+		nonlocal dy
+		gx = g.to_gpu(x)
+		mean, var = g.zeros((1, c, 1, 1), f32), g.to_gpu(np.ones((1, c, 1, 1), f32))
+		y, _, _ = Dnn.batchNormNd(gx, g.to_gpu(sc), g.to_gpu(bi), mean, var, 1e-5, 1.0, False)
+		surf.ElementWise.reluKer(f32)(y, y)
+		before = dict(lazy.counters)
+		pooled, ws = Dnn.poolNd(y, size, stride, pad, Dnn.PoolMode.max, False)
+		fusedNow = lazy.counters.get("bn_pool", 0) - before.get("bn_pool", 0)
+		if dy is None:
+			dy = rng.randn(*pooled.shape).astype(f32)
+		applied = lazy.counters.get("bn_apply_relu", 0)
+		dx = Dnn.poolNdBackward(y, pooled, g.to_gpu(dy), ws, size, stride, pad, Dnn.PoolMode.max)
+		wroteLater = lazy.counters.get("bn_apply_relu", 0) - applied
+		return pooled.get(), np.array(ws.get()), dx.get(), y.get(), fusedNow, wroteLater
+
+	fused = run()
+	lazy.disabled = {"bnpool"}
+	try:
+		plain = run()
+	finally:
+		lazy.disabled = set()
+
+	assert fused[4] == 1 and fused[5] == 0 and plain[4] == 0
+	for a, b, what in zip(fused[:4], plain[:4], ("pooled", "arg-max bytes", "input gradient", "normalised tensor read afterwards")):
+		assert np.array_equal(a, b), what
+	ref = np.maximum(plain[3], 0)
+	assert np.array_equal(ref, plain[3])

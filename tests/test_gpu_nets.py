@@ -190,7 +190,7 @@ def test_lazy_fusion_is_bit_identical_to_the_literal_sequence_and_matches_oracle
 
 	results = {}
 	variants = [(), ("bnadd", ), ("gatestats", ), ("up2", ), ("mask", ), ("sidestream", ), ("bnrelu", ), ("bnrelubwd", ), ("gate", ),
-				("addrelu", ), ("addgate", ), ("sum", ), ("bnapply", ), "literal"]
+				("addrelu", ), ("addgate", ), ("sum", ), ("bnapply", ), ("bnpool", ), "literal"]
 	for variant in variants:
 		if variant == "literal":
 			lazy.enabled = False
@@ -201,12 +201,13 @@ def test_lazy_fusion_is_bit_identical_to_the_literal_sequence_and_matches_oracle
 
 	full = results[()]
 	taken = full["taken"]
-	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 7), ("bn_bwd_gate", 7), ("gate_stats", 1), ("gate_stats_up2", 1),
+	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 6), ("bn_pool", 1), ("bn_bwd_gate", 7), ("gate_stats", 1), ("gate_stats_up2", 1),
 				   ("compact_dgrad", 2), ("gate_by_mask", 2), ("bn_bwd_from_partials", 4)):
 		assert taken.get(key, 0) == n, "%s taken %d times, expected %d: %s" % (key, taken.get(key, 0), n, taken)
 	assert set(results["literal"]["taken"]) <= {"bn_apply"}, "with the layer off nothing is deferred"
 	assert results[("bnadd", )]["taken"].get("bn_apply_add", 0) == 0 and results[("up2", )]["taken"].get("compact_dgrad", 0) == 0
 	assert results[("mask", )]["taken"].get("gate_by_mask", 0) == 0
+	assert results[("bnpool", )]["taken"].get("bn_pool", 0) == 0 and results[("bnpool", )]["taken"].get("bn_apply_relu", 0) == 7
 
 	for variant in variants[1:]:
 		other = results[variant]
