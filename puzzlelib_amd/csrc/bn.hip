@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(256) bn_merge_strips_kernel(const float4 *__re
 	for (int s = s_lo + t; s < s_hi; s += 256) {
 		const float4 e = mine[s];
 		const long left = total_px - (long)s * strip_px;
-		const double nb = (double)(left < strip_px ? left : strip_px), d = (double)e.x - R;
+		// (entries that carry their own count — the Winograd epilogue's tile blocks — say so in .w)
+		const double nb = e.w > 0.f ? (double)e.w : (double)(left < strip_px ? left : strip_px), d = (double)e.x - R;
 		S += (double)e.y + nb * d;
 		Q += (double)e.z + d * (2.0 * (double)e.y + nb * d);
 	}
@@ -701,8 +702,8 @@ int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const fl
 	PZ_REQUIRE(x && y && scale && bias && run_mean && run_var && save_mean && save_invvar && stats, "pz_bn_fwd_train_pre: null tensor");
 	PZ_REQUIRE(act == PZ_BN_ACT_NONE || act == PZ_BN_ACT_RELU, "pz_bn_fwd_train_pre: unknown fused activation %d", act);
 	const long total_px = (long)n * hw;
-	PZ_REQUIRE(strips == (int)((total_px + PZ_CONV_STATS_STRIP - 1) / PZ_CONV_STATS_STRIP),
-	           "pz_bn_fwd_train_pre: %d strips do not cover %ld pixels", strips, total_px);
+	// (strips of PZ_CONV_STATS_STRIP pixels from the implicit GEMM, or Winograd tile blocks that carry their own counts)
+	PZ_REQUIRE(strips >= 1, "pz_bn_fwd_train_pre: no statistics entries");
 	const BnGeom g = bn_geom(n, c, hw);
 	PZ_REQUIRE(workspace && ws_bytes >= bn_ws_bytes(g), "pz_bn_fwd_train_pre: workspace too small");
 
@@ -730,8 +731,8 @@ int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float 
 	if (int rc = bn_check(n, c, hw)) return rc;
 	PZ_REQUIRE(scale && bias && run_mean && run_var && save_mean && save_invvar && stats && coef, "pz_bn_fwd_train_defer: null tensor");
 	const long total_px = (long)n * hw;
-	PZ_REQUIRE(strips == (int)((total_px + PZ_CONV_STATS_STRIP - 1) / PZ_CONV_STATS_STRIP),
-	           "pz_bn_fwd_train_defer: %d strips do not cover %ld pixels", strips, total_px);
+	// (strips of PZ_CONV_STATS_STRIP pixels from the implicit GEMM, or Winograd tile blocks that carry their own counts)
+	PZ_REQUIRE(strips >= 1, "pz_bn_fwd_train_defer: no statistics entries");
 	PZ_REQUIRE(workspace && ws_bytes >= bn_pre_ws_bytes(c), "pz_bn_fwd_train_defer: workspace too small");
 
 	float *pre = (float *)workspace;

@@ -34,7 +34,8 @@ inline int stream_grid(size_t work_items, int per_block) {
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st);
+              void *workspace, hipStream_t st, float *stats = nullptr);
+int wino_stats_strips(const pz_conv_desc *d, int P, int Q);      // statistics blocks per channel of a forward launch (0: none)
 bool wino_wgrad_eligible(const pz_conv_desc *d, int P, int Q);
 size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q);
 int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float *dy, float *dw, float alpha, float beta,

@@ -2094,8 +2094,10 @@ int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(strips != nullptr, "pz_conv2d_fwd_stats_strips: null output");
-	*strips = (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || uses_winograd(d, PZ_CONV_FWD, P, Q, algo))
-	              ? 0 : pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
+	if (algo != PZ_CONV_ALGO_DIRECT && igemm_eligible(d, P, Q) && uses_winograd(d, PZ_CONV_FWD, P, Q, algo))
+		*strips = pz::wino_stats_strips(d, P, Q);      // one entry per (channel, block of 32 tiles), with explicit counts
+	else
+		*strips = (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) ? 0 : pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	return PZ_OK;
 }
 
@@ -2112,11 +2114,11 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	hipStream_t st = pz::as_stream(stream);
 
 	if (uses_winograd(d, PZ_CONV_FWD, P, Q, algo)) {
-		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: the Winograd path does not produce strip statistics");
+		PZ_REQUIRE(stats == nullptr || pz::wino_stats_strips(d, P, Q) > 0, "pz_conv2d_fwd_stats: this Winograd build does not produce statistics");
 		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
 		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
-		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, workspace, st);
+		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, workspace, st, stats);
 	}
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {

@@ -101,6 +101,10 @@ struct WinoArgs {
 	int TY, TX, tiles;       // 2x2 tiles per image column / row, N*TY*TX
 	int chunks, tblocks;
 	unsigned x_bytes, y_bytes;
+	// optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count} over the workgroup's 32 tiles of a channel,
+	// for a following batch normalisation (the strip format of the implicit GEMM's epilogue, with an explicit count:
+	// border tiles hold fewer than 4 pixels) — 8-wave kernel only
+	float4 *stats;
 };
 
 // D[m = channel][n = tile] of the 16 positions -> output tensor. Register i of a lane is row 8 (i / 4) + 4 (lane / 32) + i % 4,
@@ -442,6 +446,21 @@ __device__ __forceinline__ void wino_epilogue8(const WinoArgs &a, f32x16 (&acc)[
 			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y01), yr, kv && col1 ? o + 4u : kOOB, 0, 0);
 			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y10), yr, kv && row1 ? o + q4 : kOOB, 0, 0);
 			__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y11), yr, kv && row1 && col1 ? o + q4 + 4u : kOOB, 0, 0);
+
+			if (a.stats) {
+				// the 32 lanes of a half-wave hold this channel's 32 tiles: shifted sums about the block's first output
+				// (tile tb*TB always exists), fixed shuffle tree -> deterministic
+				const float shift = __shfl(y00, lane & 32);
+				float s1 = 0.f, s2 = 0.f, cnt = 0.f;
+				auto take = [&](float v, bool ok) {
+					const float dlt = ok ? v - shift : 0.f;
+					s1 += dlt, s2 = __builtin_fmaf(dlt, dlt, s2), cnt += ok ? 1.f : 0.f;
+				};
+				take(y00, kv), take(y01, kv && col1), take(y10, kv && row1), take(y11, kv && row1 && col1);
+#pragma unroll
+				for (int m = 16; m > 0; m >>= 1) s1 += __shfl_xor(s1, m), s2 += __shfl_xor(s2, m), cnt += __shfl_xor(cnt, m);
+				if (l31 == 0 && k < a.K) a.stats[(size_t)k * a.tblocks + tb] = make_float4(shift, s1, s2, cnt);
+			}
 		}
 		if (q < 3) __syncthreads();
 	}
@@ -1472,8 +1491,16 @@ size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q) {
 }
 
 // which = PZ_CONV_FWD: out(N,K,P,Q) = conv(in(N,C,H,W), w) + bias;  PZ_CONV_BWD_DATA: out(N,C,H,W) = conv^T(in(N,K,P,Q), w)
+int wino_stats_strips(const pz_conv_desc *d, int P, int Q) {
+#if WN_WAVES == 8
+	return ceil_div((long)d->n * ((P + 1) / 2) * ((Q + 1) / 2), TB);
+#else
+	return 0;
+#endif
+}
+
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st) {
+              void *workspace, hipStream_t st, float *stats) {
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 
@@ -1497,6 +1524,7 @@ int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, c
 	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB);
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
+	a.stats = reinterpret_cast<float4 *>(stats);
 #if WN_WAVES == 8
 	wino_conv_kernel8<<<a.tblocks * fa.kblocks, 512, 0, st>>>(a);
 #elif WN_SELFWAVE

@@ -188,7 +188,7 @@ def fused_step_counts():
 	fusedCalls, fused = counts[True]
 	literalCalls, literal = counts[False]
 	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 6), ("bn_pool", 1), ("bn_bwd_gate", 7), ("wgrad_bn_fold", 4), ("dgrad_bn_fold", 4),
-				   ("gate_stats", 1), ("gate_stats_up2", 1), ("compact_dgrad", 2), ("conv_stats", 9), ("gate_by_mask", 2)):
+				   ("gate_stats", 1), ("gate_stats_up2", 1), ("compact_dgrad", 2), ("conv_stats", 12), ("gate_by_mask", 2)):
 		assert fused.get(key, 0) == n, "%s taken %d times, expected %d (%s)" % (key, fused.get(key, 0), n, fused)
 	assert not any(k in literal for k in ("bn_apply_add", "bn_bwd_gate", "wgrad_bn_fold", "gate_stats", "compact_dgrad"))
 	assert literalCalls > fusedCalls + 30, (literalCalls, fusedCalls)

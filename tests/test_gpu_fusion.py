@@ -120,7 +120,11 @@ def test_described_tensor_sees_the_inputs_of_call_time(surf):
 
 
 @pytest.mark.parametrize("cfg", [dict(n=4, c=16, k=32, hw=(12, 12), r=1), dict(n=3, c=24, k=40, hw=(9, 11), r=1),
-								 dict(n=4, c=64, k=64, hw=(20, 20), r=3), dict(n=2, c=3, k=16, hw=(32, 32), r=7, stride=2, pad=3)])
+								 dict(n=4, c=64, k=64, hw=(20, 20), r=3), dict(n=2, c=3, k=16, hw=(32, 32), r=7, stride=2, pad=3),
+								 # Winograd (auto): tile blocks with explicit counts — odd maps (border tiles hold 1 or 2 pixels), a last
+								 # block of fewer than 32 tiles, output channels that do not fill a block of 64
+								 dict(n=3, c=32, k=64, hw=(11, 13), r=3, algo="auto"), dict(n=5, c=64, k=96, hw=(7, 7), r=3, algo="auto"),
+								 dict(n=2, c=128, k=128, hw=(28, 28), r=3, algo="auto"), dict(n=1, c=32, k=40, hw=(5, 6), r=3, pad=0, algo="auto")])
 def test_convolution_statistics_feed_the_batchnorm(surf, cfg):
 	"""Conv2D -> BatchNorm2D: the convolution's epilogue leaves per-strip sums and the batch-norm skips its statistics
 	pass (policy "always"; "adaptive" learns it after the first pass). Same mean / variance up to summation order."""
@@ -132,7 +136,7 @@ def test_convolution_statistics_feed_the_batchnorm(surf, cfg):
 	x = rng.randn(n, c, h, w).astype(np.float32)
 	wt = (rng.randn(k, c, r, r) / np.sqrt(c * r * r)).astype(np.float32)
 	(scale, bias, rm, rv), fresh = bnParams(surf, rng, k)
-	algo = surf.Dnn.ConvFwdAlgo.implicitGemm
+	algo = getattr(surf.Dnn.ConvFwdAlgo, cfg.get("algo", "implicitGemm"))
 
 	results = {}
 	for policy in ("never", "always"):
