@@ -1922,8 +1922,27 @@ struct WgradPlan {
 	size_t tab_bytes, slab_elems;
 };
 
+// Backward-filter walks the pixels in runs of 4 inside a row, rows padded to whole runs: 14-wide maps execute 16/14 of
+// their MFMAs and loads, 7-wide ones 8/7. For a pointwise, unit-stride, unpadded layer x and dy are the same plane layout
+// and the sum over pixels does not care how the plane is cut into rows, so it is read as the (rows >= 2, cols) rectangle
+// of the same area whose rows pad least (14 x 14 -> 7 x 28, 55 x 55 -> 5 x 605; 7 x 7 has no better cut).
+static void wgrad_plane(const pz_conv_desc *d, int P, int Q, int *rows, int *cols) {
+	*rows = P, *cols = Q;
+	if (!(d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1)) return;
+	const int area = P * Q;
+	long best = (long)P * ((Q + 3) / 4);
+	auto consider = [&](int r, int c) {
+		if (r < 2) return;
+		const long padded = (long)r * ((c + 3) / 4);
+		if (padded < best || (padded == best && c > *cols)) best = padded, *rows = r, *cols = c;
+	};
+	for (int r = 2; (long)r * r <= area; ++r)
+		if (area % r == 0) consider(r, area / r), consider(area / r, r);
+}
+
 WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	WgradPlan p;
+	wgrad_plane(d, P, Q, &P, &Q);
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 	p.ncrs = Cg * d->r * d->s;
 	p.bm = (Kg <= 64 || pz::ceil_div(Kg, 64) * 64 < pz::ceil_div(Kg, 128) * 128) ? 64 : 128;
@@ -2369,6 +2388,15 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 
 	int2 *tab = (int2 *)workspace;
 	float *slabs = (float *)((char *)workspace + p.tab_bytes);
+
+	// the plane as the kernel walks it (wgrad_plane: another rectangle of the same area for pointwise layers)
+	pz_conv_desc dd = *d;
+	const int P0 = P, Q0 = Q;
+	if (!split_math) {
+		wgrad_plane(d, P0, Q0, &P, &Q);
+		if (P != P0 || Q != Q0) dd.h = P, dd.w = Q;
+	}
+	d = &dd;
 
 	if (!split_math) {
 		// the gather table depends on the geometry alone: built once per (device, geometry) into memory the library keeps,
