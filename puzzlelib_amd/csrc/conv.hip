@@ -1924,20 +1924,11 @@ struct WgradPlan {
 
 // Backward-filter walks the pixels in runs of 4 inside a row, rows padded to whole runs: 14-wide maps execute 16/14 of
 // their MFMAs and loads, 7-wide ones 8/7. For a pointwise, unit-stride, unpadded layer x and dy are the same plane layout
-// and the sum over pixels does not care how the plane is cut into rows, so it is read as the (rows >= 2, cols) rectangle
-// of the same area whose rows pad least (14 x 14 -> 7 x 28, 55 x 55 -> 5 x 605; 7 x 7 has no better cut).
+// and the sum over pixels does not care how the plane is cut into rows, so it is read as ONE row of P*Q pixels: only the
+// plane's last run is partial (7 x 7 -> 13 runs instead of 14, 14 x 14 -> 49 instead of 56).
 static void wgrad_plane(const pz_conv_desc *d, int P, int Q, int *rows, int *cols) {
 	*rows = P, *cols = Q;
-	if (!(d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1)) return;
-	const int area = P * Q;
-	long best = (long)P * ((Q + 3) / 4);
-	auto consider = [&](int r, int c) {
-		if (r < 2) return;
-		const long padded = (long)r * ((c + 3) / 4);
-		if (padded < best || (padded == best && c > *cols)) best = padded, *rows = r, *cols = c;
-	};
-	for (int r = 2; (long)r * r <= area; ++r)
-		if (area % r == 0) consider(r, area / r), consider(area / r, r);
+	if (d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1) *rows = 1, *cols = P * Q;
 }
 
 WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
