@@ -89,14 +89,18 @@ def cpu_baseline(sample_batch=32):
 def spawnRanks(args):
 	"""`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
 	import socket
-	with socket.socket() as s:
+	# two free ports, both reserved at the same time: MASTER_PORT (kept for whoever reads it) and the host group's own
+	# (grid.nodeFromEnv would otherwise assume MASTER_PORT + 1 is free)
+	with socket.socket() as s, socket.socket() as t:
 		s.bind(("127.0.0.1", 0))
-		port = s.getsockname()[1]
+		t.bind(("127.0.0.1", 0))
+		port, hostPort = s.getsockname()[1], t.getsockname()[1]
 
 	procs = []
 	for rank in range(args.gpus):
 		env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-				   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+				   MASTER_PORT=str(port), PUZZLE_MI355_PORT=str(hostPort),
+				   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
 		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
 	codes = [p.wait() for p in procs]
 	sys.exit(max(codes))
@@ -404,10 +408,12 @@ def main():
 			"global_batch": world * args.batch, "parallelism": "dp%d" % world,
 			"grad_allreduce": "none" if nodeinfo is None else (
 				"single-rank rehearsal (PUZZLE_MI355_FORCE_COMM=1): " if world == 1 else "") + (
-				"RCCL sum + 1/N, 25 MB buckets in reverse execution order, overlapped with backward"
-				if nodeinfo.transport == "rccl" else
+				"RCCL (ncclCommCount = %d ranks) sum + 1/N, 25 MB buckets in reverse execution order, overlapped with backward"
+				% nodeinfo.commRanks if nodeinfo.transport == "rccl" else
 				"FALLBACK: host-staged all-reduce over TCP (RCCL communicator could not be created)"
-			)
+			),
+			"grad_transport": "none" if nodeinfo is None else nodeinfo.transport,
+			"rccl_nranks": 0 if nodeinfo is None else nodeinfo.commRanks,
 		},
 		"build": {"library_build_id": lib.buildId(), "source_id": lib.sourceId(),
 				  "matches_sources": lib.sourceId() in (None, lib.buildId())},
@@ -449,6 +455,13 @@ def main():
 	if world == 1 and not args.no_cpu_baseline:
 		result["cpu_baseline"] = cpu_baseline()
 
+	if world > 1 and nodeinfo.transport != "rccl" and os.environ.get("PUZZLE_MI355_ALLOW_FALLBACK", "0") != "1":
+		# a multi-GPU number measured over the TCP fallback is not the design's number: no JSON line on stdout, rc != 0
+		# (PUZZLE_MI355_ALLOW_FALLBACK=1 keeps the line — rehearsals with several ranks on one device)
+		print(json.dumps(result), file=sys.stderr)
+		print("bench.py: %d ranks ended on the host-staged fallback transport (RCCL communicator could not be created) — "
+			  "refusing to report it as the data-parallel result" % world, file=sys.stderr, flush=True)
+		sys.exit(3)
 	print(json.dumps(result))
 
 

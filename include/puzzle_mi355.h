@@ -413,6 +413,8 @@ int pz_comm_destroy(pz_comm_t comm);
  * for an event recorded behind collectives, polling the communicator, and aborts it after timeout_s (<= 0: no limit)
  * — the reference's star has neither (a dead child blocks the parent's queue.get() forever, Grid.py:117-121).      */
 int pz_comm_probe(void);
+/* ranks / own rank as RCCL reports them for the live communicator (ncclCommCount, ncclCommUserRank) */
+int pz_comm_info(pz_comm_t comm, int *nranks, int *rank);
 int pz_comm_async_error(pz_comm_t comm);
 int pz_comm_wait_event(pz_comm_t comm, pz_event_t event, double timeout_s);
 int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, size_t count, pz_stream_t stream);

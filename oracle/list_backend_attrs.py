@@ -2,7 +2,7 @@
 TEST INFRASTRUCTURE (build container only) — lists every attribute PuzzleLib's dispatch surface reads from the backend
 object (`backend.<name>` in Backend/*.py and Backend/Kernels/*.py, plus the methods it calls on `.blas`, `.dnn`,
 `.matmod`, `.costmod`, `.memoryPool`, `.GPUArray`) and writes them to tests/golden/backend_attrs.json. The GPU test
-tests/test_gpu_boundary.py asserts that the MI355X backend object offers each of them.
+tests/test_gpu_2_boundary.py asserts that the MI355X backend object offers each of them.
 """
 import json, os, re
 

@@ -7,10 +7,11 @@ Hip/Backend.py:19-71 on top of Cuda/GPUBackend.py:17-433): GPUArray, memoryPool,
 `<name>Ker` kernel objects, enums, SharedArray, stream/event managers, RNG, copy/concatenate/split/tile, timeKernel.
 Underneath every entry is one or two calls into libpuzzle_mi355.so — no MIOpen, no rocBLAS, no JIT.
 """
-import os, sys, time, ctypes
+import os, weakref, sys, time, ctypes
 from ctypes import byref, c_int, c_size_t, c_void_p
 from enum import Enum
 from collections import OrderedDict
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -256,7 +257,7 @@ class DnnContext:
 
 	def __init__(self, backend):
 		self.backend = backend
-		self.statsWanted = set()
+		self.statsWanted = weakref.WeakKeyDictionary()      # allocation of a filter -> byte offsets of filters a BatchNorm follows
 		self.geometry = {}
 		self.sideStream = None
 		self.sideLaunches = 0
@@ -369,9 +370,14 @@ class DnnContext:
 
 		ws = self.workspace(wsbytes, allocator)
 
-		key = W.gpudata.ptr
+		# (the filter is identified by its allocation OBJECT and offset, not by its address: a network built later in a
+		# recycled address range starts with no history, so a network's n-th step takes the same path in every process)
+		wroot = W.gpudata.root
+		key = (wroot, W.gpudata.ptr - wroot.ptr)
 		policy = DnnContext.convStatsPolicy
-		want = lazy.on("convstats") and not given and (policy == "always" or (policy == "adaptive" and key in self.statsWanted))
+		want = lazy.on("convstats") and not given and (
+			policy == "always" or (policy == "adaptive" and key[1] in self.statsWanted.get(wroot, ()))
+		)
 
 		if not want or nstrips == 0:
 			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), wsbytes, None)
@@ -380,7 +386,7 @@ class DnnContext:
 			lib.pz_conv2d_fwd_stats(
 				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), wsbytes, None
 			)
-			lazy.setFact(out, "convstats", stats)
+			lazy.setFact(out, "convstats", (stats, outshape))
 			lazy.count("conv_stats")
 
 		if lazy.enabled and not given:
@@ -780,11 +786,15 @@ class DnnContext:
 
 		# statistics: the producing convolution's strip sums when it left them; otherwise tell that convolution (by its
 		# filter's address) that a BatchNorm reads its output, so that it does from the next pass on
-		stats = lazy.fact(data, "convstats") if mode == BatchNormMode.spatial.value else None
-		if stats is None and DnnContext.convStatsPolicy == "adaptive":
+		# (per-channel sums of the convolution's (n, k, p, q) output: they are this BatchNorm's statistics only if it
+		# normalises that very tensor over the same channel axis — not a reshape, a slice or per-activation mode)
+		stats = lazy.fact(data, "convstats") if mode == BatchNormMode.spatial.value and data.ndim == 4 else None
+		if stats is not None:
+			stats = stats[0] if tuple(stats[1]) == tuple(data.shape) and stats[0].shape[0] == c else None
+		if stats is None and DnnContext.convStatsPolicy == "adaptive" and data.ndim == 4:
 			key = lazy.fact(data, "fromconv")
 			if key is not None:
-				self.statsWanted.add(key)
+				self.statsWanted.setdefault(key[0], set()).add(key[1])
 
 		lib.pz_bn_fwd_train_coef(
 			data.rptr, n, c, hw, scale.rptr, bias.rptr, mean.wptr, var.wptr, savemean.optr, saveinvvar.optr, epsilon, factor,
@@ -1342,6 +1352,9 @@ def absorbRelu(arrays, scalars):
 		return False
 
 	if lazy.sameBuffer(out, inp):
+		waiting = lazy.editable(inp)                         # in place = a write: readers by reference are settled first
+		if waiting is None:
+			return False
 		if isinstance(waiting, lazy.Zero):
 			return True                                      # relu(0) = 0
 		if isinstance(waiting, fusion.BnApply) and not waiting.relu and lazy.on("bnrelu"):
@@ -1369,7 +1382,7 @@ def absorbReluDer(arrays, scalars):
 			lazy.sameBuffer(ingrad, outdata):
 		return False
 
-	waiting = lazy.pending(ingrad)
+	waiting = lazy.editable(ingrad)
 	root = ingrad.gpudata.root
 	if isinstance(waiting, fusion.Sum) and not waiting.relu and waiting.gate is None and lazy.on("addgate"):
 		waiting.gate = outdata
@@ -1389,7 +1402,7 @@ def absorbAxpy(arrays, scalars):
 	y, x = arrays
 	if float(scalars[0]) != 1.0 or x.size != y.size or x.dtype != y.dtype or not lazy.on("sum"):
 		return False
-	waiting = lazy.pending(y)
+	waiting = lazy.editable(y)
 	if not isinstance(waiting, (lazy.Zero, fusion.Sum)) or x.gpudata.root is y.gpudata.root:
 		return False
 	if isinstance(waiting, fusion.Sum) and (waiting.relu or waiting.gate is not None or len(waiting.terms) >= 4):
@@ -1576,6 +1589,10 @@ class Mi355Backend:
 	GPUArray = GPUArray
 	Error = HipError
 	SharedArray = SharedArray
+
+	# the reference backend's `Rand` module attribute (Cuda/GPUBackend.py:33,62-63; Hip/Backend.py:29): generator class + type id
+	Rand = SimpleNamespace(__name__="puzzlelib_amd.rng", RandomNumberGenerator=RandomNumberGenerator, RAND_RNG_PSEUDO_PHILOX4_32_10=0)
+	RandomNumberGenerator = RandomNumberGenerator
 
 	GroupFormat = GroupFormat
 	ConvPerf = ConvPerf

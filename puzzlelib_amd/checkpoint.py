@@ -45,7 +45,8 @@ def collect(net, optimizer=None):
 def save(net, path, optimizer=None, format="npz"):
 	tensors = collect(net, optimizer)
 	if format == "npz":
-		np.savez(path, **{k.replace("/", "|"): v for k, v in tensors.items()})
+		with open(path, "wb") as f:           # a file object: np.savez would append ".npz" to a bare path and load() miss it
+			np.savez(f, **{k.replace("/", "|"): v for k, v in tensors.items()})
 	elif format == "hdf5":
 		import h5py
 		with h5py.File(path, "w") as hdf:
@@ -56,7 +57,9 @@ def save(net, path, optimizer=None, format="npz"):
 
 
 def read(path):
-	if str(path).endswith((".hdf", ".hdf5", ".h5")):
+	with open(path, "rb") as f:               # the container is recognised by its magic, not by the file's name
+		magic = f.read(8)
+	if magic == b"\x89HDF\r\n\x1a\n":
 		import h5py
 		out = {}
 		with h5py.File(path, "r") as hdf:

@@ -26,6 +26,8 @@ struct Rccl {
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 	ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
 	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+	ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 Rccl g_rccl;
@@ -55,6 +57,8 @@ int load_rccl() {
 	PZ_SYM(GetErrorString, "ncclGetErrorString")
 	PZ_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
 	PZ_SYM(CommAbort, "ncclCommAbort")
+	PZ_SYM(CommCount, "ncclCommCount")
+	PZ_SYM(CommUserRank, "ncclCommUserRank")
 #undef PZ_SYM
 
 	g_rccl.lib = lib;
@@ -103,8 +107,20 @@ int pz_comm_probe(void) {
 	return load_rccl();
 }
 
+int pz_comm_info(pz_comm_t comm, int *nranks, int *rank) {
+	// what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), not what the caller asked for
+	PZ_REQUIRE(comm != nullptr && comm->comm && nranks && rank, "pz_comm_info: null argument or aborted communicator");
+	PZ_NCCL(g_rccl.CommCount(comm->comm, nranks));
+	PZ_NCCL(g_rccl.CommUserRank(comm->comm, rank));
+	return PZ_OK;
+}
+
 int pz_comm_async_error(pz_comm_t comm) {
 	PZ_REQUIRE(comm != nullptr, "pz_comm_async_error: null communicator");
+	if (!comm->comm) {
+		pz::set_error("RCCL communicator of rank %d/%d was aborted", comm->rank, comm->nranks);
+		return PZ_ERR_COMM;
+	}
 	ncclResult_t state = 0;
 	PZ_NCCL(g_rccl.CommGetAsyncError(comm->comm, &state));
 	if (state != 0 && state != 7 /* ncclInProgress */) {
@@ -117,6 +133,10 @@ int pz_comm_async_error(pz_comm_t comm) {
 
 int pz_comm_wait_event(pz_comm_t comm, pz_event_t event, double timeout_s) {
 	PZ_REQUIRE(comm != nullptr && event != nullptr, "pz_comm_wait_event: null argument");
+	if (!comm->comm) {
+		pz::set_error("RCCL communicator of rank %d/%d was aborted", comm->rank, comm->nranks);
+		return PZ_ERR_COMM;
+	}
 	const auto t0 = std::chrono::steady_clock::now();
 	for (;;) {
 		const hipError_t rc = hipEventQuery((hipEvent_t)event);

@@ -250,6 +250,7 @@ class NodeInfo:
 
 class RcclNodeInfo(NodeInfo):
 	transport = "rccl"
+	commRanks = 0           # ncclCommCount of the live communicator (0: none was created)
 	timeout = float(os.environ.get("PUZZLE_MI355_COMM_TIMEOUT_S", "0"))     # > 0: host-side watchdog on every step's exchange
 
 	def __init__(self, index, gridsize, device, uniqueId, group, bucketBytes=25 << 20):
@@ -289,6 +290,13 @@ class RcclNodeInfo(NodeInfo):
 				reason = str(e)
 			if self.vote(reason is None):
 				self.comm, self.commStream = handle.value, driver.Stream()
+				# what RCCL itself reports for the live communicator (bench.py prints it next to the transport)
+				nranks, rank = ctypes.c_int(0), ctypes.c_int(0)
+				lib.pz_comm_info(self.comm, ctypes.byref(nranks), ctypes.byref(rank))
+				self.commRanks = nranks.value
+				if (nranks.value, rank.value) != (self.gridsize, self.index):
+					raise lib.CommError("RCCL reports rank %d of %d, the grid is rank %d of %d" % (
+						rank.value, nranks.value, self.index, self.gridsize))
 				return
 			if reason is None:
 				lib.pz_comm_destroy(handle.value)

@@ -106,8 +106,15 @@ def pending(ary, kind=None):
 
 
 def fact(ary, key):
-	lz = ary.gpudata.root.lz
+	"""A fact recorded about the contents of `ary`'s allocation — only if `ary` IS that allocation (contiguous, whole):
+	facts live on the root buffer, and a slice or strided view of it is a different tensor. Facts that depend on how the
+	bytes are cut into axes (per-channel statistics) carry the shape they hold for; their readers compare it."""
+	root = ary.gpudata.root
+	lz = root.lz
 	if lz is None or lz.meta is None:
+		return None
+	buf = ary.gpudata
+	if buf.ptr != root.ptr or ary.nbytes != root.size or not ary.contiguous:
 		return None
 	return lz.meta.get(key, None)
 
@@ -172,26 +179,54 @@ def readBarrier(root, buf=None, stream=None):
 		waitEvents(lz, True, stream, root if buf is None else buf)
 
 
+def settleDependents(root):
+	"""Everything whose pending description or facts derive from `root`'s CURRENT value is made independent of it: thunks
+	run (they read `root` through the read barrier, which writes `root`'s own pending description if they need it), facts
+	are dropped. Called before the value changes — by a write, or by an operator that is about to edit `root`'s pending
+	description in place (a ReLU / gate / further term joining it)."""
+	lz = root.lz
+	if lz is None or lz.deps is None:
+		return
+	deps, lz.deps = lz.deps, None
+	for ref in deps:
+		other = ref()
+		if other is not None and other.lz is not None and other is not root:
+			if other.lz.thunk is not None:
+				settle(other)
+			other.lz.meta = None
+	lz.deps = None                            # (a dependent that settled re-registered its facts: they were just dropped)
+
+
 def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
 	if lz.small is not None:
 		touchSmall(lz, root if buf is None else buf, True)
+	# dependents first: one of them may need this buffer's own pending contents (B = copy of A while A is a pending zero
+	# fill, then A is overwritten — dropping A's description before B ran would let B copy unwritten memory)
+	if lz.deps is not None:
+		settleDependents(root)
 	if lz.thunk is not None:
 		if whole:
 			lz.thunk = None
 		else:
 			settle(root)
-	if lz.deps is not None:
-		deps, lz.deps = lz.deps, None
-		for ref in deps:
-			other = ref()
-			if other is not None and other.lz is not None and other is not root:
-				if other.lz.thunk is not None:
-					settle(other)
-				other.lz.meta = None
 	lz.meta = None
 	if lz.wev is not None or lz.rev is not None:
 		waitEvents(lz, False, stream, root if buf is None else buf)
+
+
+def editable(ary, kind=None):
+	"""The pending description of `ary` (as `pending`) for an operator that wants to edit it in place. Editing changes the
+	tensor's value, so whoever captured the tensor by reference is settled first; if that made the description run there
+	is nothing left to edit and the caller falls back to its kernel."""
+	thunk = pending(ary, kind)
+	if thunk is None:
+		return None
+	root = ary.gpudata.root
+	if root.lz.deps is not None:
+		settleDependents(root)
+		thunk = pending(ary, kind)
+	return thunk
 
 
 # ---------------------------------------------------------------------------------------------- queued small adds

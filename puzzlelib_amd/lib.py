@@ -191,6 +191,7 @@ _PROTOS = {
 	"pz_comm_init_rank": [PP, c_int, c_char_p, c_int],
 	"pz_comm_destroy": [P],
 	"pz_comm_probe": [],
+	"pz_comm_info": [P, P, P],
 	"pz_comm_async_error": [P],
 	"pz_comm_wait_event": [P, P, ctypes.c_double],
 	"pz_comm_allreduce_sum_f32": [P, P, P, c_size_t, P],
@@ -264,6 +265,10 @@ def _dry(name, argtypes):
 			_store(args[1], _fakeHandle())
 		elif name == "pz_comm_init_rank":
 			_store(args[0], _fakeHandle())
+			_fake["comm"] = (int(args[1]), int(args[3]))
+		elif name == "pz_comm_info":
+			_store(args[1], _fake["comm"][0])
+			_store(args[2], _fake["comm"][1])
 		elif name in ("pz_device_count", ):
 			_store(args[0], 1)
 		elif name == "pz_device_num_cus":

@@ -10,7 +10,7 @@ While macro-batch i trains, macro-batch i+1 is staged and copied — by a worker
 the compute stream waits for a slot's `copied` event before reading it, the copy stream waits for the slot's `consumed` event (recorded on the
 compute stream after the last kernel that read it) before overwriting it, and the host waits for `copied` before it
 rewrites the pinned half of the slot. Values are untouched — the trained parameters are bit-identical to the
-synchronous path (tests/test_gpu_boundary.py).
+synchronous path (tests/test_gpu_2_boundary.py).
 """
 import ctypes
 from concurrent.futures import ThreadPoolExecutor

@@ -49,7 +49,12 @@ def bnd():
 	# the reference's unit-test runner poisons fresh allocations (Cuda/Utils.py:97-114, Unittester.py:52-55): every GPU
 	# test here runs with NaN-filled `empty()` buffers, so a kernel reading memory nobody wrote shows up as NaNs
 	gpuarray.GPUArray.debugFill = os.environ.get("PUZZLE_MI355_DEBUG_ALLOC", "1") == "1"
-	return backend.getBackend(0, initmode=2)
+	bnd_ = backend.getBackend(0, initmode=2)
+	# the backend seeds its global generator from numpy's (unseeded) global state, as the reference does
+	# (Cuda/GPUBackend.py: globalRng seeded from np.random.randint): every test run here draws the same device words —
+	# re-seeded in place, so that whoever already holds the object (surface.bound()) sees the same generator
+	bnd_.globalRng.__init__(seed=0x5eed2026)
+	return bnd_
 
 
 def assert_close(actual, desired, atol=1e-5, rtol=1e-5, what=""):

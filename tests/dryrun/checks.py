@@ -162,6 +162,67 @@ def lazy_barriers():
 	assert waits() == before, "a write next to the foreign stream's bytes must not wait for it"
 	surf.ElementWise.toVectorAddVectorKer(f32)(arena, g.to_gpu(np.zeros(256, f32)), 1.0)
 	assert waits() == before + 1 and arena.gpudata.root.lz.wev is None
+
+	# (10) ADVICE r2: overwriting a described tensor entirely must first serve whoever captured it by reference — B is a
+	# sum over A while A is still a pending zero fill; A.set(...) may drop A's description only after B has been written
+	lib.trace.clear()
+	A = g.empty(x.shape, dtype=f32)
+	A.fill(0)
+	B = g.empty(x.shape, dtype=f32)
+	B.fill(0)
+	surf.Blas.toVectorAddVector(B.ravel(), A.ravel())
+	assert names() == [] and isinstance(lazy.pending(B), fusion.Sum)
+	A.set(np.ones(A.shape, f32))
+	got = names()
+	# (two zero fills — A's own and the literal 0 + A of B — and B's axpy, all before the upload lands in A)
+	assert lazy.pending(B) is None and got.count("pz_memset_d32") == 2 and got[-1] == "pz_memcpy_h2d", got
+
+	# (11) ADVICE r2: an in-place ReLU joining a description is a write — an accumulator that took the described tensor
+	# by reference (3-d BatchNorm output: the "arr" term of a Sum) must get bn(x), not relu(bn(x))
+	x3 = g.to_gpu(np.zeros((4, 8, 64), f32))
+	lib.trace.clear()
+	y11, _, _ = surf.Dnn.batchNormNd(x3, scale, bias, mean, var, 1e-5, 1.0, False)
+	acc = g.empty(x3.shape, dtype=f32)
+	acc.fill(0)
+	surf.Blas.toVectorAddVector(acc.ravel(), y11.ravel())
+	assert isinstance(lazy.pending(acc), fusion.Sum) and lazy.pending(acc).terms[0][0] == "arr"
+	surf.ElementWise.reluKer(f32)(y11, y11)
+	assert lazy.pending(acc) is None, "the accumulator was settled before the ReLU changed the tensor it refers to"
+	relus = [a for n, a in lib.trace if n == "pz_bn_apply_add"]
+	assert relus and all(int(a[-2]) == 0 for a in relus), "bn(x) was written without the ReLU"
+	assert "pz_eltwise" in names(), "the ReLU itself then ran as a kernel on the written tensor"
+
+	# (12) the same for a further term joining a described sum that somebody refers to
+	lib.trace.clear()
+	s1 = g.empty(x.shape, dtype=f32)
+	s1.fill(0)
+	surf.Blas.toVectorAddVector(s1.ravel(), b.ravel())
+	s2 = g.empty(x.shape, dtype=f32)
+	s2.fill(0)
+	surf.Blas.toVectorAddVector(s2.ravel(), s1.ravel())            # s2 = 0 + s1 (s1 by reference)
+	surf.Blas.toVectorAddVector(s1.ravel(), b.ravel())             # s1 changes: s2 is written first
+	assert lazy.pending(s2) is None
+
+	# (13) ADVICE r2 (high): a convolution's per-channel strip sums are the statistics of a BatchNorm over that very
+	# tensor only — not of a BatchNorm over a reshape or a slice of it (second pass: the adaptive policy is armed)
+	from puzzlelib_amd import backend as B_
+	w = g.to_gpu(np.zeros((16, 8, 3, 3), f32))
+	def statsArg():
+		call = [a for n, a in lib.trace if n == "pz_bn_fwd_train_coef"][-1]
+		return call[12], call[13]                 # (statistics given: 1 / 0, strips)
+	for attempt in range(3):
+		lib.trace.clear()
+		yc = dnn.convNd(x, w, None, stride=1, pad=1)
+		yb, _, _ = surf.Dnn.batchNormNd(yc, *bnInputs(16), 1e-5, 1.0, False)
+		if attempt > 0:
+			assert statsArg()[0] == 1 and statsArg()[1] > 0, "conv -> BN takes the strip sums from the second pass on"
+		yc = dnn.convNd(x, w, None, stride=1, pad=1)
+		view = yc.reshape(4, 32, 8, 16)
+		surf.Dnn.batchNormNd(view, *bnInputs(32), 1e-5, 1.0, False)
+		assert statsArg() == (0, 0), "BN over a reshape of the convolution's output computes its own statistics"
+		yc = dnn.convNd(x, w, None, stride=1, pad=1)
+		surf.Dnn.batchNormNd(yc[:2], *bnInputs(16), 1e-5, 1.0, False)
+		assert statsArg() == (0, 0), "BN over a slice of the convolution's output computes its own statistics"
 	print("lazy barriers: OK")
 
 

@@ -398,3 +398,96 @@ def test_max_pooling_normalises_a_described_batchnorm_on_the_fly(surf, shape, si
 		assert np.array_equal(a, b), what
 	ref = np.maximum(plain[3], 0)
 	assert np.array_equal(ref, plain[3])
+
+
+def test_described_tensors_captured_by_reference_keep_their_value(surf):
+	"""(1) overwriting a described tensor entirely must first serve a tensor that refers to it —
+	B = 0 + A while A is a pending zero fill, then A.set(ones): B is zeros, not unwritten memory; (2) an in-place ReLU (or
+	a further term) joining a description changes the tensor: an accumulator that took it by reference keeps the old value."""
+	g, Dnn, El, Blas = surf.gpuarray, surf.Dnn, surf.ElementWise, surf.Blas
+	from puzzlelib_amd import lazy, fusion
+	rng = np.random.RandomState(21)
+	shape = (4, 6, 64)
+
+	A = g.empty(shape, dtype=np.float32)               # (NaN-poisoned by the test allocator)
+	A.fill(0)
+	B = g.empty(shape, dtype=np.float32)
+	B.fill(0)
+	Blas.toVectorAddVector(B.ravel(), A.ravel())
+	assert isinstance(lazy.pending(B), fusion.Sum)
+	A.set(np.ones(shape, np.float32))
+	assert np.array_equal(B.get(), np.zeros(shape, np.float32)) and np.array_equal(A.get(), np.ones(shape, np.float32))
+
+	# 3-d BatchNorm output (its description is taken by reference into a sum), then reluKer(y, y)
+	x = rng.randn(*shape).astype(np.float32)
+	(scale, bias, rm, rv), fresh = bnParams(surf, rng, 6)
+	gs, gb, grm, grv = fresh()
+	y, sm, si = Dnn.batchNormNd(g.to_gpu(x), gs, gb, grm, grv, 1e-5, 1.0, False)
+	acc = g.empty(shape, dtype=np.float32)
+	acc.fill(0)
+	Blas.toVectorAddVector(acc.ravel(), y.ravel())
+	El.reluKer(np.float32)(y, y)
+	y_ref = R.bn_fwd_train(x.reshape(4, 6, 64, 1), scale.ravel(), bias.ravel(), rm.ravel().copy(), rv.ravel().copy(), 1e-5, 1.0)[0]
+	y_ref = y_ref.reshape(shape)
+	assert_close(acc.get(), y_ref, atol=2e-5, rtol=1e-4, what="acc = bn(x), taken before the ReLU")
+	assert (acc.get() < 0).any()
+	assert_close(y.get(), np.maximum(y_ref, 0), atol=2e-5, rtol=1e-4, what="y = relu(bn(x))")
+
+	# a sum that gets a further term after somebody referred to it
+	a, b = rng.randn(*shape).astype(np.float32), rng.randn(*shape).astype(np.float32)
+	ga, gb2 = g.to_gpu(a), g.to_gpu(b)
+	s1 = g.empty(shape, dtype=np.float32)
+	s1.fill(0)
+	Blas.toVectorAddVector(s1.ravel(), ga.ravel())
+	s2 = g.empty(shape, dtype=np.float32)
+	s2.fill(0)
+	Blas.toVectorAddVector(s2.ravel(), s1.ravel())
+	Blas.toVectorAddVector(s1.ravel(), gb2.ravel())
+	assert np.array_equal(s2.get(), a) and np.array_equal(s1.get(), a + b)
+
+	# a gate joining a described fan-in that somebody referred to
+	gy = g.to_gpu(rng.randn(*shape).astype(np.float32))
+	fan = g.empty(shape, dtype=np.float32)
+	fan.fill(0)
+	Blas.toVectorAddVector(fan.ravel(), ga.ravel())
+	Blas.toVectorAddVector(fan.ravel(), gb2.ravel())
+	keep = g.empty(shape, dtype=np.float32)
+	keep.fill(0)
+	Blas.toVectorAddVector(keep.ravel(), fan.ravel())
+	El.reluDerKer(np.float32)(fan, fan, gy)
+	assert np.array_equal(keep.get(), a + b) and np.array_equal(fan.get(), (a + b) * (gy.get() > 0))
+
+
+@pytest.mark.parametrize("policy", ["adaptive", "always"])
+def test_conv_statistics_only_serve_a_batchnorm_over_the_very_tensor(surf, policy):
+	"""the strip sums a convolution's epilogue leaves are per-channel sums of its (n, k, p, q) output.
+	A BatchNorm over a reshape (Conv -> Flatten-like regrouping of channels) or over a slice of that output must compute
+	its own statistics — two passes, so that the adaptive policy is armed in the second; all three against the oracle."""
+	from puzzlelib_amd import backend, lazy
+	g, Dnn = surf.gpuarray, surf.Dnn
+	backend.DnnContext.convStatsPolicy = policy
+	rng = np.random.RandomState(8)
+	x = rng.randn(6, 8, 12, 12).astype(np.float32)
+	w = (0.2 * rng.randn(16, 8, 3, 3)).astype(np.float32)
+	gx, gw = g.to_gpu(x), g.to_gpu(w)
+	conv_ref = R.conv2d_fwd(x, w, None, 1, 1)
+
+	def bn(view, ref, c, what):
+		(scale, bias, rm, rv), fresh = bnParams(surf, rng, c)
+		gs, gb, grm, grv = fresh()
+		y, sm, si = Dnn.batchNormNd(view, gs, gb, grm, grv, 1e-5, 0.5, False)
+		rm_ref, rv_ref = rm.ravel().copy(), rv.ravel().copy()
+		y_ref, sm_ref, si_ref = R.bn_fwd_train(ref, scale.ravel(), bias.ravel(), rm_ref, rv_ref, 1e-5, 0.5, acc=np.float64)
+		assert_close(y.get(), y_ref, atol=1e-4, rtol=1e-4, what=what + ": y")
+		assert_close(sm.get().ravel(), sm_ref.ravel(), atol=1e-5, rtol=1e-4, what=what + ": saved mean")
+		assert_close(si.get().ravel(), si_ref.ravel(), atol=1e-5, rtol=1e-4, what=what + ": saved inverse deviation")
+		assert_close(grv.get().ravel(), rv_ref, atol=1e-5, rtol=1e-4, what=what + ": running variance")
+
+	for attempt in range(2):
+		lazy.counters.clear()
+		bn(Dnn.convNd(gx, gw, None, 1, 1, 1, 1, Dnn.ConvFwdAlgo.auto), conv_ref, 16, "pass %d conv -> bn" % attempt)
+		bn(Dnn.convNd(gx, gw, None, 1, 1, 1, 1, Dnn.ConvFwdAlgo.auto).reshape(6, 32, 6, 12), conv_ref.reshape(6, 32, 6, 12), 32,
+		   "pass %d conv -> reshape -> bn" % attempt)
+		bn(Dnn.convNd(gx, gw, None, 1, 1, 1, 1, Dnn.ConvFwdAlgo.auto)[:3], conv_ref[:3], 16, "pass %d conv -> slice -> bn" % attempt)
+		if attempt == 1 or policy == "always":
+			assert lazy.counters.get("conv_stats", 0) == 3, "the convolutions did leave strip sums (only the first BN may use them)"

@@ -329,10 +329,35 @@ def test_validator_and_eval_mode(bnd, mini_golden):
 	assert err == np.mean(np.argmax(pred, axis=1) != labels)
 
 
-def test_nin_step_matches_oracle(bnd):
+def adoptDeviceGates(cnet, net, spec):
+	"""Makes the oracle's backward gate with what the DEVICE gated with: ReLU outputs and max-pool inputs / outputs read back
+	from the executor's layers replace the oracle's own in its cache (flat specs: cache key = spec index). Nine ReLU layers
+	deep a pre-activation within rounding of zero can have different signs on the two sides; that single flip moves a whole
+	filter gradient by O(1e-3) relative although both sides are right to rounding (profiles/r03_nin_seed_sweep.txt: 100
+	seeds x {one / two streams} x {lazy on / off} — all device runs bit-identical, error with the device's gates <= 7.1e-7,
+	with the oracle's own gates up to 5.3e-3 on the 13 seeds that had a flip). Returns the number of flipped ReLU gates; the
+	forward tensors themselves are held to the oracle's separately by the caller."""
+	flips = 0
+	for idx, layer in enumerate(net.layers):
+		key = str(idx)
+		if layer.kind == "act":
+			y = layer.y.get()
+			assert np.abs(y - cnet.cache[key]).max() <= 1e-4 * max(1.0, np.abs(y).max()), "activation %s" % layer.name
+			flips += int(((y > 0) != (cnet.cache[key] > 0)).sum())
+			cnet.cache[key] = y
+		elif layer.kind == "pool" and spec[idx][0] == "maxpool":
+			cnet.cache[key] = (layer.x.get(), layer.y.get())
+	return flips
+
+
+@pytest.mark.parametrize("batch", [8, 128])
+def test_nin_step_matches_oracle(bnd, batch):
 	"""Config 3 (CIFAR-10 NiN, TestLib/CnnCifar10NIN.py): one full training step — forward, cross-entropy, backward,
-	WeightDecay hook, MomentumSGD update — with the device's dropout words fed to the oracle, on a reduced batch."""
-	from puzzlelib_amd import nets, optim
+	WeightDecay hook, MomentumSGD update — at a reduced batch and at the configuration's own batch of 128. Dropout words
+	come from a SEEDED device generator and are fed to the oracle (Philox here, XORWOW there: statistical parity only);
+	the oracle's backward gates with the device's ReLU / max-pool decisions (adoptDeviceGates). Tolerance: every parameter
+	gradient within 5e-5 relative L2 of the oracle's (measured <= 7.1e-7 at batch 8 over 100 seeds)."""
+	from puzzlelib_amd import nets, optim, backend
 	from puzzlelib_amd.surface import bound
 
 	gpuarray = bound().gpuarray
@@ -341,21 +366,16 @@ def test_nin_step_matches_oracle(bnd):
 	spec = nets.nin_spec()
 
 	rng = np.random.RandomState(5)
-	data = rng.randn(8, 3, 32, 32).astype(np.float32)
-	labels = rng.randint(0, 10, size=(8, )).astype(np.int32)
+	data = rng.randn(batch, 3, 32, 32).astype(np.float32)
+	labels = rng.randint(0, 10, size=(batch, )).astype(np.int32)
 
 	params = {name: p.data.get() for name, p in net.namedParams().items()}
 	cnet = N.CpuNet(spec, params)
 
-	# the device RNG is Philox, not the reference's XORWOW: parity is checked with the mask fed to the oracle
-	class Recorder:
-		def fillInteger(self, ary):
-			bnd.globalRng.fillInteger(ary)
-			self.last = ary.get()
-
+	devrng = backend.RandomNumberGenerator(seed=20260929)
 	drops = [layer for layer in net.walk() if layer.kind == "dropout"]
 	for layer in drops:
-		layer.cfg["rng"] = Recorder()
+		layer.cfg["rng"] = devrng
 
 	optimizer = optim.MomentumSGD(learnRate=0.1, momRate=0.9)
 	optimizer.setupOn(net, useGlobalState=True)
@@ -364,33 +384,32 @@ def test_nin_step_matches_oracle(bnd):
 		target.wc = 1.0
 	cost = optim.CrossEntropy()
 
+	# the device step runs undisturbed (nothing is read back before the backward pass has been issued)
 	net.trainMode()
 	pred = net(gpuarray.to_gpu(data))
-	for layer in drops:
-		cnet.dropmasks[layer.name] = layer.cfg["rng"].last
+	grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
+	optimizer.zeroGradParams()
+	net.backward(grad, updGrad=False)
 
+	for layer in drops:
+		cnet.dropmasks[layer.name] = layer.aux[0].get()
 	cnet.train = True
 	pred_ref = cnet.forward(data)
 	assert_close(pred.get(), pred_ref, atol=1e-4, rtol=1e-3, what="NiN forward")
-
-	grad = cost(pred, gpuarray.to_gpu(labels), queryError=False)
 	err_ref, grad_ref = R.cross_entropy(pred_ref, labels)
 	assert np.isclose(float(cost.devErr.get()), err_ref, rtol=1e-4)
+	assert_close(grad.get(), grad_ref, atol=1e-6, rtol=1e-4, what="NiN cross-entropy gradient")
 
-	optimizer.zeroGradParams()
-	net.backward(grad, updGrad=False)
+	adoptDeviceGates(cnet, net, spec)
 	cnet.zero_grads()
 	cnet.backward(grad_ref)
 
 	for name, p in net.namedParams().items():
 		ref = cnet.grads[name]
 		got = p.grad.get()
-		scale = np.abs(ref).max() + 1e-8
-		# nine ReLU layers deep, a pre-activation within rounding of zero may gate differently on the two sides and moves
-		# single gradient entries by O(1e-2 * max): the tensor as a whole is held to 2e-3 (relative L2), entries to 2e-2 * max
 		rel = np.linalg.norm((got - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30)
-		assert rel < 2e-3, "NiN grad %s: relative L2 error %.3e" % (name, rel)
-		assert_close(got, ref, atol=2e-2 * scale, rtol=5e-3, what="NiN grad " + name)
+		assert rel < 5e-5, "NiN b%d grad %s: relative L2 error %.3e" % (batch, name, rel)
+		assert_close(got, ref, atol=1e-4 * (np.abs(ref).max() + 1e-8), rtol=1e-3, what="NiN grad " + name)
 
 	# the update of the real step: WeightDecay(1e-4) hook + MomentumSGD(0.1, 0.9) (TestLib/CnnCifar10NIN.py:63-66)
 	optimizer.update()
@@ -398,7 +417,7 @@ def test_nin_step_matches_oracle(bnd):
 	copt.update()
 	for name, p in net.namedParams().items():
 		ref = cnet.params[name]
-		assert_close(p.data.get(), ref, atol=5e-3 * (np.abs(ref).max() + 1e-8), rtol=5e-3, what="NiN param after the step " + name)
+		assert_close(p.data.get(), ref, atol=2e-5 * (np.abs(ref).max() + 1e-8), rtol=1e-4, what="NiN param after the step " + name)
 
 
 def test_checkpoint_round_trip_continues_bit_for_bit(bnd, mini_golden, tmp_path):
@@ -424,7 +443,7 @@ def test_checkpoint_round_trip_continues_bit_for_bit(bnd, mini_golden, tmp_path)
 	net, opt, trainer = fresh(7)
 	for _ in range(2):
 		trainer.train(data, labels, random=False)
-	path = str(tmp_path / "mini.npz")
+	path = str(tmp_path / "mini_checkpoint")                             # no extension: the container is found by its magic
 	checkpoint.save(net, path, optimizer=opt)
 	for _ in range(2):
 		trainer.train(data, labels, random=False)

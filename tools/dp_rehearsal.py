@@ -3,7 +3,7 @@ device PUZZLE_MI355_DEVICE train the mini-ResNet on THE SAME batch through the f
 broadcast, overlapped bucketed gradient exchange, 1/N scaling). RCCL refuses two ranks on one device, so the exchange
 runs on the host-staged TCP fallback — everything around the transport (hooks, buckets, events, ordering) is the code
 the multi-GPU run uses. With identical shards the mean gradient equals the single-process gradient bit for bit
-((g + g) / 2 is exact), so rank 0's parameters must equal a single-process run's: tests/test_gpu_boundary.py checks that.
+((g + g) / 2 is exact), so rank 0's parameters must equal a single-process run's: tests/test_gpu_2_boundary.py checks that.
 
     python tools/dp_rehearsal.py OUT.npz            (single process)      or with RANK / WORLD_SIZE / MASTER_* set per rank"""
 import os, sys
