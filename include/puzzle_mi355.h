@@ -401,6 +401,40 @@ int pz_matvec(const float *mat, const float *vec, float *out, int z, int h, int 
               pz_stream_t stream);
 int pz_argmin_rows(const float *t, int rows, int cols, int32_t *out, pz_stream_t stream);
 int pz_argmin_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_t stream);
+/* point-wise cost kernels bceKer / hingeKer / smoothL1Ker / l1HingeKer (Cuda/Kernels/Costs.py:8-72; callers Cost/BCE.py,
+ * Hinge.py, SmoothL1.py, L1Hinge.py): `grad` (and `grad2` for l1Hinge's second operand) per element, the per-element
+ * error terms to `terms` (scratch, `total` floats), and *error += sum(terms) in a fixed order — the reference atomicAdds
+ * into the same 0-d array. a = scores / pred / x1; b = target / x2 (float, smoothL1 and l1Hinge only); labels int32;
+ * numcases = the kernel's 6th scalar (spatialDim for bce, numcases otherwise); norm / fullnorm: smoothL1 only            */
+#define PZ_COST_BCE 0
+#define PZ_COST_HINGE 1
+#define PZ_COST_SMOOTH_L1 2
+#define PZ_COST_L1_HINGE 3
+int pz_cost_pointwise(int kind, const float *a, const void *b, const int32_t *labels, float *error, float *grad, float *grad2,
+                      float *terms, size_t total, int numsamples, int numcases, float norm, float fullnorm, pz_stream_t stream);
+/* PReluModule.prelu / preluBackwardData / preluBackwardParams (Cuda/Kernels/PRelu.py:14-133); shared = one slope for
+ * all maps; pz_prelu_bwd_params leaves sum_{n, pixels} dy * x * (x <= 0) per map (the caller adds the maps up when the
+ * slope is shared, as the reference does with matsum)                                                                 */
+int pz_prelu_fwd(const float *x, const float *slopes, float *y, int n, int maps, int mapsize, int shared, pz_stream_t stream);
+int pz_prelu_bwd_data(const float *dy, const float *slopes, const float *x, float *dx, int n, int maps, int mapsize, int shared,
+                      pz_stream_t stream);
+int pz_prelu_bwd_params(const float *x, const float *dy, float *per_map, int n, int maps, int mapsize, pz_stream_t stream);
+/* PadModule.reflectpad / reflectpadBackward (Cuda/Kernels/Pad.py:45-230); 1-d tensors are planes of height 1 with
+ * upad = bpad = 0. Pads must be >= 0 and smaller than the map. The backward pass gathers (deterministic).              */
+int pz_reflectpad2d_fwd(const float *x, float *y, size_t planes, int inh, int inw, int upad, int bpad, int lpad, int rpad,
+                        pz_stream_t stream);
+int pz_reflectpad2d_bwd(const float *dy, float *dx, size_t planes, int inh, int inw, int upad, int bpad, int lpad, int rpad,
+                        pz_stream_t stream);
+/* UpsampleModule.upsample2d / 3d (+Backward), modes "nearest" (linear = 0) and "linear" (1) with integer scales
+ * (Cuda/Kernels/Upsample.py:8-455); 2-d tensors are volumes of depth 1 with sd = 1. planes = batch * maps.            */
+int pz_upsample_fwd(const float *x, float *y, size_t planes, int ind, int inh, int inw, int sd, int sh, int sw, int linear,
+                    pz_stream_t stream);
+int pz_upsample_bwd(const float *dy, float *dx, size_t planes, int ind, int inh, int inw, int sd, int sh, int sw, int linear,
+                    pz_stream_t stream);
+/* EmbedModule.embed / embedBackwardParams (Cuda/Kernels/Embedder.py:10-88): word index -1 = padding (zero row, no update) */
+int pz_embed_fwd(const int32_t *words, const float *vocab, float *out, size_t tokens, int embsize, pz_stream_t stream);
+int pz_embed_bwd_params(const int32_t *words, const float *grad, float *vocab, float scale, size_t tokens, int embsize,
+                        pz_stream_t stream);
 
 /* ---- data-parallel exchange: replaces NodeInfo.{sumTensor,broadcastBuffer} (Grid.py:54-63,103-157: IPC star)
  *      with RCCL collectives over xGMI. One communicator per process (one process per GPU).             */

@@ -721,3 +721,225 @@ def conv3d_fwd(x, w, bias, stride, pad, dilation):
 	if bias is not None:
 		y += bias.reshape(1, -1, 1, 1, 1)
 	return y
+
+
+def conv3d_bwd_data(dy, w, xshape, stride, pad, dilation):
+	"""Adjoint of conv3d_fwd in fp64 (host loops of conv3dTest, Cuda/Wrappers/CuDnn.py:101-112)."""
+	n, c, D, H, W = xshape
+	k, _, T, R, S = w.shape
+	(sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = stride, pad, dilation
+	_, _, Do, Ho, Wo = dy.shape
+	dxp = np.zeros((n, c, D + 2 * pd, H + 2 * ph, W + 2 * pw), np.float64)
+	g = dy.astype(np.float64)
+	for t in range(T):
+		for r in range(R):
+			for s in range(S):
+				dxp[:, :, t * dd:t * dd + (Do - 1) * sd + 1:sd, r * dh:r * dh + (Ho - 1) * sh + 1:sh, s * dw:s * dw + (Wo - 1) * sw + 1:sw] += \
+					np.einsum("nkdhw,kc->ncdhw", g, w[:, :, t, r, s].astype(np.float64))
+	return dxp[:, :, pd:pd + D, ph:ph + H, pw:pw + W]
+
+
+def conv3d_bwd_filter(x, dy, wshape, stride, pad, dilation):
+	"""Filter gradient of conv3d_fwd in fp64 (conv3dTest, Cuda/Wrappers/CuDnn.py:117-128); bias gradient = dy summed over
+	everything but the maps."""
+	k, c, T, R, S = wshape
+	(sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = stride, pad, dilation
+	_, _, Do, Ho, Wo = dy.shape
+	xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (pd, pd), (ph, ph), (pw, pw)))
+	g = dy.astype(np.float64)
+	dw_ = np.zeros(wshape, np.float64)
+	for t in range(T):
+		for r in range(R):
+			for s in range(S):
+				win = xp[:, :, t * dd:t * dd + (Do - 1) * sd + 1:sd, r * dh:r * dh + (Ho - 1) * sh + 1:sh, s * dw:s * dw + (Wo - 1) * sw + 1:sw]
+				dw_[:, :, t, r, s] = np.einsum("ncdhw,nkdhw->kc", win, g)
+	return dw_, g.sum(axis=(0, 2, 3, 4))
+
+
+def instance_norm_fwd(x, scale, bias, epsilon=1e-5):
+	"""Backend.instanceNorm2d — Cuda/GPUBackend.py:381-400: batch normalisation of the (1, n*c, h, w) view with the affine pair
+	tiled over the batch. Returns (y, savemean (n*c,), saveinvvar (n*c,), tiled scale)."""
+	n, c, h, w = x.shape
+	ext = np.tile(scale.ravel(), n) if n > 1 else scale.ravel()
+	extb = np.tile(bias.ravel(), n) if n > 1 else bias.ravel()
+	y, sm, si = bn_fwd_train(x.reshape(1, n * c, h, w), ext, extb, np.zeros(n * c, np.float32), np.ones(n * c, np.float32), epsilon, 1.0)
+	return y.reshape(x.shape), sm, si, ext.astype(np.float32)
+
+
+def instance_norm_bwd(dy, x, extscale, savemean, saveinvvar, affine=True):
+	"""Backend.instanceNorm2dBackward — Cuda/GPUBackend.py:403-420"""
+	n, c, h, w = x.shape
+	dx, ds, db = bn_bwd(dy.reshape(1, n * c, h, w), x.reshape(1, n * c, h, w), extscale, savemean, saveinvvar)
+	dx = dx.reshape(x.shape)
+	if not affine:
+		return dx
+	if n > 1:
+		ds, db = matsum(ds.reshape(n, -1), 0), matsum(db.reshape(n, -1), 0)
+	return dx, ds, db
+
+
+# point-wise cost kernels — Cuda/Kernels/Costs.py:8-72; each returns the SUM the kernel atomicAdds into totalError and the
+# gradient(s). Arithmetic in float32 like the kernels (expf / logf), the sum in float64.
+def bce_cost(scores, labels, numsamples, spatial):                                    # :8-22
+	s = scores.astype(F)
+	prob = F(1) / (F(1) + np.exp(-s))
+	pos = labels.reshape(s.shape) == 1
+	err = np.where(pos, -np.log(prob), -np.log(F(1) - prob)) / F(spatial)
+	grad = (pos.astype(F) - prob) / F(numsamples) / F(spatial)
+	return np.float32(err.sum(dtype=np.float64)), grad.astype(F)
+
+
+def hinge_cost(scores, labels, numsamples, numcases):                                 # :25-40
+	s, lab = scores.astype(F), labels.reshape(scores.shape)
+	err = np.maximum(F(0), F(1) - s * lab) / F(numcases)
+	grad = np.where(s * lab < F(1), lab.astype(F) / F(numsamples) / F(numcases), F(0))
+	return np.float32(err.sum(dtype=np.float64)), grad.astype(F)
+
+
+def smooth_l1_cost(pred, target, norm, fullnorm):                                     # :43-56
+	diff = (pred - target).astype(F)
+	sign = np.where(diff > 0, F(1), F(-1))
+	quad = diff * sign < F(1)
+	err = np.where(quad, diff * diff / F(2) * F(norm), (sign * diff - F(0.5)) * F(norm))
+	grad = np.where(quad, diff * F(fullnorm), sign * F(fullnorm))
+	return np.float32(err.sum(dtype=np.float64)), grad.astype(F)
+
+
+def l1_hinge_cost(x1, x2, labels, numsamples, numcases):                              # :59-76
+	diff = (x1 - x2).astype(F)
+	sign = np.where(diff > 0, F(1), F(-1))
+	lab = np.repeat(labels.ravel(), numcases).reshape(diff.shape)
+	ad = np.abs(diff)
+	err = np.where(lab == 0, np.maximum(F(0), F(1) - ad), ad) / F(numcases)
+	inside = (ad < F(1)).astype(F)
+	g1 = np.where(lab == 0, inside * -sign, sign) / F(numsamples) / F(numcases)
+	g2 = np.where(lab == 0, inside * sign, -sign) / F(numsamples) / F(numcases)
+	return np.float32(err.sum(dtype=np.float64)), g1.astype(F), g2.astype(F)
+
+
+# PReLU — Cuda/Kernels/PRelu.py:14-56 (slope index = map, or 0 when the slope is shared: maps / divFactor)
+def _slopes(x, slopes, shared):
+	shape = (1, -1) + (1, ) * (x.ndim - 2)
+	return (np.full(x.shape[1], slopes.ravel()[0], F) if shared else slopes.ravel().astype(F)).reshape(shape)
+
+
+def prelu_fwd(x, slopes, shared=False):
+	return (x * np.where(x > 0, F(1), _slopes(x, slopes, shared))).astype(F)
+
+
+def prelu_bwd_data(dy, slopes, x, shared=False):
+	return (dy * ((x > 0).astype(F) + (x <= 0).astype(F) * _slopes(x, slopes, shared))).astype(F)
+
+
+def prelu_bwd_params(x, dy, shared=False):
+	per = (dy.astype(np.float64) * x * (x <= 0)).reshape(x.shape[0], x.shape[1], -1).sum(axis=(0, 2))
+	return (np.array([per.sum()]) if shared else per).astype(F)
+
+
+# reflection pad — Cuda/Kernels/Pad.py:45-145. Source index of output position o along an axis of length `size` padded by
+# (lpad, rpad >= 0): map1d's closed form |o - l| - |o - (size + l - 1)| - o + 2l + size - 1 - max(0, l) + max(0, -l)
+def _reflect_index(size, lpad, rpad):
+	o = np.arange(size + lpad + rpad)
+	return np.abs(o - lpad) - np.abs(o - (size + lpad - 1)) - o + 2 * lpad + size - 1 - max(0, lpad) + max(0, -lpad)
+
+
+def reflectpad_fwd(x, pad):
+	if x.ndim == 3:
+		return x[:, :, _reflect_index(x.shape[2], *pad)]
+	upad, bpad, lpad, rpad = pad
+	return x[:, :, _reflect_index(x.shape[2], upad, bpad)][:, :, :, _reflect_index(x.shape[3], lpad, rpad)]
+
+
+def reflectpad_bwd(dy, pad):
+	"""every output gradient is added to the input element it was copied from (the reference scatters with atomicAdd)"""
+	if dy.ndim == 3:
+		lpad, rpad = pad
+		size = dy.shape[2] - lpad - rpad
+		dx = np.zeros(dy.shape[:2] + (size, ), np.float64)
+		np.add.at(dx, (slice(None), slice(None), _reflect_index(size, lpad, rpad)), dy)
+		return dx.astype(F)
+	upad, bpad, lpad, rpad = pad
+	inh, inw = dy.shape[2] - upad - bpad, dy.shape[3] - lpad - rpad
+	rows = np.zeros(dy.shape[:2] + (inh, dy.shape[3]), np.float64)
+	np.add.at(rows, (slice(None), slice(None), _reflect_index(inh, upad, bpad)), dy)
+	dx = np.zeros(dy.shape[:2] + (inh, inw), np.float64)
+	np.add.at(dx, (slice(None), slice(None), slice(None), _reflect_index(inw, lpad, rpad)), rows)
+	return dx.astype(F)
+
+
+# up-sampling — Cuda/Kernels/Upsample.py:8-298 (2-d and 3-d; `scale` an int or one int per spatial axis)
+def _scales(nd, scale):
+	return (int(scale), ) * nd if isinstance(scale, (int, np.integer)) else tuple(int(v) for v in scale)
+
+
+def _linear_taps(insize, outsize):
+	"""(i0, i1, w0, w1) per output position with the kernels' float32 arithmetic: pos = r*o, i0 = (int)pos,
+	i1 = i0 + (i0 < in - 1), w1 = pos - i0, w0 = 1 - w1; r = float32((in - 1) / (out - 1)) (Upsample.py:336,408)"""
+	r = F((insize - 1) / (outsize - 1)) if outsize > 1 else F(0)
+	pos = r * np.arange(outsize, dtype=F)
+	i0 = pos.astype(np.int64)
+	i1 = i0 + (i0 < insize - 1)
+	w1 = (pos - i0.astype(F)).astype(F)
+	return i0, i1, (F(1) - w1).astype(F), w1
+
+
+def _linear_matrix(insize, outsize):
+	"""(out, in) interpolation matrix of one axis"""
+	i0, i1, w0, w1 = _linear_taps(insize, outsize)
+	m = np.zeros((outsize, insize), np.float64)
+	np.add.at(m, (np.arange(outsize), i0), w0)
+	np.add.at(m, (np.arange(outsize), i1), w1)
+	return m
+
+
+def upsample_fwd(x, scale, mode="nearest"):
+	nd = x.ndim - 2
+	scales = _scales(nd, scale)
+	y = x.astype(np.float64)
+	for axis, s in enumerate(scales):
+		if mode == "nearest":
+			y = np.repeat(y, s, axis=2 + axis)
+		else:
+			insize = x.shape[2 + axis]
+			y = np.moveaxis(np.tensordot(_linear_matrix(insize, insize * s), y, axes=(1, 2 + axis)), 0, 2 + axis)
+	return y.astype(F)
+
+
+def upsample_bwd(dy, scale, mode="nearest"):
+	nd = dy.ndim - 2
+	scales = _scales(nd, scale)
+	if mode == "nearest":
+		# float32 running sum over the block in (depth, row, column) order, as upsample3dNearestBackward does
+		# (Upsample.py:84-104; the 2-d kernel :36-54 walks columns first — same terms)
+		sd, sh, sw = ((1, ) + scales) if nd == 2 else scales
+		g5 = dy.reshape(dy.shape[:2] + ((1, ) if nd == 2 else ()) + dy.shape[2:]).astype(F)
+		acc = np.zeros(g5.shape[:2] + (g5.shape[2] // sd, g5.shape[3] // sh, g5.shape[4] // sw), F)
+		for a in range(sd):
+			for b in range(sh):
+				for c in range(sw):
+					acc = (acc + g5[:, :, a::sd, b::sh, c::sw]).astype(F)
+		return acc.reshape(acc.shape[:2] + acc.shape[(3 if nd == 2 else 2):])
+	g = dy.astype(np.float64)
+	for axis, s in enumerate(scales):
+		outsize = dy.shape[2 + axis]
+		insize = outsize // s
+		if mode == "nearest":
+			shape = g.shape[:2 + axis] + (insize, s) + g.shape[3 + axis:]
+			g = g.reshape(shape).sum(axis=3 + axis)
+		else:
+			g = np.moveaxis(np.tensordot(_linear_matrix(insize, outsize).T, g, axes=(1, 2 + axis)), 0, 2 + axis)
+	return g.astype(F)
+
+
+# embedding — Cuda/Kernels/Embedder.py:10-45 (word index -1 = padding: zero row, no update)
+def embed_fwd(words, vocab):
+	out = vocab[np.maximum(words, 0)].astype(F)
+	out[words == -1] = 0
+	return out
+
+
+def embed_bwd_params(words, grad, vocab, scale):
+	"""vocabulary[word] += scale * grad[token] for every token (in place; rows repeat, so the adds accumulate)"""
+	ok = words.ravel() != -1
+	np.add.at(vocab, words.ravel()[ok], (F(scale) * grad.reshape(-1, grad.shape[-1])[ok]).astype(F))
+	return vocab

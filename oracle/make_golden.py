@@ -10,6 +10,9 @@ What it does
      oracle function whose counterpart the reference CPU backend implements: conv forward, max/avg pool
      forward, batch-norm inference, GEMM, column sum, bias add, every activation fwd/bwd, dropout with a
      given mask, axpy/add/linear/weight-decay and all nine optimizer kernels (the gcc-JIT'd C loops);
+  2b. does the same for the operators beside the hot path (f3: conv3d, deconvolutions, instance norm, both LRN modes, mask
+     pooling / unpooling, batched matvec, SVM, PReLU, reflection pad, up-sampling, embedding) and binds the oracle's
+     point-wise cost kernels into the reference's Cost modules (BCE, Hinge, SmoothL1, L1Hinge) to run THEIR tests;
   2. runs the reference's own `bnd`-parameterised unit tests (Cuda/Wrappers/CuDnn.py conv2dTest,
      convGroupTest, maxpool2dTest, softmax2dTest; CuDnnNorm.py batchNorm2dTest; CuBlas.py matrixTest;
      Cuda/Kernels/MatVec.py calcTest; Cuda/Kernels/Costs.py crossEntropyTest) against a stand-in `bnd`
@@ -452,6 +455,343 @@ def run_reference_tests_on_oracle():
 
 
 # ----------------------------------------------------------------------------------------------
+# 2b. operators beside the hot path: the reference's own tests for them, judged on the oracle
+# ----------------------------------------------------------------------------------------------
+
+def make_oracle_f3():
+	"""Oracle-backed stand-ins for what the reference's f3 tests drive: a `bnd` with N-d convolution / deconvolution, both
+	LRN modes and instance normalisation, and the kernel modules (pool, matvec, cost, PReLU, pad, upsample, embed)."""
+	H = HostArray
+	base = make_oracle_bnd()
+
+	def triple(v):
+		return (int(v), ) * 3 if isinstance(v, (int, np.integer)) else tuple(int(a) for a in v)
+
+	def inshape(grad, W, stride, pad, dilation, groups, nd):
+		st, pd, dl = (R.pair(stride), R.pair(pad), R.pair(dilation)) if nd == 2 else (triple(stride), triple(pad), triple(dilation))
+		spatial = tuple((o - 1) * s + d * (f - 1) - 2 * p + 1 for o, s, d, f, p in zip(grad.shape[2:], st, dl, W.shape[2:], pd))
+		return (grad.shape[0], W.shape[1] * groups) + spatial
+
+	class Dnn(base.dnn):
+		@staticmethod
+		def convNd(data, W, bias=None, stride=1, pad=0, dilation=1, groups=1, **_):
+			if data.ndim == 5:
+				assert groups == 1
+				y = R.conv3d_fwd(data.a, W.a, None if bias is None else bias.a, triple(stride), triple(pad), triple(dilation))
+				return H(y.astype(np.float32))
+			return base.dnn.convNd(data, W, bias, stride, pad, dilation, groups)
+
+		@staticmethod
+		def convNdBackwardData(grad, W, bias=None, data=None, stride=1, pad=0, dilation=1, postpad=0, groups=1, **_):
+			nd = grad.ndim - 2
+			shape = data.shape if data is not None else inshape(grad, W, stride, pad, dilation, groups, nd)
+			if nd == 3:
+				assert groups == 1
+				dx = R.conv3d_bwd_data(grad.a, W.a, shape, triple(stride), triple(pad), triple(dilation))
+			else:
+				dx = R.conv2d_bwd_data(grad.a, W.a, shape, stride, pad, dilation, groups)
+			if bias is not None:            # deconvolution forward (Hip/Wrappers/MIOpen.py:368-400 adds the bias over the maps)
+				dx = dx + bias.a.reshape((1, -1) + (1, ) * nd)
+			return H(dx.astype(np.float32))
+
+		@staticmethod
+		def convNdBackwardParams(data, grad, W, stride=1, pad=0, dilation=1, groups=1, withbias=False, deconv=False,
+								 wgrad=None, bgrad=None, scale=1.0, momentum=0.0, **_):
+			nd = data.ndim - 2
+			if nd == 3:
+				assert groups == 1 and wgrad is None and bgrad is None
+				dw, db = R.conv3d_bwd_filter(data.a, grad.a, W.shape, triple(stride), triple(pad), triple(dilation))
+			else:
+				res = R.conv2d_bwd_filter(data.a, grad.a, W.shape, stride, pad, dilation, groups, True)
+				dw, db = res
+			if deconv:                      # the bias gradient sums over `data`'s maps (MIOpen.py:435-436)
+				db = data.a.sum(axis=(0, ) + tuple(range(2, data.ndim)), dtype=np.float64)
+			dw, db = dw.astype(np.float32), np.asarray(db, dtype=np.float32)
+			return (H(dw), H(db)) if withbias else H(dw)
+
+		@staticmethod
+		def mapLRN(data, means=None, N=5, alpha=1e-4, beta=0.75, K=2.0, **_):
+			return H(R.lrn_fwd(data.a, N, alpha, beta, K, cross=False))
+
+		@staticmethod
+		def mapLRNBackward(data, grad, means=None, N=5, alpha=1e-4, beta=0.75, K=2.0, **_):
+			return H(R.lrn_bwd(data.a, grad.a, N, alpha, beta, K, cross=False))
+
+		@staticmethod
+		def crossMapLRN(data, N=5, alpha=1e-4, beta=0.75, K=2.0, **_):
+			return H(R.lrn_fwd(data.a, N, alpha, beta, K, cross=True))
+
+		@staticmethod
+		def crossMapLRNBackward(data, outdata, grad, N=5, alpha=1e-4, beta=0.75, K=2.0, **_):
+			return H(R.lrn_bwd(data.a, grad.a, N, alpha, beta, K, cross=True))
+
+	def instanceNorm2d(data, scale, bias, epsilon=1e-5, **_):
+		return tuple(H(a) for a in R.instance_norm_fwd(data.a, scale.a, bias.a, epsilon))
+
+	def instanceNorm2dBackward(grad, data, extscale, savemean, saveinvvar, epsilon, affine=True, **_):
+		res = R.instance_norm_bwd(grad.a, data.a, extscale.a, savemean.a, saveinvvar.a, affine)
+		return tuple(H(a) for a in res) if affine else H(res)
+
+	bnd = types.SimpleNamespace(
+		GPUArray=H, dnn=Dnn, blas=base.blas, PoolMode=base.PoolMode, SoftMaxMode=base.SoftMaxMode, nthreads=256,
+		instanceNorm2d=instanceNorm2d, instanceNorm2dBackward=instanceNorm2dBackward
+	)
+
+	poolmod = types.SimpleNamespace(
+		GPUArray=H,
+		maxpool2d=lambda data, size, stride, pad, allocator=None: tuple(H(a) for a in R.maskpool2d_fwd(data.a, size, stride, pad)),
+		maxpool2dBackward=lambda grad, origshape, mask, size, stride, pad, allocator=None: H(R.maskpool2d_bwd(grad.a, mask.a, origshape)),
+		maxunpool2d=lambda data, origshape, mask, allocator=None: H(R.maxunpool2d_fwd(data.a, mask.a, origshape)),
+		maxunpool2dBackward=lambda grad, poolshape, mask, allocator=None: H(R.maxunpool2d_bwd(grad.a, mask.a)),
+	)
+
+	matmod = types.SimpleNamespace(
+		GPUArray=H,
+		addVecToMat=lambda vec, mat, axis=0, out=None, allocator=None: H(R.add_vec_to_mat(vec.a, mat.a, axis)),
+		matsum=lambda t, axis=0, out=None, alpha=1.0, beta=0.0, allocator=None: H(R.matsum(t.a, axis)),
+		matvec=lambda mat, vec, axis=0, out=None, alpha=1.0, beta=0.0, allocator=None: H(R.matvec(mat.a, vec.a, axis)),
+		argmax=lambda t, axis=0, allocator=None: H(R.argmax(t.a, axis)),
+	)
+
+	def svm(scores, labels, mode, error=None, allocator=None):
+		err, grad = R.svm_cost(scores.a, labels.a, mode)
+		return H(np.array(err, dtype=np.float32)), H(grad)
+
+	costmod = types.SimpleNamespace(GPUArray=H, svm=svm)
+
+	prelumod = types.SimpleNamespace(
+		GPUArray=H,
+		prelu=lambda data, slopes, inplace=False, sharedMaps=False, allocator=None: H(R.prelu_fwd(data.a, slopes.a, sharedMaps)),
+		preluBackwardData=lambda grad, slopes, indata, sharedMaps=False, allocator=None:
+			H(R.prelu_bwd_data(grad.a, slopes.a, indata.a, sharedMaps)),
+		preluBackwardParams=lambda indata, outgrad, sharedMaps=False, allocator=None: H(R.prelu_bwd_params(indata.a, outgrad.a, sharedMaps)),
+	)
+	padmod = types.SimpleNamespace(
+		GPUArray=H,
+		reflectpad=lambda data, pad, allocator=None: H(R.reflectpad_fwd(data.a, pad)),
+		reflectpadBackward=lambda grad, pad, allocator=None: H(R.reflectpad_bwd(grad.a, pad)),
+	)
+	upsamplemod = types.SimpleNamespace(
+		GPUArray=H,
+		upsample2d=lambda data, scale, mode="nearest", allocator=None: H(R.upsample_fwd(data.a, scale, mode)),
+		upsample2dBackward=lambda grad, scale, mode="nearest", allocator=None: H(R.upsample_bwd(grad.a, scale, mode)),
+		upsample3d=lambda data, scale, mode="nearest", allocator=None: H(R.upsample_fwd(data.a, scale, mode)),
+		upsample3dBackward=lambda grad, scale, mode="nearest", allocator=None: H(R.upsample_bwd(grad.a, scale, mode)),
+	)
+	embedmod = types.SimpleNamespace(
+		GPUArray=H,
+		embed=lambda data, W, allocator=None: H(R.embed_fwd(data.a, W.a)),
+		embedBackwardParams=lambda indata, grad, W, scale: R.embed_bwd_params(indata.a, grad.a, W.a, scale),
+	)
+	return bnd, dict(poolmod=poolmod, matmod=matmod, costmod=costmod, prelumod=prelumod, padmod=padmod, upsamplemod=upsamplemod,
+					 embedmod=embedmod)
+
+
+def run_reference_f3_tests_on_oracle():
+	"""The tests the reference holds for the operators beside the hot path — they need a device in the reference
+	(Unittester.py:114-122 runs them for the Hip backend) — executed here with the oracle as the backend under test."""
+	from PuzzleLib.Cuda.Wrappers import CuDnn, CuDnnNorm
+	from PuzzleLib.Cuda.Kernels import Pool, MatVec, Costs, PRelu, Pad, Upsample, Embedder
+
+	bnd, mods = make_oracle_f3()
+	for seed in range(3):
+		np.random.seed(300 + seed)
+		CuDnn.conv3dTest(bnd, np.float32, ATOL)
+		CuDnn.deconv2dTest(bnd, np.float32, ATOL)
+		CuDnn.deconv3dTest(bnd, np.float32, ATOL)
+		CuDnn.deconvGroupTest(bnd, np.float32, ATOL)
+		CuDnnNorm.instanceNorm2dTest(bnd, np.float32, ATOL, np.float32)
+		CuDnnNorm.mapLRN2dTest(bnd, np.float32, ATOL)
+		CuDnnNorm.crossMapLRN2dTest(bnd, np.float32, ATOL)
+		Pool.poolTest(mods["poolmod"])
+		Pool.unpoolTest(mods["poolmod"])
+		MatVec.batchCalcTest(mods["matmod"], np.float32, 1e-4)
+		Costs.svmTest(mods["costmod"])
+		PRelu.preluTest(mods["prelumod"])
+		Pad.reflectpad1dTest(mods["padmod"], np.float32)
+		Pad.reflectpad2dTest(mods["padmod"], np.float32, ATOL)
+		Upsample.upsample2dNearestTest(mods["upsamplemod"])
+		Upsample.upsample2dLinearTest(mods["upsamplemod"])
+		Upsample.upsample3dNearestTest(mods["upsamplemod"])
+		Upsample.upsample3dLinearTest(mods["upsamplemod"])
+		Embedder.embedTest(mods["embedmod"], np.float32, ATOL)
+
+	# point-wise cost kernels: the reference's Cost modules (Cost/BCE.py, Hinge.py, SmoothL1.py, L1Hinge.py) import their
+	# kernel from Backend/Kernels/Costs.py, which binds nothing on the CPU backend; bound to the oracle's restatement of the
+	# device kernels (Cuda/Kernels/Costs.py:8-72) the modules' own unit tests judge it.
+	from PuzzleLib.Backend.Kernels import Costs as KCosts
+
+	def onCpu(fn, ngrads):
+		def ker(*args):
+			arrays = [a.data if hasattr(a, "data") and isinstance(a.data, np.ndarray) else a for a in args]
+			return fn(*arrays)
+		return ker
+
+	def bce(scores, labels, err, grad, numsamples, spatial):
+		e, g = R.bce_cost(scores, labels, numsamples, spatial)
+		err[...] += e
+		grad[...] = g.reshape(grad.shape)
+
+	def hinge(scores, labels, err, grad, numsamples, numcases):
+		e, g = R.hinge_cost(scores, labels, numsamples, numcases)
+		err[...] += e
+		grad[...] = g
+
+	def smoothl1(pred, target, err, grad, norm, fullnorm):
+		e, g = R.smooth_l1_cost(pred, target, norm, fullnorm)
+		err[...] += e
+		grad[...] = g
+
+	def l1hinge(x1, x2, labels, err, g1, g2, numsamples, numcases):
+		e, a, b = R.l1_hinge_cost(x1, x2, labels, numsamples, numcases)
+		err[...] += e
+		g1[...], g2[...] = a, b
+
+	KCosts.bceKer, KCosts.hingeKer = onCpu(bce, 1), onCpu(hinge, 1)
+	KCosts.smoothL1Ker, KCosts.l1HingeKer = onCpu(smoothl1, 1), onCpu(l1hinge, 2)
+
+	import importlib
+	for seed in range(3):
+		np.random.seed(400 + seed)
+		importlib.import_module("PuzzleLib.Cost.BCE")
+		sys.modules["PuzzleLib.Cost.BCE"].errorTest()
+		importlib.import_module("PuzzleLib.Cost.Hinge")
+		sys.modules["PuzzleLib.Cost.Hinge"].errorValTest()
+		importlib.import_module("PuzzleLib.Cost.SmoothL1")
+		sys.modules["PuzzleLib.Cost.SmoothL1"].errorTest()
+		sys.modules["PuzzleLib.Cost.SmoothL1"].valTest()
+		importlib.import_module("PuzzleLib.Cost.L1Hinge")
+		sys.modules["PuzzleLib.Cost.L1Hinge"].errorTest()
+
+	print("[2b] reference tests of the operators beside the hot path (conv3d / deconv2d / deconv3d / deconvGroup / instanceNorm2d / "
+		  "mapLRN / crossMapLRN / maskpool / unpool / batched matvec / svm / prelu / reflectpad 1d+2d / upsample 2d+3d nearest+linear / "
+		  "embed; Cost modules BCE / Hinge / SmoothL1 / L1Hinge) pass on the oracle: OK")
+
+
+def f3_fixtures(fx):
+	"""Inputs and oracle outputs (orc_) for the GPU tests of the f3 operators, written after 2b pinned the oracle."""
+	rng = np.random.RandomState(777)
+	f32 = np.float32
+
+	x = rng.randn(3, 4, 7, 6).astype(f32)
+	y, mask = R.maskpool2d_fwd(x, (3, 2), (2, 2), (1, 0))
+	dy = rng.randn(*y.shape).astype(f32)
+	fx["f3_pool_x"], fx["f3_pool_cfg"], fx["f3_pool_dy"] = x, np.array([3, 2, 2, 2, 1, 0], np.int32), dy
+	fx["f3_pool_orc_y"], fx["f3_pool_orc_mask"] = y, mask
+	fx["f3_pool_orc_dx"] = R.maskpool2d_bwd(dy, mask, x.shape)
+	up = R.maxunpool2d_fwd(y, mask, x.shape)
+	gup = rng.randn(*up.shape).astype(f32)
+	fx["f3_unpool_orc_y"], fx["f3_unpool_g"], fx["f3_unpool_orc_dx"] = up, gup, R.maxunpool2d_bwd(gup, mask)
+
+	x = rng.randn(2, 7, 6, 5).astype(f32)
+	dy = rng.randn(*x.shape).astype(f32)
+	fx["f3_lrn_x"], fx["f3_lrn_dy"], fx["f3_lrn_cfg"] = x, dy, np.array([5, 1.0, 0.5, 2.0])
+	for cross, tag in ((False, "map"), (True, "cross")):
+		fx["f3_lrn_orc_%s_y" % tag] = R.lrn_fwd(x, 5, 1.0, 0.5, 2.0, cross)
+		fx["f3_lrn_orc_%s_dx" % tag] = R.lrn_bwd(x, dy, 5, 1.0, 0.5, 2.0, cross)
+
+	x = rng.randn(3, 4, 5, 6).astype(f32)
+	scale, bias = rng.randn(4).astype(f32), rng.randn(4).astype(f32)
+	y, sm, si, ext = R.instance_norm_fwd(x, scale, bias, 1e-5)
+	dy = rng.randn(*x.shape).astype(f32)
+	dx, ds, db = R.instance_norm_bwd(dy, x, ext, sm, si)
+	fx["f3_in_x"], fx["f3_in_scale"], fx["f3_in_bias"], fx["f3_in_dy"] = x, scale, bias, dy
+	fx["f3_in_orc_y"], fx["f3_in_orc_mean"], fx["f3_in_orc_invvar"] = y, sm, si
+	fx["f3_in_orc_dx"], fx["f3_in_orc_dscale"], fx["f3_in_orc_dbias"] = dx, ds, db
+
+	# 3-d convolution and 3-d deconvolution (stride 2, pad 1; filters 3 x 2 x 3)
+	x = rng.randn(2, 3, 5, 6, 7).astype(f32)
+	w = (0.3 * rng.randn(4, 3, 3, 2, 3)).astype(f32)
+	b = rng.randn(4).astype(f32)
+	st, pd, dl = (2, 1, 2), (1, 0, 1), (1, 1, 1)
+	y = R.conv3d_fwd(x, w, b, st, pd, dl).astype(f32)
+	dy = rng.randn(*y.shape).astype(f32)
+	dw, db = R.conv3d_bwd_filter(x, dy, w.shape, st, pd, dl)
+	fx["f3_c3_x"], fx["f3_c3_w"], fx["f3_c3_b"], fx["f3_c3_dy"] = x, w, b, dy
+	fx["f3_c3_cfg"] = np.array([*st, *pd, *dl], np.int32)
+	fx["f3_c3_orc_y"], fx["f3_c3_orc_dx"] = y, R.conv3d_bwd_data(dy, w, x.shape, st, pd, dl).astype(f32)
+	fx["f3_c3_orc_dw"], fx["f3_c3_orc_db"] = dw.astype(f32), db.astype(f32)
+	# deconvolution: data (2, 4, 2, 3, 3) with the same filter bank read as (inmaps=4, outmaps=3, ...)
+	d = rng.randn(2, 4, 2, 3, 3).astype(f32)
+	bd = rng.randn(3).astype(f32)
+	oshape = (2, 3) + tuple((o - 1) * s + (f - 1) - 2 * p + 1 for o, s, f, p in zip(d.shape[2:], st, w.shape[2:], pd))
+	out = (R.conv3d_bwd_data(d, w, oshape, st, pd, dl) + bd.reshape(1, -1, 1, 1, 1)).astype(f32)
+	g = rng.randn(*out.shape).astype(f32)
+	dwd, _ = R.conv3d_bwd_filter(g, d, w.shape, st, pd, dl)
+	fx["f3_d3_x"], fx["f3_d3_b"], fx["f3_d3_g"] = d, bd, g
+	fx["f3_d3_orc_y"] = out
+	fx["f3_d3_orc_dx"] = R.conv3d_fwd(g, w, None, st, pd, dl).astype(f32)
+	fx["f3_d3_orc_dw"], fx["f3_d3_orc_db"] = dwd.astype(f32), g.sum(axis=(0, 2, 3, 4), dtype=np.float64).astype(f32)
+
+	# matvec / svm
+	A = rng.randn(5, 12, 9).astype(f32)
+	v, w_ = rng.randn(5, 9).astype(f32), rng.randn(5, 12).astype(f32)
+	fx["f3_mv_A"], fx["f3_mv_v"], fx["f3_mv_w"] = A, v, w_
+	fx["f3_mv_orc_rows"], fx["f3_mv_orc_cols"] = R.matvec(A, v, 1), R.matvec(A, w_, 0)
+	s = rng.randn(10, 5, 3).astype(f32)
+	lab = rng.randint(0, 5, size=(10, 3)).astype(np.int32)
+	fx["f3_svm_scores"], fx["f3_svm_labels"] = s, lab
+	for mode in ("l1", "l2"):
+		err, grad = R.svm_cost(s, lab, mode)
+		fx["f3_svm_orc_%s_err" % mode], fx["f3_svm_orc_%s_grad" % mode] = np.array([err], f32), grad
+
+	# point-wise costs
+	s = (1.5 * rng.randn(12, 1, 3, 4)).astype(f32)
+	lab = rng.randint(0, 2, size=(12, 3, 4)).astype(np.int32)
+	err, grad = R.bce_cost(s, lab, 12, 12)
+	fx["f3_bce_scores"], fx["f3_bce_labels"], fx["f3_bce_orc_err"], fx["f3_bce_orc_grad"] = s, lab, np.array([err], f32), grad
+	s = rng.randn(15, 6).astype(f32)
+	lab = (rng.randint(0, 2, size=(15, 6)) * 2 - 1).astype(np.int32)
+	err, grad = R.hinge_cost(s, lab, 15, 6)
+	fx["f3_hinge_scores"], fx["f3_hinge_labels"], fx["f3_hinge_orc_err"], fx["f3_hinge_orc_grad"] = s, lab, np.array([err], f32), grad
+	p, t = (2 * rng.randn(9, 11)).astype(f32), rng.randn(9, 11).astype(f32)
+	err, grad = R.smooth_l1_cost(p, t, 1.0 / 11, 1.0 / 99)
+	fx["f3_sl1_pred"], fx["f3_sl1_target"], fx["f3_sl1_orc_err"], fx["f3_sl1_orc_grad"] = p, t, np.array([err], f32), grad
+	x1, x2 = rng.randn(14, 5).astype(f32), rng.randn(14, 5).astype(f32)
+	lab = rng.randint(0, 2, size=(14, )).astype(np.int32)
+	err, g1, g2 = R.l1_hinge_cost(x1, x2, lab, 14, 5)
+	fx["f3_l1h_x1"], fx["f3_l1h_x2"], fx["f3_l1h_labels"] = x1, x2, lab
+	fx["f3_l1h_orc_err"], fx["f3_l1h_orc_g1"], fx["f3_l1h_orc_g2"] = np.array([err], f32), g1, g2
+
+	# PReLU (per map and shared), reflection pad, up-sampling, embedding
+	x = rng.randn(4, 5, 3, 7).astype(f32)
+	dy = rng.randn(*x.shape).astype(f32)
+	slopes, one = rng.randn(5).astype(f32), rng.randn(1).astype(f32)
+	fx["f3_prelu_x"], fx["f3_prelu_dy"], fx["f3_prelu_slopes"], fx["f3_prelu_shared"] = x, dy, slopes, one
+	for shared, sl, tag in ((False, slopes, "map"), (True, one, "shared")):
+		fx["f3_prelu_orc_%s_y" % tag] = R.prelu_fwd(x, sl, shared)
+		fx["f3_prelu_orc_%s_dx" % tag] = R.prelu_bwd_data(dy, sl, x, shared)
+		fx["f3_prelu_orc_%s_ds" % tag] = R.prelu_bwd_params(x, dy, shared)
+
+	x = rng.randn(2, 3, 6, 9).astype(f32)
+	pad2 = (2, 3, 4, 1)
+	y = R.reflectpad_fwd(x, pad2)
+	g = rng.randn(*y.shape).astype(f32)
+	fx["f3_pad2_x"], fx["f3_pad2_pad"], fx["f3_pad2_g"] = x, np.array(pad2, np.int32), g
+	fx["f3_pad2_orc_y"], fx["f3_pad2_orc_dx"] = y, R.reflectpad_bwd(g, pad2)
+	x = rng.randn(3, 2, 11).astype(f32)
+	y = R.reflectpad_fwd(x, (3, 5))
+	g = rng.randn(*y.shape).astype(f32)
+	fx["f3_pad1_x"], fx["f3_pad1_g"], fx["f3_pad1_orc_y"], fx["f3_pad1_orc_dx"] = x, g, y, R.reflectpad_bwd(g, (3, 5))
+
+	x2, x3 = rng.randn(2, 3, 5, 4).astype(f32), rng.randn(2, 2, 3, 4, 5).astype(f32)
+	for tag, x, scale in (("2d", x2, (2, 3)), ("3d", x3, (2, 1, 3))):
+		fx["f3_up%s_x" % tag], fx["f3_up%s_scale" % tag] = x, np.array(scale, np.int32)
+		for mode in ("nearest", "linear"):
+			y = R.upsample_fwd(x, scale, mode)
+			g = rng.randn(*y.shape).astype(f32)
+			fx["f3_up%s_%s_g" % (tag, mode)] = g
+			fx["f3_up%s_orc_%s_y" % (tag, mode)], fx["f3_up%s_orc_%s_dx" % (tag, mode)] = y, R.upsample_bwd(g, scale, mode)
+
+	words = rng.randint(-1, 40, size=(6, 7)).astype(np.int32)
+	vocab = rng.randn(40, 9).astype(f32)
+	g = rng.randn(6, 7, 9).astype(f32)
+	fx["f3_emb_words"], fx["f3_emb_vocab"], fx["f3_emb_g"] = words, vocab, g
+	fx["f3_emb_orc_y"] = R.embed_fwd(words, vocab)
+	fx["f3_emb_orc_vocab_after"] = R.embed_bwd_params(words, g, vocab.copy(), 0.25)
+
+
+# ----------------------------------------------------------------------------------------------
 # 3. LeNet: reference forward vs oracle runner; oracle full step
 # ----------------------------------------------------------------------------------------------
 
@@ -547,6 +887,8 @@ def main():
 	ops = {}
 	check_against_reference(ops)
 	run_reference_tests_on_oracle()
+	run_reference_f3_tests_on_oracle()
+	f3_fixtures(ops)
 	lenet = lenet_fixture()
 	mini, minispec = miniresnet_fixture()
 

@@ -974,9 +974,19 @@ class conv3d:
 
 	@classmethod
 	def backwardData(cls, dnn, grad, W, bias, data, stride, pad, dilation, postpad, groups, algo, out, allocator):
-		if data is None or bias is not None:
-			raise NotImplementedError("3-d deconvolution forward is not implemented on this backend")
+		if data is None:
+			# deconvolution forward (Modules/Deconv3D.py through Dnn.deconvNd): the produced shape follows from the geometry
+			(sd_, sh_, sw_), (pd_, ph_, pw_), (dd_, dh_, dw_) = cls.triple(stride), cls.triple(pad), cls.triple(dilation)
+			qd, qh, qw = cls.triple(postpad if postpad is not None else 0)
+			n_, _, od, oh, ow = grad.shape
+			_, cg, T_, R_, S_ = W.shape
+			data = cls.Shape((
+				n_, cg * groups, (od - 1) * sd_ + dd_ * (T_ - 1) - 2 * pd_ + 1 + qd, (oh - 1) * sh_ + dh_ * (R_ - 1) - 2 * ph_ + 1 + qh,
+				(ow - 1) * sw_ + dw_ * (S_ - 1) - 2 * pw_ + 1 + qw
+			))
 		(sd, pd, dd, T, Dout), kw = cls.geometry(data.shape, W.shape, stride, pad, dilation)
+		if Dout != grad.shape[2]:
+			raise ValueError("gradient depth %d does not match the convolution geometry (%d)" % (grad.shape[2], Dout))
 		n, c, D, h, w = data.shape
 		k = W.shape[0]
 		memmod = dnn.backend.memmod
@@ -985,15 +995,18 @@ class conv3d:
 		dxu = dnn.convNdBackwardData(
 			g2, W2, None, cls.Shape((n * Dout, c * T, h, w)), groups=groups, algo=algo, allocator=allocator, **kw
 		)
-		dx = GPUArray.zeros(data.shape, dtype=data.dtype, allocator=allocator) if out is None else out
+		dx = GPUArray.zeros(data.shape, dtype=grad.dtype, allocator=allocator) if out is None else out
 		if out is not None:
 			out.fill(0)
 		sN, sD, sC, sT, sH, sW = contiguousStrides((n, Dout, c, T, h, w), 4)
 		for t, d0, count, z0 in cls.taps(D, Dout, T, sd, pd, dd):
-			part = GPUArray.zeros(data.shape, dtype=data.dtype, allocator=allocator)
+			part = GPUArray.zeros(data.shape, dtype=grad.dtype, allocator=allocator)
 			src = MemModule.viewLike(dxu, (n, c, count, h, w), (sN, sC, sD, sH, sW), d0 * sD + t * sT)
 			part[:, :, z0:z0 + (count - 1) * sd + 1:sd].stridedCopyFrom(src)
 			dnn.backend.toVectorAddVectorKer(np.float32)(dx.ravel(), part.ravel(), 1.0)
+		if bias is not None:           # deconvolution forward: bias over the produced maps (rows of the (n*maps, voxels) view)
+			assert bias.size == dx.shape[1]
+			lib.pz_bias_add(dx.wptr, dx.rptr, bias.rptr, 1, dx.shape[0] * dx.shape[1], prod(dx.shape[2:]), dx.shape[1], 0, None)
 		return dx
 
 
@@ -1006,8 +1019,19 @@ class conv3d:
 	@classmethod
 	def backwardParams(cls, dnn, data, grad, W, stride, pad, dilation, groups, withbias, deconv, wgrad, bgrad, scale, momentum,
 					   algo, allocator):
-		if deconv:
-			raise NotImplementedError("3-d deconvolution is not implemented on this backend")
+		if deconv and withbias:
+			# deconvolution (`data` = the gradient of what the deconvolution produced, `grad` = its input): the filter gradient is
+			# the same contraction; the bias gradient sums over `data`'s maps (Hip/Wrappers/MIOpen.py:435-436)
+			wg = cls.backwardParams(dnn, data, grad, W, stride, pad, dilation, groups, False, False, wgrad, None, scale, momentum,
+									algo, allocator)
+			accumulate = bgrad is not None and (scale != 1.0 or momentum != 0.0)
+			nn_, maps = data.shape[:2]
+			bg = GPUArray.empty((maps, ), dtype=data.dtype, allocator=allocator) if bgrad is None else bgrad
+			matmod = dnn.backend.matmod
+			persample = matmod.matsum(data.reshape(nn_ * maps, prod(data.shape[2:])), axis=1, allocator=allocator)
+			matmod.matsum(persample.reshape(nn_, maps), axis=0, out=bg, alpha=scale if accumulate else 1.0,
+						  beta=momentum if accumulate else 0.0)
+			return wg, bg
 		(sd, pd, dd, T, Dout), kw = cls.geometry(data.shape, W.shape, stride, pad, dilation)
 		n, k = data.shape[0], W.shape[0]
 		xu = cls.unfold(data, T, Dout, sd, pd, dd, allocator)
@@ -1342,6 +1366,194 @@ class StubModule:
 		return raiser
 
 
+class PointwiseCost:
+	"""bceKer / hingeKer / smoothL1Ker / l1HingeKer — direct callables with the reference's argument lists
+	(Cuda/Kernels/Costs.py:8-72; callers Cost/BCE.py:20, Hinge.py, SmoothL1.py, L1Hinge.py):
+	  bceKer(scores, labels, totalError, grad, numsamples, spatialDim)        hingeKer(scores, labels, totalError, grad, numsamples, numcases)
+	  smoothL1Ker(pred, target, totalError, grad, norm, fullnorm)             l1HingeKer(x1, x2, labels, totalError, g1, g2, numsamples, numcases)
+	The error is ADDED to totalError (the reference's kernels atomicAdd into it; the cost modules zero it first)."""
+
+	def __init__(self, kind, name):
+		self.kind, self.name = kind, name
+
+	def __call__(self, *args, slice=None, stream=None, allocator=None):
+		assert slice is None, "%s takes whole tensors" % self.name
+		kind = self.kind
+		grad2 = labels = other = None
+		norm = fullnorm = 0.0
+		numsamples = numcases = 1
+		if kind in (lib.COST_BCE, lib.COST_HINGE):
+			a, labels, error, grad, numsamples, numcases = args
+			assert labels.dtype == np.int32 and labels.size == a.size
+		elif kind == lib.COST_SMOOTH_L1:
+			a, other, error, grad, norm, fullnorm = args
+			assert other.dtype == np.float32 and other.size == a.size
+		else:
+			a, other, labels, error, grad, grad2, numsamples, numcases = args
+			assert labels.dtype == np.int32 and other.size == a.size and grad2.size == a.size
+			assert labels.size * int(numcases) == a.size
+		requireF32(a, error, grad)
+		assert grad.size == a.size
+		terms = GPUArray.empty((a.size, ), dtype=np.float32, allocator=allocator)
+		lib.pz_cost_pointwise(
+			kind, a.rptr, rptrOf(other), rptrOf(labels), error.wptr, grad.optr,
+			None if grad2 is None else grad2.optr, terms.optr, a.size, int(numsamples), int(numcases), float(norm), float(fullnorm),
+			streamHandle(stream)
+		)
+
+
+class PReluModule:
+	"""prelu / preluBackwardData / preluBackwardParams — Cuda/Kernels/PRelu.py:58-133"""
+
+	def __init__(self, matmod):
+		self.matmod, self.backend, self.GPUArray = matmod, matmod.backend, GPUArray
+
+
+	@staticmethod
+	def geometry(data, slopes, sharedMaps):
+		assert slopes.shape == (1, ) if sharedMaps else data.shape[1] == slopes.shape[0]
+		return data.shape[0], data.shape[1], prod(data.shape[2:])
+
+
+	def prelu(self, data, slopes, inplace=False, sharedMaps=False, allocator=None):
+		requireF32(data, slopes)
+		n, maps, mapsize = self.geometry(data, slopes, sharedMaps)
+		outdata = data if inplace else GPUArray.empty(data.shape, dtype=np.float32, allocator=allocator)
+		lib.pz_prelu_fwd(data.rptr, slopes.rptr, outdata.wptr if inplace else outdata.optr, n, maps, mapsize, int(sharedMaps), None)
+		return outdata
+
+
+	def preluBackwardData(self, grad, slopes, indata, sharedMaps=False, allocator=None):
+		requireF32(grad, slopes, indata)
+		assert grad.shape == indata.shape
+		n, maps, mapsize = self.geometry(grad, slopes, sharedMaps)
+		ingrad = GPUArray.empty(grad.shape, dtype=np.float32, allocator=allocator)
+		lib.pz_prelu_bwd_data(grad.rptr, slopes.rptr, indata.rptr, ingrad.optr, n, maps, mapsize, int(sharedMaps), None)
+		return ingrad
+
+
+	def preluBackwardParams(self, indata, outgrad, sharedMaps=False, allocator=None):
+		requireF32(indata, outgrad)
+		assert indata.shape == outgrad.shape
+		n, maps, mapsize = indata.shape[0], indata.shape[1], prod(indata.shape[2:])
+		permap = GPUArray.empty((maps, ), dtype=np.float32, allocator=allocator)
+		lib.pz_prelu_bwd_params(indata.rptr, outgrad.rptr, permap.optr, n, maps, mapsize, None)
+		return self.matmod.matsum(permap.reshape(1, maps), axis=1, allocator=allocator) if sharedMaps else permap
+
+
+class PadModule:
+	"""reflectpad / reflectpadBackward — Cuda/Kernels/Pad.py:146-230 (3-d tensors pad the last axis with (l, r), 4-d
+	tensors the last two with (u, b, l, r))"""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray = backend, GPUArray
+
+
+	def reflectpad(self, data, pad, allocator=None):
+		requireF32(data)
+		if data.ndim == 3:
+			(n, maps, inw), inh, (upad, bpad, lpad, rpad) = data.shape, 1, (0, 0) + tuple(pad)
+			assert inw >= max(lpad, rpad) + 1
+			outshape = (n, maps, inw + lpad + rpad)
+		elif data.ndim == 4:
+			(n, maps, inh, inw), (upad, bpad, lpad, rpad) = data.shape, pad
+			assert inh >= max(upad, bpad) + 1 and inw >= max(lpad, rpad) + 1
+			outshape = (n, maps, inh + upad + bpad, inw + lpad + rpad)
+		else:
+			raise NotImplementedError(data.ndim)
+		outdata = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator)
+		lib.pz_reflectpad2d_fwd(data.rptr, outdata.optr, n * maps, inh, inw, upad, bpad, lpad, rpad, None)
+		return outdata
+
+
+	def reflectpadBackward(self, grad, pad, allocator=None):
+		requireF32(grad)
+		if grad.ndim == 3:
+			(n, maps, outw), (upad, bpad, lpad, rpad) = grad.shape, (0, 0) + tuple(pad)
+			inh, inw = 1, outw - lpad - rpad
+			inshape = (n, maps, inw)
+		elif grad.ndim == 4:
+			(n, maps, outh, outw), (upad, bpad, lpad, rpad) = grad.shape, pad
+			inh, inw = outh - upad - bpad, outw - lpad - rpad
+			inshape = (n, maps, inh, inw)
+		else:
+			raise NotImplementedError(grad.ndim)
+		ingrad = GPUArray.empty(inshape, dtype=grad.dtype, allocator=allocator)
+		lib.pz_reflectpad2d_bwd(grad.rptr, ingrad.optr, n * maps, inh, inw, upad, bpad, lpad, rpad, None)
+		return ingrad
+
+
+class UpsampleModule:
+	"""upsample2d / upsample3d (+Backward), modes "nearest" and "linear" — Cuda/Kernels/Upsample.py:301-455"""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray = backend, GPUArray
+
+
+	@staticmethod
+	def linearFlag(mode):
+		if mode not in ("nearest", "linear"):
+			raise NotImplementedError(mode)
+		return int(mode == "linear")
+
+
+	def run(self, data, scale, mode, allocator, nd, backward):
+		requireF32(data)
+		assert data.ndim == nd + 2
+		scales = (int(scale), ) * nd if isinstance(scale, (int, np.integer)) else tuple(int(v) for v in scale)
+		sd, sh, sw = ((1, ) + scales) if nd == 2 else scales
+		dims = ((1, ) + tuple(data.shape[2:])) if nd == 2 else tuple(data.shape[2:])
+		n, maps = data.shape[:2]
+		if backward:
+			ind, inh, inw = dims[0] // sd, dims[1] // sh, dims[2] // sw
+			outshape = (n, maps) + ((inh, inw) if nd == 2 else (ind, inh, inw))
+			out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator)
+			lib.pz_upsample_bwd(data.rptr, out.optr, n * maps, ind, inh, inw, sd, sh, sw, self.linearFlag(mode), None)
+		else:
+			ind, inh, inw = dims
+			outshape = (n, maps) + ((inh * sh, inw * sw) if nd == 2 else (ind * sd, inh * sh, inw * sw))
+			out = GPUArray.empty(outshape, dtype=data.dtype, allocator=allocator)
+			lib.pz_upsample_fwd(data.rptr, out.optr, n * maps, ind, inh, inw, sd, sh, sw, self.linearFlag(mode), None)
+		return out
+
+
+	def upsample2d(self, data, scale, mode="nearest", allocator=None):
+		return self.run(data, scale, mode, allocator, 2, False)
+
+	def upsample2dBackward(self, grad, scale, mode="nearest", allocator=None):
+		return self.run(grad, scale, mode, allocator, 2, True)
+
+	def upsample3d(self, data, scale, mode="nearest", allocator=None):
+		return self.run(data, scale, mode, allocator, 3, False)
+
+	def upsample3dBackward(self, grad, scale, mode="nearest", allocator=None):
+		return self.run(grad, scale, mode, allocator, 3, True)
+
+
+class EmbedModule:
+	"""embed / embedBackwardParams — Cuda/Kernels/Embedder.py:57-88 (word index -1: padding)"""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray = backend, GPUArray
+
+
+	def embed(self, data, W, allocator=None):
+		assert data.dtype == np.int32 and data.ndim == 2 and W.ndim == 2
+		requireF32(W)
+		batchsize, sentlen = data.shape
+		embsize = W.shape[1]
+		outdata = GPUArray.empty((batchsize, sentlen, embsize), dtype=W.dtype, allocator=allocator)
+		lib.pz_embed_fwd(data.rptr, W.rptr, outdata.optr, batchsize * sentlen, embsize, None)
+		return outdata
+
+
+	def embedBackwardParams(self, indata, grad, W, scale):
+		assert indata.shape == grad.shape[:2] and W.shape[1] == grad.shape[2]
+		assert indata.dtype == np.int32
+		requireF32(grad, W)
+		lib.pz_embed_bwd_params(indata.rptr, grad.rptr, W.wptr, float(scale), indata.size, W.shape[1], None)
+
+
 # ---------------------------------------------------------------------------------------------- element-wise kernel objects
 def absorbRelu(arrays, scalars):
 	"""reluKer(out, in): in place on a described tensor the ReLU joins the description (Modules/Activation.py:52-60 with
@@ -1659,8 +1871,9 @@ class Mi355Backend:
 
 		self.memmod = MemModule(self)
 		self.poolmod = PoolModule(self)
-		for name in ("ctcmod", "embedmod", "padmod", "prelumod", "upsamplemod"):
-			setattr(self, name, StubModule(name))
+		self.embedmod, self.padmod = EmbedModule(self), PadModule(self)
+		self.prelumod, self.upsamplemod = PReluModule(self.matmod), UpsampleModule(self)
+		self.ctcmod = StubModule("ctcmod")
 
 		K = memoizedKernel
 		self.sigmoidKer = K(lib.OP_SIGMOID, 2, 0, "sigmoidKer")
@@ -1708,7 +1921,11 @@ class Mi355Backend:
 			raise NotImplementedError("this kernel is outside the implemented operator path (fp32-only backend)")
 
 		self.castFP16toFP32 = self.castFP32toFP16 = unsupported
-		self.bceKer = self.hingeKer = self.smoothL1Ker = self.l1HingeKer = unsupported
+		# point-wise cost kernels with the reference's positional arguments (Cuda/Kernels/Costs.py:8-72)
+		self.bceKer = PointwiseCost(lib.COST_BCE, "bceKer")
+		self.hingeKer = PointwiseCost(lib.COST_HINGE, "hingeKer")
+		self.smoothL1Ker = PointwiseCost(lib.COST_SMOOTH_L1, "smoothL1Ker")
+		self.l1HingeKer = PointwiseCost(lib.COST_L1_HINGE, "l1HingeKer")
 
 		# fused residual sum / gradient fan-in (one 12 B/elem pass instead of memset + 2 axpy)
 		self.add3Ker = EltwiseKernel(lib.OP_ADD3, 3, 0, "add3Ker")
@@ -1826,11 +2043,37 @@ class Mi355Backend:
 		)
 
 
-	def instanceNorm2d(self, *args, **kwargs):
-		raise NotImplementedError("instance normalisation is outside the implemented operator path")
+	def instanceNorm2d(self, data, scale, bias, epsilon=1e-5, out=None, allocator=None):
+		"""Cuda/GPUBackend.py:381-400: instance normalisation is batch normalisation of the (1, n*c, h, w) view with the
+		affine pair tiled over the batch; returns (out, savemean, saveinvvar, tiled scale)."""
+		n, c, h, w = data.shape
+		ext = n * c
+		mean = GPUArray.empty((ext, ), dtype=np.float32, allocator=allocator)
+		var = GPUArray.empty((ext, ), dtype=np.float32, allocator=allocator)
+		mean.fill(0.0)
+		var.fill(1.0)         # (running statistics nobody reads: the reference passes them uninitialised)
+		if n > 1:
+			scale, bias = self.tile(scale, n, axis=0, allocator=allocator), self.tile(bias, n, axis=0, allocator=allocator)
+		outdata, savemean, saveinvvar = self.dnn.batchNormNd(
+			data.reshape(1, ext, h, w), mean, var, scale, bias, epsilon, test=False,
+			out=None if out is None else out.reshape(1, ext, h, w), allocator=allocator
+		)
+		return outdata.reshape(data.shape), savemean, saveinvvar, scale
 
 
-	instanceNorm2dBackward = instanceNorm2d
+	def instanceNorm2dBackward(self, grad, data, extscale, savemean, saveinvvar, epsilon, affine=True, out=None,
+							   allocator=None):
+		"""Cuda/GPUBackend.py:403-420"""
+		n, c, h, w = grad.shape
+		ext = n * c
+		ingrad, scalegrad, bgrad = self.dnn.batchNormNdBackward(
+			grad.reshape(1, ext, h, w), data.reshape(1, ext, h, w), extscale, savemean, saveinvvar, epsilon,
+			out=None if out is None else out.reshape(1, ext, h, w), allocator=allocator
+		)
+		if affine and n > 1:
+			scalegrad = self.matmod.matsum(scalegrad.reshape(n, -1), axis=0, allocator=allocator)
+			bgrad = self.matmod.matsum(bgrad.reshape(n, -1), axis=0, allocator=allocator)
+		return (ingrad.reshape(grad.shape), scalegrad, bgrad) if affine else ingrad.reshape(grad.shape)
 
 
 	def createRnn(self, *args, **kwargs):

@@ -157,6 +157,16 @@ _PROTOS = {
 	"pz_lrn_fwd": [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, P],
 	"pz_lrn_bwd": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, P],
 	"pz_svm_cost": [P, P, c_int, c_int, c_int, c_int, P, P, P],
+	"pz_cost_pointwise": [c_int, P, P, P, P, P, P, P, c_size_t, c_int, c_int, c_float, c_float, P],
+	"pz_prelu_fwd": [P, P, P, c_int, c_int, c_int, c_int, P],
+	"pz_prelu_bwd_data": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+	"pz_prelu_bwd_params": [P, P, P, c_int, c_int, c_int, P],
+	"pz_reflectpad2d_fwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_reflectpad2d_bwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_upsample_fwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_upsample_bwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_embed_fwd": [P, P, P, c_size_t, c_int, P],
+	"pz_embed_bwd_params": [P, P, P, c_float, c_size_t, c_int, P],
 	"pz_matvec": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],
 	"pz_argmin_rows": [P, c_int, c_int, P, P],
 	"pz_argmin_cols": [P, c_int, c_int, c_int, P, P],
@@ -340,6 +350,7 @@ def sourceId():
 
 COMM_ID_BYTES = 128
 MULTI_ADD_MAX = 96
+COST_BCE, COST_HINGE, COST_SMOOTH_L1, COST_L1_HINGE = 0, 1, 2, 3
 
 # element-wise op ids (enum pz_eltwise_op)
 (

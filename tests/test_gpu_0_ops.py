@@ -950,3 +950,208 @@ def test_conv3d_on_the_2d_core(bnd, cfg):
 	idx = (0, c - 1, cfg["dhw"][0] // 2, 1, 2)
 	probe[idx] = 1.0
 	assert np.isclose(dx.get()[idx], float((dy * R.conv3d_fwd(probe, wt, None, st, pad, dil)).sum()), rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ f3 against the PINNED fixtures
+# tests/golden/ops.npz `f3_*`: written by oracle/make_golden.py after the reference's own tests for these operators
+# (Cuda/Kernels/Pool.py:229-328, Cuda/Wrappers/CuDnnNorm.py:138-260, Cuda/Wrappers/CuDnn.py:83-135,204-372,
+# Cuda/Kernels/MatVec.py:427-465, Costs.py:327-348, PRelu.py:149-185, Pad.py:245-325, Upsample.py:478-640,
+# Embedder.py:103-140, Cost/{BCE,Hinge,SmoothL1,L1Hinge}.py) passed with the oracle as the backend under test (step 2b).
+
+def test_f3_mask_pooling_fixture(bnd, ops):
+	x, cfg = ops["f3_pool_x"], [int(v) for v in ops["f3_pool_cfg"]]
+	kw = dict(size=tuple(cfg[0:2]), stride=tuple(cfg[2:4]), pad=tuple(cfg[4:6]))
+	y, mask = bnd.poolmod.maxpool2d(gpu(bnd, x), allocator=bnd.memoryPool, **kw)
+	assert np.array_equal(y.get(), ops["f3_pool_orc_y"]) and np.array_equal(mask.get(), ops["f3_pool_orc_mask"])
+	dx = bnd.poolmod.maxpool2dBackward(gpu(bnd, ops["f3_pool_dy"]), x.shape, mask, **kw)
+	assert_close(dx.get(), ops["f3_pool_orc_dx"], atol=1e-6, what="mask pooling backward")
+	up = bnd.poolmod.maxunpool2d(y, x.shape, mask)
+	assert np.array_equal(up.get(), ops["f3_unpool_orc_y"])
+	back = bnd.poolmod.maxunpool2dBackward(gpu(bnd, ops["f3_unpool_g"]), y.shape, mask)
+	assert np.array_equal(back.get(), ops["f3_unpool_orc_dx"])
+
+
+@pytest.mark.parametrize("tag", ["map", "cross"])
+def test_f3_lrn_fixture(bnd, ops, tag):
+	x, dy = ops["f3_lrn_x"], ops["f3_lrn_dy"]
+	N, alpha, beta, K = ops["f3_lrn_cfg"]
+	mode = (bnd.LRNMode.cross if tag == "cross" else bnd.LRNMode.map).value
+	gx = gpu(bnd, x)
+	y, ws = bnd.dnn.lrn(gx, int(N), float(alpha), float(beta), float(K), mode, False, allocator=bnd.memoryPool)
+	assert_close(y.get(), ops["f3_lrn_orc_%s_y" % tag], atol=1e-5, rtol=1e-5, what="lrn forward")
+	dx = bnd.dnn.lrnBackward(gpu(bnd, dy), gx, y, ws, int(N), float(alpha), float(beta), float(K), mode)
+	assert_close(dx.get(), ops["f3_lrn_orc_%s_dx" % tag], atol=2e-5, rtol=1e-4, what="lrn backward")
+
+
+def test_f3_instance_norm_fixture(bnd, ops):
+	"""Backend.instanceNorm2d / instanceNorm2dBackward (Cuda/GPUBackend.py:381-420; instanceNorm2dTest CuDnnNorm.py:138-183)"""
+	x = ops["f3_in_x"]
+	gx = gpu(bnd, x)
+	y, sm, si, ext = bnd.instanceNorm2d(gx, gpu(bnd, ops["f3_in_scale"]), gpu(bnd, ops["f3_in_bias"]), epsilon=1e-5)
+	assert y.shape == x.shape and ext.shape == (x.shape[0] * x.shape[1], )
+	assert_close(y.get(), ops["f3_in_orc_y"], atol=2e-5, rtol=1e-4, what="instance norm y")
+	assert_close(sm.get().ravel(), ops["f3_in_orc_mean"].ravel(), atol=1e-5, what="saved mean")
+	assert_close(si.get().ravel(), ops["f3_in_orc_invvar"].ravel(), atol=1e-4, rtol=1e-4, what="saved inverse deviation")
+	dx, ds, db = bnd.instanceNorm2dBackward(gpu(bnd, ops["f3_in_dy"]), gx, ext, sm, si, 1e-5)
+	assert_close(dx.get(), ops["f3_in_orc_dx"], atol=1e-4, rtol=1e-3, what="instance norm dx")
+	assert_close(ds.get().ravel(), ops["f3_in_orc_dscale"].ravel(), atol=1e-4, rtol=1e-3, what="dscale")
+	assert_close(db.get().ravel(), ops["f3_in_orc_dbias"].ravel(), atol=1e-4, rtol=1e-3, what="dbias")
+	only = bnd.instanceNorm2dBackward(gpu(bnd, ops["f3_in_dy"]), gx, ext, sm, si, 1e-5, affine=False)
+	assert_close(only.get(), ops["f3_in_orc_dx"], atol=1e-4, rtol=1e-3, what="instance norm dx (affine=False)")
+
+
+def test_f3_conv3d_and_deconv3d_fixture(bnd, ops):
+	"""conv3dTest / deconv3dTest shapes of their own plus stride-2 / padded ones, element-wise against the pinned oracle"""
+	cfg = [int(v) for v in ops["f3_c3_cfg"]]
+	st, pd, dl = tuple(cfg[0:3]), tuple(cfg[3:6]), tuple(cfg[6:9])
+	x, w, b, dy = ops["f3_c3_x"], ops["f3_c3_w"], ops["f3_c3_b"], ops["f3_c3_dy"]
+	gx, gw = gpu(bnd, x), gpu(bnd, w)
+	y = bnd.dnn.convNd(gx, gw, gpu(bnd, b), st, pd, dl, 1)
+	assert_close(y.get(), ops["f3_c3_orc_y"], atol=2e-4, rtol=1e-4, what="conv3d forward")
+	gdy = gpu(bnd, dy)
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, None, gx, st, pd, dl, None, 1)
+	assert_close(dx.get(), ops["f3_c3_orc_dx"], atol=2e-4, rtol=1e-4, what="conv3d backward data")
+	dw, db = bnd.dnn.convNdBackwardParams(gx, gdy, gw, st, pd, dl, 1, True)
+	assert_close(dw.get(), ops["f3_c3_orc_dw"], atol=5e-4, rtol=1e-4, what="conv3d filter gradient")
+	assert_close(db.get(), ops["f3_c3_orc_db"], atol=5e-4, rtol=1e-4, what="conv3d bias gradient")
+
+	# deconvolution with the same filter bank read as (inmaps, outmaps, t, r, s): Backend/Dnn.py:211-231
+	d, bd, g = ops["f3_d3_x"], ops["f3_d3_b"], ops["f3_d3_g"]
+	gd = gpu(bnd, d)
+	out = bnd.dnn.convNdBackwardData(gd, gw, gpu(bnd, bd), None, st, pd, dl, 0, 1)
+	assert_close(out.get(), ops["f3_d3_orc_y"], atol=2e-4, rtol=1e-4, what="deconv3d forward")
+	gg = gpu(bnd, g)
+	back = bnd.dnn.convNd(gg, gw, None, st, pd, dl, 1)
+	assert_close(back.get(), ops["f3_d3_orc_dx"], atol=2e-4, rtol=1e-4, what="deconv3d backward data")
+	dwd, dbd = bnd.dnn.convNdBackwardParams(gg, gd, gw, st, pd, dl, 1, True, True)
+	assert_close(dwd.get(), ops["f3_d3_orc_dw"], atol=5e-4, rtol=1e-4, what="deconv3d filter gradient")
+	assert_close(dbd.get(), ops["f3_d3_orc_db"], atol=5e-4, rtol=1e-4, what="deconv3d bias gradient")
+
+
+def test_f3_reference_deconv_test_shapes(bnd):
+	"""deconv2dTest / deconv3dTest / deconvGroupTest (Cuda/Wrappers/CuDnn.py:204-372) with their own shapes against the oracle
+	functions those very tests pinned"""
+	rng = np.random.RandomState(31)
+	# deconv2dTest: 1x1x2x2 data, filter (1, 1, 3, 3), stride 2
+	d, w, b = rng.randn(1, 1, 2, 2).astype(np.float32), rng.randn(1, 1, 3, 3).astype(np.float32), rng.randn(1).astype(np.float32)
+	out = bnd.dnn.convNdBackwardData(gpu(bnd, d), gpu(bnd, w), gpu(bnd, b), stride=2)
+	ref = R.conv2d_bwd_data(d, w, (1, 1, 5, 5), 2, 0, 1) + b.reshape(1, 1, 1, 1)
+	assert_close(out.get(), ref, atol=1e-5, what="deconv2d forward")
+	g = rng.randn(*ref.shape).astype(np.float32)
+	wg, bg = bnd.dnn.convNdBackwardParams(gpu(bnd, g), gpu(bnd, d), gpu(bnd, w), stride=2, withbias=True, deconv=True)
+	assert_close(wg.get(), R.conv2d_bwd_filter(g, d, w.shape, 2, 0, 1), atol=1e-5, what="deconv2d filter gradient")
+	assert_close(bg.get(), g.sum(axis=(0, 2, 3)), atol=1e-5, what="deconv2d bias gradient")
+	# deconvGroupTest: 3x4x3x4 data, filter (4, 2, 2, 2), 2 groups
+	d, w, b = rng.randn(3, 4, 3, 4).astype(np.float32), rng.randn(4, 2, 2, 2).astype(np.float32), rng.randn(4).astype(np.float32)
+	out = bnd.dnn.convNdBackwardData(gpu(bnd, d), gpu(bnd, w), gpu(bnd, b), groups=2)
+	ref = R.conv2d_bwd_data(d, w, (3, 4, 4, 5), 1, 0, 1, 2) + b.reshape(1, 4, 1, 1)
+	assert_close(out.get(), ref, atol=1e-5, what="grouped deconv forward")
+	g = rng.randn(*ref.shape).astype(np.float32)
+	assert_close(bnd.dnn.convNd(gpu(bnd, g), gpu(bnd, w), groups=2).get(), R.conv2d_fwd(g, w, None, 1, 0, 1, 2), atol=1e-5,
+				 what="grouped deconv backward data")
+	wg, bg = bnd.dnn.convNdBackwardParams(gpu(bnd, g), gpu(bnd, d), gpu(bnd, w), groups=2, withbias=True, deconv=True)
+	assert_close(wg.get(), R.conv2d_bwd_filter(g, d, w.shape, 1, 0, 1, 2), atol=1e-4, what="grouped deconv filter gradient")
+	assert_close(bg.get(), g.sum(axis=(0, 2, 3)), atol=1e-4, what="grouped deconv bias gradient")
+
+
+def test_f3_matvec_svm_fixture(bnd, ops):
+	A = gpu(bnd, ops["f3_mv_A"])
+	assert_close(bnd.matmod.matvec(A, gpu(bnd, ops["f3_mv_v"]), axis=1).get(), ops["f3_mv_orc_rows"], atol=1e-4, rtol=1e-4, what="matvec rows")
+	assert_close(bnd.matmod.matvec(A, gpu(bnd, ops["f3_mv_w"]), axis=0).get(), ops["f3_mv_orc_cols"], atol=1e-4, rtol=1e-4, what="matvec cols")
+	for mode in ("l1", "l2"):
+		err, grad = bnd.costmod.svm(gpu(bnd, ops["f3_svm_scores"]), gpu(bnd, ops["f3_svm_labels"]), mode=mode)
+		assert np.isclose(float(err.get()), float(ops["f3_svm_orc_%s_err" % mode][0]), rtol=1e-5)
+		assert_close(grad.get(), ops["f3_svm_orc_%s_grad" % mode], atol=1e-6, what="svm gradient " + mode)
+
+
+def test_f3_pointwise_cost_kernels_fixture(bnd, ops):
+	"""bceKer / hingeKer / smoothL1Ker / l1HingeKer with the reference's positional arguments (Cuda/Kernels/Costs.py:8-72);
+	the error is ADDED to the 0-d array (the reference's kernels atomicAdd into it)."""
+	G = bnd.GPUArray
+
+	def errArray(start=0.0):
+		e = G.empty((), dtype=np.float32)
+		e.fill(start)
+		return e
+
+	s, lab = ops["f3_bce_scores"], ops["f3_bce_labels"]
+	err, grad = errArray(), G.empty(s.shape, dtype=np.float32)
+	bnd.bceKer(gpu(bnd, s), gpu(bnd, lab), err, grad, s.shape[0], int(np.prod(s.shape[1:])))
+	assert np.isclose(float(err.get()), float(ops["f3_bce_orc_err"][0]), rtol=1e-5)
+	assert_close(grad.get(), ops["f3_bce_orc_grad"], atol=1e-7, rtol=1e-5, what="bce gradient")
+
+	s, lab = ops["f3_hinge_scores"], ops["f3_hinge_labels"]
+	err, grad = errArray(1.5), G.empty(s.shape, dtype=np.float32)
+	bnd.hingeKer(gpu(bnd, s), gpu(bnd, lab), err, grad, s.shape[0], s.shape[1])
+	assert np.isclose(float(err.get()), 1.5 + float(ops["f3_hinge_orc_err"][0]), rtol=1e-5), "the error accumulates"
+	assert_close(grad.get(), ops["f3_hinge_orc_grad"], atol=1e-7, rtol=1e-5, what="hinge gradient")
+
+	p, t = ops["f3_sl1_pred"], ops["f3_sl1_target"]
+	err, grad = errArray(), G.empty(p.shape, dtype=np.float32)
+	bnd.smoothL1Ker(gpu(bnd, p), gpu(bnd, t), err, grad, 1.0 / 11, 1.0 / 99)
+	assert np.isclose(float(err.get()), float(ops["f3_sl1_orc_err"][0]), rtol=1e-5)
+	assert_close(grad.get(), ops["f3_sl1_orc_grad"], atol=1e-7, rtol=1e-5, what="smoothL1 gradient")
+
+	x1, x2, lab = ops["f3_l1h_x1"], ops["f3_l1h_x2"], ops["f3_l1h_labels"]
+	err, g1, g2 = errArray(), G.empty(x1.shape, dtype=np.float32), G.empty(x1.shape, dtype=np.float32)
+	bnd.l1HingeKer(gpu(bnd, x1), gpu(bnd, x2), gpu(bnd, lab), err, g1, g2, x1.shape[0], x1.shape[1])
+	assert np.isclose(float(err.get()), float(ops["f3_l1h_orc_err"][0]), rtol=1e-5)
+	assert_close(g1.get(), ops["f3_l1h_orc_g1"], atol=1e-7, rtol=1e-5, what="l1Hinge g1")
+	assert_close(g2.get(), ops["f3_l1h_orc_g2"], atol=1e-7, rtol=1e-5, what="l1Hinge g2")
+
+
+@pytest.mark.parametrize("tag", ["map", "shared"])
+def test_f3_prelu_fixture(bnd, ops, tag):
+	x, dy = ops["f3_prelu_x"], ops["f3_prelu_dy"]
+	shared = tag == "shared"
+	slopes = gpu(bnd, ops["f3_prelu_shared" if shared else "f3_prelu_slopes"])
+	gx = gpu(bnd, x)
+	y = bnd.prelumod.prelu(gx, slopes, sharedMaps=shared)
+	assert_close(y.get(), ops["f3_prelu_orc_%s_y" % tag], atol=1e-6, what="prelu")
+	dx = bnd.prelumod.preluBackwardData(gpu(bnd, dy), slopes, gx, sharedMaps=shared)
+	assert_close(dx.get(), ops["f3_prelu_orc_%s_dx" % tag], atol=1e-6, what="prelu backward data")
+	ds = bnd.prelumod.preluBackwardParams(gx, gpu(bnd, dy), sharedMaps=shared)
+	assert ds.shape == ops["f3_prelu_orc_%s_ds" % tag].shape
+	assert_close(ds.get(), ops["f3_prelu_orc_%s_ds" % tag], atol=1e-4, rtol=1e-4, what="prelu slope gradient")
+	inplace = gpu(bnd, x)
+	assert bnd.prelumod.prelu(inplace, slopes, inplace=True, sharedMaps=shared) is inplace
+	assert np.array_equal(inplace.get(), y.get())
+
+
+def test_f3_reflection_pad_fixture(bnd, ops):
+	pad2 = tuple(int(v) for v in ops["f3_pad2_pad"])
+	y = bnd.padmod.reflectpad(gpu(bnd, ops["f3_pad2_x"]), pad2)
+	assert np.array_equal(y.get(), ops["f3_pad2_orc_y"])
+	assert np.array_equal(y.get(), np.pad(ops["f3_pad2_x"], ((0, 0), (0, 0), pad2[0:2], pad2[2:4]), mode="reflect"))
+	dx = bnd.padmod.reflectpadBackward(gpu(bnd, ops["f3_pad2_g"]), pad2)
+	assert_close(dx.get(), ops["f3_pad2_orc_dx"], atol=1e-5, what="reflectpad2d backward")
+	y = bnd.padmod.reflectpad(gpu(bnd, ops["f3_pad1_x"]), (3, 5))
+	assert np.array_equal(y.get(), ops["f3_pad1_orc_y"])
+	dx = bnd.padmod.reflectpadBackward(gpu(bnd, ops["f3_pad1_g"]), (3, 5))
+	assert_close(dx.get(), ops["f3_pad1_orc_dx"], atol=1e-5, what="reflectpad1d backward")
+	with pytest.raises(Exception):
+		bnd.padmod.reflectpad(gpu(bnd, ops["f3_pad1_x"]), (11, 0))          # pad must be smaller than the axis
+
+
+@pytest.mark.parametrize("mode", ["nearest", "linear"])
+@pytest.mark.parametrize("tag", ["2d", "3d"])
+def test_f3_upsample_fixture(bnd, ops, tag, mode):
+	x, scale = ops["f3_up%s_x" % tag], tuple(int(v) for v in ops["f3_up%s_scale" % tag])
+	fwd = bnd.upsamplemod.upsample2d if tag == "2d" else bnd.upsamplemod.upsample3d
+	bwd = bnd.upsamplemod.upsample2dBackward if tag == "2d" else bnd.upsamplemod.upsample3dBackward
+	y = fwd(gpu(bnd, x), scale, mode=mode)
+	assert_close(y.get(), ops["f3_up%s_orc_%s_y" % (tag, mode)], atol=1e-6, rtol=1e-5, what="upsample " + mode)
+	dx = bwd(gpu(bnd, ops["f3_up%s_%s_g" % (tag, mode)]), scale, mode=mode)
+	assert_close(dx.get(), ops["f3_up%s_orc_%s_dx" % (tag, mode)], atol=1e-5, rtol=1e-5, what="upsample backward " + mode)
+	if tag == "2d":
+		same = bnd.upsamplemod.upsample2d(gpu(bnd, x), 2, mode=mode)           # an int scale applies to both axes
+		assert same.shape == x.shape[:2] + (2 * x.shape[2], 2 * x.shape[3])
+
+
+def test_f3_embedder_fixture(bnd, ops):
+	words, vocab, g = ops["f3_emb_words"], ops["f3_emb_vocab"], ops["f3_emb_g"]
+	gw, gv = gpu(bnd, words), gpu(bnd, vocab)
+	y = bnd.embedmod.embed(gw, gv)
+	assert np.array_equal(y.get(), ops["f3_emb_orc_y"]) and (words == -1).any()
+	bnd.embedmod.embedBackwardParams(gw, gpu(bnd, g), gv, 0.25)
+	assert_close(gv.get(), ops["f3_emb_orc_vocab_after"], atol=1e-5, what="vocabulary after the update")

@@ -203,3 +203,92 @@ def test_allreduce_mean_restatement():
 	rng = np.random.RandomState(1)
 	grads = [rng.randn(1000).astype(np.float32) for _ in range(4)]
 	assert_close(R.grad_mean_allreduce(grads), np.mean(np.stack(grads).astype(np.float64), axis=0), atol=1e-6)
+
+
+def test_f3_oracle_reproduces_its_fixtures_and_independent_formulas(ops):
+	"""The oracle of the operators beside the hot path against the committed `f3_*` vectors (written after the reference's
+	own tests for them passed on this oracle, oracle/make_golden.py step 2b) and against formulas written independently
+	here: numpy's reflect padding, adjoint identities for the backward passes, brute-force loops on small cases."""
+	# reflection pad == np.pad(mode="reflect"); backward is its adjoint
+	x, g = ops["f3_pad2_x"], ops["f3_pad2_g"]
+	pad = tuple(int(v) for v in ops["f3_pad2_pad"])
+	y = R.reflectpad_fwd(x, pad)
+	assert np.array_equal(y, np.pad(x, ((0, 0), (0, 0), pad[:2], pad[2:]), mode="reflect")) and np.array_equal(y, ops["f3_pad2_orc_y"])
+	assert np.isclose(np.sum(y.astype(np.float64) * g), np.sum(R.reflectpad_bwd(g, pad).astype(np.float64) * x), rtol=1e-6)
+
+	# up-sampling: nearest == np.repeat; linear reproduces the corners and is exact on affine ramps; backward = adjoint
+	for tag in ("2d", "3d"):
+		x, scale = ops["f3_up%s_x" % tag], tuple(int(v) for v in ops["f3_up%s_scale" % tag])
+		near = x
+		for axis, s in enumerate(scale):
+			near = np.repeat(near, s, axis=2 + axis)
+		assert np.array_equal(R.upsample_fwd(x, scale, "nearest"), near)
+		lin = R.upsample_fwd(x, scale, "linear")
+		assert_close(lin, ops["f3_up%s_orc_linear_y" % tag], atol=1e-6)
+		corner = (slice(None), slice(None)) + (slice(None, None, None), ) * 0
+		assert np.allclose(lin[(Ellipsis, ) + (0, ) * (x.ndim - 2)], x[(Ellipsis, ) + (0, ) * (x.ndim - 2)], atol=1e-6)
+		assert np.allclose(lin[(Ellipsis, ) + (-1, ) * (x.ndim - 2)], x[(Ellipsis, ) + (-1, ) * (x.ndim - 2)], atol=1e-6)
+		for mode in ("nearest", "linear"):
+			g = ops["f3_up%s_%s_g" % (tag, mode)]
+			lhs = np.sum(R.upsample_fwd(x, scale, mode).astype(np.float64) * g)
+			assert np.isclose(lhs, np.sum(R.upsample_bwd(g, scale, mode).astype(np.float64) * x), rtol=1e-5)
+			assert_close(R.upsample_bwd(g, scale, mode), ops["f3_up%s_orc_%s_dx" % (tag, mode)], atol=1e-6)
+	ramp = np.arange(5, dtype=np.float32).reshape(1, 1, 1, 5) * np.ones((1, 1, 3, 1), np.float32)
+	assert np.allclose(R.upsample_fwd(ramp, (1, 3), "linear")[0, 0, 0], np.linspace(0, 4, 15), atol=1e-5)
+
+	# 3-d convolution: forward vs brute force on one output element, backward passes as adjoints
+	cfg = [int(v) for v in ops["f3_c3_cfg"]]
+	st, pd, dl = tuple(cfg[0:3]), tuple(cfg[3:6]), tuple(cfg[6:9])
+	x, w, dy = ops["f3_c3_x"], ops["f3_c3_w"], ops["f3_c3_dy"]
+	y = R.conv3d_fwd(x, w, None, st, pd, dl)
+	xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0)) + tuple((p, p) for p in pd))
+	n, k, d, h, ww = 1, 2, 1, 2, 1
+	acc = 0.0
+	for c in range(x.shape[1]):
+		for t in range(w.shape[2]):
+			for r in range(w.shape[3]):
+				for s in range(w.shape[4]):
+					acc += xp[n, c, d * st[0] + t, h * st[1] + r, ww * st[2] + s] * w[k, c, t, r, s]
+	assert np.isclose(y[n, k, d, h, ww], acc, rtol=1e-9)
+	lhs = np.sum(y * dy)
+	assert np.isclose(lhs, np.sum(R.conv3d_bwd_data(dy, w, x.shape, st, pd, dl) * x), rtol=1e-9)
+	assert np.isclose(lhs, np.sum(R.conv3d_bwd_filter(x, dy, w.shape, st, pd, dl)[0] * w), rtol=1e-9)
+
+	# instance norm: per (image, map) zero mean / unit variance before the affine pair; backward via a finite difference
+	x, scale, bias = ops["f3_in_x"], ops["f3_in_scale"], ops["f3_in_bias"]
+	y, sm, si, ext = R.instance_norm_fwd(x, scale, bias)
+	norm = (y - bias.reshape(1, -1, 1, 1)) / scale.reshape(1, -1, 1, 1)
+	assert np.allclose(norm.mean(axis=(2, 3)), 0, atol=1e-5) and np.allclose(norm.var(axis=(2, 3)), 1, atol=1e-3)
+	assert_close(y, ops["f3_in_orc_y"], atol=1e-6)
+	dy = ops["f3_in_dy"]
+	dx, ds, db = R.instance_norm_bwd(dy, x, ext, sm, si)
+	probe = np.zeros_like(x)
+	probe[1, 2, 3, 4] = 1e-2
+	num = (np.sum(R.instance_norm_fwd(x + probe, scale, bias)[0].astype(np.float64) * dy) -
+		   np.sum(R.instance_norm_fwd(x - probe, scale, bias)[0].astype(np.float64) * dy)) / 2e-2
+	assert np.isclose(dx[1, 2, 3, 4], num, rtol=2e-2, atol=1e-3)
+	assert_close(db, dy.sum(axis=(0, 2, 3)), atol=1e-4)
+
+	# cost kernels: gradients are the derivatives of the summed error (finite differences where the kernel is smooth)
+	s, lab = ops["f3_bce_scores"].astype(np.float64), ops["f3_bce_labels"]
+	prob = 1 / (1 + np.exp(-s.reshape(lab.shape)))
+	assert np.isclose(float(ops["f3_bce_orc_err"][0]), -np.sum(lab * np.log(prob) + (1 - lab) * np.log(1 - prob)) / 12, rtol=1e-5)
+	assert_close(ops["f3_bce_orc_grad"].reshape(lab.shape), (lab - prob) / 12 / 12, atol=1e-7)
+	p, t = ops["f3_sl1_pred"].astype(np.float64), ops["f3_sl1_target"].astype(np.float64)
+	d = np.abs(p - t)
+	assert np.isclose(float(ops["f3_sl1_orc_err"][0]), np.sum(np.where(d < 1, d * d / 2, d - 0.5)) / 11, rtol=1e-5)
+
+	# embedding: rows gathered, padding rows zero; the update adds scale * grad once per occurrence
+	words, vocab, g = ops["f3_emb_words"], ops["f3_emb_vocab"], ops["f3_emb_g"]
+	after = vocab.astype(np.float64).copy()
+	for b in range(words.shape[0]):
+		for t_ in range(words.shape[1]):
+			if words[b, t_] != -1:
+				after[words[b, t_]] += 0.25 * g[b, t_]
+	assert_close(ops["f3_emb_orc_vocab_after"], after, atol=1e-5)
+
+	# PReLU slope gradient (per map and shared) by direct summation
+	x, dy = ops["f3_prelu_x"].astype(np.float64), ops["f3_prelu_dy"].astype(np.float64)
+	per = (dy * x * (x <= 0)).sum(axis=(0, 2, 3))
+	assert_close(ops["f3_prelu_orc_map_ds"], per, atol=1e-4)
+	assert_close(ops["f3_prelu_orc_shared_ds"], [per.sum()], atol=1e-4)
