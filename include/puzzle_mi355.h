@@ -76,6 +76,8 @@ int pz_strided_copy(void *dst, const int64_t *dst_strides, const void *src, cons
 
 /* ---- streams / events: replaces Driver.Stream / Driver.Event (Cuda/Source/Core/Stream.c:101-239) ---- */
 int pz_stream_create(pz_stream_t *stream);
+/* level < 0 / 0 / > 0: lowest / middle / highest queue priority of the device (hipStreamCreateWithPriority) */
+int pz_stream_create_priority(pz_stream_t *stream, int level);
 int pz_stream_destroy(pz_stream_t stream);
 int pz_stream_sync(pz_stream_t stream);
 int pz_stream_wait_event(pz_stream_t stream, pz_event_t event);
@@ -119,6 +121,23 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 /* dx = conv^T(dy, w); dx has the (n,c,h,w) of the descriptor */
 int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx,
                        int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* Filter operands prepared ahead of the pass (they depend on the parameters only): pz_conv2d_prepack_bytes = size of what
+ * pass `which` (PZ_CONV_FWD / PZ_CONV_BWD_DATA) derives from the filter tensor — 0 when it reads the tensor itself;
+ * pz_conv2d_prepack fills any number of them in a few launches; pz_conv2d_{fwd,bwd_data}_pre are pz_conv2d_fwd_stats /
+ * pz_conv2d_bwd_data taking the prepared operand instead of the filter tensor. The caller owns the buffers and re-prepares
+ * them when the parameters change (puzzlelib_amd/backend.py: once per training step, behind the optimizer's update).    */
+typedef struct {
+	pz_conv_desc desc;
+	int which, algo;
+	const float *w;
+	void *packed;
+} pz_prepack_job;
+int pz_conv2d_prepack_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
+int pz_conv2d_prepack(const pz_prepack_job *jobs, int njobs, pz_stream_t stream);
+int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed, const float *bias, float *y, float *stats,
+                      int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
+                           size_t ws_bytes, pz_stream_t stream);
 /* dw <- beta*dw + alpha*sum(x (x) dy); db (optional) <- beta*db + alpha*sum(dy): the accumulate contract of
  * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue.         */
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db,

@@ -262,6 +262,7 @@ class DnnContext:
 		self.sideStream = None
 		self.sideLaunches = 0
 		self.poolBnCache = {}
+		self.packCache = weakref.WeakKeyDictionary()        # allocation of a filter -> {(offset, pass, algo, geometry): PackEntry}
 		self.convMath = None
 		self.setConvMath(self.convMathDefault)
 
@@ -272,6 +273,7 @@ class DnnContext:
 			raise ValueError("PUZZLE_MI355_MATH / setConvMath: %r is not one of %s" % (name, sorted(self.MATH)))
 		lib.pz_conv_math_set(self.MATH[name])
 		self.geometry.clear()
+		self.packCache.clear()
 		self.convMath = name
 		return self
 
@@ -306,6 +308,53 @@ class DnnContext:
 		if nbytes == 0:
 			return None
 		return GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
+
+
+	# ---- filter operands prepared once per parameter version -------------------------------------------------------------
+	# What a pass derives from the filter tensor alone (the implicit GEMM's packed forward operand and gather table, the
+	# Winograd kernels' transformed filters) used to be one ~5 us launch per layer and pass, every step, each on the
+	# critical path: 69 of ResNet-50's launches. They are kept per (filter, pass, geometry) instead and are current while
+	# the write-version of the filter's allocation stands (lazy.State.version: every write barrier bumps it — the
+	# optimizer's update, .set(), a foreign stream's write). The first convolution that finds its operand stale prepares
+	# ALL operands of that allocation that were used since the last time, in one batched launch per kernel family
+	# (pz_conv2d_prepack): with the parameters in one flat arena that is once per training step, behind the optimizer.
+	class PackEntry:
+		__slots__ = ("offset", "desc", "which", "algo", "packed", "version", "used")
+
+	def prepared(self, W, desc, which, algo):
+		"""address of the prepared filter operand of this pass, or None when the pass reads the filter tensor itself"""
+		if not lazy.on("prepack"):
+			return None
+		root = W.gpudata.root
+		entries = self.packCache.get(root)
+		if entries is None:
+			entries = self.packCache[root] = {}
+		offset = W.gpudata.ptr - root.ptr
+		key = (offset, which, algo, desc.n, desc.c, desc.h, desc.w, desc.k, desc.r, desc.s, desc.stride_h, desc.stride_w,
+			   desc.pad_h, desc.pad_w, desc.dil_h, desc.dil_w, desc.groups)
+		entry = entries.get(key)
+		if entry is None:
+			nbytes = c_size_t(0)
+			lib.pz_conv2d_prepack_bytes(byref(desc), which, algo, byref(nbytes))
+			entry = entries[key] = self.PackEntry()
+			entry.offset, entry.which, entry.algo, entry.version, entry.used = offset, which, algo, -1, False
+			entry.desc = ConvDesc.from_buffer_copy(desc)
+			entry.packed = GPUArray.empty((nbytes.value, ), dtype=np.uint8) if nbytes.value > 0 else None
+		if entry.packed is None:
+			return None
+		entry.used = True
+		lz = lazy.stateOf(root)
+		if entry.version != lz.version:
+			lazy.readBarrier(root)                      # pending contents written, foreign writers waited for (whole allocation)
+			stale = [e for e in entries.values() if e.packed is not None and e.used and e.version != lz.version]
+			jobs = (lib.PrepackJob * len(stale))()
+			for job, e in zip(jobs, stale):
+				job.desc, job.which, job.algo, job.w, job.packed = e.desc, e.which, e.algo, root.ptr + e.offset, e.packed.gpudata.ptr
+				e.version, e.used = lz.version, False
+			entry.used = True
+			lib.pz_conv2d_prepack(jobs, len(stale), None)
+			lazy.count("prepack_launch")
+		return entry.packed.gpudata.ptr
 
 
 	def convGeometry(self, desc, which, algo):
@@ -379,13 +428,22 @@ class DnnContext:
 			policy == "always" or (policy == "adaptive" and key[1] in self.statsWanted.get(wroot, ()))
 		)
 
-		if not want or nstrips == 0:
+		stats = None
+		if want and nstrips > 0:
+			stats = GPUArray.empty((W.shape[0], nstrips, 4), dtype=np.float32, allocator=allocator)
+		packed = self.prepared(W, desc, lib.CONV_FWD, algo)
+		if packed is not None:
+			lib.pz_conv2d_fwd_pre(
+				byref(desc), data.rptr, packed, rptrOf(bias), out.optr, None if stats is None else stats.optr, algo, rptrOf(ws),
+				wsbytes, None
+			)
+		elif stats is None:
 			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), wsbytes, None)
 		else:
-			stats = GPUArray.empty((W.shape[0], nstrips, 4), dtype=np.float32, allocator=allocator)
 			lib.pz_conv2d_fwd_stats(
 				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), wsbytes, None
 			)
+		if stats is not None:
 			lazy.setFact(out, "convstats", (stats, outshape))
 			lazy.count("conv_stats")
 
@@ -470,7 +528,11 @@ class DnnContext:
 			)
 			lazy.count("dgrad_bn_fold")
 		else:
-			lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None)
+			packed = self.prepared(W, desc, lib.CONV_BWD_DATA, algo)
+			if packed is not None:
+				lib.pz_conv2d_bwd_data_pre(byref(desc), grad.rptr, packed, out.optr, algo, rptrOf(ws), wsbytes, None)
+			else:
+				lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None)
 
 		if bias is not None:           # deconvolution forward: bias over the produced maps, rows of the (n*maps, pixels) view
 			assert bias.size == out.shape[1]
@@ -504,7 +566,8 @@ class DnnContext:
 		if self.sideWorkMean > self.sideStreamMaxGflop:
 			return None
 		if self.sideStream is None:
-			self.sideStream = driver.Stream()
+			prio = os.environ.get("PUZZLE_MI355_SIDE_PRIORITY", "")
+			self.sideStream = driver.Stream(priority={"low": -1, "mid": 0, "high": 1}.get(prio))
 		self.sideLaunches += 1
 		return self.sideStream
 

@@ -34,7 +34,10 @@ inline int stream_grid(size_t work_items, int per_block) {
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats = nullptr);
+              void *workspace, hipStream_t st, float *stats = nullptr, bool filters_ready = false);
+// transformed filters of up to kWinoBatch (layer, pass) pairs in one launch; u[i] = what wino_conv expects at `workspace`
+constexpr int kWinoBatch = 40;
+int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st);
 int wino_stats_strips(const pz_conv_desc *d, int P, int Q);      // statistics blocks per channel of a forward launch (0: none)
 bool wino_wgrad_eligible(const pz_conv_desc *d, int P, int Q);
 size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q);

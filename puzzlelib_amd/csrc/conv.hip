@@ -155,12 +155,12 @@ struct PackArgs {
 	int tapmajor, chans;
 };
 
-__global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
+__device__ __forceinline__ void pack_filter_body(const PackArgs &a, long first, long step) {
 	const long total = (long)a.groups * a.kred_pad * a.mpad;
 	const int RS = a.mode == 0 ? a.R * a.S : a.Rc * a.Sc;
 	const int Sx = a.mode == 0 ? a.S : a.Sc;
 
-	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+	for (long i = first; i < total; i += step) {
 		const int m = (int)(i % a.mpad);
 		const long t = i / a.mpad;
 		const int kr = (int)(t % a.kred_pad);
@@ -197,6 +197,25 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
 			a.tab[kr] = e;
 		}
 	}
+}
+
+__global__ void __launch_bounds__(256) pack_filter_kernel(PackArgs a) {
+	pack_filter_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// Several layers' filter operands in ONE launch (pz_conv2d_prepack): job j owns the blocks [start[j], start[j + 1])
+constexpr int kPackBatch = 24;
+struct PackBatch {
+	int n, start[kPackBatch + 1];
+	PackArgs job[kPackBatch];
+};
+static_assert(sizeof(PackBatch) <= 4000, "kernel arguments");
+
+__global__ void __launch_bounds__(256) pack_filter_batch_kernel(PackBatch b) {
+	int j = 0;
+	while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
+	const int nb = b.start[j + 1] - b.start[j];
+	pack_filter_body(b.job[j], (long)(blockIdx.x - b.start[j]) * 256 + threadIdx.x, (long)nb * 256);
 }
 
 // The same filters for the split kernels (tap-major orders only): pre-split into bf16 terms and laid out as the 16-byte
@@ -2111,25 +2130,54 @@ int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips) {
 	return PZ_OK;
 }
 
+// The forward pass's filter operand of the implicit GEMM: [wp | tab] at `base`
+static FwdPlan fwd_pack_args(const pz_conv_desc *d, int P, int Q, const float *w, char *base, PackArgs *out) {
+	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
+	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups, Cg);
+	PackArgs pa{};
+	pa.w = w, pa.wp = (float *)base, pa.tab = (int2 *)(base + p.wp_bytes);
+	pa.Kg = Kg, pa.Cg = Cg, pa.R = d->r, pa.S = d->s, pa.groups = d->groups, pa.mode = 0;
+	pa.M = Kg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
+	pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = d->h, pa.in_w = d->w;
+	pa.tapmajor = Cg % 16 == 0, pa.chans = Cg;
+	*out = pa;
+	return p;
+}
+
+static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, int algo,
                   void *workspace, size_t ws_bytes, pz_stream_t stream) {
-	return pz_conv2d_fwd_stats(d, x, w, bias, y, nullptr, algo, workspace, ws_bytes, stream);
+	return conv2d_fwd_impl(d, x, w, nullptr, bias, y, nullptr, algo, workspace, ws_bytes, stream);
 }
 
 int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, float *stats,
                         int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	return conv2d_fwd_impl(d, x, w, nullptr, bias, y, stats, algo, workspace, ws_bytes, stream);
+}
+
+int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed, const float *bias, float *y, float *stats,
+                      int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	PZ_REQUIRE(packed != nullptr, "pz_conv2d_fwd_pre: no prepared filter operand");
+	return conv2d_fwd_impl(d, x, nullptr, packed, bias, y, stats, algo, workspace, ws_bytes, stream);
+}
+
+static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
-	PZ_REQUIRE(x && w && y, "pz_conv2d_fwd: null tensor");
+	PZ_REQUIRE(x && (w || packed) && y, "pz_conv2d_fwd: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
 	if (uses_winograd(d, PZ_CONV_FWD, P, Q, algo)) {
 		PZ_REQUIRE(stats == nullptr || pz::wino_stats_strips(d, P, Q) > 0, "pz_conv2d_fwd_stats: this Winograd build does not produce statistics");
-		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
-		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+		size_t need = packed ? 0 : pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
+		PZ_REQUIRE(packed || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
-		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, workspace, st, stats);
+		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, packed ? const_cast<void *>(packed) : workspace, st, stats, packed != nullptr);
 	}
+	PZ_REQUIRE(packed == nullptr || (algo != PZ_CONV_ALGO_DIRECT && igemm_eligible(d, P, Q)), "pz_conv2d_fwd_pre: this configuration takes no prepared operand");
 
 	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) {
 		PZ_REQUIRE(stats == nullptr, "pz_conv2d_fwd_stats: this configuration cannot produce strip statistics");
@@ -2144,24 +2192,22 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
-	FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups, Cg);
-
-	float *wp = (float *)workspace;
-	int2 *tab = (int2 *)((char *)workspace + p.wp_bytes);
-	float *slabs = (float *)((char *)workspace + p.wp_bytes + p.tab_bytes);
-
 	PackArgs pa{};
-	pa.w = w, pa.wp = wp, pa.tab = tab;
-	pa.Kg = Kg, pa.Cg = Cg, pa.R = d->r, pa.S = d->s, pa.groups = d->groups, pa.mode = 0;
-	pa.M = Kg, pa.mpad = p.mpad, pa.kred = p.kred, pa.kred_pad = p.kred_pad;
-	pa.dil_h = d->dil_h, pa.dil_w = d->dil_w, pa.in_h = d->h, pa.in_w = d->w;
-	pa.tapmajor = Cg % 16 == 0, pa.chans = Cg;
-	const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
-	if (p.split)
-		pack_filter_split_kernel<<<pz::stream_grid(ptotal / 8, 256), 256, 0, st>>>(pa);
-	else
-		pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
-	PZ_LAUNCH_CHECK();
+	FwdPlan p = fwd_pack_args(d, P, Q, w, packed ? (char *)const_cast<void *>(packed) : (char *)workspace, &pa);
+	PZ_REQUIRE(packed == nullptr || !p.split, "pz_conv2d_fwd_pre: the split math modes prepare their operands per call");
+
+	float *wp = pa.wp;
+	int2 *tab = pa.tab;
+	float *slabs = packed ? (float *)workspace : (float *)((char *)workspace + p.wp_bytes + p.tab_bytes);
+
+	if (!packed) {
+		const long ptotal = (long)d->groups * p.kred_pad * p.mpad;
+		if (p.split)
+			pack_filter_split_kernel<<<pz::stream_grid(ptotal / 8, 256), 256, 0, st>>>(pa);
+		else
+			pack_filter_kernel<<<pz::stream_grid(ptotal, 256), 256, 0, st>>>(pa);
+		PZ_LAUNCH_CHECK();
+	}
 
 	IgemmArgs a{};
 	a.x = x, a.wp = wp, a.tab = tab, a.bias = bias, a.y = y;
@@ -2183,6 +2229,75 @@ int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, c
 	return PZ_OK;
 }
 
+// ---- filter operands prepared ahead of the pass, many layers per launch ------------------------------------------------
+// What a pass derives from the filter tensor alone — the implicit GEMM's packed forward operand + gather table, the
+// Winograd kernels' transformed filters (forward: G g G^T; backward-data: the same of the flipped, transposed filters) —
+// depends on the parameters only. A training step used to launch one ~5 us kernel per layer and pass for it, each on the
+// critical path of its stream; pz_conv2d_prepack prepares any number of them in a few launches (the caller keeps them
+// until the parameters change) and pz_conv2d_{fwd,bwd_data}_pre consume them.
+int pz_conv2d_prepack_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(nbytes != nullptr && (which == PZ_CONV_FWD || which == PZ_CONV_BWD_DATA), "pz_conv2d_prepack_bytes: bad arguments");
+	*nbytes = 0;
+	if (uses_winograd(d, which, P, Q, algo)) {
+		*nbytes = align256(pz::wino_workspace_bytes(d, which, P, Q));
+		return PZ_OK;
+	}
+	if (which != PZ_CONV_FWD || algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) return PZ_OK;
+	PackArgs pa;
+	FwdPlan p = fwd_pack_args(d, P, Q, nullptr, nullptr, &pa);
+	if (!p.split) *nbytes = p.wp_bytes + p.tab_bytes;
+	return PZ_OK;
+}
+
+int pz_conv2d_prepack(const pz_prepack_job *jobs, int njobs, pz_stream_t stream) {
+	PZ_REQUIRE(jobs != nullptr || njobs == 0, "pz_conv2d_prepack: null job list");
+	hipStream_t st = pz::as_stream(stream);
+	PackBatch batch{};
+	auto flush = [&]() -> int {
+		if (batch.n == 0) return PZ_OK;
+		pack_filter_batch_kernel<<<batch.start[batch.n], 256, 0, st>>>(batch);
+		PZ_LAUNCH_CHECK();
+		batch.n = 0;
+		return PZ_OK;
+	};
+	const pz_conv_desc *wd[pz::kWinoBatch];
+	int wwhich[pz::kWinoBatch], nw = 0;
+	const float *ww[pz::kWinoBatch];
+	float *wu[pz::kWinoBatch];
+	auto flush_wino = [&]() -> int {
+		if (nw == 0) return PZ_OK;
+		int rc = pz::wino_filter_batch(wd, wwhich, ww, wu, nw, st);
+		nw = 0;
+		return rc;
+	};
+
+	for (int i = 0; i < njobs; ++i) {
+		const pz_prepack_job &job = jobs[i];
+		int P, Q;
+		if (int rc = check_desc(&job.desc, &P, &Q)) return rc;
+		size_t nbytes;
+		if (int rc = pz_conv2d_prepack_bytes(&job.desc, job.which, job.algo, &nbytes)) return rc;
+		PZ_REQUIRE(nbytes > 0 && job.w && job.packed, "pz_conv2d_prepack: job %d has nothing to prepare (or null pointers)", i);
+		if (uses_winograd(&job.desc, job.which, P, Q, job.algo)) {
+			wd[nw] = &job.desc, wwhich[nw] = job.which, ww[nw] = job.w, wu[nw] = (float *)job.packed;
+			if (++nw == pz::kWinoBatch)
+				if (int rc = flush_wino()) return rc;
+			continue;
+		}
+		PackArgs pa;
+		FwdPlan p = fwd_pack_args(&job.desc, P, Q, job.w, (char *)job.packed, &pa);
+		const long ptotal = (long)job.desc.groups * p.kred_pad * p.mpad;
+		batch.job[batch.n] = pa;
+		batch.start[batch.n + 1] = batch.start[batch.n] + pz::stream_grid(ptotal, 1024);      // 4 elements per thread
+		if (++batch.n == kPackBatch)
+			if (int rc = flush()) return rc;
+	}
+	if (int rc = flush()) return rc;
+	return flush_wino();
+}
+
 // convolutions whose gathers can apply a following BatchNorm's backward on the fly (pz_conv2d_bwd_*_bn): pointwise
 // filter without padding (no padded tap would turn the affine constant into a contribution), ungrouped, MFMA path,
 // reduction channels in whole k-tiles
@@ -2200,7 +2315,13 @@ int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported)
 }
 
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
-                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed = nullptr);
+
+int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
+                           size_t ws_bytes, pz_stream_t stream) {
+	PZ_REQUIRE(packed != nullptr, "pz_conv2d_bwd_data_pre: no prepared filter operand");
+	return conv2d_bwd_data_impl(d, dy, nullptr, nullptr, nullptr, dx, algo, workspace, ws_bytes, stream, packed);
+}
 
 int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx, int algo, void *workspace,
                        size_t ws_bytes, pz_stream_t stream) {
@@ -2217,18 +2338,21 @@ int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *b
 }
 
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
-                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
-	PZ_REQUIRE(dy && w && dx, "pz_conv2d_bwd_data: null tensor");
+	PZ_REQUIRE(dy && (w || packed) && dx, "pz_conv2d_bwd_data: null tensor");
 	hipStream_t st = pz::as_stream(stream);
 
 	if (bnx == nullptr && uses_winograd(d, PZ_CONV_BWD_DATA, P, Q, algo)) {
-		size_t need = pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q);
-		PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		size_t need = packed ? 0 : pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q);
+		PZ_REQUIRE(packed || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
-		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, workspace, st);
+		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st, nullptr,
+		                     packed != nullptr);
 	}
+	// (only the Winograd form of backward-data takes a prepared operand: the pointwise layers read the filter tensor itself)
+	PZ_REQUIRE(packed == nullptr, "pz_conv2d_bwd_data_pre: this configuration takes no prepared operand");
 
 	// a handful of input maps behind a stride-2 filter (the network's first layer): the dedicated vector-ALU kernel
 	if (algo == PZ_CONV_ALGO_AUTO && bnx == nullptr && pz::thin_dgrad_eligible(d, P, Q)) {

@@ -370,6 +370,16 @@ int pz_stream_create(pz_stream_t *stream) {
 	return PZ_OK;
 }
 
+int pz_stream_create_priority(pz_stream_t *stream, int level) {
+	// level < 0: the device's lowest priority, > 0: its highest, 0: as pz_stream_create
+	int least = 0, greatest = 0;
+	PZ_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+	hipStream_t s;
+	PZ_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, level < 0 ? least : (level > 0 ? greatest : (least + greatest) / 2)));
+	*stream = s;
+	return PZ_OK;
+}
+
 int pz_stream_destroy(pz_stream_t stream) {
 	if (stream) PZ_HIP(hipStreamDestroy(pz::as_stream(stream)));
 	return PZ_OK;

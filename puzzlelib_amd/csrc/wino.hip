@@ -52,9 +52,9 @@ struct WinoFilterArgs {
 	int kblocks, chunks;
 };
 
-__global__ void __launch_bounds__(256) wino_filter_kernel(WinoFilterArgs a) {
+__device__ __forceinline__ void wino_filter_body(const WinoFilterArgs &a, long first, long step) {
 	const long total = (long)a.kblocks * a.chunks * KB * BC;
-	for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+	for (long i = first; i < total; i += step) {
 		const int ci = (int)(i % 2), kk = (int)((i / 2) % KB), h = (int)((i / (2 * KB)) % 2);
 		const long blk = i / (2 * KB * 2);
 		const int chunk = (int)(blk % a.chunks), kb = (int)(blk / a.chunks);
@@ -89,6 +89,24 @@ __global__ void __launch_bounds__(256) wino_filter_kernel(WinoFilterArgs a) {
 			dst[(r * 4 + 3) * (2 * KB * 2)] = u3;
 		}
 	}
+}
+
+__global__ void __launch_bounds__(256) wino_filter_kernel(WinoFilterArgs a) {
+	wino_filter_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// the filter transforms of several layers / passes in one launch (pz_conv2d_prepack); job j owns blocks [start[j], start[j + 1])
+struct WinoFilterBatch {
+	int n, start[pz::kWinoBatch + 1];
+	WinoFilterArgs job[pz::kWinoBatch];
+};
+static_assert(sizeof(WinoFilterBatch) <= 4000, "kernel arguments");
+
+__global__ void __launch_bounds__(256) wino_filter_batch_kernel(WinoFilterBatch b) {
+	int j = 0;
+	while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
+	const int nb = b.start[j + 1] - b.start[j];
+	wino_filter_body(b.job[j], (long)(blockIdx.x - b.start[j]) * 256 + threadIdx.x, (long)nb * 256);
 }
 
 struct WinoArgs {
@@ -1499,18 +1517,43 @@ int wino_stats_strips(const pz_conv_desc *d, int P, int Q) {
 #endif
 }
 
+static WinoFilterArgs wino_filter_args(const pz_conv_desc *d, int which, int P, int Q, const float *w, float *u) {
+	int prod, red;
+	wino_dims(d, which, P, Q, &prod, &red);
+	WinoFilterArgs fa{};
+	fa.w = w, fa.u = u, fa.mode = which == PZ_CONV_FWD ? 0 : 1;
+	fa.K = d->k, fa.C = d->c, fa.prod = prod, fa.red = red;
+	fa.kblocks = ceil_div(prod, KB), fa.chunks = red / BC;
+	return fa;
+}
+
+int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st) {
+	WinoFilterBatch b{};
+	for (int i = 0; i < n; ++i) {
+		int P, Q;
+		P = (descs[i]->h + 2 * descs[i]->pad_h - 3) + 1, Q = (descs[i]->w + 2 * descs[i]->pad_w - 3) + 1;      // 3x3, stride 1, undilated
+		b.job[i] = wino_filter_args(descs[i], which[i], P, Q, w[i], u[i]);
+		const long ftotal = (long)b.job[i].kblocks * b.job[i].chunks * KB * BC;
+		b.start[i + 1] = b.start[i] + stream_grid(ftotal, 256);
+	}
+	b.n = n;
+	if (n == 0) return PZ_OK;
+	wino_filter_batch_kernel<<<b.start[n], 256, 0, st>>>(b);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats) {
+              void *workspace, hipStream_t st, float *stats, bool filters_ready) {
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 
-	WinoFilterArgs fa{};
-	fa.w = w, fa.u = (float *)workspace, fa.mode = which == PZ_CONV_FWD ? 0 : 1;
-	fa.K = d->k, fa.C = d->c, fa.prod = prod, fa.red = red;
-	fa.kblocks = ceil_div(prod, KB), fa.chunks = red / BC;
-	const long ftotal = (long)fa.kblocks * fa.chunks * KB * BC;
-	wino_filter_kernel<<<stream_grid(ftotal, 256), 256, 0, st>>>(fa);
-	PZ_LAUNCH_CHECK();
+	WinoFilterArgs fa = wino_filter_args(d, which, P, Q, w, (float *)workspace);
+	if (!filters_ready) {
+		const long ftotal = (long)fa.kblocks * fa.chunks * KB * BC;
+		wino_filter_kernel<<<stream_grid(ftotal, 256), 256, 0, st>>>(fa);
+		PZ_LAUNCH_CHECK();
+	}
 
 	WinoArgs a{};
 	a.x = in, a.u = (const float *)workspace, a.bias = bias, a.y = out;

@@ -75,9 +75,13 @@ Device.current = 0
 
 
 class Stream:
-	def __init__(self):
+	def __init__(self, priority=None):
+		"""priority: None = a plain stream; -1 / 0 / +1 = the device's lowest / middle / highest queue priority"""
 		handle = c_void_p()
-		lib.pz_stream_create(byref(handle))
+		if priority is None:
+			lib.pz_stream_create(byref(handle))
+		else:
+			lib.pz_stream_create_priority(byref(handle), int(priority))
 		self.handle = handle.value
 
 

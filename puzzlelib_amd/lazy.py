@@ -47,11 +47,13 @@ def on(pattern):
 class State:
 	"""thunk: pending contents; deps: weak references to allocations whose thunk / facts derive from this one's contents;
 	meta: facts about the contents; wev / rev: [(event, stream, lo, hi)] — byte ranges a foreign stream still writes / reads"""
-	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small")
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small", "version")
 
 	def __init__(self, base):
 		self.thunk, self.deps, self.meta, self.wev, self.rev, self.base = None, None, None, None, None, base
 		self.small = None         # [(lo, hi, written)] byte ranges that queued small adds (deferAdd) will write / read
+		self.version = 0          # bumped by every write barrier: what was derived from the contents (prepared filter
+		                          # operands, DnnContext.prepared) is current while the number stands
 
 
 def stateOf(root):
@@ -199,6 +201,7 @@ def settleDependents(root):
 
 def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
+	lz.version += 1
 	if lz.small is not None:
 		touchSmall(lz, root if buf is None else buf, True)
 	# dependents first: one of them may need this buffer's own pending contents (B = copy of A while A is a pending zero

@@ -31,6 +31,10 @@ class ConvDesc(ctypes.Structure):
 	)]
 
 
+class PrepackJob(ctypes.Structure):
+	_fields_ = [("desc", ConvDesc), ("which", c_int), ("algo", c_int), ("w", c_void_p), ("packed", c_void_p)]
+
+
 class PoolDesc(ctypes.Structure):
 	_fields_ = [(name, c_int) for name in (
 		"n", "c", "h", "w", "size_h", "size_w", "stride_h", "stride_w", "pad_h", "pad_w", "mode"
@@ -92,6 +96,7 @@ _PROTOS = {
 	"pz_strided_copy": [P, POINTER(c_int64), P, POINTER(c_int64), POINTER(c_int64), c_int, P],
 
 	"pz_stream_create": [PP],
+	"pz_stream_create_priority": [PP, c_int],
 	"pz_stream_destroy": [P],
 	"pz_stream_sync": [P],
 	"pz_stream_wait_event": [P, P],
@@ -108,6 +113,10 @@ _PROTOS = {
 	"pz_conv2d_fwd_stats_strips": [POINTER(ConvDesc), c_int, POINTER(c_int)],
 	"pz_conv2d_fwd_stats": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_data": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_prepack_bytes": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
+	"pz_conv2d_prepack": [POINTER(PrepackJob), c_int, P],
+	"pz_conv2d_fwd_pre": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_bwd_data_pre": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 
 	"pz_conv2d_algo_used": [POINTER(ConvDesc), c_int, c_int, POINTER(c_int)],
@@ -244,7 +253,7 @@ def _bind(name, argtypes):
 
 
 _HOST_ONLY = {
-	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
+	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
 	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get"
 }
@@ -269,7 +278,7 @@ def _dry(name, argtypes):
 			_store(args[0], _fakeHandle(args[1]))
 		elif name == "pz_pool_alloc":
 			_store(args[2], _fakeHandle(args[1]))
-		elif name in ("pz_pool_create", "pz_stream_create", "pz_event_create"):
+		elif name in ("pz_pool_create", "pz_stream_create", "pz_stream_create_priority", "pz_event_create"):
 			_store(args[0], _fakeHandle())
 		elif name == "pz_rng_create":
 			_store(args[1], _fakeHandle())

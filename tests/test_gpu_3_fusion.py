@@ -491,3 +491,75 @@ def test_conv_statistics_only_serve_a_batchnorm_over_the_very_tensor(surf, polic
 		bn(Dnn.convNd(gx, gw, None, 1, 1, 1, 1, Dnn.ConvFwdAlgo.auto)[:3], conv_ref[:3], 16, "pass %d conv -> slice -> bn" % attempt)
 		if attempt == 1 or policy == "always":
 			assert lazy.counters.get("conv_stats", 0) == 3, "the convolutions did leave strip sums (only the first BN may use them)"
+
+
+def test_prepared_filter_operands_follow_every_write_of_the_filter(surf):
+	"""DnnContext.prepared: packed / Winograd-transformed filters are kept per (filter, pass, geometry) and must be
+	re-derived whenever the filter's allocation was written — by .set(), through a slice view, in place by a kernel, by a
+	kernel on a borrowed stream. Implicit-GEMM forward (1x1, 3-map stem-like), Winograd forward and backward-data."""
+	from puzzlelib_amd import lazy
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	rng = np.random.RandomState(12)
+	cases = [((4, 32, 9, 9), (48, 32, 1, 1), 1, 0), ((4, 3, 20, 20), (16, 3, 5, 5), 2, 2), ((4, 32, 10, 10), (32, 32, 3, 3), 1, 1)]
+	auto = (Dnn.ConvFwdAlgo.auto, Dnn.ConvBwdDataAlgo.auto)
+	for xshape, wshape, stride, pad in cases:
+		x = rng.randn(*xshape).astype(np.float32)
+		gx = g.to_gpu(x)
+		arena = g.to_gpu(rng.randn(int(np.prod(wshape)) + 64).astype(np.float32))            # the filter is a VIEW into an arena
+		gw = arena[32:32 + int(np.prod(wshape))].reshape(wshape)
+
+		def check(what):
+			lazy.counters.clear()
+			w = gw.get()
+			y = Dnn.convNd(gx, gw, None, stride, pad, 1, 1, auto[0])
+			ref = R.conv2d_fwd(x, w, None, stride, pad, acc=np.float64)
+			assert_close(y.get(), ref, atol=2e-4 * np.abs(ref).max(), rtol=1e-4, what="%s %s: forward" % (wshape, what))
+			dy = rng.randn(*ref.shape).astype(np.float32)
+			dx = Dnn.convNdBackwardData(g.to_gpu(dy), gw, gx, stride, pad, 1, 1, auto[1])
+			dref = R.conv2d_bwd_data(dy, w, x.shape, stride, pad, acc=np.float64)
+			assert_close(dx.get(), dref, atol=2e-4 * np.abs(dref).max(), rtol=1e-4, what="%s %s: backward data" % (wshape, what))
+			return lazy.counters.get("prepack_launch", 0)
+
+		assert check("first use") >= 1
+		assert check("unchanged") == 0, "nothing is prepared again while the filter stands"
+		gw.set(rng.randn(*wshape).astype(np.float32))
+		assert check("after .set()") >= 1
+		gw[1:2].set(rng.randn(1, *wshape[1:]).astype(np.float32))
+		assert check("after a write through a slice") >= 1
+		El.linearKer(np.float32)(gw, gw, 0.5, 0.25)
+		assert check("after an in-place kernel") >= 1
+		stream = g.streamManager.borrow(1)[0]
+		El.toVectorAddVectorKer(np.float32)(arena, g.to_gpu(rng.randn(arena.size).astype(np.float32)), 1.0, stream=stream)
+		assert check("after a kernel on a borrowed stream wrote the arena") >= 1
+		g.streamManager.give([stream])
+
+
+def test_training_steps_with_prepared_operands_equal_per_call_packing(surf, mini_golden):
+	"""Three Adam steps of the mini-ResNet: parameters bit-identical whether the filter operands are prepared once per
+	step in batched launches or packed inside every convolution call (lazy.disabled = {"prepack"})."""
+	from puzzlelib_amd import nets, optim, lazy
+	g = surf.gpuarray
+	spec = nets.resnet_spec(stages=((8, 1), (16, 2)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	data, labels = g.to_gpu(mini_golden["data"]), g.to_gpu(mini_golden["labels"])
+
+	def run(prepack):
+		lazy.disabled = set() if prepack else {"prepack"}
+		lazy.counters.clear()
+		np.random.seed(77)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		opt = optim.Adam(alpha=1e-3)
+		opt.setupOn(net, useGlobalState=True)
+		trainer = optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=4)
+		for _ in range(3):
+			trainer.train(data, labels, random=False)
+		return {k: p.data.get() for k, p in net.namedParams().items()}, lazy.counters.get("prepack_launch", 0)
+
+	try:
+		with_, launches = run(True)
+		without, none = run(False)
+	finally:
+		lazy.disabled = set()
+	assert none == 0 and launches >= 3
+	for key in with_:
+		assert np.array_equal(with_[key], without[key]), key
