@@ -273,6 +273,7 @@ class DnnContext:
 			raise ValueError("PUZZLE_MI355_MATH / setConvMath: %r is not one of %s" % (name, sorted(self.MATH)))
 		lib.pz_conv_math_set(self.MATH[name])
 		self.geometry.clear()
+		DnnContext.descCache.clear()
 		self.packCache.clear()
 		self.convMath = name
 		return self
@@ -293,15 +294,33 @@ class DnnContext:
 		return tuple(shape[:2]) + (1, ) * (4 - len(shape)) + tuple(shape[2:])
 
 
+	descCache = {}       # call-site arguments -> descriptor: a network asks for the same few dozen every step
+
 	@staticmethod
 	def convDesc(dataShape, Wshape, stride, pad, dilation, groups):
+		"""The library's descriptor of a 2-D convolution; `.key` = its fields as a tuple, `.geo` = what the library
+		answered about it per (pass, algo) (convGeometry). One object per distinct argument list: small networks are bound
+		by the host's call rate, and building / hashing descriptors was a tenth of a convolution call."""
+		try:
+			args = (dataShape, Wshape, stride, pad, dilation, groups)
+			return DnnContext.descCache[args]
+		except KeyError:
+			pass
+		except TypeError:                        # (lists as stride / pad: not hashable — no caching)
+			args = None
 		if len(dataShape) != 4 or len(Wshape) != 4:
 			raise NotImplementedError("convolution descriptors are 2-D (1-D tensors are lifted by the callers)")
 
 		(sh, sw), (ph, pw), (dh, dw) = pair(stride), pair(pad), pair(dilation)
 		n, c, h, w = dataShape
 		k, _, r, s = Wshape
-		return ConvDesc(n, c, h, w, k, r, s, sh, sw, ph, pw, dh, dw, groups)
+		desc = ConvDesc(n, c, h, w, k, r, s, sh, sw, ph, pw, dh, dw, groups)
+		desc.key, desc.geo = (n, c, h, w, k, r, s, sh, sw, ph, pw, dh, dw, groups), {}
+		if args is not None:
+			if len(DnnContext.descCache) > 4096:
+				DnnContext.descCache.clear()
+			DnnContext.descCache[args] = desc
+		return desc
 
 
 	def workspace(self, nbytes, allocator):
@@ -330,8 +349,7 @@ class DnnContext:
 		if entries is None:
 			entries = self.packCache[root] = {}
 		offset = W.gpudata.ptr - root.ptr
-		key = (offset, which, algo, desc.n, desc.c, desc.h, desc.w, desc.k, desc.r, desc.s, desc.stride_h, desc.stride_w,
-			   desc.pad_h, desc.pad_w, desc.dil_h, desc.dil_w, desc.groups)
+		key = (offset, which, algo, desc.key)
 		entry = entries.get(key)
 		if entry is None:
 			nbytes = c_size_t(0)
@@ -360,8 +378,7 @@ class DnnContext:
 	def convGeometry(self, desc, which, algo):
 		"""(P, Q, workspace bytes, statistics strips) of a convolution pass — host-side queries of the library, asked once
 		per (geometry, pass, algo): small networks are bound by the host's call rate (NiN: ~120 launches in 3 ms)."""
-		key = (which, algo) + tuple(getattr(desc, name) for name, _ in ConvDesc._fields_)
-		hit = self.geometry.get(key)
+		hit = desc.geo.get((which, algo))
 		if hit is None:
 			p, q, size, strips = c_int(0), c_int(0), c_size_t(0), c_int(0)
 			lib.pz_conv2d_out_shape(byref(desc), byref(p), byref(q))
@@ -371,7 +388,7 @@ class DnnContext:
 			fold = c_int(0)
 			if which != lib.CONV_FWD:
 				lib.pz_conv2d_bn_fold_supported(byref(desc), algo, byref(fold))
-			hit = self.geometry[key] = (p.value, q.value, size.value, strips.value, bool(fold.value))
+			hit = desc.geo[(which, algo)] = (p.value, q.value, size.value, strips.value, bool(fold.value))
 		return hit
 
 

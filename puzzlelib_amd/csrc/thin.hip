@@ -1,4 +1,4 @@
-// Backward-data of a stride-2 convolution with very few input maps — the stem of an ImageNet network (3 maps, 7x7 / 2,
+// Backward-data of a stride-2 (and, below, unit-stride) convolution with very few input maps — the stem of an ImageNet network (3 maps, 7x7 / 2,
 // Models/Nets/ResNet.py:88): dx has 3 channels, so as an implicit GEMM its M side fills 3 of 64 tile rows (the 128x128 /
 // 64x256 MFMA tiles of conv.hip spend 9.5 ms on 60 GFLOP of useful work at batch 256). This is the direct form, shaped
 // for the vector ALU instead:
@@ -179,6 +179,147 @@ PZ_UNROLL(PZ_THIN_UNROLL)
 			}
 }
 
+// ---- unit stride ---------------------------------------------------------------------------------------------------------
+// The first layer of a CIFAR-sized network (config 3, TestLib/CnnCifar10NIN.py: 3 -> 192 maps, 5x5 / 1, pad 2) has the same
+// problem without the stride: as an implicit GEMM its input gradient fills 3 of 64 tile rows and, with 512 tiles of 300
+// k-tiles each, holds every CU for 0.68 ms of a 3 ms step (5.8 TFLOP/s) while the filter-gradient stream starves behind
+// it. Direct form:   dx[n, c, h, w] = sum_k sum_{r, s} dy[n, k, h + pad - r, w + pad - s] * w[k, c, r, s]
+// A thread owns NC vertically adjacent pixels of one column (lanes along w: every load is 256 contiguous bytes per wave);
+// per reduction channel it loads their joint (R + NC - 1) x S window of dy and issues one fma per (pixel, tap, channel
+// pair): the channels of a tap are an aligned pair of wave-uniform weights (wpk[k][R-1-r][S-1-s][c], channels padded to
+// even), so a tap costs ceil(C / 2) v_pk_fma_f32 per pixel.
+#ifndef PZ_THIN1_CELLS
+#define PZ_THIN1_CELLS 4
+#endif
+constexpr int kThin1Cells = PZ_THIN1_CELLS;
+
+template <int C, int R, int S>
+__global__ void __launch_bounds__(256) thin1_pack_kernel(const float *__restrict__ w, float *__restrict__ wpk, int K) {
+	constexpr int CP = (C + 1) / 2 * 2, per_k = R * S * CP;
+	const int idx = blockIdx.x * 256 + threadIdx.x;
+	if (idx >= K * per_k) return;
+	int t = idx;
+	const int c = t % CP;
+	t /= CP;
+	const int ds = t % S;
+	t /= S;
+	const int dr = t % R, k = t / R;
+	wpk[idx] = c < C ? w[((k * C + c) * R + (R - 1 - dr)) * S + (S - 1 - ds)] : 0.f;
+}
+
+// KS waves of a workgroup share the reduction channels (wave w takes k = w, w + KS, ...: still wave-uniform weights) and
+// add their partial sums through LDS in wave order: at batch 128 a 32x32 map is 32 768 threads of 4 pixels — 2 waves per
+// CU, every one of them waiting on its own loads (0.28 ms); with 8 k-slices the same loads are spread over 16 waves per CU.
+template <int C, int R, int S, int PH, int PW, int KS>
+__global__ void __launch_bounds__(64 * KS) thin1_dgrad_kernel(const float *__restrict__ dy, const float *__restrict__ wpk,
+                                                              float *__restrict__ dx, int K, int P, int Q, int H, int W, int Hg,
+                                                              unsigned dy_bytes) {
+	constexpr int NC = kThin1Cells, WROWS = R + NC - 1, CP2 = (C + 1) / 2;
+	const int lane = threadIdx.x & 63, ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int grp = blockIdx.x * 64 + lane;                    // (group of NC rows, column), row-major: lanes along w
+	const int n = blockIdx.y;
+	const bool live = grp < Hg * W;
+	const int ig = grp / W, x = grp - ig * W, h0 = ig * NC;
+
+	unsigned woff[WROWS][S];
+#pragma unroll
+	for (int dr = 0; dr < WROWS; ++dr)
+#pragma unroll
+		for (int ds = 0; ds < S; ++ds) {
+			const int p = h0 + PH - (R - 1) + dr, q = x + PW - (S - 1) + ds;
+			woff[dr][ds] = (live && (unsigned)p < (unsigned)P && (unsigned)q < (unsigned)Q) ? (unsigned)(p * Q + q) * 4u : kOOB;
+		}
+
+	const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, dy_bytes, 0x00020000);
+	const unsigned plane = (unsigned)(P * Q) * 4u;
+	unsigned soff = ((unsigned)n * (unsigned)K + (unsigned)ks) * plane;
+
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	f32x2 acc[NC][CP2];
+#pragma unroll
+	for (int e = 0; e < NC; ++e)
+#pragma unroll
+		for (int c = 0; c < CP2; ++c) acc[e][c] = f32x2{0.f, 0.f};
+
+	constexpr int per_k = R * S * CP2 * 2;
+	for (int k = ks; k < K; k += KS, soff += KS * plane) {
+		float v[WROWS][S];
+#pragma unroll
+		for (int dr = 0; dr < WROWS; ++dr)
+#pragma unroll
+			for (int ds = 0; ds < S; ++ds)
+				v[dr][ds] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, woff[dr][ds], soff, 0));
+
+		const f32x2 *wk = reinterpret_cast<const f32x2 *>(wpk + (size_t)k * per_k);      // wave-uniform: scalar loads
+#pragma unroll
+		for (int dr = 0; dr < R; ++dr)
+#pragma unroll
+			for (int ds = 0; ds < S; ++ds)
+#pragma unroll
+				for (int c = 0; c < CP2; ++c) {
+					const f32x2 w2 = wk[(dr * S + ds) * CP2 + c];
+#pragma unroll
+					for (int e = 0; e < NC; ++e) {
+						const float xv = v[dr + e][ds];
+						if (2 * c + 1 < C)
+							acc[e][c] = __builtin_elementwise_fma(f32x2{xv, xv}, w2, acc[e][c]);
+						else                      // the odd last channel: no 0 * dy term for the padding slot
+							acc[e][c][0] = __builtin_fmaf(xv, w2[0], acc[e][c][0]);
+					}
+				}
+	}
+
+	if constexpr (KS > 1) {
+		__shared__ f32x2 part[KS - 1][NC * CP2][64];
+		if (ks > 0) {
+#pragma unroll
+			for (int e = 0; e < NC; ++e)
+#pragma unroll
+				for (int c = 0; c < CP2; ++c) part[ks - 1][e * CP2 + c][lane] = acc[e][c];
+		}
+		__syncthreads();
+		if (ks > 0) return;
+#pragma unroll
+		for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+			for (int e = 0; e < NC; ++e)
+#pragma unroll
+				for (int c = 0; c < CP2; ++c) acc[e][c] += part[q][e * CP2 + c][lane];
+	}
+
+	if (!live) return;
+#pragma unroll
+	for (int c = 0; c < C; ++c)
+#pragma unroll
+		for (int e = 0; e < NC; ++e) {
+			const int h = h0 + e;
+			if (h < H) dx[(((size_t)n * C + c) * H + h) * W + x] = acc[e][c / 2][c & 1];
+		}
+}
+
+template <int C, int R, int S, int PH, int PW>
+int thin1_launch(const pz_conv_desc *d, int P, int Q, const float *dy, const float *w, float *dx, void *workspace, hipStream_t st) {
+	float *wpk = (float *)workspace;
+	constexpr int per_k = R * S * ((C + 1) / 2 * 2);
+	thin1_pack_kernel<C, R, S><<<pz::ceil_div((long)d->k * per_k, 256), 256, 0, st>>>(w, wpk, d->k);
+	PZ_LAUNCH_CHECK();
+	const int Hg = pz::ceil_div(d->h, kThin1Cells);
+	dim3 grid(pz::ceil_div((long)Hg * d->w, 64), d->n);
+	const unsigned dy_bytes = (unsigned)((size_t)d->n * d->k * P * Q * 4);
+	// k-slices: enough waves for 16 per CU, at least 8 reduction channels per slice
+	const long waves = (long)grid.x * grid.y;
+	int ks = 1;
+	while (ks < 8 && waves * ks < 16L * pz::kNumCU && d->k / (2 * ks) >= 8) ks *= 2;
+#define PZ_THIN1_GO(KS) thin1_dgrad_kernel<C, R, S, PH, PW, KS><<<grid, 64 * KS, 0, st>>>(dy, wpk, dx, d->k, P, Q, d->h, d->w, Hg, dy_bytes)
+	if (ks == 8) PZ_THIN1_GO(8);
+	else if (ks == 4) PZ_THIN1_GO(4);
+	else if (ks == 2) PZ_THIN1_GO(2);
+	else PZ_THIN1_GO(1);
+#undef PZ_THIN1_GO
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 // the shapes instantiated: (C, R, S, pad_h, pad_w)
 template <int C, int R, int S, int PH, int PW>
 bool thin_match(const pz_conv_desc *d) {
@@ -204,22 +345,36 @@ int thin_launch(const pz_conv_desc *d, int P, int Q, const float *dy, const floa
 namespace pz {
 
 #define PZ_THIN_SHAPES(X) X(3, 7, 7, 3, 3) X(3, 3, 3, 1, 1) X(1, 7, 7, 3, 3) X(3, 5, 5, 2, 2) X(4, 7, 7, 3, 3) X(1, 3, 3, 1, 1)
+// ... and with unit stride
+#define PZ_THIN1_SHAPES(X) X(3, 5, 5, 2, 2) X(3, 3, 3, 1, 1) X(1, 5, 5, 2, 2) X(1, 3, 3, 1, 1) X(3, 7, 7, 3, 3) X(1, 5, 5, 0, 0) X(3, 5, 5, 0, 0)
 
 bool thin_dgrad_eligible(const pz_conv_desc *d, int P, int Q) {
-	if (d->stride_h != 2 || d->stride_w != 2 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
+	if (d->dil_h != 1 || d->dil_w != 1 || d->groups != 1 || d->stride_h != d->stride_w) return false;
 	if ((size_t)d->n * d->k * P * Q * 4 >= 0xfffffff0ull || d->n > 65535) return false;
+	if (d->stride_h == 2) {
 #define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return true;
-	PZ_THIN_SHAPES(X)
+		PZ_THIN_SHAPES(X)
 #undef X
+	} else if (d->stride_h == 1) {
+#define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return true;
+		PZ_THIN1_SHAPES(X)
+#undef X
+	}
 	return false;
 }
 
 size_t thin_dgrad_workspace_bytes(const pz_conv_desc *d) {
+	if (d->stride_h == 1) return (size_t)d->k * d->r * d->s * ((d->c + 1) / 2 * 2) * sizeof(float);
 	// window <= ceil(R/2)+1 per axis, 2x2 parities, C channels
 	return (size_t)d->k * ((d->r + 1) / 2 + 1) * ((d->s + 1) / 2 + 1) * 4 * d->c * sizeof(float);
 }
 
 int thin_dgrad(const pz_conv_desc *d, int P, int Q, const float *dy, const float *w, float *dx, void *workspace, hipStream_t st) {
+	if (d->stride_h == 1) {
+#define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return thin1_launch<C, R, S, PH, PW>(d, P, Q, dy, w, dx, workspace, st);
+		PZ_THIN1_SHAPES(X)
+#undef X
+	}
 #define X(C, R, S, PH, PW) if (thin_match<C, R, S, PH, PW>(d)) return thin_launch<C, R, S, PH, PW>(d, P, Q, dy, w, dx, workspace, st);
 	PZ_THIN_SHAPES(X)
 #undef X

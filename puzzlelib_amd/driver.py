@@ -186,7 +186,7 @@ class Buffer:
 			ptr, self.ptr, self.owner = self.ptr, None, False
 
 			if isinstance(self.parent, MemoryPool):
-				self.parent.release(ptr)
+				self.parent.release(ptr, self.size)
 			else:
 				lib.pz_free(ptr)
 
@@ -244,28 +244,75 @@ class MemoryPool:
 	"""Size-class free list living in the native library (pz_pool_*): allocate / freeHeld / getStats — the reference's
 	Driver.MemoryPool (Cuda/Source/Core/Allocator.c:29-75,359-362). Passed around as `allocator=`."""
 
+	# A training step allocates and frees the same few dozen sizes over and over (NiN: 80 tensors per 3 ms step), and each
+	# trip into the native pool is two foreign calls. Blocks released by Python are therefore parked HERE first, per size
+	# class (the native pool's own classes: 4 per octave, >= 256 B), and handed out again without leaving the interpreter;
+	# the native pool sees them as live until `freeHeld` / an allocation failure returns them.
+	frontLimit = 64 << 30          # bytes parked on the Python side at most (beyond that a released block goes to the native pool)
+
 	def __init__(self):
 		handle = c_void_p()
 		lib.pz_pool_create(byref(handle))
 		self.handle = handle.value
 		self.holding = True
+		self.front, self.frontBytes, self.frontBlocks = {}, 0, 0
+
+
+	@staticmethod
+	def classSize(n):
+		"""pool_class_size of csrc/runtime.hip"""
+		if n <= 256:
+			return 256
+		step = 1 << max((n - 1).bit_length() - 3, 8)
+		return (n + step - 1) // step * step
 
 
 	def allocate(self, nbytes):
 		nbytes = int(nbytes)
+		cls = self.classSize(nbytes)
+		parked = self.front.get(cls)
+		if parked:
+			self.frontBytes -= cls
+			self.frontBlocks -= 1
+			return Buffer(parked.pop(), nbytes, parent=self, owner=True)
 		ptr = c_void_p()
-		lib.pz_pool_alloc(self.handle, max(nbytes, 1), byref(ptr))
+		try:
+			lib.pz_pool_alloc(self.handle, cls, byref(ptr))
+		except lib.HipError:
+			if self.frontBlocks == 0:
+				raise
+			self.flushFront()                  # what is parked here may be what the driver needs back
+			lib.pz_pool_free_held(self.handle)
+			lib.pz_pool_alloc(self.handle, cls, byref(ptr))
 		return Buffer(ptr.value, nbytes, parent=self, owner=True)
 
 
-	def release(self, ptr):
-		if self.handle is not None:
-			lib.pz_pool_release(self.handle, ptr)
-			if not self.holding:
-				lib.pz_pool_free_held(self.handle)
+	def release(self, ptr, nbytes=None):
+		if self.handle is None:
+			return
+		if nbytes is not None and self.holding and self.frontBytes < self.frontLimit:
+			cls = self.classSize(nbytes)
+			parked = self.front.get(cls)
+			if parked is None:
+				parked = self.front[cls] = []
+			parked.append(ptr)
+			self.frontBytes += cls
+			self.frontBlocks += 1
+			return
+		lib.pz_pool_release(self.handle, ptr)
+		if not self.holding:
+			lib.pz_pool_free_held(self.handle)
+
+
+	def flushFront(self):
+		front, self.front, self.frontBytes, self.frontBlocks = self.front, {}, 0, 0
+		for parked in front.values():
+			for ptr in parked:
+				lib.pz_pool_release(self.handle, ptr)
 
 
 	def freeHeld(self):
+		self.flushFront()
 		lib.pz_pool_free_held(self.handle)
 
 
@@ -277,8 +324,9 @@ class MemoryPool:
 	def getStats(self):
 		vals = [c_size_t(0) for _ in range(4)]
 		lib.pz_pool_stats(self.handle, *[byref(v) for v in vals])
-		return {"heldBytes": vals[0].value, "liveBytes": vals[1].value, "heldBlocks": vals[2].value,
-				"liveBlocks": vals[3].value}
+		# (blocks parked on the Python side are held, not live, whatever the native pool thinks)
+		return {"heldBytes": vals[0].value + self.frontBytes, "liveBytes": vals[1].value - self.frontBytes,
+				"heldBlocks": vals[2].value + self.frontBlocks, "liveBlocks": vals[3].value - self.frontBlocks}
 
 
 def memcpy2D(width, height, src, srcPitch, dst, dstPitch, srcX=0, dstX=0, stream=None):

@@ -7,7 +7,7 @@ empty/zeros/emptyLike/zerosLike/toGpu, __getitem__; Python part Cuda/GPUArray.py
 fill/astype/min/max/+/*/+=/*=/__setitem__), re-implemented over raw device pointers and the C ABI. Views share the
 parent's Buffer; ops never retain their inputs. All arithmetic runs in HIP kernels (pz_eltwise / pz_reduce_*).
 """
-import ctypes, os
+import ctypes, math, os
 import numpy as np
 
 from puzzlelib_amd import lib, lazy
@@ -67,6 +67,11 @@ def viewStridesForReshape(oldshape, oldstrides, newshape):
 	return tuple(newstrides)
 
 
+DTYPES = {t: np.dtype(t) for t in (np.float32, np.int32, np.uint32, np.uint8, np.float64, np.int64, np.float16, np.int8)}
+PTRS = {n: ctypes.c_void_p * n for n in range(1, 9)}
+FLOATS = {n: ctypes.c_float * n for n in range(1, 9)}
+
+
 class GPUArray:
 	__slots__ = ["shape", "_strides", "dtype", "gpudata", "size", "ndim", "nbytes", "contiguous", "__weakref__"]
 
@@ -78,11 +83,11 @@ class GPUArray:
 		if isinstance(shape, (int, np.integer)):
 			shape = (int(shape), )
 
-		self.shape = tuple(int(d) for d in shape)
-		self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
-		self.ndim = len(self.shape)
-		self.size = prod(self.shape)
-		self.nbytes = self.size * self.dtype.itemsize
+		self.shape = shape = tuple(map(int, shape))
+		self.dtype = dtype = dtype if type(dtype) is np.dtype else DTYPES.get(dtype) or np.dtype(dtype)
+		self.ndim = len(shape)
+		self.size = size = math.prod(shape)
+		self.nbytes = size * dtype.itemsize
 
 		if strides is None:                      # dense: the strides are derived on demand (most arrays never need them)
 			self._strides, self.contiguous = None, True
@@ -501,7 +506,7 @@ def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None)
 		readonly = range(1, nptrs)
 
 	if stream is None:
-		ptrs = (ctypes.c_void_p * nptrs)(*[a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)])
+		ptrs = (PTRS.get(nptrs) or ctypes.c_void_p * nptrs)(*[a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)])
 	else:
 		# a borrowed stream (Optimizer.update(useStreams=True)): it follows the main stream up to here, and what it writes
 		# carries its completion event, so the main stream waits exactly when it touches those buffers again
@@ -509,9 +514,13 @@ def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None)
 		ready = lazy.foreignBegin(stream)
 
 	# scalars travel as raw float32 words (bit patterns such as the dropout threshold must survive untouched)
-	sc = np.ascontiguousarray(scalars, dtype=np.float32) if not isinstance(scalars, np.ndarray) else scalars
-	nsc = sc.size
-	scptr = sc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if nsc > 0 else None
+	if isinstance(scalars, np.ndarray):
+		sc = scalars
+		nsc = sc.size
+		scptr = sc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if nsc > 0 else None
+	else:                                      # plain numbers: rounded to float32 by ctypes exactly as numpy would
+		nsc = len(scalars)
+		scptr = (FLOATS.get(nsc) or ctypes.c_float * nsc)(*scalars) if nsc > 0 else None
 
 	if slc is None:
 		start, stop, step = 0, count, 1

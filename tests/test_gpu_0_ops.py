@@ -718,6 +718,39 @@ def test_thin_backward_data_of_the_stem(bnd, cfg):
 	assert_close(dx, dx_ig, atol=1e-5 * scale, rtol=1e-4, what="thin backward-data vs implicit GEMM")
 
 
+@pytest.mark.parametrize("cfg", [
+	dict(n=4, c=3, k=192, hw=(32, 32), r=5, pad=2),       # the first layer of the CIFAR-10 NiN (config 3), small batch
+	dict(n=2, c=3, k=7, hw=(13, 17), r=5, pad=2),         # rows not a multiple of the cells a thread owns
+	dict(n=3, c=3, k=5, hw=(9, 10), r=3, pad=1),
+	dict(n=2, c=1, k=6, hw=(11, 8), r=5, pad=2),
+	dict(n=2, c=1, k=4, hw=(7, 7), r=3, pad=1),
+	dict(n=2, c=3, k=9, hw=(15, 15), r=7, pad=3),
+	dict(n=2, c=3, k=6, hw=(12, 14), r=5, pad=0),         # LeNet-style valid convolution
+	dict(n=5, c=3, k=33, hw=(70, 66), r=5, pad=2),        # more pixel groups than one workgroup
+])
+def test_thin_backward_data_with_unit_stride(bnd, cfg):
+	"""Unit-stride convolutions with <= 3 input maps (the first layer of NiN, TestLib/CnnCifar10NIN.py:16): `auto`
+	backward-data runs thin1_dgrad_kernel (csrc/thin.hip); fp64 oracle and the implicit GEMM it replaces."""
+	rng = np.random.RandomState(23)
+	n, c, k, (h, w_), r, pad = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"], cfg["pad"]
+	kw = dict(stride=(1, 1), pad=(pad, pad), dilation=(1, 1), groups=1)
+	x = rng.randn(n, c, h, w_).astype(np.float32)
+	wt = rng.randn(k, c, r, r).astype(np.float32)
+	y_ref = R.conv2d_fwd(x, wt, None, acc=np.float64, **kw)
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	gx, gw, gdy = gpu(bnd, x), gpu(bnd, wt), gpu(bnd, dy)
+
+	desc = bnd.dnn.convDesc(x.shape, wt.shape, (1, 1), (pad, pad), (1, 1), 1)
+	assert bnd.dnn.convAlgoUsed(desc, lib_bwd_data(), -1) == 1 and bnd.dnn.convAlgoUsed(desc, lib_bwd_data(), 5) == 5
+
+	dx_ref = R.conv2d_bwd_data(dy, wt, x.shape, acc=np.float64, **kw)
+	scale = np.abs(dx_ref).max()
+	dx = bnd.dnn.convNdBackwardData(gdy, gw, data=gx, **kw).get()
+	assert_close(dx, dx_ref, atol=1e-5 * scale, rtol=1e-4, what="unit-stride thin backward-data vs oracle")
+	dx_ig = bnd.dnn.convNdBackwardData(gdy, gw, data=gx, algo=bnd.ConvBwdDataAlgo.implicitGemm.value, **kw).get()
+	assert_close(dx, dx_ig, atol=1e-5 * scale, rtol=1e-4, what="unit-stride thin backward-data vs implicit GEMM")
+
+
 def lib_bwd_data():
 	from puzzlelib_amd import lib
 	return lib.CONV_BWD_DATA

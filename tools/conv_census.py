@@ -30,9 +30,15 @@ def main():
 	ap.add_argument("--only", type=int, default=-1)
 	ap.add_argument("--passes", default="fwd,dgrad,wgrad")
 	ap.add_argument("--config2", action="store_true", help="BASELINE.json config 2: Conv2D 3x3, 64 -> 128, 56x56, batch 128")
+	ap.add_argument("--nin", action="store_true", help="BASELINE.json config 3: the nine convolutions of the CIFAR-10 NiN, batch 128, with bias")
 	args = ap.parse_args()
-	if args.config2:
+	if args.nin:
 		global CENSUS
+		CENSUS = [((3, 32, 32), (192, 5, 1, 2), 1), ((192, 32, 32), (160, 1, 1, 0), 1), ((160, 32, 32), (96, 1, 1, 0), 1),
+				  ((96, 16, 16), (192, 5, 1, 2), 1), ((192, 16, 16), (192, 1, 1, 0), 2), ((192, 8, 8), (192, 3, 1, 1), 1),
+				  ((192, 8, 8), (192, 1, 1, 0), 1), ((192, 8, 8), (10, 1, 1, 0), 1)]
+		args.batch = 128
+	if args.config2:
 		CENSUS, args.batch = [((64, 56, 56), (128, 3, 1, 1), 1)], 128
 
 	from puzzlelib_amd import backend, lib, lazy
