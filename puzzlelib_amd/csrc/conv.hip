@@ -1822,6 +1822,15 @@ FwdPlan plan_igemm(int M, int kred, long npix, int groups, int chans) {
 		if ((1.0 - best_cost) * nk < PZ_TAIL_MIN_GAIN) best = 1;
 		if (best > 1) p.full_tiles = tiles - rem, p.tail_splits = best;
 	}
+	// A launch of few, long tiles (a 5x5 layer on 16x16 maps at batch 128: 256 tiles of 300 k-tiles) leaves a CU one or two
+	// workgroups, whose four waves cannot keep the matrix pipes busy on their own: every tile is cut along k until the chip
+	// holds ~4 workgroups per CU (NiN's 96 <- 192 5x5 backward-data: 0.41 -> 0.30 ms); slices keep >= 8 k-tiles, slabs <= 64 MB.
+	if (groups == 1 && p.tail_splits == 1 && tiles <= 2 * pz::kNumCU && nk >= 32) {
+		int sp = pz::ceil_div(4 * pz::kNumCU, tiles);
+		if (sp > nk / 8) sp = nk / 8;
+		if (sp > 1024 / tiles) sp = 1024 / tiles;
+		if (sp >= 2) p.full_tiles = 0, p.tail_splits = sp;
+	}
 	const int ntail = tiles - p.full_tiles;
 	p.blocks = p.full_tiles + ntail * p.tail_splits;
 	p.slab_bytes = p.tail_splits > 1 ? align256((size_t)ntail * p.tail_splits * p.bm * p.bn * sizeof(float)) : 0;
