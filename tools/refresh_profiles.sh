@@ -1,8 +1,16 @@
-cd /root/repo
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.txt 2>&1; echo "pytest exit $?" >> gpurun_out/gpu_tests.txt
-bash tools/prof_bench.sh two_streams > gpurun_out/summary_two_streams.txt 2>&1
-bash tools/prof_bench.sh one_stream PUZZLE_MI355_LAZY_OFF=sidestream > gpurun_out/summary_one_stream.txt 2>&1
+#!/bin/bash
+# Everything the round's profiles/ entries are made of, in one GPU call (≈6 minutes): the full -m gpu suite, the rocprofv3
+# kernel statistics of the bench command, the PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate passes, calibrated),
+# the bench line itself, the two censuses and the NiN step timeline. Copy what is to be judged into profiles/ afterwards
+# (tools/collect_profiles.sh <round tag>).
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+python -c "from puzzlelib_amd import lib; print('build', lib.buildId())" > gpurun_out/gpu_tests.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -q >> gpurun_out/gpu_tests.txt 2>&1; echo "pytest exit $?" >> gpurun_out/gpu_tests.txt
+bash tools/prof_bench.sh one_stream > gpurun_out/summary_one_stream.txt 2>&1
 bash tools/pmc_bench.sh > gpurun_out/pmc_bench.txt 2>&1
-PUZZLE_MI355_MATH=split6 bash tools/prof_bench.sh split6 > gpurun_out/summary_split6.txt 2>&1
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -3 gpurun_out/gpu_tests.txt; cat gpurun_out/bench_final.json
+python tools/conv_census.py --reps 10 > gpurun_out/census_resnet50.txt 2>&1
+python tools/conv_census.py --nin --reps 20 > gpurun_out/census_nin.txt 2>&1
+bash tools/nin_trace.sh > gpurun_out/nin_step_trace.txt 2>&1
+tail -3 gpurun_out/gpu_tests.txt; tail -c 1500 gpurun_out/bench_final.json
