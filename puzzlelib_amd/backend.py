@@ -352,6 +352,8 @@ class DnnContext:
 		key = (offset, which, algo, desc.key)
 		entry = entries.get(key)
 		if entry is None:
+			if len(entries) >= 1024:                    # (a process that keeps changing batch sizes: start over rather than grow)
+				entries.clear()
 			nbytes = c_size_t(0)
 			lib.pz_conv2d_prepack_bytes(byref(desc), which, algo, byref(nbytes))
 			entry = entries[key] = self.PackEntry()

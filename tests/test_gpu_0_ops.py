@@ -186,6 +186,33 @@ def test_conv_fresh_vs_oracle(bnd, cs):
 	assert_close(db.get(), db_ref, atol=2e-6 * scale * 30, rtol=1e-4, what="bias grad")
 
 
+def _random_conv_cases(count, seed):
+	"""seeded sweep over the whole descriptor space: channel counts around the tile edges (1..200), maps 1..40, filters 1..7,
+	strides 1-3, pads up to the filter, dilation 1-2, groups 1-4, batch 1..9"""
+	rng = np.random.RandomState(seed)
+	cases = []
+	while len(cases) < count:
+		g = int(rng.choice([1, 1, 1, 2, 4]))
+		c, k = g * int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 48, 64])), g * int(rng.choice([1, 2, 3, 7, 16, 31, 40, 50]))
+		r, s = int(rng.randint(1, 8)), int(rng.randint(1, 8))
+		dil = int(rng.choice([1, 1, 1, 2]))
+		stride = (int(rng.randint(1, 4)), int(rng.randint(1, 4))) if rng.rand() < 0.3 else int(rng.choice([1, 1, 2]))
+		pad = (int(rng.randint(0, r)), int(rng.randint(0, s)))
+		h, w = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+		if h + 2 * pad[0] < dil * (r - 1) + 1 or w + 2 * pad[1] < dil * (s - 1) + 1:
+			continue
+		cases.append(dict(n=int(rng.randint(1, 10)), c=c, h=h, w=w, k=k, r=r, s=s, stride=stride, pad=pad, dil=dil, groups=g))
+	return cases
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_conv_random_descriptors_vs_oracle(bnd, block):
+	"""90 seeded random convolution descriptors (15 per block), all three passes against the fp64 oracle: whatever kernel
+	family / tile plan / k-slicing the library picks for a shape nobody listed by hand."""
+	for cs in _random_conv_cases(15, 1000 + block):
+		test_conv_fresh_vs_oracle(bnd, cs)
+
+
 def test_conv_errors(bnd):
 	x = bnd.GPUArray.zeros((1, 4, 5, 5), dtype=np.float32)
 	w = bnd.GPUArray.zeros((6, 4, 7, 7), dtype=np.float32)
@@ -778,6 +805,46 @@ def test_gemm_tiles_split_k_and_unaligned_operands(bnd, shape):
 		acc = gpu(bnd, c0)
 		bnd.blas.gemm(ga, gb, acc, ta, tb, 0.5, -2.0, bnd.memoryPool)
 		assert_close(acc.get(), 0.5 * ref - 2.0 * c0, what="alpha / beta epilogue", **tol)
+
+
+def test_gemm_and_pool_random_shapes_vs_oracle(bnd):
+	"""Seeded random sweeps: 40 GEMM shapes (1..300 on every side, every layout, alpha / beta) against fp64 products, and 40
+	pooling descriptors (max / both averages, windows 1-4, strides 1-3, pads below the window) forward and backward
+	against the oracle — shapes nobody listed by hand."""
+	rng = np.random.RandomState(2026)
+	for _ in range(40):
+		m, k, n = (int(v) for v in rng.randint(1, 301, size=3))
+		ta, tb = [(False, False), (False, True), (True, False)][int(rng.randint(3))]
+		alpha, beta = float(rng.choice([1.0, 0.5, -1.25])), float(rng.choice([0.0, 1.0, -0.5]))
+		a, b, c0 = rng.randn(m, k).astype(np.float32), rng.randn(k, n).astype(np.float32), rng.randn(m, n).astype(np.float32)
+		acc = gpu(bnd, c0)
+		bnd.blas.gemm(gpu(bnd, a.T.copy() if ta else a), gpu(bnd, b.T.copy() if tb else b), acc, ta, tb, alpha, beta, bnd.memoryPool)
+		ref = alpha * (a.astype(np.float64) @ b.astype(np.float64)) + beta * c0
+		assert_close(acc.get(), ref, atol=2e-6 * np.sqrt(k) * 8, rtol=1e-5, what="gemm %dx%dx%d %s%s" % (m, k, n, "T" if ta else "N", "T" if tb else "N"))
+
+	modes = [(bnd.PoolMode.max.value, R.POOL_MAX), (bnd.PoolMode.avgWithPad.value, R.POOL_AVG_WITH_PAD),
+			 (bnd.PoolMode.avgNoPad.value, R.POOL_AVG_NO_PAD)]
+	done = 0
+	while done < 40:
+		size = (int(rng.randint(1, 5)), int(rng.randint(1, 5)))
+		stride = (int(rng.randint(1, 4)), int(rng.randint(1, 4)))
+		pad = (int(rng.randint(0, size[0])), int(rng.randint(0, size[1])))
+		shape = (int(rng.randint(1, 5)), int(rng.randint(1, 9)), int(rng.randint(1, 30)), int(rng.randint(1, 30)))
+		if shape[2] + 2 * pad[0] < size[0] or shape[3] + 2 * pad[1] < size[1]:
+			continue
+		if 2 * pad[0] > size[0] or 2 * pad[1] > size[1]:        # (windows lying entirely in the padding have no maximum)
+			continue
+		done += 1
+		mode, omode = modes[int(rng.randint(3))]
+		x = rng.permutation(int(np.prod(shape))).reshape(shape).astype(np.float32) / 7.0          # tie-free
+		y_ref = R.pool2d_fwd(x, size, stride, pad, omode)
+		dy = rng.randn(*y_ref.shape).astype(np.float32)
+		gx = gpu(bnd, x)
+		y, ws = bnd.dnn.poolNd(gx, size=size, stride=stride, pad=pad, mode=mode, test=False)
+		assert_close(y.get(), y_ref, atol=1e-5, what="pool %s %s %s %s mode %d" % (shape, size, stride, pad, mode))
+		dx = bnd.dnn.poolNdBackward(gpu(bnd, dy), gx, y, ws, size=size, stride=stride, pad=pad, mode=mode)
+		assert_close(dx.get(), R.pool2d_bwd(dy, x, y_ref, size, stride, pad, omode), atol=1e-5,
+					 what="pool backward %s %s %s %s mode %d" % (shape, size, stride, pad, mode))
 
 
 def test_gemm_batched_group_formats(bnd):
