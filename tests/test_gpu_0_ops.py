@@ -847,6 +847,22 @@ def test_gemm_and_pool_random_shapes_vs_oracle(bnd):
 					 what="pool backward %s %s %s %s mode %d" % (shape, size, stride, pad, mode))
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 16, 16), (1, 2, 9, 12), (2, 2, 33, 20), (1, 1, 112, 112), (3, 1, 7, 8), (1, 2, 40, 4)])
+def test_maxpool_3x3_stride2_backward_by_parities(bnd, shape):
+	"""The stem's pooling geometry (3x3 / 2, unpadded, width a multiple of 4) takes the parity-structured backward (a thread
+	reads the 2 x 3 windows around a 2 x 4 block of input pixels once): against the oracle on tie-free data, odd and even
+	heights, maps shorter than one band and longer than several."""
+	rng = np.random.RandomState(sum(shape))
+	x = rng.permutation(int(np.prod(shape))).reshape(shape).astype(np.float32) / 3.0
+	y_ref = R.pool2d_fwd(x, 3, 2, 0, R.POOL_MAX)
+	dy = rng.randn(*y_ref.shape).astype(np.float32)
+	gx = gpu(bnd, x)
+	y, ws = bnd.dnn.poolNd(gx, size=3, stride=2, pad=0, mode=bnd.PoolMode.max.value, test=False)
+	assert np.array_equal(y.get(), y_ref)
+	dx = bnd.dnn.poolNdBackward(gpu(bnd, dy), gx, y, ws, size=3, stride=2, pad=0, mode=bnd.PoolMode.max.value)
+	assert_close(dx.get(), R.pool2d_bwd(dy, x, y_ref, 3, 2, 0, R.POOL_MAX), atol=1e-6, what="3x3/2 max-pool backward %s" % (shape, ))
+
+
 def test_gemm_batched_group_formats(bnd):
 	"""BlasContext.gemmBatched in the reference's three layout combinations and transposes
 	(Cuda/Wrappers/CuBlas.py:50-176: gbpGbpTest, gbpBgpTest, bgpGbpTest, bgpBgpTest shapes)."""
