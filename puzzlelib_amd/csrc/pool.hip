@@ -294,27 +294,55 @@ inline bool pool_lds_fits(const pz_pool_desc *d, int Q, bool fwd) {
 	return (size_t)(kPoolBwdBand / st + sz + 1) * Q <= kPoolBandFloats * 4 / 5;
 }
 
-// average over the whole plane (window = plane, no padding, one output): one wave per plane, coalesced, shuffle-reduced
+// average over the whole plane (window = plane, no padding, one output). Planes are short (7 x 7 = 196 bytes at the end of
+// ResNet-50, half a million of them at batch 256): one wave per plane left 15 of 64 lanes without an element and made
+// every plane its own latency-bound trip (74 us for 26 MB). A group of LANES lanes takes a plane (LANES = the power of two
+// covering hw / 4, at most 64), so a wave reads 64 / LANES consecutive planes = one contiguous stretch, and sums with a
+// fixed shuffle tree inside the group.
+template <int LANES>
 __global__ void __launch_bounds__(256) pool_global_avg_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                    unsigned planes, int hw) {
-	const unsigned plane = blockIdx.x * 4u + (threadIdx.x >> 6);
-	if (plane >= planes) return;
-	const float *img = x + (size_t)plane * hw;
+	constexpr int PER_BLOCK = 256 / LANES;
+	const unsigned plane = blockIdx.x * (unsigned)PER_BLOCK + threadIdx.x / LANES;
+	const int sub = threadIdx.x % LANES;
 	float s = 0.f;
-	for (int i = threadIdx.x & 63; i < hw; i += 64) s += img[i];
-	s = wave_sum(s);
-	if ((threadIdx.x & 63) == 0) y[plane] = s / (float)hw;
+	if (plane < planes) {
+		const float *img = x + (size_t)plane * hw;
+		for (int i = sub; i < hw; i += LANES) s += img[i];
+	}
+#pragma unroll
+	for (int m = LANES / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+	if (sub == 0 && plane < planes) y[plane] = s / (float)hw;
 }
 
+// the backward pass writes dy[plane] / hw over every plane: a thread owns 4 consecutive elements (one 16-byte store when
+// they lie in one plane and the address allows it; planes of 49 floats rarely do, so the store type is 4-byte aligned)
 __global__ void __launch_bounds__(256) pool_global_avg_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx,
-                                                                   size_t total, int hw) {
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-		dx[i] = dy[(unsigned)(i / (unsigned)hw)] / (float)hw;
+                                                                   size_t total, int hw, unsigned magic_hw) {
+	typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+	const float inv = 1.f / (float)hw;
+	// the workgroup's first element: plane and offset inside it by one (wave-uniform) 64-bit division; the 1 024 elements
+	// behind it by multiply-high (exact: r < 2^16 + 1 024, magic_hw = ceil(2^32 / hw))
+	const size_t first = (size_t)blockIdx.x * 1024;
+	const size_t p_first = first / (size_t)hw;
+	const unsigned r_first = (unsigned)(first - p_first * (size_t)hw);
+	const size_t i = first + (size_t)threadIdx.x * 4;
+	if (i >= total) return;
+	float v[4];
+#pragma unroll
+	for (int e = 0; e < 4; ++e) {
+		const unsigned r = r_first + threadIdx.x * 4u + e;
+		v[e] = i + e < total ? dy[p_first + __umulhi(r, magic_hw)] * inv : 0.f;
+	}
+	if (i + 4 <= total)
+		*reinterpret_cast<f4u *>(dx + i) = f4u{v[0], v[1], v[2], v[3]};
+	else
+		for (int e = 0; i + e < total; ++e) dx[i + e] = v[e];
 }
 
 inline bool pool_is_global_avg(const pz_pool_desc *d, int P, int Q) {
 	return d->mode != 0 && P == 1 && Q == 1 && d->pad_h == 0 && d->pad_w == 0 && d->size_h == d->h && d->size_w == d->w &&
-	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32);
+	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32) && d->h * d->w < (1 << 16);
 }
 
 // windows the LDS kernels are instantiated for: square 2x2/2, 3x3/2, 3x3/1
@@ -369,7 +397,10 @@ int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *inde
 	const unsigned blocks = (g.planes + g.group - 1) / g.group;
 	hipStream_t st = pz::as_stream(stream);
 	if (pool_is_global_avg(d, P, Q)) {
-		pool_global_avg_fwd_kernel<<<(g.planes + 3) / 4, 256, 0, st>>>(x, y, g.planes, d->h * d->w);
+		const int hw = d->h * d->w;
+		if (hw <= 16) pool_global_avg_fwd_kernel<4><<<(g.planes + 63) / 64, 256, 0, st>>>(x, y, g.planes, hw);
+		else if (hw <= 64) pool_global_avg_fwd_kernel<16><<<(g.planes + 15) / 16, 256, 0, st>>>(x, y, g.planes, hw);
+		else pool_global_avg_fwd_kernel<64><<<(g.planes + 3) / 4, 256, 0, st>>>(x, y, g.planes, hw);
 	} else if (d->mode == 0 && pool_lds_window(d) && pool_lds_fits(d, Q, true) && g.planes < 65536u * 32768u) {
 		const dim3 grid(g.planes, (P + kPoolFwdBand - 1) / kPoolFwdBand);
 		if (d->size_h == 3 && d->stride_h == 2) maxpool_fwd_lds_kernel<3, 2><<<grid, 256, 0, st>>>(*d, g, x, y, index_ws);
@@ -428,7 +459,9 @@ int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const 
 	hipStream_t st = pz::as_stream(stream);
 	if (pool_is_global_avg(d, P, Q)) {
 		const size_t total = (size_t)g.planes * d->h * d->w;
-		pool_global_avg_bwd_kernel<<<pz::stream_grid(total, 256), 256, 0, st>>>(dy, dx, total, d->h * d->w);
+		const int hw = d->h * d->w;
+		pool_global_avg_bwd_kernel<<<(unsigned)((total + 1023) / 1024), 256, 0, st>>>(dy, dx, total, hw,
+		                                                                               (unsigned)((((unsigned long long)1 << 32) + hw - 1) / hw));
 	} else if (d->mode == 0 && index_ws && pool_lds_window(d) && pool_lds_fits(d, Q, false)) {
 		const dim3 grid(g.planes, (d->h + kPoolBwdBand - 1) / kPoolBwdBand);
 		if (d->size_h == 3 && d->stride_h == 2) maxpool_bwd_lds_kernel<3, 2><<<grid, 256, 0, st>>>(*d, g, dy, index_ws, dx);
