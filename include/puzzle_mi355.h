@@ -450,6 +450,15 @@ int pz_upsample_fwd(const float *x, float *y, size_t planes, int ind, int inh, i
                     pz_stream_t stream);
 int pz_upsample_bwd(const float *dy, float *dx, size_t planes, int ind, int inh, int inw, int sd, int sh, int sw, int linear,
                     pz_stream_t stream);
+/* CTCModule.ctcLoss (Cuda/Kernels/CTC.py:232-270; Cost/CTC.py:23-30): probs (T, batch, vocab) softmax outputs, datalen[batch],
+ * labels concatenated, offsets[batch + 1] their prefix sums. Per sample the caller also passes the extended-label positions
+ * sorted by label (`order`, at element offset 2 * offsets[b] + b like the alphas' rows), the bounds of the runs of equal
+ * labels (`seg_start`: nseg_b + 1 local bounds at seg_off[b] + b) and their labels (`seg_label` at seg_off[b]). Writes the
+ * forward variables (T * (2 * offsets[batch] + batch) floats), nll[batch], grad (zero-initialised by the caller beyond
+ * datalen) and adds sum nll to *error (fixed order; the reference atomicAdds).                                          */
+int pz_ctc_loss(const float *probs, const int32_t *datalen, const int32_t *labels, const int32_t *offsets, const int32_t *order,
+                const int32_t *seg_start, const int32_t *seg_label, const int32_t *seg_off, int T, int batch, int vocab, int blank,
+                int max_positions, float *alphas, float *nll, float *grad, float *error, pz_stream_t stream);
 /* EmbedModule.embed / embedBackwardParams (Cuda/Kernels/Embedder.py:10-88): word index -1 = padding (zero row, no update) */
 int pz_embed_fwd(const int32_t *words, const float *vocab, float *out, size_t tokens, int embsize, pz_stream_t stream);
 int pz_embed_bwd_params(const int32_t *words, const float *grad, float *vocab, float scale, size_t tokens, int embsize,

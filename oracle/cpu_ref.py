@@ -943,3 +943,79 @@ def embed_bwd_params(words, grad, vocab, scale):
 	ok = words.ravel() != -1
 	np.add.at(vocab, words.ravel()[ok], (F(scale) * grad.reshape(-1, grad.shape[-1])[ok]).astype(F))
 	return vocab
+
+
+# CTC loss — Cuda/Kernels/CTC.py:9-270 (kernels calcAlphas / calcBetas and the module's softmax / offsets bookkeeping)
+def ctc_loss(data, datalen, labels, lengths, blank, normalized=False):
+	"""(summed negative log-likelihood, grad (T, batch, vocab), alphas flat) for scores `data` (T, batch, vocab); the forward
+	and backward variables in log space over the extended label sequence blank, l0, blank, l1, ..., blank of each sample,
+	float32 like the kernels; grad[t, b, v] = p - exp(logsum_{i: ext[i] = v}(alpha + beta) - log p + nll_b), negated — what
+	the kernel leaves (Cost/CTC.py hands it on as the descent direction); zero beyond datalen and for impossible samples."""
+	T, batch, vocab = data.shape
+	if normalized:
+		p = data.astype(F)
+	else:
+		e = np.exp(data - data.max(axis=-1, keepdims=True))
+		p = (e / e.sum(axis=-1, keepdims=True)).astype(F)
+	offsets = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+	alphas = np.full(T * (2 * int(offsets[-1]) + batch), np.nan, F)
+	grad = np.zeros(p.shape, F)
+	total = np.float64(0.0)
+	NEG = F(-np.inf)
+
+	def lp(a, b):                  # logPlus, element-wise, float32
+		with np.errstate(invalid="ignore", divide="ignore"):
+			m, d = np.maximum(a, b), -np.abs(a - b)
+			out = (np.log1p(np.exp(d, dtype=F), dtype=F) + m).astype(F)
+		out = np.where(np.isneginf(a), b, out)
+		return np.where(np.isneginf(b), a, out).astype(F)
+
+	for b in range(batch):
+		L, Tb = int(lengths[b]), int(datalen[b])
+		S = 2 * L + 1
+		ext = np.full(S, blank, np.int64)
+		ext[1::2] = labels[offsets[b]:offsets[b] + L]
+		skip = np.zeros(S, bool)                               # position i may also be reached from i - 2
+		skip[2:] = (ext[2:] != blank) & (ext[2:] != ext[:-2])
+		base = (2 * int(offsets[b]) + b) * T
+		alpha = alphas[base:base + T * S].reshape(T, S)
+		with np.errstate(divide="ignore"):
+			logp = np.log(p[:, b, :][:, ext]).astype(F)        # (T, S)
+
+		alpha[0] = NEG
+		alpha[0, :2] = logp[0, :2]
+		for t in range(1, Tb):
+			prev = alpha[t - 1].copy()
+			prev[1:] = lp(prev[1:], alpha[t - 1, :-1])
+			via2 = np.full(S, NEG, F)
+			via2[2:] = alpha[t - 1, :-2]
+			prev = np.where(skip, lp(prev, via2), prev)
+			alpha[t] = prev + logp[t]
+		loglike = lp(alpha[Tb - 1, S - 2], alpha[Tb - 1, S - 1]) if S > 1 else alpha[Tb - 1, 0]
+		nll = F(-loglike)
+		total += np.float64(nll)
+		if not np.isfinite(nll):
+			continue
+
+		fwd_skip = np.zeros(S, bool)                           # position i may also go on to i + 2
+		fwd_skip[:-2] = (ext[:-2] != blank) & (ext[:-2] != ext[2:])
+		beta = np.full(S, NEG, F)
+		beta[max(S - 2, 0):] = logp[Tb - 1, max(S - 2, 0):]
+		for t in range(Tb - 1, -1, -1):
+			if t < Tb - 1:
+				nxt = beta.copy()
+				nxt[:-1] = lp(nxt[:-1], beta[1:])
+				via2 = np.full(S, NEG, F)
+				via2[:-2] = beta[2:]
+				nxt = np.where(fwd_skip, lp(nxt, via2), nxt)
+				beta = (nxt + logp[t]).astype(F)
+			ab = (alpha[t] + beta).astype(F)
+			g = -p[t, b].copy()
+			for v in np.unique(ext):
+				acc = NEG
+				for i in np.flatnonzero(ext == v):             # ascending position, as the sorted segments are walked
+					acc = lp(acc, ab[i])
+				if p[t, b, v] > 0:
+					g[v] += np.exp(F(acc) - np.log(p[t, b, v]) + nll, dtype=F)
+			grad[t, b] = g
+	return np.float32(total), grad, alphas

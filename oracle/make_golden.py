@@ -583,15 +583,22 @@ def make_oracle_f3():
 		embed=lambda data, W, allocator=None: H(R.embed_fwd(data.a, W.a)),
 		embedBackwardParams=lambda indata, grad, W, scale: R.embed_bwd_params(indata.a, grad.a, W.a, scale),
 	)
+	def ctcLoss(data, datalen, labels, lengths, blank, error=None, normalized=False, returnAlphas=False, allocator=None):
+		err, grad, alphas = R.ctc_loss(data.a, datalen.a, labels.a, lengths, blank, normalized)
+		err = H(np.array(err, dtype=np.float32))
+		return (err, H(grad), H(alphas)) if returnAlphas else (err, H(grad))
+
+	ctcmod = types.SimpleNamespace(GPUArray=H, ctcLoss=ctcLoss)
 	return bnd, dict(poolmod=poolmod, matmod=matmod, costmod=costmod, prelumod=prelumod, padmod=padmod, upsamplemod=upsamplemod,
-					 embedmod=embedmod)
+					 embedmod=embedmod, ctcmod=ctcmod)
 
 
 def run_reference_f3_tests_on_oracle():
 	"""The tests the reference holds for the operators beside the hot path — they need a device in the reference
 	(Unittester.py:114-122 runs them for the Hip backend) — executed here with the oracle as the backend under test."""
 	from PuzzleLib.Cuda.Wrappers import CuDnn, CuDnnNorm
-	from PuzzleLib.Cuda.Kernels import Pool, MatVec, Costs, PRelu, Pad, Upsample, Embedder
+	from PuzzleLib.Cuda.Kernels import Pool, MatVec, Costs, PRelu, Pad, Upsample, Embedder, CTC
+	import random
 
 	bnd, mods = make_oracle_f3()
 	for seed in range(3):
@@ -615,6 +622,8 @@ def run_reference_f3_tests_on_oracle():
 		Upsample.upsample3dNearestTest(mods["upsamplemod"])
 		Upsample.upsample3dLinearTest(mods["upsamplemod"])
 		Embedder.embedTest(mods["embedmod"], np.float32, ATOL)
+		random.seed(300 + seed)                 # (CTC.createData draws the label lengths from `random`)
+		CTC.ctcLossTest(mods["ctcmod"])
 
 	# point-wise cost kernels: the reference's Cost modules (Cost/BCE.py, Hinge.py, SmoothL1.py, L1Hinge.py) import their
 	# kernel from Backend/Kernels/Costs.py, which binds nothing on the CPU backend; bound to the oracle's restatement of the
@@ -665,7 +674,7 @@ def run_reference_f3_tests_on_oracle():
 
 	print("[2b] reference tests of the operators beside the hot path (conv3d / deconv2d / deconv3d / deconvGroup / instanceNorm2d / "
 		  "mapLRN / crossMapLRN / maskpool / unpool / batched matvec / svm / prelu / reflectpad 1d+2d / upsample 2d+3d nearest+linear / "
-		  "embed; Cost modules BCE / Hinge / SmoothL1 / L1Hinge) pass on the oracle: OK")
+		  "embed / ctcLoss; Cost modules BCE / Hinge / SmoothL1 / L1Hinge) pass on the oracle: OK")
 
 
 def f3_fixtures(fx):
@@ -789,6 +798,20 @@ def f3_fixtures(fx):
 	fx["f3_emb_words"], fx["f3_emb_vocab"], fx["f3_emb_g"] = words, vocab, g
 	fx["f3_emb_orc_y"] = R.embed_fwd(words, vocab)
 	fx["f3_emb_orc_vocab_after"] = R.embed_bwd_params(words, g, vocab.copy(), 0.25)
+
+	# CTC: three samples, the second shorter in time, repeated labels, blank 0 and (second set) blank 3
+	T, batch, vocab = 12, 3, 7
+	scores = rng.randn(T, batch, vocab).astype(f32)
+	datalen = np.array([12, 9, 12], np.int32)
+	lengths = np.array([4, 3, 5], np.int32)
+	fx["f3_ctc_scores"], fx["f3_ctc_datalen"], fx["f3_ctc_lengths"] = scores, datalen, lengths
+	for tag, blank in (("b0", 0), ("b3", 3)):
+		pool = [v for v in range(vocab) if v != blank]
+		lab = np.array([pool[i] for i in rng.randint(0, len(pool), size=int(lengths.sum()))], np.int32)
+		lab[1] = lab[0]                                        # a repeated label needs the blank between its two copies
+		err, grad, alphas = R.ctc_loss(scores, datalen, lab, lengths, blank)
+		fx["f3_ctc_%s_labels" % tag] = lab
+		fx["f3_ctc_%s_orc_err" % tag], fx["f3_ctc_%s_orc_grad" % tag] = np.array([err], f32), grad
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1612,6 +1612,62 @@ class UpsampleModule:
 		return self.run(grad, scale, mode, allocator, 3, True)
 
 
+class CTCModule:
+	"""ctcLoss — Cuda/Kernels/CTC.py:232-270 (Backend/Kernels/Costs.py:68-69 -> Cost/CTC.py:23-30)"""
+
+	def __init__(self, backend):
+		self.backend, self.GPUArray, self.dnn = backend, GPUArray, backend.dnn
+
+
+	def ctcLoss(self, data, datalen, labels, lengths, blank, error=None, normalized=False, returnAlphas=False, allocator=None):
+		requireF32(data)
+		assert data.ndim == 3 and datalen.dtype == np.int32 and labels.dtype == np.int32
+		T, batchsize, vocabsize = data.shape
+		lengths = np.asarray(lengths, dtype=np.int32)
+		assert lengths.shape == (batchsize, ) and datalen.size == batchsize
+
+		if not normalized:
+			data = self.dnn.softmaxNd(data.reshape(T * batchsize, vocabsize, 1, 1), allocator=allocator).reshape(
+				T, batchsize, vocabsize
+			)
+
+		offsets = np.zeros(batchsize + 1, dtype=np.int32)
+		offsets[1:] = np.cumsum(lengths, dtype=np.int32)
+		total = int(offsets[-1])
+
+		# positions of every sample's extended label sequence grouped by label (stable: ascending position inside a group) —
+		# the reference sorts inside its kernel; the label lengths are host data in its API and the labels follow them here
+		hostLabels = labels.get()
+		order = np.empty(2 * total + batchsize, dtype=np.int32)
+		segStart, segLabel, segOff = [], [], np.zeros(batchsize + 1, dtype=np.int32)
+		for b in range(batchsize):
+			L = int(lengths[b])
+			ext = np.full(2 * L + 1, blank, dtype=np.int32)
+			ext[1::2] = hostLabels[offsets[b]:offsets[b] + L]
+			by = np.argsort(ext, kind="stable").astype(np.int32)
+			order[2 * offsets[b] + b:2 * offsets[b] + b + 2 * L + 1] = by
+			keys = ext[by]
+			starts = np.flatnonzero(np.concatenate(([True], keys[1:] != keys[:-1]))).astype(np.int32)
+			segStart.append(np.concatenate((starts, [2 * L + 1])).astype(np.int32))
+			segLabel.append(keys[starts])
+			segOff[b + 1] = segOff[b] + starts.size
+
+		toGpu = lambda a: GPUArray.toGpu(np.ascontiguousarray(a, dtype=np.int32), allocator=allocator)
+		alphas = GPUArray.empty((T * (2 * total + batchsize), ), dtype=np.float32, allocator=allocator)
+		nll = GPUArray.empty((batchsize, ), dtype=np.float32, allocator=allocator)
+		error = GPUArray.zeros((), dtype=np.float32, allocator=allocator) if error is None else error
+		grad = GPUArray.zeros(data.shape, dtype=np.float32, allocator=allocator)
+
+		# (the index tables stay referenced until the launch is queued: a temporary would go back to the pool — and to the
+		# next table — before the call)
+		tables = [toGpu(a) for a in (offsets, order, np.concatenate(segStart), np.concatenate(segLabel), segOff)]
+		lib.pz_ctc_loss(
+			data.rptr, datalen.rptr, labels.rptr, tables[0].rptr, tables[1].rptr, tables[2].rptr, tables[3].rptr, tables[4].rptr,
+			T, batchsize, vocabsize, int(blank), int(2 * lengths.max() + 1), alphas.optr, nll.optr, grad.wptr, error.wptr, None
+		)
+		return (error, grad) if not returnAlphas else (error, grad, alphas)
+
+
 class EmbedModule:
 	"""embed / embedBackwardParams — Cuda/Kernels/Embedder.py:57-88 (word index -1: padding)"""
 
@@ -1955,7 +2011,7 @@ class Mi355Backend:
 		self.poolmod = PoolModule(self)
 		self.embedmod, self.padmod = EmbedModule(self), PadModule(self)
 		self.prelumod, self.upsamplemod = PReluModule(self.matmod), UpsampleModule(self)
-		self.ctcmod = StubModule("ctcmod")
+		self.ctcmod = CTCModule(self)
 
 		K = memoizedKernel
 		self.sigmoidKer = K(lib.OP_SIGMOID, 2, 0, "sigmoidKer")

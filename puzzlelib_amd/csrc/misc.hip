@@ -15,6 +15,7 @@
 //                   forward's own float expressions (reference: atomicAdd scatter). The reference's 3-d linear forward reads
 //                   `d1 * inw * inw` for one of its eight taps (Upsample.py:221) — a typo invisible to its test (inh == inw);
 //                   here every tap uses inh * inw.
+//   CTC loss        — Cuda/Kernels/CTC.py:9-270: log-space forward / backward variables per sample (see below)
 //   embedding       — Cuda/Kernels/Embedder.py:10-88: out[t, :] = vocabulary[word[t], :] (word -1: row of zeros);
 //                   vocabulary[word[t], :] += scale * grad[t, :] with fp32 atomic adds (as the reference: rows repeat)
 // None of these is on a timed path; they are HBM-bound one-output-per-thread kernels with lanes along the contiguous axis.
@@ -280,9 +281,135 @@ __global__ void __launch_bounds__(kT) embed_bwd_kernel(const int32_t *__restrict
 	atomicAdd(&vocab[(size_t)word * embsize + i % embsize], scale * grad[i]);
 }
 
+// ------------------------------------------------------------------------------------------------ CTC loss
+// Cuda/Kernels/CTC.py:9-192 (ctcmod.ctcLoss; caller Cost/CTC.py:23-30): one workgroup per sample. probs (T, batch, vocab) are
+// softmax outputs; the extended label sequence of sample b is blank, l0, blank, l1, ..., blank (S = 2 L + 1 positions).
+//   alphas : forward variables in log space, kept in global memory (T x S per sample at row offset T * (2 * off[b] + b))
+//   betas  : backward variables, two rows in LDS; per time step the positions that carry the same label are summed
+//            (logPlus, ascending position) and grad[t, b, v] = -p + exp(sum_v - log p + nll_b)
+// The reference groups equal labels with an in-kernel radix sort; here the caller passes, per sample, the positions sorted
+// by label (stable) and the segment bounds — the labels are host data in the reference's own API (`lengths` is), so the
+// grouping is a numpy argsort.
+constexpr int kCtcMaxS = 4096;
+
+__device__ __forceinline__ float log_plus(float a, float b) {
+	if (a <= -INFINITY) return b;
+	if (b <= -INFINITY) return a;
+	return log1pf(expf(-fabsf(a - b))) + fmaxf(a, b);
+}
+
+struct CtcArgs {
+	const float *probs;
+	const int32_t *datalen, *labels, *offsets;      // offsets[batch + 1]: prefix sums of the label lengths
+	float *alphas, *nll, *grad;
+	const int32_t *order, *seg_start, *seg_label, *seg_off;     // per sample: positions by label, segment bounds (local), labels
+	int T, batch, vocab, blank;
+};
+
+__global__ void __launch_bounds__(256) ctc_alphas_kernel(CtcArgs a) {
+	__shared__ int32_t ext[kCtcMaxS];
+	const int b = blockIdx.x;
+	const int off = a.offsets[b], S = 2 * (a.offsets[b + 1] - off) + 1;
+	const float *p = a.probs + (size_t)b * a.vocab;
+	const size_t tstride = (size_t)a.batch * a.vocab;
+	float *alpha = a.alphas + (size_t)a.T * (2 * off + b);
+
+	for (int i = threadIdx.x; i < S; i += 256) {
+		const int label = (i & 1) == 0 ? a.blank : a.labels[off + i / 2];
+		ext[i] = label;
+		alpha[i] = i < 2 ? logf(p[label]) : -INFINITY;
+	}
+	__syncthreads();
+	const int T = a.datalen[b];
+	for (int t = 1; t < T; ++t) {
+		for (int i = threadIdx.x; i < S; i += 256) {
+			float prev = alpha[(size_t)(t - 1) * S + i];
+			if (i > 0) {
+				prev = log_plus(prev, alpha[(size_t)(t - 1) * S + i - 1]);
+				if (i > 1 && ext[i] != a.blank && ext[i] != ext[i - 2]) prev = log_plus(prev, alpha[(size_t)(t - 1) * S + i - 2]);
+			}
+			alpha[(size_t)t * S + i] = prev + logf(p[(size_t)t * tstride + ext[i]]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		a.nll[b] = -(S > 1 ? log_plus(alpha[(size_t)(T - 1) * S + S - 2], alpha[(size_t)(T - 1) * S + S - 1]) : alpha[(size_t)(T - 1) * S]);
+}
+
+__global__ void __launch_bounds__(256) ctc_betas_kernel(CtcArgs a) {
+	__shared__ int32_t ext[kCtcMaxS];
+	__shared__ float beta[2][kCtcMaxS];
+	const int b = blockIdx.x;
+	const int off = a.offsets[b], S = 2 * (a.offsets[b + 1] - off) + 1;
+	const float *p = a.probs + (size_t)b * a.vocab;
+	float *g = a.grad + (size_t)b * a.vocab;
+	const size_t tstride = (size_t)a.batch * a.vocab;
+	const float *alpha = a.alphas + (size_t)a.T * (2 * off + b);
+	const float loglike = a.nll[b];
+	if (loglike >= INFINITY) return;                       // no valid alignment: the gradient stays zero
+
+	for (int i = threadIdx.x; i < S; i += 256) ext[i] = (i & 1) == 0 ? a.blank : a.labels[off + i / 2];
+	const int32_t *order = a.order + (2 * off + b);
+	const int seg0 = a.seg_off[b], nseg = a.seg_off[b + 1] - seg0;
+	const int32_t *seg_start = a.seg_start + seg0 + b;     // nseg + 1 entries per sample
+	const int32_t *seg_label = a.seg_label + seg0;
+	const int T = a.datalen[b];
+	__syncthreads();
+
+	int src = 0;
+	for (int t = T - 1; t >= 0; --t) {
+		if (t < T - 1) {
+			const int dst = src ^ 1;
+			for (int i = threadIdx.x; i < S; i += 256) {
+				float next = beta[src][i];
+				if (i < S - 1) {
+					next = log_plus(next, beta[src][i + 1]);
+					if (i < S - 2 && ext[i] != a.blank && ext[i] != ext[i + 2]) next = log_plus(next, beta[src][i + 2]);
+				}
+				beta[dst][i] = next + logf(p[(size_t)t * tstride + ext[i]]);
+			}
+			src = dst;
+		} else {
+			for (int i = threadIdx.x; i < S; i += 256)
+				beta[0][i] = i >= S - 2 ? logf(p[(size_t)(T - 1) * tstride + ext[i]]) : -INFINITY;
+		}
+		for (int i = threadIdx.x; i < a.vocab; i += 256) g[(size_t)t * tstride + i] = -p[(size_t)t * tstride + i];
+		__syncthreads();
+		for (int j = threadIdx.x; j < nseg; j += 256) {
+			float gr = -INFINITY;
+			for (int k = seg_start[j]; k < seg_start[j + 1]; ++k) {
+				const int i = order[k];
+				gr = log_plus(gr, alpha[(size_t)t * S + i] + beta[src][i]);
+			}
+			const size_t at = (size_t)t * tstride + seg_label[j];
+			const float data = p[at];
+			if (data > 0.0f) g[at] += expf(gr - logf(data) + loglike);
+		}
+		__syncthreads();
+	}
+}
+
 }  // namespace
 
 extern "C" {
+
+int pz_ctc_loss(const float *probs, const int32_t *datalen, const int32_t *labels, const int32_t *offsets, const int32_t *order,
+                const int32_t *seg_start, const int32_t *seg_label, const int32_t *seg_off, int T, int batch, int vocab, int blank,
+                int max_positions, float *alphas, float *nll, float *grad, float *error, pz_stream_t stream) {
+	PZ_REQUIRE(probs && datalen && labels && offsets && order && seg_start && seg_label && seg_off && alphas && nll && grad && error,
+	           "pz_ctc_loss: null argument");
+	PZ_REQUIRE(T > 0 && batch > 0 && vocab > 0 && blank >= 0 && blank < vocab, "pz_ctc_loss: bad geometry");
+	PZ_REQUIRE(max_positions <= kCtcMaxS, "pz_ctc_loss: %d extended label positions (the kernel holds %d)", max_positions, kCtcMaxS);
+	hipStream_t st = pz::as_stream(stream);
+	CtcArgs a{probs, datalen, labels, offsets, alphas, nll, grad, order, seg_start, seg_label, seg_off, T, batch, vocab, blank};
+	ctc_alphas_kernel<<<batch, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+	ctc_betas_kernel<<<batch, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+	add_sum_kernel<<<1, 1024, 0, st>>>(nll, (size_t)batch, error);      // error += sum_b nll[b], fixed order
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
 
 int pz_cost_pointwise(int kind, const float *a, const void *b, const int32_t *labels, float *error, float *grad, float *grad2, float *terms,
                       size_t total, int numsamples, int numcases, float norm, float fullnorm, pz_stream_t stream) {

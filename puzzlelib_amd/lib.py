@@ -174,6 +174,7 @@ _PROTOS = {
 	"pz_reflectpad2d_bwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, P],
 	"pz_upsample_fwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
 	"pz_upsample_bwd": [P, P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
+	"pz_ctc_loss": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P],
 	"pz_embed_fwd": [P, P, P, c_size_t, c_int, P],
 	"pz_embed_bwd_params": [P, P, P, c_float, c_size_t, c_int, P],
 	"pz_matvec": [P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P],

@@ -1271,3 +1271,32 @@ def test_f3_embedder_fixture(bnd, ops):
 	assert np.array_equal(y.get(), ops["f3_emb_orc_y"]) and (words == -1).any()
 	bnd.embedmod.embedBackwardParams(gw, gpu(bnd, g), gv, 0.25)
 	assert_close(gv.get(), ops["f3_emb_orc_vocab_after"], atol=1e-5, what="vocabulary after the update")
+
+
+@pytest.mark.parametrize("tag,blank", [("b0", 0), ("b3", 3)])
+def test_f3_ctc_loss_fixture(bnd, ops, tag, blank):
+	"""ctcmod.ctcLoss (Cuda/Kernels/CTC.py:232-270; ctcLossTest :283-298 passed on the oracle that wrote the fixture): summed
+	negative log-likelihood added to the error scalar, gradient w.r.t. the scores' softmax as the kernel leaves it, zero
+	beyond a sample's length; repeated labels, a sample shorter than T, blank 0 and blank 3."""
+	scores, datalen, lengths = ops["f3_ctc_scores"], ops["f3_ctc_datalen"], ops["f3_ctc_lengths"]
+	labels = ops["f3_ctc_%s_labels" % tag]
+	err = bnd.GPUArray.empty((), dtype=np.float32)
+	err.fill(0.25)
+	_, grad = bnd.ctcmod.ctcLoss(gpu(bnd, scores), gpu(bnd, datalen), gpu(bnd, labels), lengths, blank, error=err)
+	assert np.isclose(float(err.get()), 0.25 + float(ops["f3_ctc_%s_orc_err" % tag][0]), rtol=1e-5)
+	assert_close(grad.get(), ops["f3_ctc_%s_orc_grad" % tag], atol=2e-5, rtol=1e-4, what="ctc gradient")
+	assert not grad.get()[int(datalen[1]):, 1].any(), "no gradient beyond the sample's length"
+	# the gradient of the summed loss w.r.t. the scores (through the softmax) by a central difference on one score
+	probe = scores.astype(np.float64).copy()
+	t, b, v = 3, 0, int(labels[0])
+	def loss(sc):
+		e = bnd.GPUArray.empty((), dtype=np.float32)
+		e.fill(0.0)
+		bnd.ctcmod.ctcLoss(gpu(bnd, sc.astype(np.float32)), gpu(bnd, datalen), gpu(bnd, labels), lengths, blank, error=e)
+		return float(e.get())
+	h = 1e-2
+	up, down = probe.copy(), probe.copy()
+	up[t, b, v] += h
+	down[t, b, v] -= h
+	num = (loss(up) - loss(down)) / (2 * h)
+	assert np.isclose(-grad.get()[t, b, v], num, rtol=5e-2, atol=2e-3), "(the kernel leaves the descent direction, Cost/CTC.py)"
