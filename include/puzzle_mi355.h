@@ -153,6 +153,14 @@ int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy,
 int pz_conv_math_set(int products);
 int pz_conv_math_get(int *products);
 
+/* Output tile of the Winograd 3x3 forward / backward-data kernels (ConvFwdAlgo.winograd, Hip/Wrappers/MIOpen.py:28 — MIOpen
+ * picks its Winograd variant itself): 0 = by multiplication count per layer (F(4x4,3x3) where the map fills 4x4 tiles, else
+ * F(2x2,3x3)), 2 = F(2x2,3x3) only, 4 = F(4x4,3x3) on every eligible layer. F(4x4) multiplies 4x less than the direct sum
+ * (F(2x2): 2.25x) and rounds ~8x coarser (about 4e-6 relative L2 in fp32). Process-wide; set it before querying workspace
+ * sizes or preparing filter operands.                                                                                  */
+int pz_conv_winograd_tile_set(int tile);
+int pz_conv_winograd_tile_get(int *tile);
+
 /* Launch-level profiling of the convolution kernels (bench.py's roofline leg; the analogue of the reference's
  * Driver timing hooks, Cuda/GPUBackend.py:332-368): while enabled, every MFMA convolution launch is bracketed by
  * HIP events on the launch stream. collect() synchronises, sums per kernel family and resets.

@@ -252,6 +252,8 @@ class DnnContext:
 	# "split6" / "split9" = exact 3-way bf16 split of every operand, 6 / 9 bf16 partial products, fp32 accumulation
 	MATH = {"f32": 0, "split6": 6, "split9": 9}
 	convMathDefault = os.environ.get("PUZZLE_MI355_MATH", "f32")
+	# Output tile of the Winograd 3x3 kernels (pz_conv_winograd_tile_set): 0 = per layer by multiplication count, 2 / 4 pinned
+	winogradTileDefault = int(os.environ.get("PUZZLE_MI355_WINO_TILE", "0"))
 	sideStreamMaxGflop = float(os.environ.get("PUZZLE_MI355_SIDE_MAX_GFLOP", "15"))      # mean GFLOP per filter-gradient launch
 	sideWorkMean = 0.0
 
@@ -265,6 +267,7 @@ class DnnContext:
 		self.packCache = weakref.WeakKeyDictionary()        # allocation of a filter -> {(offset, pass, algo, geometry): PackEntry}
 		self.convMath = None
 		self.setConvMath(self.convMathDefault)
+		self.setWinogradTile(self.winogradTileDefault)
 
 
 	def setConvMath(self, name):
@@ -276,6 +279,16 @@ class DnnContext:
 		DnnContext.descCache.clear()
 		self.packCache.clear()
 		self.convMath = name
+		return self
+
+
+	def setWinogradTile(self, tile):
+		"""process-wide like the math mode: workspace sizes and prepared filter operands depend on it"""
+		lib.pz_conv_winograd_tile_set(int(tile))
+		self.geometry.clear()
+		DnnContext.descCache.clear()
+		self.packCache.clear()
+		self.winogradTile = int(tile)
 		return self
 
 

@@ -44,6 +44,14 @@ size_t wino_wgrad_workspace_bytes(const pz_conv_desc *d, int P, int Q);
 int wino_wgrad(const pz_conv_desc *d, int P, int Q, const float *x, const float *dy, float *dw, float alpha, float beta,
                void *workspace, hipStream_t st);
 
+// Winograd F(4x4, 3x3) forward / backward-data (wino4.hip), taken by the wino_* entry points above where wino4_pick says so
+bool wino4_pick(const pz_conv_desc *d, int which, int P, int Q);
+size_t wino4_workspace_bytes(const pz_conv_desc *d, int which);
+int wino4_stats_strips(const pz_conv_desc *d, int P, int Q);
+int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st);
+int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
+               void *workspace, hipStream_t st, float *stats, bool filters_ready);
+
 // direct backward-data for stride-2 convolutions with <= 4 input maps (thin.hip): the stem layer
 bool thin_dgrad_eligible(const pz_conv_desc *d, int P, int Q);
 size_t thin_dgrad_workspace_bytes(const pz_conv_desc *d);

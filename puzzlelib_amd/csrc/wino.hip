@@ -1503,6 +1503,7 @@ bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q) {
 }
 
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q) {
+	if (wino4_pick(d, which, P, Q)) return wino4_workspace_bytes(d, which);
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 	return (size_t)ceil_div(prod, KB) * (red / BC) * kUFloats * sizeof(float);
@@ -1510,6 +1511,7 @@ size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q) {
 
 // which = PZ_CONV_FWD: out(N,K,P,Q) = conv(in(N,C,H,W), w) + bias;  PZ_CONV_BWD_DATA: out(N,C,H,W) = conv^T(in(N,K,P,Q), w)
 int wino_stats_strips(const pz_conv_desc *d, int P, int Q) {
+	if (wino4_pick(d, PZ_CONV_FWD, P, Q)) return wino4_stats_strips(d, P, Q);
 #if WN_WAVES == 8
 	return ceil_div((long)d->n * ((P + 1) / 2) * ((Q + 1) / 2), TB);
 #else
@@ -1527,16 +1529,26 @@ static WinoFilterArgs wino_filter_args(const pz_conv_desc *d, int which, int P, 
 	return fa;
 }
 
-int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st) {
+int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n_all, hipStream_t st) {
 	WinoFilterBatch b{};
-	for (int i = 0; i < n; ++i) {
+	const pz_conv_desc *d4[kWinoBatch];
+	int which4[kWinoBatch], n4 = 0, n = 0;
+	const float *w4[kWinoBatch];
+	float *u4[kWinoBatch];
+	for (int i = 0; i < n_all; ++i) {
 		int P, Q;
 		P = (descs[i]->h + 2 * descs[i]->pad_h - 3) + 1, Q = (descs[i]->w + 2 * descs[i]->pad_w - 3) + 1;      // 3x3, stride 1, undilated
-		b.job[i] = wino_filter_args(descs[i], which[i], P, Q, w[i], u[i]);
-		const long ftotal = (long)b.job[i].kblocks * b.job[i].chunks * KB * BC;
-		b.start[i + 1] = b.start[i] + stream_grid(ftotal, 256);
+		if (wino4_pick(descs[i], which[i], P, Q)) {
+			d4[n4] = descs[i], which4[n4] = which[i], w4[n4] = w[i], u4[n4] = u[i], ++n4;
+			continue;
+		}
+		b.job[n] = wino_filter_args(descs[i], which[i], P, Q, w[i], u[i]);
+		const long ftotal = (long)b.job[n].kblocks * b.job[n].chunks * KB * BC;
+		b.start[n + 1] = b.start[n] + stream_grid(ftotal, 256);
+		++n;
 	}
 	b.n = n;
+	if (int rc = wino4_filter_batch(d4, which4, w4, u4, n4, st)) return rc;
 	if (n == 0) return PZ_OK;
 	wino_filter_batch_kernel<<<b.start[n], 256, 0, st>>>(b);
 	PZ_LAUNCH_CHECK();
@@ -1545,6 +1557,7 @@ int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const 
 
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
               void *workspace, hipStream_t st, float *stats, bool filters_ready) {
+	if (wino4_pick(d, which, P, Q)) return wino4_conv(d, which, P, Q, in, w, bias, out, workspace, st, stats, filters_ready);
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 

@@ -1,0 +1,571 @@
+// Winograd F(4x4, 3x3) convolution for gfx950: the 3x3 / stride-1 / undilated / ungrouped forward and backward-data
+// passes on maps large enough to fill 4x4 output tiles (ConvFwdAlgo.winograd of Hip/Wrappers/MIOpen.py:28). 4x fewer
+// multiply-accumulates than the direct sum (F(2x2, 3x3) of wino.hip: 2.25x), all of them on v_mfma_f32_32x32x2_f32:
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 4x4 output tile, 6x6 input patch d, 3x3 filter g
+//
+// with the interpolation points 0, +-1, +-2, inf. Per output pixel everything but the transforms' own arithmetic shrinks by
+// 36/16 : 16/4 = 0.56 against F(2x2): the multiplies, the patch elements gathered, the transformed values through LDS, the
+// transformed filters read. The price is rounding: ~4e-6 relative L2 / 1e-5 of the output scale in fp32 (F(2x2): 5e-7), see
+// DESIGN.md 3.1g and tests/test_gpu_0_ops.py::test_winograd_convolution.
+//
+// One launch; nothing transformed goes through HBM except the filters (36 values per 3x3 filter, pz_conv2d_prepack):
+//   * a workgroup (4 waves, two workgroups per CU: 144 accumulator registers per lane) owns 32 tiles x 32 produced channels x
+//     all 36 transform positions = 36 MFMA tiles; wave w accumulates positions 9w..9w+8;
+//   * the reduction runs over chunks of 4 channels. Wave w gathers channel w of the chunk for all 32 tiles: a lane owns one
+//     row of a 6x6 patch (b128 + b64 buffer loads, zero padding by out-of-range offsets, three rows per lane), applies
+//     (.) B along the row and parks the result in a wave-private LDS block; then a lane owns one COLUMN of a patch, reads its
+//     six values back, applies B^T and leaves V[pos][tile][c] in the stage the MFMAs of chunk + 2 will read (two stages of
+//     18 KB) — the transform costs 18 long-lived registers instead of the 48 a whole half patch per lane would. A position
+//     belongs to one wave, so the transformed filters never need LDS: every wave loads its own A fragments U[pos][k][c]
+//     straight from global memory (L2-resident), and both fragment sets are reloaded in place — for the next chunk — right
+//     after their last use; one barrier per chunk;
+//   * the epilogue passes the accumulators through LDS 8 channels at a time so that one thread holds the 36 positions of a
+//     (tile, channel), applies A^T . A, adds the bias, stores four rows of 16 bytes (lanes along the tile row) and, when
+//     asked, leaves the shifted sums of its 32 tiles for the batch normalisation that follows (the strip format of wino.hip).
+#include "common.h"
+
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef W4_ABL
+#define W4_ABL 0        // timing-only ablations (wrong results): 1 no patch loads, 2 no transform / LDS stores, 4 no MFMAs, 8 no epilogue,
+                        // 16 patch rows from 16-byte aligned offsets, 32 no filter fragment loads in the loop, 64 patches of chunk 0 only
+#endif
+
+namespace {
+
+constexpr unsigned kOOB = 0xffffff00u;      // buffer byte offset beyond every tensor (+16 does not wrap): loads return 0, stores are dropped
+
+constexpr int TB = 32;       // tiles per workgroup
+constexpr int KB = 32;       // produced channels per workgroup
+constexpr int BC = 4;        // reduction channels per chunk
+constexpr int NP = 36;       // transform positions
+constexpr int kV = NP * TB * BC;     // floats of transformed patches per chunk (18 KB)
+constexpr int kU = NP * KB * BC;     // floats of transformed filters per (channel block, chunk) (18 KB)
+
+struct W4FilterArgs {
+	const float *w;          // (K, C, 3, 3)
+	float *u;                // [kblocks][chunks][4 waves]{[4 position pairs][2][KB][2 positions][2], [2][KB][2]}: w4_u_index
+	int mode;                // 0: forward (produced = K, reduction = C); 1: backward-data (produced = C, reduction = K, taps flipped)
+	int K, C;                // dims of w
+	int prod, red;
+	int kblocks, chunks;
+};
+
+// Where U[pos][h][kk][ci] of a (channel block, chunk) lives, in floats: wave pos / 9 reads its nine positions as four 16-byte
+// fragments (two positions each) and one 8-byte fragment per lane (h, kk)
+__device__ __forceinline__ int w4_u_index(int pos, int h, int kk, int ci) {
+	const int wave = pos / 9, local = pos % 9;
+	const int base = wave * (9 * 2 * KB * 2);
+	if (local < 8) return base + (((local >> 1) * 2 + h) * KB + kk) * 4 + (local & 1) * 2 + ci;
+	return base + 4 * (2 * KB * 4) + (h * KB + kk) * 2 + ci;
+}
+
+// one row of G . (g0, g1, g2)
+__device__ __forceinline__ void w4_g_row(float g0, float g1, float g2, float (&o)[6]) {
+	const float s = g0 + g2;
+	o[0] = 0.25f * g0;
+	o[1] = (-1.f / 6.f) * (s + g1);
+	o[2] = (-1.f / 6.f) * (s - g1);
+	const float e = (1.f / 24.f) * g0 + (1.f / 6.f) * g2, f = (1.f / 12.f) * g1;
+	o[3] = e + f;
+	o[4] = e - f;
+	o[5] = g2;
+}
+
+__device__ __forceinline__ void w4_filter_body(const W4FilterArgs &a, long first, long step) {
+	const long total = (long)a.kblocks * a.chunks * KB * BC;
+	for (long i = first; i < total; i += step) {
+		const int ci = (int)(i % 2), kk = (int)((i / 2) % KB), h = (int)((i / (2 * KB)) % 2);
+		const long blk = i / (2 * KB * 2);
+		const int chunk = (int)(blk % a.chunks), kb = (int)(blk / a.chunks);
+		const int k = kb * KB + kk, c = chunk * BC + h * 2 + ci;
+
+		float g[3][3];
+#pragma unroll
+		for (int r = 0; r < 3; ++r)
+#pragma unroll
+			for (int s = 0; s < 3; ++s) {
+				float v = 0.f;
+				if (k < a.prod && c < a.red)
+					v = a.mode == 0 ? a.w[((long)k * a.C + c) * 9 + r * 3 + s] : a.w[((long)c * a.C + k) * 9 + (2 - r) * 3 + (2 - s)];
+				g[r][s] = v;
+			}
+
+		float t[3][6];           // t[s][r] = (G g)[r][s]
+#pragma unroll
+		for (int s = 0; s < 3; ++s) w4_g_row(g[0][s], g[1][s], g[2][s], t[s]);
+		float *dst = a.u + blk * kU;
+#pragma unroll
+		for (int r = 0; r < 6; ++r) {
+			float u[6];
+			w4_g_row(t[0][r], t[1][r], t[2][r], u);
+#pragma unroll
+			for (int s = 0; s < 6; ++s) dst[w4_u_index(r * 6 + s, h, kk, ci)] = u[s];
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256) wino4_filter_kernel(W4FilterArgs a) {
+	w4_filter_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+struct W4FilterBatch {
+	int n, start[pz::kWinoBatch + 1];
+	W4FilterArgs job[pz::kWinoBatch];
+};
+static_assert(sizeof(W4FilterBatch) <= 4000, "kernel arguments");
+
+__global__ void __launch_bounds__(256) wino4_filter_batch_kernel(W4FilterBatch b) {
+	int j = 0;
+	while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
+	const int nb = b.start[j + 1] - b.start[j];
+	w4_filter_body(b.job[j], (long)(blockIdx.x - b.start[j]) * 256 + threadIdx.x, (long)nb * 256);
+}
+
+struct W4Args {
+	const float *x;          // gathered tensor (N, C, H, W)
+	const float *u;          // transformed filters
+	const float *bias;       // per produced channel or NULL
+	float *y;                // (N, K, P, Q)
+	int N, C, H, W, K, P, Q;
+	int pad_h, pad_w;
+	int TY, TX, tiles;       // 4x4 tiles per image column / row, N*TY*TX
+	int chunks, tblocks;
+	unsigned x_bytes, y_bytes;
+	float4 *stats;           // optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count}
+};
+
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+	(f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+	static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// B^T applied to six values along one axis
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&o)[6]) {
+	o[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+	o[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+	const float u = __builtin_fmaf(-4.f, d[2], d[4]), v = __builtin_fmaf(-4.f, d[1], d[3]);
+	o[1] = u + v, o[2] = u - v;
+	const float p = d[4] - d[2], q = d[3] - d[1];
+	o[3] = __builtin_fmaf(2.f, q, p), o[4] = __builtin_fmaf(-2.f, q, p);
+}
+
+// A^T applied to six values: four results
+__device__ __forceinline__ void w4_at(const float (&m)[6], float (&o)[4]) {
+	const float p12 = m[1] + m[2], d12 = m[1] - m[2], p34 = m[3] + m[4], d34 = m[3] - m[4];
+	o[0] = m[0] + p12 + p34;
+	o[1] = __builtin_fmaf(2.f, d34, d12);
+	o[2] = __builtin_fmaf(4.f, p34, p12);
+	o[3] = __builtin_fmaf(8.f, d34, d12) + m[5];
+}
+
+__device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], float *Ms, int kb, int tb, int tid, int pbase, int lane) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+
+	const int t = tb * TB + l31;
+	const bool tv = t < a.tiles;
+	const int n = t / (a.TY * a.TX), rr = t - n * (a.TY * a.TX);
+	const int ty = rr / a.TX, tx = rr - ty * a.TX;
+	bool rowok[4], colok[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) rowok[i] = 4 * ty + i < a.P, colok[i] = 4 * tx + i < a.Q;
+	const bool wide = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(tv && !colok[3]) == 0ull)) != 0;
+	const unsigned pq4 = (unsigned)(a.P * a.Q) * 4u, q4 = (unsigned)a.Q * 4u;
+	const unsigned obase = (unsigned)((((long)n * a.K) * a.P + 4 * ty) * a.Q + 4 * tx) * 4u;
+	const int kk = tid >> 5;                           // 256 threads = 32 tiles x 8 channels
+
+#pragma unroll
+	for (int qq = 0; qq < 4; ++qq) {
+		// accumulator rows 8 qq .. 8 qq + 7 (registers 4 qq .. 4 qq + 3 of both lane halves) -> Ms[position][8 channels][32 tiles]
+#pragma unroll
+		for (int i = 0; i < 9; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) Ms[((pbase + i) * 8 + 4 * lhi + r) * 32 + l31] = acc[i][4 * qq + r];
+		__syncthreads();
+
+		{
+			const int k = kb * KB + qq * 8 + kk;
+			float s[4][6];                             // A^T m, one column of m at a time
+#pragma unroll
+			for (int c = 0; c < 6; ++c) {
+				float m[6], o[4];
+#pragma unroll
+				for (int r = 0; r < 6; ++r) m[r] = Ms[((r * 6 + c) * 8 + kk) * 32 + l31];
+				w4_at(m, o);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) s[i][c] = o[i];
+			}
+			const float b = (a.bias != nullptr && k < a.K) ? a.bias[k] : 0.f;
+			const bool kv = tv && k < a.K;
+			const unsigned o = obase + (unsigned)k * pq4;
+
+			float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				float y[4];
+				w4_at(s[i], y);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) y[j] += b;
+
+				const bool rv = kv && rowok[i];
+				const unsigned orow = o + (unsigned)i * q4;
+				// whole tile rows as 16 bytes; the tile at the right edge of a map whose width is no multiple of 4 word by word
+				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{y[0], y[1], y[2], y[3]}), yr, rv && colok[3] ? orow : kOOB, 0, 0);
+				if (!wide) {
+					const bool edge = rv && !colok[3];
+					__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[0]), yr, edge && colok[0] ? orow : kOOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[1]), yr, edge && colok[1] ? orow + 4u : kOOB, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[2]), yr, edge && colok[2] ? orow + 8u : kOOB, 0, 0);
+				}
+
+				if (a.stats) {
+					// the 32 lanes of a half-wave hold this channel's 32 tiles: shifted sums about the block's first output
+					// (tile tb*TB always exists), fixed shuffle tree -> deterministic
+					if (i == 0) shift = __shfl(y[0], lane & 32);
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const bool ok = rv && colok[j];
+						const float dlt = ok ? y[j] - shift : 0.f;
+						s1 += dlt, s2 = __builtin_fmaf(dlt, dlt, s2), cnt += ok ? 1.f : 0.f;
+					}
+				}
+			}
+			if (a.stats) {
+#pragma unroll
+				for (int msk = 16; msk > 0; msk >>= 1) s1 += __shfl_xor(s1, msk), s2 += __shfl_xor(s2, msk), cnt += __shfl_xor(cnt, msk);
+				if (l31 == 0 && k < a.K) a.stats[(size_t)k * a.tblocks + tb] = make_float4(shift, s1, s2, cnt);
+			}
+		}
+		if (qq < 3) __syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) wino4_conv_kernel(W4Args a) {
+	// two stages of V, then the waves' private blocks of row-transformed patches; the epilogue's block reuses all of it
+	__shared__ __attribute__((aligned(16))) float smem[3 * kV];                  // 54 KB
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const int kb = blockIdx.x / a.tblocks, tb = blockIdx.x - kb * a.tblocks;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)(a.u + (size_t)kb * a.chunks * kU), 0, (unsigned)a.chunks * (kU * 4u), 0x00020000);
+	const unsigned hw4 = (unsigned)(a.H * a.W) * 4u;
+
+	// ---- patch role: channel `wave` of the chunk, tile l31; round r (0-2): image row 2 r + lhi of the patch, then column 2 r + lhi
+	unsigned voff[3];                           // byte offsets of the three rows (below zero as two's complement: see the fixed variant)
+	bool colok[6];
+	bool anyfix = false;
+	{
+		const int t = tb * TB + l31;
+		const bool tv = t < a.tiles;
+		const int n = t / (a.TY * a.TX), r0 = t - n * (a.TY * a.TX);
+		const int ty = r0 / a.TX, tx = r0 - ty * a.TX;
+		const int col0 = 4 * tx - a.pad_w;
+#pragma unroll
+		for (int r = 0; r < 3; ++r) {
+			const int row = 4 * ty - a.pad_h + 2 * r + lhi;
+			const bool ok = tv && (unsigned)row < (unsigned)a.H;
+			const long off = (((long)n * a.C + wave) * a.H + row) * a.W + col0;
+#if W4_ABL & 16
+			voff[r] = ok ? (unsigned)(off * 4) & ~15u : kOOB;
+#else
+			voff[r] = ok ? (unsigned)(off * 4) : kOOB;
+#endif
+			anyfix = anyfix || (ok && off < 0);
+		}
+#pragma unroll
+		for (int j = 0; j < 6; ++j) colok[j] = (unsigned)(col0 + j) < (unsigned)a.W;
+	}
+	anyfix = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(anyfix) != 0ull)) != 0;
+	float *Rs = smem + 2 * kV + wave * (NP * TB) + l31;                                 // + (e * 6 + j) * 32
+	const unsigned vdst = (unsigned)(((wave >> 1) * TB + l31) * 2 + (wave & 1));        // + pos * (TB * BC)
+
+	// ---- MFMA role: positions 9 wave .. 9 wave + 8
+	const int pbase = 9 * wave;
+	const unsigned vfrag = (unsigned)(((pbase * 2 + lhi) * TB + l31) * 2);
+	const unsigned uvoff = (unsigned)((lhi * KB + l31) * 16);      // within a pair's 1 KB; the ninth position's 8-byte fragments: half of it
+	const unsigned uwave = (unsigned)(wave * (9 * 2 * KB * 2 * 4));
+
+	f32x4 sa[3];
+	f32x2 sb[3];                                // staged patch rows (6 floats each)
+	float rt[6];                                // a transformed row / column on its way to LDS
+
+	// row `r` of the next but two chunk. The one workgroup whose first patch starts in front of the tensor loads word by word
+	// and turns offsets below zero into out-of-range ones: they read as the padding they are.
+	auto issue_row = [&](auto fixed, auto rc, int chunk) {
+		constexpr int R = decltype(rc)::value;
+#if !(W4_ABL & 1)
+#if W4_ABL & 64
+		const unsigned soff = 0;
+#else
+		const unsigned soff = (unsigned)chunk * (BC * hw4);
+#endif
+		if constexpr (decltype(fixed)::value) {
+			float v[6];
+#pragma unroll
+			for (int j = 0; j < 6; ++j) {
+				const int o = (int)voff[R] + 4 * j;              // this workgroup's rows sit in the tensor's first image: offsets fit an int
+				v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o < 0 ? kOOB : (unsigned)o, soff, 0));
+			}
+			sa[R] = f32x4{v[0], v[1], v[2], v[3]}, sb[R] = f32x2{v[4], v[5]};
+		} else {
+			sa[R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[R], soff, 0));
+			sb[R] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[R] + 16u, soff, 0));
+		}
+#else
+		(void)chunk;
+#endif
+	};
+
+	// slot S (0-17, one per MFMA of the chunk) of the transform of the staged rows into stage `stg`:
+	//   2 r: row r (.) B;  2 r + 1: parked in the wave's block, the row of chunk `reload` requested;
+	//   6 + 3 c .. 8 + 3 c: column c read back, B^T, stored as V
+	auto patch_slot = [&](auto fixed, auto slot, float *stg, int reload) {
+		constexpr int S = decltype(slot)::value;
+#if W4_ABL & 2
+		return;
+#endif
+		if constexpr (S < 6 && S % 2 == 0) {
+			constexpr int R = S / 2;
+			float d[6];
+#pragma unroll
+			for (int j = 0; j < 6; ++j) d[j] = colok[j] ? (j < 4 ? sa[R][j & 3] : sb[R][j & 1]) : 0.f;
+			w4_bt(d, rt);
+		} else if constexpr (S < 6) {
+			constexpr int R = S / 2;
+#pragma unroll
+			for (int j = 0; j < 6; ++j) Rs[(((2 * R) * 6 + j) * 32) + lhi * (6 * 32)] = rt[j];
+			if (reload >= 0) issue_row(fixed, IC<R>{}, reload);
+		} else if constexpr (S < 15) {
+			constexpr int Cc = (S - 6) / 3, G = (S - 6) % 3;
+			if constexpr (G == 0) {
+#pragma unroll
+				for (int e = 0; e < 6; ++e) rt[e] = Rs[(e * 6 + 2 * Cc) * 32 + lhi * 32];
+			} else if constexpr (G == 1) {
+				float o[6];
+				w4_bt(rt, o);
+#pragma unroll
+				for (int e = 0; e < 6; ++e) rt[e] = o[e];
+			} else {
+				float *dst = stg + vdst + (unsigned)(2 * Cc) * (TB * BC) + lhi * (TB * BC);
+#pragma unroll
+				for (int i = 0; i < 6; ++i) dst[(i * 6) * (TB * BC)] = rt[i];
+			}
+		}
+	};
+
+	f32x16 acc[9];
+	f32x2 bv[9], avs;
+	f32x4 avp[4];                               // A fragments of positions (2 s, 2 s + 1), both reduction steps; avs: position 8
+
+	auto load_b = [&](const float *stg, auto ic) {
+		constexpr int I = decltype(ic)::value;
+		bv[I] = *reinterpret_cast<const f32x2 *>(stg + vfrag + I * (2 * TB * 2));
+	};
+	auto load_a = [&](auto sc, int chunk) {            // s = 0-3: a pair of positions, 4: the ninth
+		constexpr int S = decltype(sc)::value;
+		const unsigned soff = (unsigned)chunk * (kU * 4u) + uwave;
+		if constexpr (S < 4)
+			avp[S] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, uvoff, soff + (unsigned)(S * 2 * KB * 16), 0));
+		else
+			avs = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ur, uvoff >> 1, soff + 4u * (2 * KB * 16), 0));
+	};
+	auto a_of = [&](auto ic, auto s2c) -> float {
+		constexpr int I = decltype(ic)::value, S2 = decltype(s2c)::value;
+		if constexpr (I < 8)
+			return avp[I / 2][(I & 1) * 2 + S2];
+		else
+			return avs[S2];
+	};
+
+	auto run = [&](auto fixed) {
+		const int last = a.chunks - 1;
+
+		// ---- prologue: V(0), V(1) into the two stages, the fragments of chunk 0 into registers
+		static_for<5>([&](auto sc) { load_a(sc, 0); });
+		static_for<3>([&](auto rc) { issue_row(fixed, rc, 0); });
+		static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem, min(1, last)); });
+		static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem + kV, min(2, last)); });
+#pragma unroll
+		for (int i = 0; i < 9; ++i)
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+		__syncthreads();
+		static_for<9>([&](auto ic) { load_b(smem, ic); });
+		__syncthreads();
+
+		for (int ch = 0; ch <= last; ++ch) {
+			const float *rd = smem + ((ch + 1) & 1) * kV;        // V(ch + 1): fragments for the next chunk
+			float *wr = smem + (ch & 1) * kV;                    // V(ch + 2) goes where V(ch) was
+			const int nxt = min(ch + 1, last), reload = min(ch + 3, last);
+
+			static_for<3>([&](auto gc) {
+				constexpr int G = decltype(gc)::value;
+				static_for<6>([&](auto jc) {
+					constexpr int J = decltype(jc)::value, I = 3 * G + J % 3, S2 = J / 3;
+#if !(W4_ABL & 4)
+#ifdef W4_PRIO
+					__builtin_amdgcn_s_setprio(1);
+#endif
+					acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(IC<I>{}, IC<S2>{}), bv[I][S2], acc[I], 0, 0, 0);
+#ifdef W4_PRIO
+					__builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+					patch_slot(fixed, IC<6 * G + J>{}, wr, reload);
+#ifndef W4_NOSB
+					__builtin_amdgcn_sched_barrier(0);
+#endif
+				});
+				// the fragments are reloaded in place for chunk ch + 1 once their positions are through
+				static_for<3>([&](auto jc) { load_b(rd, IC<3 * G + decltype(jc)::value>{}); });
+#if !(W4_ABL & 32)
+				if constexpr (G == 0) {
+					load_a(IC<0>{}, nxt);
+				} else if constexpr (G == 1) {
+					load_a(IC<1>{}, nxt);
+					load_a(IC<2>{}, nxt);
+				} else {
+					load_a(IC<3>{}, nxt);
+					load_a(IC<4>{}, nxt);
+				}
+#endif
+			});
+			__syncthreads();
+		}
+
+#if W4_ABL & 8
+		{
+			float sum = 0.f;
+#pragma unroll
+			for (int i = 0; i < 9; ++i) sum += acc[i][i] + acc[i][15 - i];
+			a.y[(size_t)blockIdx.x * 256 + tid] = sum;
+			return;
+		}
+#endif
+		w4_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
+	};
+
+	if (anyfix)
+		run(IC<1>{});
+	else
+		run(IC<0>{});
+}
+
+}  // namespace
+
+namespace pz {
+
+static void w4_dims(const pz_conv_desc *d, int which, int *prod, int *red) {
+	*prod = which == PZ_CONV_FWD ? d->k : d->c;
+	*red = which == PZ_CONV_FWD ? d->c : d->k;
+}
+
+// F(4x4) where it multiplies less than F(2x2) once the ragged tiles at the right / bottom edge are counted
+// (36 per 16 outputs against 16 per 4), on the same layers wino_eligible admits
+int g_wino_tile = 0;      // pz_conv_winograd_tile_set
+
+bool wino4_pick(const pz_conv_desc *d, int which, int P, int Q) {
+	const int mode = g_wino_tile;
+	if (mode == 2) return false;
+	const int OP = which == PZ_CONV_FWD ? P : d->h, OQ = which == PZ_CONV_FWD ? Q : d->w;      // produced map
+	if (mode == 4) return true;
+	const double c4 = 36.0 * ((OP + 3) / 4) * ((OQ + 3) / 4), c2 = 16.0 * ((OP + 1) / 2) * ((OQ + 1) / 2);
+	return c4 < 0.9 * c2;
+}
+
+size_t wino4_workspace_bytes(const pz_conv_desc *d, int which) {
+	int prod, red;
+	w4_dims(d, which, &prod, &red);
+	return (size_t)ceil_div(prod, KB) * (red / BC) * kU * sizeof(float);
+}
+
+int wino4_stats_strips(const pz_conv_desc *d, int P, int Q) { return ceil_div((long)d->n * ((P + 3) / 4) * ((Q + 3) / 4), TB); }
+
+static W4FilterArgs w4_filter_args(const pz_conv_desc *d, int which, const float *w, float *u) {
+	int prod, red;
+	w4_dims(d, which, &prod, &red);
+	W4FilterArgs fa{};
+	fa.w = w, fa.u = u, fa.mode = which == PZ_CONV_FWD ? 0 : 1;
+	fa.K = d->k, fa.C = d->c, fa.prod = prod, fa.red = red;
+	fa.kblocks = ceil_div(prod, KB), fa.chunks = red / BC;
+	return fa;
+}
+
+int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st) {
+	if (n == 0) return PZ_OK;
+	W4FilterBatch b{};
+	for (int i = 0; i < n; ++i) {
+		b.job[i] = w4_filter_args(descs[i], which[i], w[i], u[i]);
+		const long ftotal = (long)b.job[i].kblocks * b.job[i].chunks * KB * BC;
+		b.start[i + 1] = b.start[i] + stream_grid(ftotal, 256);
+	}
+	b.n = n;
+	wino4_filter_batch_kernel<<<b.start[n], 256, 0, st>>>(b);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
+               void *workspace, hipStream_t st, float *stats, bool filters_ready) {
+	W4FilterArgs fa = w4_filter_args(d, which, w, (float *)workspace);
+	if (!filters_ready) {
+		const long ftotal = (long)fa.kblocks * fa.chunks * KB * BC;
+		wino4_filter_kernel<<<stream_grid(ftotal, 256), 256, 0, st>>>(fa);
+		PZ_LAUNCH_CHECK();
+	}
+
+	W4Args a{};
+	a.x = in, a.u = (const float *)workspace, a.bias = bias, a.y = out;
+	a.N = d->n, a.C = fa.red, a.K = fa.prod;
+	if (which == PZ_CONV_FWD) {
+		a.H = d->h, a.W = d->w, a.P = P, a.Q = Q, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
+	} else {
+		a.H = P, a.W = Q, a.P = d->h, a.Q = d->w, a.pad_h = 2 - d->pad_h, a.pad_w = 2 - d->pad_w;
+	}
+	a.TY = (a.P + 3) / 4, a.TX = (a.Q + 3) / 4, a.tiles = a.N * a.TY * a.TX;
+	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB);
+	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
+	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
+	a.stats = reinterpret_cast<float4 *>(stats);
+	wino4_conv_kernel<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+}  // namespace pz
+
+extern "C" {
+
+int pz_conv_winograd_tile_set(int tile) {
+	PZ_REQUIRE(tile == 0 || tile == 2 || tile == 4, "pz_conv_winograd_tile_set: %d is not one of 0 (by cost), 2, 4", tile);
+	pz::g_wino_tile = tile;
+	return PZ_OK;
+}
+
+int pz_conv_winograd_tile_get(int *tile) {
+	PZ_REQUIRE(tile != nullptr, "pz_conv_winograd_tile_get: null output");
+	*tile = pz::g_wino_tile;
+	return PZ_OK;
+}
+
+}  // extern "C"

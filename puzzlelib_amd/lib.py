@@ -122,6 +122,8 @@ _PROTOS = {
 	"pz_conv2d_algo_used": [POINTER(ConvDesc), c_int, c_int, POINTER(c_int)],
 	"pz_conv_math_set": [c_int],
 	"pz_conv_math_get": [POINTER(c_int)],
+	"pz_conv_winograd_tile_set": [c_int],
+	"pz_conv_winograd_tile_get": [POINTER(c_int)],
 	"pz_conv_profile_enable": [c_int],
 	"pz_conv_profile_collect": [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_longlong)],
 
@@ -256,7 +258,8 @@ def _bind(name, argtypes):
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
-	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get"
+	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get",
+	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get"
 }
 _fake = {"next": 0x7000_0000_0000}
 

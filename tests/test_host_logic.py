@@ -242,8 +242,20 @@ def test_convolution_family_resolution_without_device():
 			assert used(desc, which, lib.CONV_ALGO_AUTO) == lib.CONV_ALGO_IMPLICIT_GEMM
 
 	size = ctypes.c_size_t()
+	tile = ctypes.c_int(-1)
+	lib.pz_conv_winograd_tile_get(ctypes.byref(tile))
+	assert tile.value == 0                                  # per layer by multiplication count
 	lib.pz_conv2d_workspace_bytes(ctypes.byref(c3), lib.CONV_FWD, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
-	assert size.value == 2 * 32 * 16 * 64 * 4 * 4          # 2 channel blocks x 32 chunks x 16 positions x 64 x 4 floats
+	assert size.value == 4 * 32 * 36 * 32 * 4 * 4          # F(4x4): 4 channel blocks x 32 chunks x 36 positions x 32 x 4 floats
+	lib.pz_conv_winograd_tile_set(2)
+	lib.pz_conv2d_workspace_bytes(ctypes.byref(c3), lib.CONV_FWD, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
+	assert size.value == 2 * 32 * 16 * 64 * 4 * 4          # F(2x2): 2 channel blocks x 32 chunks x 16 positions x 64 x 4 floats
+	small = ConvDesc(8, 64, 6, 6, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1)            # 6x6 map: 2x2 tiles of 4x4 cost what 3x3 tiles of 2x2 do
+	lib.pz_conv_winograd_tile_set(0)
+	lib.pz_conv2d_workspace_bytes(ctypes.byref(small), lib.CONV_FWD, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
+	assert size.value == 1 * 16 * 16 * 64 * 4 * 4          # ... so it stays with F(2x2)
+	with pytest.raises(ValueError, match="not one of"):
+		lib.pz_conv_winograd_tile_set(3)
 	lib.pz_conv2d_workspace_bytes(ctypes.byref(c3), lib.CONV_BWD_FILTER, lib.CONV_ALGO_WINOGRAD, ctypes.byref(size))
 	assert 0 < size.value < 1 << 30
 

@@ -1,0 +1,16 @@
+#!/bin/bash
+# development aid: builds variants of wino4.hip with extra -D flags: bash tools/dev/w4_var.sh build name "-DFLAG" ...; run name...
+cd "$(dirname "$0")/../.."
+mode=$1; shift
+if [ "$mode" = build ]; then
+	mkdir -p tools/dev/abl
+	name=$1; shift
+	hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c puzzlelib_amd/csrc/wino4.hip -o tools/dev/abl/wino4_$name.o || exit 1
+	objs=$(ls puzzlelib_amd/csrc/build/*.o | grep -v wino4.o)
+	hipcc --offload-arch=gfx950 -shared -fPIC -o tools/dev/abl/lib_$name.so $objs tools/dev/abl/wino4_$name.o -ldl || exit 1
+else
+	for v in "$@"; do
+		echo "== $v"
+		PUZZLE_MI355_LIB=$PWD/tools/dev/abl/lib_$v.so timeout 300 python tools/dev/w4_time.py 2>&1 | grep -v Warn
+	done
+fi

@@ -1,8 +1,8 @@
 """
-Winograd F(2x2, 3x3) against the implicit GEMM on the device: max abs difference and time per pass for the 3x3 layers of
-the ResNet-50 census plus ragged shapes. Development tool (parity proper lives in tests/).
+Winograd (F(2x2, 3x3) or F(4x4, 3x3): --tile) against the implicit GEMM on the device: max abs difference and time per pass
+for the 3x3 layers of the ResNet-50 census plus ragged shapes. Development tool (parity proper lives in tests/).
 
-    python tools/wino_check.py [--reps 10]
+    python tools/wino_check.py [--reps 10] [--tile 0|2|4]
 """
 import argparse, os, sys
 
@@ -21,11 +21,13 @@ def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--reps", type=int, default=10)
 	ap.add_argument("--only", type=int, default=-1)
+	ap.add_argument("--tile", type=int, default=0)
 	args = ap.parse_args()
 
 	from puzzlelib_amd import backend, lib
 	bnd = backend.getBackend(0, initmode=2)
 	G, dnn = bnd.GPUArray, bnd.dnn
+	dnn.setWinogradTile(args.tile)
 	rng = np.random.RandomState(0)
 
 	def timed(fn):
