@@ -471,6 +471,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 		run(IC<0>{});
 }
 
+
 }  // namespace
 
 namespace pz {
@@ -551,6 +552,7 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
+
 
 }  // namespace pz
 

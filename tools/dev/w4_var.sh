@@ -11,6 +11,6 @@ if [ "$mode" = build ]; then
 else
 	for v in "$@"; do
 		echo "== $v"
-		PUZZLE_MI355_LIB=$PWD/tools/dev/abl/lib_$v.so timeout 300 python tools/dev/w4_time.py 2>&1 | grep -v Warn
+		PUZZLE_MI355_LIB=$PWD/tools/dev/abl/lib_$v.so timeout 300 python tools/dev/w4_time.py $W4ARGS 2>&1 | grep -v Warn
 	done
 fi
