@@ -34,7 +34,7 @@ FLOP_CONV1_DGRAD = 0.236e9       # per image; executed on the drop-in path, not 
 WINO_FLOP_PER_IMAGE = 3 * 3.67482e9             # direct-convolution FLOP of the 16 3x3 stride-1 layers, three passes
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 FAMILY = ["igemm_conv_kernel<128,128> (fwd + bwd-data)", "igemm_conv_kernel<64,256> (fwd + bwd-data)",
-		  "wgrad_conv_kernel (bwd-filter)", "wino_conv_kernel / wino_wgrad_kernel F(2x2,3x3) (all three passes of the 3x3 layers)"]
+		  "wgrad_conv_kernel (bwd-filter)", "Winograd 3x3: wino4_conv_kernel F(4x4,3x3) (fwd, bwd-data) + wino_wgrad_kernel F(2x2,3x3) (bwd-filter)"]
 NFAM = len(FAMILY)
 ROOF_STEPS = 3
 
@@ -390,8 +390,9 @@ def main():
 					"launches": int(timed[i][2]), "avg_launch_ms": timed[i][0] / timed[i][2],
 					"apparent_tflops": timed[i][1] / (timed[i][0] * 1e-3) / 1e12
 				}
-			if i == 3:         # direct-convolution FLOP / time; the matrix pipe executes 1/2.25 of them
-				fams[-1]["note"] = "algorithmic (direct-convolution) TFLOP/s; MFMA-executed = achieved / 2.25"
+			if i == 3:         # direct-convolution FLOP / time; the matrix pipe executes 1/4 (F(4x4)) or 1/2.25 (F(2x2)) of them
+				fams[-1]["note"] = ("algorithmic (direct-convolution) TFLOP/s; the matrix pipe executes 1/4 of the forward / "
+									"backward-data share (F(4x4,3x3)) and 1/2.25 of the backward-filter share (F(2x2,3x3))")
 	dom = max(range(NFAM), key=lambda i: ms[i])
 	achieved = flops[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
 
@@ -419,7 +420,8 @@ def main():
 		pass
 
 	per_gpu = images_per_sec / world
-	executed = (FLOP_PER_IMAGE - WINO_FLOP_PER_IMAGE * (1.0 - 1.0 / 2.25) + FLOP_CONV1_DGRAD) * per_gpu / 1e12
+	wino_executed = WINO_FLOP_PER_IMAGE * (2.0 / 3.0 / 4.0 + 1.0 / 3.0 / 2.25)      # fwd + bwd-data on F(4x4), bwd-filter on F(2x2)
+	executed = (FLOP_PER_IMAGE - WINO_FLOP_PER_IMAGE + wino_executed + FLOP_CONV1_DGRAD) * per_gpu / 1e12
 	result = {
 		"metric": "images/sec fwd+bwd+Adam ResNet-50 224x224 fp32 b256 per GPU", "value": images_per_sec,
 		"unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,8 +447,9 @@ def main():
 		"model_tflops_per_gpu": per_gpu * FLOP_PER_IMAGE / 1e12,
 		"pct_of_f32_mfma_peak": per_gpu * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,
 		"pct_of_f32_mfma_peak_executed": executed / PEAK_F32_MFMA_TFLOPS * 100.0,
-		"pct_executed_note": "FLOP the matrix pipe actually executes per step: the 3x3 layers' Winograd kernels do 1/2.25 of "
-							 "their direct-convolution share; conv1's input gradient is executed and counted here",
+		"pct_executed_note": "FLOP the matrix pipe actually executes per step: the 3x3 layers' Winograd kernels do 1/4 (forward, "
+							 "backward-data: F(4x4,3x3)) and 1/2.25 (backward-filter: F(2x2,3x3)) of their direct-convolution share, "
+							 "tile padding not counted; conv1's input gradient is executed and counted here",
 		"final_loss": loss,
 		"pool_out_of_memory_events": oomEvents(lib),
 		"timed_region_host": {

@@ -164,8 +164,8 @@ int pz_conv_winograd_tile_get(int *tile);
 /* Launch-level profiling of the convolution kernels (bench.py's roofline leg; the analogue of the reference's
  * Driver timing hooks, Cuda/GPUBackend.py:332-368): while enabled, every MFMA convolution launch is bracketed by
  * HIP events on the launch stream. collect() synchronises, sums per kernel family and resets.
- * family: 0 = igemm 128x128 tile, 1 = igemm 64x256 tile, 2 = backward-filter (all tiles), 3 = Winograd F(2x2,3x3)
- * (forward, backward-data and backward-filter of 3x3 stride-1 layers). `total_flops` is the algorithmic (direct-convolution) count in every family; the Winograd
+ * family: 0 = igemm 128x128 tile, 1 = igemm 64x256 tile, 2 = backward-filter (all tiles), 3 = Winograd
+ * (forward, backward-data and backward-filter of 3x3 stride-1 layers; F(4x4,3x3) / F(2x2,3x3) tiles, see pz_conv_winograd_tile_set). `total_flops` is the algorithmic (direct-convolution) count in every family; the Winograd
  * kernel executes 1/2.25 of it on the matrix pipe (times the padding of odd maps to whole 2x2 tiles).            */
 #define PZ_CONV_PROFILE_FAMILIES 4
 int pz_conv_profile_enable(int on);
