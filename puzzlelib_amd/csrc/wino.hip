@@ -1494,10 +1494,13 @@ static void wino_dims(const pz_conv_desc *d, int which, int P, int Q, int *prod,
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q) {
 	if (which != PZ_CONV_FWD && which != PZ_CONV_BWD_DATA) return false;
 	if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
-	if (d->pad_h != d->pad_w || d->pad_h > 1) return false;      // the shifted-row fix-up of the first tensor row assumes one padding column
+	if (d->pad_h != d->pad_w || d->pad_h > 1) return false;
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 	if (red % BC != 0) return false;
+	// backward-data of an unpadded layer pads by 2: the F(2x2) kernel's patch code assumes at most one padding column (its
+	// second column is never masked, the first tensor row is shifted by one) — only the F(4x4) kernel serves that case
+	if (which == PZ_CONV_BWD_DATA && d->pad_h == 0 && !wino4_pick(d, which, P, Q)) return false;
 	const size_t lim = 0xfffffff0u;
 	return (size_t)d->n * d->c * d->h * d->w * 4 < lim && (size_t)d->n * d->k * P * Q * 4 < lim;
 }

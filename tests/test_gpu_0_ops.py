@@ -625,6 +625,8 @@ def test_deconv_layer(bnd, groups):
 	dict(n=2, c=8, k=8, hw=(6, 6), pad=1),             # the launch's first tile: its first row starts in front of the tensor
 	dict(n=3, c=12, k=20, hw=(7, 9), pad=1),           # odd maps: half tiles at the right / bottom edge, ragged channel block
 	dict(n=2, c=16, k=70, hw=(5, 8), pad=0),           # no padding, two channel blocks
+	dict(n=2, c=16, k=24, hw=(9, 10), pad=0),          # no padding: backward-data pads by 2 (F(4x4): its first patch row starts 2 in
+	                                                   # front of the tensor; F(2x2) hands that pass to the implicit GEMM)
 	dict(n=5, c=36, k=96, hw=(14, 14), pad=1),         # 9 chunks: every pipeline stage and fragment set, tiles = 245 (ragged)
 	dict(n=1, c=4, k=3, hw=(3, 3), pad=1),             # a single chunk, fewer tiles than a block
 	dict(n=4, c=64, k=64, hw=(55, 55), pad=1),         # the reference network's odd stage-2 maps
