@@ -23,6 +23,7 @@ def surf(bnd):
 	yield bound()
 	lazy.enabled, lazy.disabled = True, set()
 	backend.DnnContext.convStatsPolicy = "adaptive"
+	bnd.dnn.setWinogradTile(bnd.dnn.winogradTileDefault)
 
 
 def both(fn):
@@ -124,12 +125,18 @@ def test_described_tensor_sees_the_inputs_of_call_time(surf):
 								 # Winograd (auto): tile blocks with explicit counts — odd maps (border tiles hold 1 or 2 pixels), a last
 								 # block of fewer than 32 tiles, output channels that do not fill a block of 64
 								 dict(n=3, c=32, k=64, hw=(11, 13), r=3, algo="auto"), dict(n=5, c=64, k=96, hw=(7, 7), r=3, algo="auto"),
-								 dict(n=2, c=128, k=128, hw=(28, 28), r=3, algo="auto"), dict(n=1, c=32, k=40, hw=(5, 6), r=3, pad=0, algo="auto")])
-def test_convolution_statistics_feed_the_batchnorm(surf, cfg):
+								 dict(n=2, c=128, k=128, hw=(28, 28), r=3, algo="auto"), dict(n=1, c=32, k=40, hw=(5, 6), r=3, pad=0, algo="auto"),
+								 # the same through the F(4x4, 3x3) kernel's epilogue (strips of 32 tiles of 16 pixels, counted): ragged
+								 # maps, fewer than 32 tiles, a channel block that is not full, several tile blocks
+								 dict(n=3, c=32, k=64, hw=(11, 13), r=3, algo="auto", tile=4), dict(n=5, c=64, k=96, hw=(7, 7), r=3, algo="auto", tile=4),
+								 dict(n=1, c=32, k=40, hw=(5, 6), r=3, pad=0, algo="auto", tile=4),
+								 dict(n=6, c=64, k=64, hw=(28, 28), r=3, algo="auto", tile=4)])
+def test_convolution_statistics_feed_the_batchnorm(surf, bnd, cfg):
 	"""Conv2D -> BatchNorm2D: the convolution's epilogue leaves per-strip sums and the batch-norm skips its statistics
 	pass (policy "always"; "adaptive" learns it after the first pass). Same mean / variance up to summation order."""
 	from puzzlelib_amd import backend, lazy
 	g, Dnn = surf.gpuarray, surf.Dnn
+	bnd.dnn.setWinogradTile(cfg.get("tile", 0))          # (the fixture restores the default)
 	rng = np.random.RandomState(5)
 	n, c, k, (h, w), r = cfg["n"], cfg["c"], cfg["k"], cfg["hw"], cfg["r"]
 	stride, pad = cfg.get("stride", 1), cfg.get("pad", r // 2)
