@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 	auto run = [&](auto fixed) {
 		const int last = a.chunks - 1;
+#ifdef W4_DUMMY_VALU
+		float dummy = 1.f;
+#endif
 
 		// ---- prologue: V(0), V(1) into the two stages, the fragments of chunk 0 into registers
 		static_for<5>([&](auto sc) { load_a(sc, 0); });
@@ -432,6 +435,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #endif
 #endif
 					patch_slot(fixed, IC<6 * G + J>{}, wr, reload);
+#ifdef W4_DUMMY_VALU      // measurement aid: N extra vector instructions behind every MFMA (experiment 12: they cost their full issue time)
+#pragma unroll
+					for (int dv = 0; dv < W4_DUMMY_VALU; ++dv) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+#endif
 #ifndef W4_NOSB
 					__builtin_amdgcn_sched_barrier(0);
 #endif
