@@ -697,6 +697,41 @@ def winograd_convolution_case(bnd, cfg, tol):
 	assert np.array_equal(bnd.dnn.convNdBackwardParams(gx, gdy, gw, algo=wino, **kw).get(), dw.get())
 
 
+@pytest.mark.parametrize("tile", [2, 4])
+def test_winograd_random_shapes_vs_oracle(bnd, tile):
+	"""40 seeded random 3x3 / stride-1 layers per tile (maps 3..23 wide and high, ragged against 2x2 and 4x4 tiles, pad 0 or 1,
+	1..12 images, channel counts that leave partial blocks and 1..12 reduction chunks), forward with bias and backward-data
+	with the Winograd algorithm pinned, against the fp64 oracle; tolerance as in test_winograd_convolution. Where a pass is
+	not a Winograd problem for the pinned tile (reduction channels no multiple of 4; unpadded backward-data on 2x2 tiles)
+	the request resolves to the implicit GEMM and the comparison still holds."""
+	rng = np.random.RandomState(4100 + tile)
+	tol = 2e-5 if tile == 2 else 6e-5
+	bnd.dnn.setWinogradTile(tile)
+	try:
+		for _ in range(40):
+			n, h, w_ = int(rng.randint(1, 13)), int(rng.randint(3, 24)), int(rng.randint(3, 24))
+			c, k = int(rng.choice([4, 8, 12, 20, 36, 48])), int(rng.choice([3, 8, 24, 40, 64, 72]))
+			pad = int(rng.randint(0, 2))
+			if h + 2 * pad < 3 or w_ + 2 * pad < 3:
+				continue
+			kw = dict(stride=(1, 1), pad=(pad, pad), dilation=(1, 1), groups=1)
+			x = rng.randn(n, c, h, w_).astype(np.float32)
+			wt = (rng.randn(k, c, 3, 3) / np.sqrt(9 * c)).astype(np.float32)
+			bias = rng.randn(k).astype(np.float32)
+			what = "n=%d c=%d k=%d %dx%d pad=%d tile=%d" % (n, c, k, h, w_, pad, tile)
+
+			y = bnd.dnn.convNd(gpu(bnd, x), gpu(bnd, wt), gpu(bnd, bias), algo=bnd.ConvFwdAlgo.winograd.value, **kw)
+			y_ref = R.conv2d_fwd(x, wt, bias, acc=np.float64, **kw)
+			assert_close(y.get(), y_ref, atol=tol * max(1.0, float(np.abs(y_ref).max())), rtol=0, what="forward, " + what)
+
+			dy = rng.randn(*y_ref.shape).astype(np.float32)
+			dx = bnd.dnn.convNdBackwardData(gpu(bnd, dy), gpu(bnd, wt), None, gpu(bnd, x), algo=bnd.ConvBwdDataAlgo.winograd.value, **kw)
+			dx_ref = R.conv2d_bwd_data(dy, wt, x.shape, acc=np.float64, **kw)
+			assert_close(dx.get(), dx_ref, atol=tol * max(1.0, float(np.abs(dx_ref).max())), rtol=0, what="backward-data, " + what)
+	finally:
+		bnd.dnn.setWinogradTile(bnd.dnn.winogradTileDefault)
+
+
 def test_optimize_for_shape_enumerates_kernel_families(bnd):
 	"""Modules/ConvND.py:52-61 optimizeForShape over convNdbenchmark (Hip/Wrappers/MIOpen.py:465-519): every family that
 	serves the layer is timed — for a wide 3x3 layer implicit GEMM, Winograd and direct — the fastest within the memory
