@@ -138,7 +138,7 @@ struct W4Args {
 	int N, C, H, W, K, P, Q;
 	int pad_h, pad_w;
 	int TY, TX, tiles;       // 4x4 tiles per image column / row, N*TY*TX
-	int chunks, tblocks;
+	int chunks, tblocks, kblocks;
 	unsigned x_bytes, y_bytes;
 	float4 *stats;           // optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count}
 };
@@ -263,7 +263,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int l31 = lane & 31, lhi = lane >> 5;
-	const int kb = blockIdx.x / a.tblocks, tb = blockIdx.x - kb * a.tblocks;
+	// block b runs on XCD b % 8: the channel blocks of one tile block go side by side to one XCD and share its patches in that
+	// XCD's L2 (-3 % on the 55x55 and 28x28 layers; the grid is padded to whole groups of 8 tile blocks)
+	const int xl = blockIdx.x >> 3, kb = xl % a.kblocks, tb = (xl / a.kblocks) * 8 + (blockIdx.x & 7);
+	if (tb >= a.tblocks) return;
 
 	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
 	const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(
@@ -557,11 +560,11 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 		a.H = P, a.W = Q, a.P = d->h, a.Q = d->w, a.pad_h = 2 - d->pad_h, a.pad_w = 2 - d->pad_w;
 	}
 	a.TY = (a.P + 3) / 4, a.TX = (a.Q + 3) / 4, a.tiles = a.N * a.TY * a.TX;
-	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB);
+	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB), a.kblocks = fa.kblocks;
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
 	a.stats = reinterpret_cast<float4 *>(stats);
-	wino4_conv_kernel<<<a.tblocks * fa.kblocks, 256, 0, st>>>(a);
+	wino4_conv_kernel<<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
