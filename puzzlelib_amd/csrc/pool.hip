@@ -340,9 +340,11 @@ __global__ void __launch_bounds__(256) pool_global_avg_bwd_kernel(const float *_
 		for (int e = 0; i + e < total; ++e) dx[i + e] = v[e];
 }
 
+// (a 1 x 1 plane is excluded: ceil(2^32 / 1) does not fit the 32-bit magic of the backward kernel, and the generic kernels
+// copy such a tensor just as well)
 inline bool pool_is_global_avg(const pz_pool_desc *d, int P, int Q) {
 	return d->mode != 0 && P == 1 && Q == 1 && d->pad_h == 0 && d->pad_w == 0 && d->size_h == d->h && d->size_w == d->w &&
-	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32) && d->h * d->w < (1 << 16);
+	       (size_t)d->n * d->c * d->h * d->w < ((size_t)1 << 32) && d->h * d->w < (1 << 16) && d->h * d->w >= 2;
 }
 
 // windows the LDS kernels are instantiated for: square 2x2/2, 3x3/2, 3x3/1
