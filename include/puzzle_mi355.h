@@ -106,6 +106,9 @@ int pz_conv2d_out_shape(const pz_conv_desc *d, int *p, int *q);
  * under the requested `algo` (what convNdbenchmark, Hip/Wrappers/MIOpen.py:465-519, enumerates and times). */
 int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used);
 int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
+/* ... the same for a pass that is handed a prepared filter operand (pz_conv2d_fwd_pre / pz_conv2d_bwd_data_pre): only what
+ * the launch itself needs (slabs of k-sliced tiles), not a second copy of the packed filters. */
+int pz_conv2d_workspace_bytes_pre(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
 /* y = conv(x, w) (+ bias[k] when bias != NULL) */
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                   int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
@@ -368,9 +371,10 @@ enum pz_eltwise_op {
 	PZ_OP_L1_PENALTY,         /* outgrad, ingrad, data; a                                      */
 	PZ_OP_L1_GRAD,            /* grad, pred, target; norm                                      */
 	PZ_OP_RBM,                /* out, in, uni                                                  */
-	PZ_OP_ADAM,               /* param, grad, mg, ms; learnRate, fix1, fix2, epsilon           */
-	PZ_OP_CLASSIC_MOM_SGD,    /* param, grad, mom; learnRate, momRate                          */
-	PZ_OP_NESTEROV_MOM_SGD,   /* param, grad, mom; learnRate, momRate                          */
+	PZ_OP_ADAM,               /* param, grad, mg, ms; learnRate, fix1, fix2, epsilon, gradScale (the gradient is read as
+	                           * grad * gradScale: 1, or 1/N behind a data-parallel sum — Grid.py:126-133) */
+	PZ_OP_CLASSIC_MOM_SGD,    /* param, grad, mom; learnRate, momRate, gradScale               */
+	PZ_OP_NESTEROV_MOM_SGD,   /* param, grad, mom; learnRate, momRate, gradScale               */
 	PZ_OP_RMSPROP,            /* param, grad, ms; learnRate, factor, epsilon                   */
 	PZ_OP_ADAGRAD,            /* param, grad, h; learnRate, epsilon                            */
 	PZ_OP_ADADELTA,           /* param, grad, msg, msdx; rho, epsilon                          */

@@ -28,8 +28,12 @@ except ImportError:
 
 
 class CpuNet:
-	def __init__(self, spec, params, attrs=None, bn_epsilon=1e-5, bn_init_factor=1.0, bn_min_factor=0.1):
-		"""params: {"<name>.W": ndarray, ...}; attrs: {"<name>.mean"/".var": ndarray} for BN running stats."""
+	def __init__(self, spec, params, attrs=None, bn_epsilon=1e-5, bn_init_factor=1.0, bn_min_factor=0.1, acc=np.float32):
+		"""params: {"<name>.W": ndarray, ...}; attrs: {"<name>.mean"/".var": ndarray} for BN running stats.
+		acc: accumulation type INSIDE the convolution / GEMM / batch-norm reductions (np.float64: every operator is the
+		correctly rounded fp32 result of its fp32 inputs — what a device result is measured against when the fp32 sums' own
+		rounding matters, as it does 53 layers deep); tensors between operators stay fp32 either way."""
+		self.acc = acc
 		self.spec = spec
 		self.params = {k: np.array(v, dtype=np.float32) for k, v in params.items()}
 		self.attrs = {k: np.array(v, dtype=np.float32) for k, v in (attrs or {}).items()}
@@ -52,7 +56,7 @@ class CpuNet:
 			if kind == "conv":
 				_, name, _, _, _, stride, pad, bias = layer
 				self.cache[key] = x
-				x = R.conv2d_fwd(x, self.params[name + ".W"], self.params[name + ".b"] if bias else None, stride, pad)
+				x = R.conv2d_fwd(x, self.params[name + ".W"], self.params[name + ".b"] if bias else None, stride, pad, acc=self.acc)
 
 			elif kind == "bn":
 				name = layer[1]
@@ -64,7 +68,7 @@ class CpuNet:
 					self.numOfProps[name] = n
 					factor = max(self.initFactor / n, self.minFactor)
 
-					y, smean, sinv = R.bn_fwd_train(x, scale, bias, mean, var, self.eps, factor)
+					y, smean, sinv = R.bn_fwd_train(x, scale, bias, mean, var, self.eps, factor, acc=self.acc)
 					self.cache[key] = (x, smean, sinv)
 					x = y
 				else:
@@ -96,7 +100,7 @@ class CpuNet:
 			elif kind == "linear":
 				name = layer[1]
 				self.cache[key] = x
-				x = R.gemm(x, self.params[name + ".W"])
+				x = R.gemm(x, self.params[name + ".W"], acc=self.acc)
 				x = R.add_vec_to_mat(self.params[name + ".b"], x, axis=1)
 
 			elif kind == "softmax":
@@ -127,17 +131,17 @@ class CpuNet:
 				_, name, _, _, _, stride, pad, bias = layer
 				x, W = self.cache[key], self.params[name + ".W"]
 
-				dx = R.conv2d_bwd_data(g, W, x.shape, stride, pad)
+				dx = R.conv2d_bwd_data(g, W, x.shape, stride, pad, acc=self.acc)
 				R.conv2d_bwd_filter(
 					x, g, W.shape, stride, pad, withbias=bias, wgrad=self.grads[name + ".W"],
-					bgrad=self.grads[name + ".b"] if bias else None, scale=scale, momentum=momentum
+					bgrad=self.grads[name + ".b"] if bias else None, scale=scale, momentum=momentum, acc=self.acc
 				)
 				g = dx
 
 			elif kind == "bn":
 				name = layer[1]
 				x, smean, sinv = self.cache[key]
-				g, dscale, dbias = R.bn_bwd(g, x, self.params[name + ".scale"].ravel(), smean, sinv)
+				g, dscale, dbias = R.bn_bwd(g, x, self.params[name + ".scale"].ravel(), smean, sinv, acc=self.acc)
 
 				for pname, d in ((".scale", dscale), (".bias", dbias)):
 					gr = self.grads[name + pname]
@@ -165,9 +169,9 @@ class CpuNet:
 				name = layer[1]
 				x, W = self.cache[key], self.params[name + ".W"]
 
-				dx = R.gemm(g, W, transpB=True)
-				R.gemm(x, g, out=self.grads[name + ".W"], transpA=True, alpha=scale, beta=momentum)
-				R.matsum(g, axis=0, out=self.grads[name + ".b"], alpha=scale, beta=momentum)
+				dx = R.gemm(g, W, transpB=True, acc=self.acc)
+				R.gemm(x, g, out=self.grads[name + ".W"], transpA=True, alpha=scale, beta=momentum, acc=self.acc)
+				R.matsum(g, axis=0, out=self.grads[name + ".b"], alpha=scale, beta=momentum, acc=self.acc)
 				g = dx
 
 			elif kind == "softmax":

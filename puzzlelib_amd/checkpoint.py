@@ -9,6 +9,10 @@ indices, group `links` maps "<module path>.<param>" to an index (so tied variabl
 (h5py is not part of this image); with h5py importable, `format="hdf5"` writes the identical structure as HDF5 groups and
 datasets. `layer` is the spec's layer name (= the reference's module name for the shipped networks).
 
+`load` also reads what the REFERENCE writes: "<net>.<module>.<field>" entry names (assumeUniqueNames=True, the form
+Models/Nets/ResNet.py:118-119 loads) or container-qualified ones, no `meta` entry — tests/golden/refckpt_mini_*.npz are
+the reference's own Module.save output (oracle/make_checkpoint_fixture.py), tests/test_gpu_5_nets.py loads them.
+
 What a round trip must restore for training to continue bit for bit: parameters, running mean / variance, the batch-norm
 layers' pass counters (their momentum factor is 1/passes until it reaches minFactor, Modules/BatchNormND.py:55-58), the
 optimizer's step count and state tensors.
@@ -69,24 +73,56 @@ def read(path):
 		return {k.replace("|", "/"): z[k] for k in z.files}
 
 
-def load(net, path, optimizer=None):
-	"""Restores `net` (and `optimizer`, which must already be set up on it the same way) from a checkpoint."""
-	tensors = read(path)
-	meta = json.loads(bytes(tensors["meta/json"]).decode())
+def resolver(tensors, group, path):
+	"""-> function("<layer>.<field>") -> key of that entry in `group`.
 
+	This package writes "<layer>.<field>". The reference writes "<net>.<module>.<field>" with assumeUniqueNames=True (how
+	Models/Nets/ResNet.py:118-119 loads) and "<net>.<container>. ... .<module>.<field>" without (Modules/Module.py:187-203,
+	Containers/Container.py:149-153): its entries are found by their last two name components, which is exactly the
+	identity assumeUniqueNames relies on; an entry name claimed by two different modules is refused."""
+	prefix = group + "/"
+	exact, tails = {}, {}
+	for key in tensors:
+		if key.startswith(prefix):
+			name = key[len(prefix):]
+			exact[name] = key
+			tails.setdefault(".".join(name.split(".")[-2:]), []).append(key)
+
+	def find(name):
+		if name in exact:
+			return exact[name]
+		hits = tails.get(name, [])
+		if len(hits) == 1:
+			return hits[0]
+		if not hits:
+			raise KeyError("checkpoint %s has no entry %s%s" % (path, prefix, name))
+		raise KeyError("checkpoint %s: %s%s is ambiguous (%s)" % (path, prefix, name, ", ".join(sorted(hits))))
+	return find
+
+
+def load(net, path, optimizer=None):
+	"""Restores `net` (and `optimizer`, which must already be set up on it the same way) from a checkpoint — one of this
+	package's, or a file the reference's Module.save / Container.save wrote (Modules/Module.py:179-283: groups params / links /
+	attrs, no meta entry; batch-norm pass counters then start at 0 as they do in a freshly loaded reference module, whose
+	numOfProps is not saved, Modules/BatchNormND.py:33-58)."""
+	tensors = read(path)
+	meta = json.loads(bytes(tensors["meta/json"]).decode()) if "meta/json" in tensors else {}
+
+	link, attrOf = resolver(tensors, "links", path), resolver(tensors, "attrs", path)
 	for name, param in net.namedParams().items():
-		key = "links/" + name
-		if key not in tensors:
-			raise KeyError("checkpoint %s has no parameter %s" % (path, name))
-		value = tensors["params/%d" % int(tensors[key])]
+		value = tensors["params/%d" % int(tensors[link(name)])]
 		if value.shape != param.data.shape:
 			raise ValueError("parameter %s: checkpoint shape %s, network shape %s" % (name, value.shape, param.data.shape))
-		param.data.set(value.astype(np.float32, casting="safe", copy=False))
+		param.data.set(np.ascontiguousarray(value.astype(np.float32, casting="safe", copy=False)))
 	for name, attr in net.namedAttrs().items():
-		attr.set(tensors["attrs/" + name].astype(np.float32, casting="safe", copy=False))
+		value = tensors[attrOf(name)]
+		if value.shape != attr.shape:
+			raise ValueError("attribute %s: checkpoint shape %s, network shape %s" % (name, value.shape, attr.shape))
+		attr.set(np.ascontiguousarray(value.astype(np.float32, casting="safe", copy=False)))
+	passes = meta.get("bn_passes", {})
 	for layer in net.walk():
 		if layer.kind == "bn":
-			layer.cfg["passes"] = int(meta["bn_passes"].get(layer.name, 0))
+			layer.cfg["passes"] = int(passes.get(layer.name, 0))
 
 	if optimizer is not None:
 		saved = meta.get("optimizer")

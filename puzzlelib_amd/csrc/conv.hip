@@ -2030,6 +2030,18 @@ bool uses_winograd(const pz_conv_desc *d, int which, int P, int Q, int algo) {
 	return algo == PZ_CONV_ALGO_WINOGRAD || (d->c >= 32 && d->k >= 32);
 }
 
+// One place decides which kernel family serves a request — execution, workspace sizes and pz_conv2d_algo_used all ask
+// here: Winograd first, then the thin backward-data kernels (reported as `direct`: vector-ALU kernels), then the implicit
+// GEMM, else the one-thread-per-output kernels.
+enum ConvPath { PATH_DIRECT, PATH_WINOGRAD, PATH_THIN, PATH_IGEMM };
+
+ConvPath conv_path(const pz_conv_desc *d, int which, int P, int Q, int algo) {
+	if (uses_winograd(d, which, P, Q, algo)) return PATH_WINOGRAD;
+	if (which == PZ_CONV_BWD_DATA && algo == PZ_CONV_ALGO_AUTO && pz::thin_dgrad_eligible(d, P, Q)) return PATH_THIN;
+	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || (which == PZ_CONV_BWD_DATA && !dgrad_uses_igemm(d))) return PATH_DIRECT;
+	return PATH_IGEMM;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2074,39 +2086,39 @@ int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(used != nullptr && which >= PZ_CONV_FWD && which <= PZ_CONV_BWD_FILTER, "pz_conv2d_algo_used: bad arguments");
-	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q) || (which == PZ_CONV_BWD_DATA && !dgrad_uses_igemm(d)) ||
-	    (which == PZ_CONV_BWD_DATA && algo == PZ_CONV_ALGO_AUTO && pz::thin_dgrad_eligible(d, P, Q)))
-		*used = PZ_CONV_ALGO_DIRECT;
-	else
-		*used = uses_winograd(d, which, P, Q, algo) ? PZ_CONV_ALGO_WINOGRAD : PZ_CONV_ALGO_IMPLICIT_GEMM;
+	const ConvPath path = conv_path(d, which, P, Q, algo);
+	*used = path == PATH_WINOGRAD ? PZ_CONV_ALGO_WINOGRAD : path == PATH_IGEMM ? PZ_CONV_ALGO_IMPLICIT_GEMM : PZ_CONV_ALGO_DIRECT;
 	return PZ_OK;
 }
 
-int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
+// `prepared`: the pass is going to be handed a prepared filter operand (pz_conv2d_{fwd,bwd_data}_pre): the workspace then
+// only holds what the launch itself needs (the slabs of k-sliced tiles), not a second copy of the packed filters
+static int conv_workspace_bytes(const pz_conv_desc *d, int which, int algo, bool prepared, size_t *nbytes) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_workspace_bytes: null output");
+	PZ_REQUIRE(which >= PZ_CONV_FWD && which <= PZ_CONV_BWD_FILTER, "pz_conv2d_workspace_bytes: unknown pass %d", which);
 	*nbytes = 0;
-	if (uses_winograd(d, which, P, Q, algo)) {
+	const ConvPath path = conv_path(d, which, P, Q, algo);
+	if (path == PATH_WINOGRAD) {
 		*nbytes = which == PZ_CONV_BWD_FILTER
 		              ? align256(pz::wino_wgrad_workspace_bytes(d, P, Q)) + align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float))
-		              : pz::wino_workspace_bytes(d, which, P, Q);
+		              : prepared ? 0 : pz::wino_workspace_bytes(d, which, P, Q);
 		return PZ_OK;
 	}
-	if (algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q)) return PZ_OK;
+	if (path == PATH_THIN) {
+		*nbytes = align256(pz::thin_dgrad_workspace_bytes(d));
+		return PZ_OK;
+	}
+	if (path == PATH_DIRECT) return PZ_OK;
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 
 	if (which == PZ_CONV_FWD) {
 		FwdPlan p = plan_igemm(Kg, Cg * d->r * d->s, (long)d->n * P * Q, d->groups, Cg);
-		*nbytes = p.wp_bytes + p.tab_bytes + p.slab_bytes;
+		*nbytes = prepared && !p.split ? p.slab_bytes : p.wp_bytes + p.tab_bytes + p.slab_bytes;
 
 	} else if (which == PZ_CONV_BWD_DATA) {
-		if (algo == PZ_CONV_ALGO_AUTO && pz::thin_dgrad_eligible(d, P, Q)) {
-			*nbytes = align256(pz::thin_dgrad_workspace_bytes(d));
-			return PZ_OK;
-		}
-		if (!dgrad_uses_igemm(d)) return PZ_OK;
 		DgradClass cls[16];
 		bool nz;
 		const int nc = dgrad_classes(d, cls, &nz);
@@ -2117,15 +2129,20 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
 		}
 		*nbytes = total;
 
-	} else if (which == PZ_CONV_BWD_FILTER) {
+	} else {
 		WgradPlan p = wgrad_split_eligible(d) ? plan_wgrad_split(d, P, Q) : plan_wgrad(d, P, Q);
 		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0) +
 		          align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float));       // bias-gradient partials
-
-	} else {
-		PZ_REQUIRE(false, "pz_conv2d_workspace_bytes: unknown pass %d", which);
 	}
 	return PZ_OK;
+}
+
+int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
+	return conv_workspace_bytes(d, which, algo, false, nbytes);
+}
+
+int pz_conv2d_workspace_bytes_pre(const pz_conv_desc *d, int which, int algo, size_t *nbytes) {
+	return conv_workspace_bytes(d, which, algo, true, nbytes);
 }
 
 int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips) {
@@ -2197,8 +2214,8 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 	}
 
 	size_t need;
-	pz_conv2d_workspace_bytes(d, PZ_CONV_FWD, algo, &need);
-	PZ_REQUIRE(workspace != nullptr && ws_bytes >= need, "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+	conv_workspace_bytes(d, PZ_CONV_FWD, algo, packed != nullptr, &need);
+	PZ_REQUIRE(need == 0 || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 	PackArgs pa{};

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int kMaxPtrs = 5, kMaxScalars = 4;
+constexpr int kMaxPtrs = 5, kMaxScalars = 5;
 
 struct EltArgs {
 	float *p[kMaxPtrs];
@@ -60,16 +60,20 @@ PZ_ELT(OpL1Penalty, 3, 0b110, 0b001,                                            
 PZ_ELT(OpL1Grad, 3, 0b110, 0b001, v[0] = (v[1] - v[2] > 0.f ? -s[0] : s[0]);)                        // :1135-1140
 PZ_ELT(OpRbm, 3, 0b110, 0b001, const float p = 1.f / (1.f + expf(-v[1])); v[0] = v[2] < p ? 1.f : 0.f;)   // :1102-1108
 
+// The update rules read the gradient as v[1] * (last scalar): 1 normally (exact), 1/N when the data-parallel exchange left the
+// arena holding the SUM over ranks (Grid.py:126-133 divides inside its reduce; here the division rides in the update kernel
+// instead of a pass of its own over the arena — same rounding: one fp32 product per element)
 PZ_ELT(OpAdam, 4, 0b1111, 0b1101,                                                                     // :710-757
-       const float g = v[1];
+       const float g = __fmul_rn(v[1], s[4]);        // (rounded on its own: never contracted into the sums below)
        v[2] += s[1] * (g - v[2]);
        v[3] += s[2] * (g * g - v[3]);
        v[0] += s[0] * v[2] / (sqrtf(v[3]) + s[3]);)
-PZ_ELT(OpClassicMomSGD, 3, 0b111, 0b101, v[2] = s[1] * v[2] + s[0] * v[1]; v[0] += v[2];)            // :760-806
+PZ_ELT(OpClassicMomSGD, 3, 0b111, 0b101, const float g = __fmul_rn(v[1], s[2]); v[2] = s[1] * v[2] + s[0] * g; v[0] += v[2];)   // :760-806
 PZ_ELT(OpNesterovMomSGD, 3, 0b111, 0b101,                                                             // :809-857
        const float m = v[2];
-       v[2] = s[1] * m + s[0] * v[1];
-       v[0] += s[1] * s[1] * m + (1.f + s[1]) * s[0] * v[1];)
+       const float g = __fmul_rn(v[1], s[2]);
+       v[2] = s[1] * m + s[0] * g;
+       v[0] += s[1] * s[1] * m + (1.f + s[1]) * s[0] * g;)
 PZ_ELT(OpRmsprop, 3, 0b111, 0b101,                                                                    // :860-905
        v[2] = s[1] * v[2] + (1.f - s[1]) * v[1] * v[1];
        v[0] += s[0] * v[1] / (sqrtf(v[2]) + s[2]);)
@@ -285,9 +289,9 @@ int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *
 		PZ_CASE(PZ_OP_L1_PENALTY, OpL1Penalty, 1)
 		PZ_CASE(PZ_OP_L1_GRAD, OpL1Grad, 1)
 		PZ_CASE(PZ_OP_RBM, OpRbm, 0)
-		PZ_CASE(PZ_OP_ADAM, OpAdam, 4)
-		PZ_CASE(PZ_OP_CLASSIC_MOM_SGD, OpClassicMomSGD, 2)
-		PZ_CASE(PZ_OP_NESTEROV_MOM_SGD, OpNesterovMomSGD, 2)
+		PZ_CASE(PZ_OP_ADAM, OpAdam, 5)
+		PZ_CASE(PZ_OP_CLASSIC_MOM_SGD, OpClassicMomSGD, 3)
+		PZ_CASE(PZ_OP_NESTEROV_MOM_SGD, OpNesterovMomSGD, 3)
 		PZ_CASE(PZ_OP_RMSPROP, OpRmsprop, 3)
 		PZ_CASE(PZ_OP_ADAGRAD, OpAdagrad, 2)
 		PZ_CASE(PZ_OP_ADADELTA, OpAdadelta, 2)

@@ -7,7 +7,7 @@ over the C ABI of libpuzzle_mi355.so. Ownership follows the reference: device me
 a pool-backed Buffer returns its block to the pool when the last Python reference dies, views (`buffer[a:b]`)
 keep their parent alive.
 """
-import ctypes
+import ctypes, threading, weakref
 from ctypes import byref, c_int, c_size_t, c_void_p, c_float
 
 from puzzlelib_amd import lib
@@ -166,7 +166,14 @@ class Buffer:
 	@classmethod
 	def allocate(cls, nbytes):
 		ptr = c_void_p()
-		lib.pz_malloc(byref(ptr), max(int(nbytes), 1))
+		try:
+			lib.pz_malloc(byref(ptr), max(int(nbytes), 1))
+		except lib.HipMemoryError:
+			# blocks parked in the pools' Python-side front caches count as live for the native pools: hand them back
+			# (and let the pools return what they hold to the driver) before giving up
+			if not MemoryPool.reclaimAll():
+				raise
+			lib.pz_malloc(byref(ptr), max(int(nbytes), 1))
 		return cls(ptr.value, int(nbytes), parent=None, owner=True)
 
 
@@ -248,7 +255,12 @@ class MemoryPool:
 	# trip into the native pool is two foreign calls. Blocks released by Python are therefore parked HERE first, per size
 	# class (the native pool's own classes: 4 per octave, >= 256 B), and handed out again without leaving the interpreter;
 	# the native pool sees them as live until `freeHeld` / an allocation failure returns them.
-	frontLimit = 64 << 30          # bytes parked on the Python side at most (beyond that a released block goes to the native pool)
+	# Bounds: bytes in all, and blocks per size class (a step's working set re-uses a handful of blocks per class; what is
+	# released beyond that goes to the native pool, whose out-of-memory path can return it to the driver). A release can
+	# come from any thread (Buffer.__del__ on the input pipeline's worker): the front cache is guarded by a lock.
+	frontLimit = 64 << 30
+	frontPerClass = 64
+	pools = weakref.WeakSet()
 
 	def __init__(self):
 		handle = c_void_p()
@@ -256,6 +268,20 @@ class MemoryPool:
 		self.handle = handle.value
 		self.holding = True
 		self.front, self.frontBytes, self.frontBlocks = {}, 0, 0
+		self.lock = threading.Lock()
+		MemoryPool.pools.add(self)
+
+
+	@classmethod
+	def reclaimAll(cls):
+		"""every pool's parked and held blocks back to the driver; True if there was anything to give back"""
+		any_ = False
+		for pool in list(cls.pools):
+			if pool.handle is not None:
+				any_ = any_ or pool.frontBlocks > 0 or pool.getStats()["heldBytes"] > 0
+				pool.flushFront()
+				lib.pz_pool_free_held(pool.handle)
+		return any_
 
 
 	@staticmethod
@@ -270,19 +296,19 @@ class MemoryPool:
 	def allocate(self, nbytes):
 		nbytes = int(nbytes)
 		cls = self.classSize(nbytes)
-		parked = self.front.get(cls)
-		if parked:
-			self.frontBytes -= cls
-			self.frontBlocks -= 1
-			return Buffer(parked.pop(), nbytes, parent=self, owner=True)
+		with self.lock:
+			parked = self.front.get(cls)
+			if parked:
+				self.frontBytes -= cls
+				self.frontBlocks -= 1
+				return Buffer(parked.pop(), nbytes, parent=self, owner=True)
 		ptr = c_void_p()
 		try:
 			lib.pz_pool_alloc(self.handle, cls, byref(ptr))
 		except lib.HipError:
-			if self.frontBlocks == 0:
+			# what is parked here — or in another pool's front cache — may be what the driver needs back
+			if not MemoryPool.reclaimAll():
 				raise
-			self.flushFront()                  # what is parked here may be what the driver needs back
-			lib.pz_pool_free_held(self.handle)
 			lib.pz_pool_alloc(self.handle, cls, byref(ptr))
 		return Buffer(ptr.value, nbytes, parent=self, owner=True)
 
@@ -292,20 +318,23 @@ class MemoryPool:
 			return
 		if nbytes is not None and self.holding and self.frontBytes < self.frontLimit:
 			cls = self.classSize(nbytes)
-			parked = self.front.get(cls)
-			if parked is None:
-				parked = self.front[cls] = []
-			parked.append(ptr)
-			self.frontBytes += cls
-			self.frontBlocks += 1
-			return
+			with self.lock:
+				parked = self.front.get(cls)
+				if parked is None:
+					parked = self.front[cls] = []
+				if len(parked) < self.frontPerClass:
+					parked.append(ptr)
+					self.frontBytes += cls
+					self.frontBlocks += 1
+					return
 		lib.pz_pool_release(self.handle, ptr)
 		if not self.holding:
 			lib.pz_pool_free_held(self.handle)
 
 
 	def flushFront(self):
-		front, self.front, self.frontBytes, self.frontBlocks = self.front, {}, 0, 0
+		with self.lock:
+			front, self.front, self.frontBytes, self.frontBlocks = self.front, {}, 0, 0
 		for parked in front.values():
 			for ptr in parked:
 				lib.pz_pool_release(self.handle, ptr)

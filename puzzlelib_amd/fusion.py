@@ -19,6 +19,8 @@ backend.py create and consume these.
                                                                                       pz_conv2d_bwd_{data,filter}_bn
   Up2(compact)           convNdBackwardData of a stride-2 pointwise convolution       zero fill + strided copy; folded into
                                                                                       pz_bn_gate_stats_up2
+  Scaled(1/N)            nodeinfo.sumTensor on the gradient arena (the mean of the    linear kernel in place; folded into the
+                         data-parallel exchange, Optimizers/Optimizer.py:166-167)     Adam / momentum-SGD update kernels
 """
 import ctypes
 from ctypes import byref, c_size_t
@@ -107,6 +109,19 @@ class Gate(Thunk):
 		ptrs = (ctypes.c_void_p * 3)(out.gpudata.ptr, out.gpudata.ptr, self.y.rptr)
 		lib.pz_eltwise(lib.OP_RELU_DER, out.size, ptrs, 3, None, 0, 0, out.size, 1, None)
 		lazy.count("gate")
+
+
+class Scaled(Thunk):
+	"""In place: the buffer holds g (the sum of the ranks' gradients), its value is g * scale."""
+
+	def __init__(self, scale):
+		self.scale = float(scale)
+
+	def run(self, out):
+		ptrs = (ctypes.c_void_p * 2)(out.gpudata.ptr, out.gpudata.ptr)
+		words = (ctypes.c_float * 2)(self.scale, 0.0)
+		lib.pz_eltwise(lib.OP_LINEAR, out.size, ptrs, 2, words, 2, 0, out.size, 1, None)
+		lazy.count("grad_scale_pass")
 
 
 class Sum(Thunk):

@@ -498,15 +498,18 @@ def findParentAllocator(*buffers):
 	return None
 
 
-def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None):
+def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None, rawIdx=-1):
 	"""One launch of the element-wise family: pz_eltwise(op, count, ptrs, scalars, start, stop, step).
-	`readonly`: indices of arrays the op only reads (default: every array but the first)."""
+	`readonly`: indices of arrays the op only reads (default: every array but the first). `rawIdx`: an operand whose pending
+	description the caller evaluates itself (through a scalar of the op): its address is taken without the read barrier."""
 	nptrs = len(arrays)
 	if readonly is None:
 		readonly = range(1, nptrs)
 
 	if stream is None:
-		ptrs = (PTRS.get(nptrs) or ctypes.c_void_p * nptrs)(*[a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)])
+		ptrs = (PTRS.get(nptrs) or ctypes.c_void_p * nptrs)(*[
+			a.gpudata.ptr if i == rawIdx else a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)
+		])
 	else:
 		# a borrowed stream (Optimizer.update(useStreams=True)): it follows the main stream up to here, and what it writes
 		# carries its completion event, so the main stream waits exactly when it touches those buffers again

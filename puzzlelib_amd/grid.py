@@ -317,6 +317,12 @@ class RcclNodeInfo(NodeInfo):
 			lib.pz_comm_destroy(self.comm)
 			self.comm = None
 
+	def commSummary(self):
+		"""per-step exposed exchange time and per-bucket bus rates of the overlapped reducer (None: nothing measured)"""
+		reducer = self.reducers.get("grad", None)
+		stats = getattr(getattr(reducer, "ops", None), "stats", None)
+		return None if stats is None else stats.summary()
+
 	def meanValue(self, value):
 		return value if self.gridsize == 1 else self.group.reduce(value, "sum") / self.gridsize
 
@@ -362,10 +368,61 @@ class RcclNodeInfo(NodeInfo):
 		reducer.beginStep()
 
 
+class CommStats:
+	"""What one rank saw of its gradient exchange, per step: the EXPOSED time (compute stream idle behind the exchange: from
+	the event recorded when the optimizer asks for the mean to the completion of the last bucket's collective) and every
+	bucket's own duration on the communication stream. Read one step late (the events have completed by then): no host wait
+	is added to the step."""
+
+	def __init__(self, gridsize):
+		self.gridsize = gridsize
+		self.steps, self.exposedMs, self.bucketMs, self.bucketBytes = 0, 0.0, {}, {}
+		self.pending = []             # steps whose events may not have completed yet (the host runs ahead of the device), oldest first
+
+	def stepIssued(self, tail, buckets):
+		"""buckets: [(start byte, bytes, begin event, done event)] of the step just issued; tail: event on the compute stream"""
+		if buckets:
+			self.pending.append((tail, buckets))
+		self.collect(wait=len(self.pending) > 64)
+
+	def collect(self, wait=False):
+		while self.pending:
+			tail, buckets = self.pending[0]
+			last = buckets[-1][3]
+			if wait:
+				last.synchronize()
+				tail.synchronize()
+			elif not (last.query() and tail.query()):
+				return
+			self.pending.pop(0)
+			self.steps += 1
+			self.exposedMs += max(0.0, max(tail.timeTill(done) for _, _, _, done in buckets))
+			for start, nbytes, begin, done in buckets:
+				self.bucketMs[start] = self.bucketMs.get(start, 0.0) + begin.timeTill(done)
+				self.bucketBytes[start] = nbytes
+
+	def summary(self):
+		self.collect(wait=True)
+		if self.steps == 0:
+			return None
+		n = self.gridsize
+		factor = 2.0 * (n - 1) / n if n > 1 else 1.0          # ring all-reduce: bytes each rank sends + receives per payload byte
+		rows = []
+		for start in sorted(self.bucketMs):
+			ms = self.bucketMs[start] / self.steps
+			rows.append({"mbytes": self.bucketBytes[start] / 1e6, "ms": ms,
+						 "bus_gb_per_s": factor * self.bucketBytes[start] / (ms * 1e-3) / 1e9 if ms > 0 else None})
+		return {"steps_measured": self.steps, "exposed_ms_per_step": self.exposedMs / self.steps, "buckets": rows,
+				"note": "exposed = compute stream waiting for the last collective after backward's last kernel; bucket ms = "
+						"collective alone on the communication stream (includes waiting for slower ranks); bus GB/s = "
+						"2(N-1)/N x bytes / ms (payload rate at N = 1)"}
+
+
 class HipReduceOps:
 	def __init__(self, node, tensor):
 		self.node, self.tensor = node, tensor
 		self.events = []
+		self.stats = CommStats(node.gridsize)
 
 	def markReady(self):
 		"""'final up to here' = an event on the compute stream plus one behind the filter-gradient stream, where the
@@ -386,24 +443,38 @@ class HipReduceOps:
 		if side is not None:
 			node.commStream.waitEvent(side)
 		ptr = self.tensor.gpudata.ptr + start      # ordering is carried by the two events, not by the arena's barrier
+		begin = driver.Event()
+		begin.record(node.commStream)
 		lib.pz_comm_allreduce_sum_f32(node.comm, ptr, ptr, (stop - start) // 4, node.commStream.handle)
 
 		done = driver.Event()
 		done.record(node.commStream)
-		self.events.append((token, done))
+		self.events.append((token, done, start, stop - start, begin))
 
 	def finish(self, scale):
-		from puzzlelib_amd import lib
+		from puzzlelib_amd import lib, lazy, fusion, driver
 		from puzzlelib_amd.gpuarray import eltwise
 
 		lib.pz_comm_async_error(self.node.comm)
-		if self.node.timeout > 0.0 and self.events:
-			lib.pz_comm_wait_event(self.node.comm, self.events[-1][1].handle, self.node.timeout)
-		for _, done in self.events:
+		tail = driver.Event()
+		tail.record(None)                          # the compute stream has nothing left but to wait for the exchange
+		if self.node.timeout > 0.0:
+			# the watchdog follows EVERY bucket (a rank that never joined bucket k blocks k, not only the last one)
+			for _, done, _, _, _ in self.events:
+				lib.pz_comm_wait_event(self.node.comm, done.handle, self.node.timeout)
+		for _, done, _, _, _ in self.events:
 			lib.pz_stream_wait_event(None, done.handle)
+		self.stats.stepIssued(tail, [(start, nbytes, begin, done) for _, done, start, nbytes, begin in self.events])
 		self.events = []
 
-		eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
+		# The mean's 1/N: the arena now holds the SUM. Its division rides in the optimizer's update kernel (the description
+		# fusion.Scaled; Grid.py:126-133 divides inside its reduce): no pass of its own over the arena. Anything else that
+		# touches the gradients first (a hook, a test reading them) makes the description run as the linear pass it stands for.
+		if lazy.on("gradscale") and lazy.whole(self.tensor) and lazy.pending(self.tensor) is None:
+			self.tensor.wptr                       # write barrier: version, dependents, foreign readers — the value changes
+			lazy.attach(self.tensor, fusion.Scaled(scale))
+		else:
+			eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
 
 
 class HostStagedReduceOps:

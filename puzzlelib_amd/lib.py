@@ -109,6 +109,7 @@ _PROTOS = {
 
 	"pz_conv2d_out_shape": [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)],
 	"pz_conv2d_workspace_bytes": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
+	"pz_conv2d_workspace_bytes_pre": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
 	"pz_conv2d_fwd": [POINTER(ConvDesc), P, P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_fwd_stats_strips": [POINTER(ConvDesc), c_int, POINTER(c_int)],
 	"pz_conv2d_fwd_stats": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
@@ -256,7 +257,7 @@ def _bind(name, argtypes):
 
 
 _HOST_ONLY = {
-	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
+	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_workspace_bytes_pre", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
 	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get",
 	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get"
@@ -337,6 +338,25 @@ for _name, _argtypes in _PROTOS.items():
 		globals()[_name] = _bind(_name, _argtypes)
 	else:
 		raise ImportError("%s does not export %s: rebuild the library (make -C puzzlelib_amd/csrc)" % (LIBPATH, _name))
+
+# The layout of a prepared filter operand and every workspace size depend on two process-wide modes of the library (fp32 /
+# split math, Winograd output tile). Whoever changes them — any DnnContext, a test, a tool — goes through these wrappers,
+# which advance `modeEpoch`; caches keyed by geometry alone (backend.DnnContext.prepared / convDesc / convGeometry) compare
+# their epoch with it and start over.
+modeEpoch = 0
+
+
+def _epochBumping(call):
+	def wrapper(*args):
+		global modeEpoch
+		call(*args)
+		modeEpoch += 1
+	wrapper.__name__ = call.__name__
+	return wrapper
+
+
+pz_conv_math_set = _epochBumping(pz_conv_math_set)
+pz_conv_winograd_tile_set = _epochBumping(pz_conv_winograd_tile_set)
 
 pz_version = _lib.pz_version
 pz_version.restype = c_int

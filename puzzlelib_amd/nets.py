@@ -70,8 +70,23 @@ def _resid(inmaps, hmaps, stride, blockname, convShortcut):
 	return [("resid", branch, shortcut), ("relu", "res%s_relu" % blockname)]
 
 
-def resnet_spec(stages=((64, 3), (128, 4), (256, 6), (512, 3)), classes=1000, stem=64, softmax=True):
-	"""ResNet-50 by default; smaller `stages` give the mini-ResNets used by the parity tests."""
+def resnet_blocknames(layers):
+	"""Block names per level as Models/Nets/ResNet.py:70-92 spells them: letters for ResNet-50 ("3a" ... "3d"), "<level>a" +
+	"<level>b<number>" for the long stages of ResNet-101 / -152."""
+	if layers == "50":
+		level3, level4 = ["3%s" % a for a in string.ascii_lowercase[1:4]], ["4%s" % a for a in string.ascii_lowercase[1:6]]
+	elif layers == "101":
+		level3, level4 = ["3b%d" % i for i in range(1, 4)], ["4b%d" % i for i in range(1, 23)]
+	elif layers == "152":
+		level3, level4 = ["3b%d" % i for i in range(1, 8)], ["4b%d" % i for i in range(1, 36)]
+	else:
+		raise ValueError("Unsupported ResNet layers mode")
+	return {2: ["2a", "2b", "2c"], 3: ["3a"] + level3, 4: ["4a"] + level4, 5: ["5a", "5b", "5c"]}
+
+
+def resnet_spec(stages=((64, 3), (128, 4), (256, 6), (512, 3)), classes=1000, stem=64, softmax=True, blocknames=None):
+	"""ResNet-50 by default; smaller `stages` give the mini-ResNets used by the parity tests; `blocknames` ({level: [name, ...]},
+	resnet_blocknames) overrides the lettered block names and the stage lengths."""
 	spec = [
 		("conv", "conv1", 3, stem, 7, 2, 3, False),
 		("bn", "bn_conv1", stem),
@@ -81,8 +96,8 @@ def resnet_spec(stages=((64, 3), (128, 4), (256, 6), (512, 3)), classes=1000, st
 
 	inmaps = stem
 	for level, (hmaps, nblocks) in enumerate(stages, start=2):
-		for b in range(nblocks):
-			blockname = "%d%s" % (level, string.ascii_lowercase[b])
+		names = blocknames[level] if blocknames is not None else ["%d%s" % (level, string.ascii_lowercase[b]) for b in range(nblocks)]
+		for b, blockname in enumerate(names):
 			spec += _resid(inmaps, hmaps, (1 if level == 2 else 2) if b == 0 else 1, blockname, b == 0)
 			inmaps = 4 * hmaps
 
@@ -171,9 +186,12 @@ def build(spec, name=None, initscheme=None, wscale=1.0, actInplace=False, bnInpl
 
 
 def loadLeNet(modelpath=None, initscheme="none", name="lenet-5-like"):
-	"""Models/Nets/LeNet.py:13-33 (checkpoints: puzzlelib_amd/checkpoint.py; modelpath must be None here)."""
-	assert modelpath is None
-	return build(lenet_spec(), name=name, initscheme=initscheme)
+	"""Models/Nets/LeNet.py:13-33; `modelpath`: a file the reference's Module.save wrote (puzzlelib_amd/checkpoint.py)."""
+	net = build(lenet_spec(), name=name, initscheme=initscheme)
+	if modelpath is not None:
+		from puzzlelib_amd import checkpoint
+		checkpoint.load(net, modelpath)
+	return net
 
 
 def buildNiN():
@@ -182,14 +200,19 @@ def buildNiN():
 
 
 def loadResNet(modelpath=None, layers="50", actInplace=False, bnInplace=False, initscheme="none", name=None):
-	"""Models/Nets/ResNet.py:69-121 (layers "50" only)."""
-	assert modelpath is None
-	stages = {"50": ((64, 3), (128, 4), (256, 6), (512, 3))}[layers]
+	"""Models/Nets/ResNet.py:69-121: ResNet-50 / -101 / -152 (3-4-6-3, 3-4-23-3, 3-8-36-3 bottleneck blocks). `modelpath`: a file
+	the reference's Module.save wrote, read the way ResNet.py:118-119 does (net.load(modelpath, assumeUniqueNames=True))."""
+	names = resnet_blocknames(layers)
+	stages = tuple((hmaps, len(names[level])) for level, hmaps in zip((2, 3, 4, 5), (64, 128, 256, 512)))
 
-	return build(
-		resnet_spec(stages), name="ResNet-%s" % layers if name is None else name, initscheme=initscheme,
+	net = build(
+		resnet_spec(stages, blocknames=names), name="ResNet-%s" % layers if name is None else name, initscheme=initscheme,
 		actInplace=actInplace, bnInplace=bnInplace
 	)
+	if modelpath is not None:
+		from puzzlelib_amd import checkpoint
+		checkpoint.load(net, modelpath)
+	return net
 
 
 def namedVariables(net):

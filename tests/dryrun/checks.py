@@ -256,6 +256,42 @@ def fused_step_counts():
 	print("fused step: %d launches against %d with the lazy layer off" % (fusedCalls, literalCalls))
 
 
+def reference_checkpoint_names():
+	"""checkpoint.load resolves the entries of a file the REFERENCE wrote (tests/golden/refckpt_mini_*.npz: Module.save output of
+	a small network built from the reference's own residBlock, both naming forms), refuses ambiguous and missing entries."""
+	import numpy as np
+	from puzzlelib_amd import nets, checkpoint
+	golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "golden")
+	spec = nets.resnet_spec(stages=((4, 2), (8, 1)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 4, 1, 0) for l in spec]
+	net = nets.build(spec, name="ResNet-mini")
+	for tag in ("unique", "full"):
+		path = os.path.join(golden, "refckpt_mini_%s.npz" % tag)
+		tensors = checkpoint.read(path)
+		assert "meta/json" not in tensors
+		link = checkpoint.resolver(tensors, "links", path)
+		seen = set()
+		for name, param in net.namedParams().items():
+			key = link(name)
+			assert key.endswith(name) and key not in seen
+			seen.add(key)
+			assert tensors["params/%d" % int(tensors[key])].shape == param.data.shape, name
+		assert len(seen) == len([k for k in tensors if k.startswith("links/")])
+		assert checkpoint.load(net, path) == {}
+		assert all(l.cfg["passes"] == 0 for l in net.walk() if l.kind == "bn")
+
+	tensors = {"links/netA.blk1.conv.W": np.array(0), "links/netA.blk2.conv.W": np.array(1), "links/fc.W": np.array(2)}
+	find = checkpoint.resolver(tensors, "links", "<test>")
+	assert find("fc.W") == "links/fc.W"
+	for bad, word in (("conv.W", "ambiguous"), ("conv2.W", "no entry")):
+		try:
+			find(bad)
+		except KeyError as e:
+			assert word in str(e)
+		else:
+			raise AssertionError("%s resolved" % bad)
+
+
 def no_leaks_without_gc():
 	"""device memory is returned by reference counting alone: after a step and reset() no activation buffer survives
 	(a cycle through a buffer would keep gigabytes until the collector happens to run)"""

@@ -39,6 +39,10 @@ def test_fused_paths_taken_and_switchable():
 	run("fused_step_counts")
 
 
+def test_checkpoints_written_by_the_reference_resolve():
+	run("reference_checkpoint_names")
+
+
 def test_buffers_are_freed_by_reference_counting():
 	run("no_leaks_without_gc")
 

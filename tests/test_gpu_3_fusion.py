@@ -541,6 +541,73 @@ def test_prepared_filter_operands_follow_every_write_of_the_filter(surf):
 		g.streamManager.give([stream])
 
 
+@pytest.mark.parametrize("rule", ["adam", "classicMomSGD", "nesterovMomSGD"])
+def test_gradient_mean_rides_in_the_update_kernel(surf, rule):
+	"""The data-parallel mean (Optimizers/Optimizer.py:166-167 -> Grid.py:126-133 sums and divides in one pass): the exchange
+	leaves the arena described as `sum x 1/N` (fusion.Scaled) and the Adam / momentum-SGD kernels take the factor as a scalar.
+	Bit-identical to scaling first; the description stays valid for whoever reads the gradients afterwards; a hook that
+	touches the gradients before the update makes it run as the linear pass it stands for."""
+	from puzzlelib_amd import lazy, fusion
+	g, El = surf.gpuarray, surf.ElementWise
+	rng = np.random.RandomState(31)
+	n, scale = 100003, 0.125 + 1.0 / 3.0
+	host = {k: rng.randn(n).astype(np.float32) for k in ("param", "grad", "mg")}
+	host["ms"] = np.abs(rng.randn(n)).astype(np.float32)
+
+	def update(param, grad, mg, ms):
+		if rule == "adam":
+			El.adamKer(np.float32)(param, grad, mg, ms, 1e-3, 0.1, 0.001, 1e-8)
+		elif rule == "classicMomSGD":
+			El.classicMomSGDKer(np.float32)(param, grad, mg, 0.01, 0.9)
+		else:
+			El.nesterovMomSGDKer(np.float32)(param, grad, mg, 0.01, 0.9)
+
+	a = {k: g.to_gpu(v) for k, v in host.items()}
+	El.linearKer(np.float32)(a["grad"], a["grad"], scale, 0.0)
+	update(a["param"], a["grad"], a["mg"], a["ms"])
+
+	b = {k: g.to_gpu(v) for k, v in host.items()}
+	lazy.counters.clear()
+	lazy.attach(b["grad"], fusion.Scaled(scale))
+	update(b["param"], b["grad"], b["mg"], b["ms"])
+	assert lazy.counters.get("grad_scale_folded", 0) == 1 and lazy.counters.get("grad_scale_pass", 0) == 0
+	for key in ("param", "mg", "ms"):
+		assert np.array_equal(a[key].get(), b[key].get()), "%s: %s differs from scaling first" % (rule, key)
+	assert np.array_equal(b["grad"].get(), a["grad"].get()), "the described gradient reads as the scaled one"
+	assert lazy.counters.get("grad_scale_pass", 0) == 1
+
+	c = {k: g.to_gpu(v) for k, v in host.items()}
+	lazy.counters.clear()
+	lazy.attach(c["grad"], fusion.Scaled(scale))
+	El.weightDecayKer(c["grad"], c["param"], 0.0)             # a hook touching the gradient first (rate 0: value unchanged)
+	update(c["param"], c["grad"], c["mg"], c["ms"])
+	assert lazy.counters.get("grad_scale_pass", 0) == 1 and lazy.counters.get("grad_scale_folded", 0) == 0
+	assert np.array_equal(a["param"].get(), c["param"].get())
+
+
+def test_prepared_filter_operands_follow_the_library_modes(surf):
+	"""The layout of a prepared operand depends on process-wide modes of the library (Winograd output tile, math mode). Whoever
+	changes them — here: a direct call of the C entry point, the way tools and other contexts do — must not leave this
+	context consuming operands prepared under the old mode (round-3 advisor finding): lib.modeEpoch advances, the caches
+	start over, results stay right."""
+	from puzzlelib_amd import lazy, lib
+	g, Dnn = surf.gpuarray, surf.Dnn
+	rng = np.random.RandomState(21)
+	x = rng.randn(4, 32, 12, 12).astype(np.float32)
+	w = (rng.randn(32, 32, 3, 3) / 17).astype(np.float32)
+	gx, gw = g.to_gpu(x), g.to_gpu(w)
+	ref = R.conv2d_fwd(x, w, None, 1, 1, acc=np.float64)
+	try:
+		for tile in (4, 2, 4, 0):
+			lib.pz_conv_winograd_tile_set(tile)                  # behind the context's back
+			lazy.counters.clear()
+			y = Dnn.convNd(gx, gw, None, 1, 1, 1, 1, Dnn.ConvFwdAlgo.auto)
+			assert lazy.counters.get("prepack_launch", 0) == 1, "tile %d: operands of the previous mode were reused" % tile
+			assert_close(y.get(), ref, atol=6e-5 * np.abs(ref).max(), rtol=0, what="forward after the tile changed to %d" % tile)
+	finally:
+		lib.pz_conv_winograd_tile_set(0)
+
+
 def test_training_steps_with_prepared_operands_equal_per_call_packing(surf, mini_golden):
 	"""Three Adam steps of the mini-ResNet: parameters bit-identical whether the filter operands are prepared once per
 	step in batched launches or packed inside every convolution call (lazy.disabled = {"prepack"})."""

@@ -234,6 +234,26 @@ def test_elementwise_and_norm_edge_cases(bnd):
 	one = bnd.dnn.poolNd(gp, size=(1, 1), stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.max.value, test=True)
 	assert np.array_equal(one.get(), xp)
 
+	# average pooling of 1x1 planes (a network whose last map is already 1x1): window == plane, forward and backward are copies
+	# (round-3 advisor finding: the global-average fast path's 32-bit magic division does not cover hw == 1)
+	for mode in (bnd.PoolMode.avgWithPad.value, bnd.PoolMode.avgNoPad.value):
+		x1 = np.random.RandomState(5).randn(37, 300, 1, 1).astype(np.float32)          # > 1024 elements: several workgroups
+		g1 = gpu(bnd, x1)
+		y1, ws1 = bnd.dnn.poolNd(g1, size=(1, 1), stride=(1, 1), pad=(0, 0), mode=mode, test=False)
+		assert np.array_equal(y1.get(), x1)
+		dy1 = np.random.RandomState(6).randn(*x1.shape).astype(np.float32)
+		dx1 = bnd.dnn.poolNdBackward(gpu(bnd, dy1), g1, y1, ws1, size=(1, 1), stride=(1, 1), pad=(0, 0), mode=mode)
+		assert np.array_equal(dx1.get(), dy1), "average pooling backward on 1x1 planes"
+	# ... and the fast path itself on the smallest plane it takes (2 elements) and on 7x7, backward against the oracle
+	for hw in ((1, 2), (7, 7)):
+		xa = np.random.RandomState(7).randn(9, 130, *hw).astype(np.float32)
+		ga = gpu(bnd, xa)
+		ya, wsa = bnd.dnn.poolNd(ga, size=hw, stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.avgWithPad.value, test=False)
+		assert_close(ya.get(), xa.mean(axis=(2, 3), keepdims=True), atol=1e-6, what="global average %s" % (hw, ))
+		dya = np.random.RandomState(8).randn(9, 130, 1, 1).astype(np.float32)
+		dxa = bnd.dnn.poolNdBackward(gpu(bnd, dya), ga, ya, wsa, size=hw, stride=(1, 1), pad=(0, 0), mode=bnd.PoolMode.avgWithPad.value)
+		assert_close(dxa.get(), np.broadcast_to(dya / (hw[0] * hw[1]), xa.shape), atol=1e-7, rtol=1e-6, what="global average backward %s" % (hw, ))
+
 
 @pytest.mark.parametrize("tile", [2, 4])
 @pytest.mark.parametrize("shape", [(256, 64, 55, 55), (256, 128, 28, 28), (256, 256, 14, 14), (256, 512, 7, 7)])

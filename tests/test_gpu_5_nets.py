@@ -5,6 +5,8 @@ fixture were computed by the REFERENCE's own CPU backend on the same seed), a tw
 BN, ReLU, pooling, residual add, linear, cross-entropy, Adam; oracle fixture), NiN (config 3) and the batch loops.
 Tolerances: forward logits atol 1e-4; parameters after one step atol 2e-5 (updates are O(lr)); gradients rtol 1e-3.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -418,6 +420,53 @@ def test_nin_step_matches_oracle(bnd, batch):
 	for name, p in net.namedParams().items():
 		ref = cnet.params[name]
 		assert_close(p.data.get(), ref, atol=2e-5 * (np.abs(ref).max() + 1e-8), rtol=1e-4, what="NiN param after the step " + name)
+
+
+@pytest.mark.parametrize("form", ["unique", "full"])
+def test_network_loads_what_the_reference_saved(bnd, form):
+	"""Modules/Module.py:233-283 load of a file Module.save wrote (:179-231; both naming forms, Models/Nets/ResNet.py:118-119 uses
+	assumeUniqueNames=True): tests/golden/refckpt_mini_<form>.npz is the reference's OWN output for a small ResNet built from
+	its residBlock (oracle/make_checkpoint_fixture.py; .npz mirror of the HDF5 tree), refckpt_mini_io.npz the reference's
+	evaluation-mode scores on a fixed input (numpy CPU backend). Every parameter and running statistic has a distinct value:
+	the device network reproduces the scores only if each tensor lands in its place."""
+	from conftest import GOLDEN, Golden
+	from puzzlelib_amd import nets, checkpoint
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	io = Golden("refckpt_mini_io.npz")
+	spec = nets.resnet_spec(stages=((4, 2), (8, 1)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 4, 1, 0) for l in spec]
+	net = nets.build(spec, name="ResNet-mini", initscheme="gaussian")
+	meta = checkpoint.load(net, os.path.join(GOLDEN, "refckpt_mini_%s.npz" % form))
+	assert meta == {}
+	net.evalMode()
+	scores = net(gpuarray.to_gpu(io["data"])).get()
+	assert_close(scores, io["scores"], atol=2e-5 * np.abs(io["scores"]).max(), rtol=1e-4, what="scores after loading the reference's file")
+
+	# ... and against the oracle network fed the file's tensors directly
+	tensors = checkpoint.read(os.path.join(GOLDEN, "refckpt_mini_%s.npz" % form))
+	link, attrOf = checkpoint.resolver(tensors, "links", form), checkpoint.resolver(tensors, "attrs", form)
+	params = {name: tensors["params/%d" % int(tensors[link(name)])] for name in net.namedParams()}
+	attrs = {name: tensors[attrOf(name)] for name in net.namedAttrs()}
+	cnet = N.CpuNet(spec, params, attrs)
+	cnet.train = False
+	assert_close(cnet.forward(io["data"]), io["scores"], atol=2e-5 * np.abs(io["scores"]).max(), rtol=1e-4, what="oracle network on the file's tensors")
+
+
+@pytest.mark.parametrize("layers", ["50", "101", "152"])
+def test_resnet_variants_run(bnd, layers):
+	"""Models/Nets/ResNet.py:124-143 (the reference's unittest): all three depths build and push one image through."""
+	from puzzlelib_amd import nets
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	np.random.seed(5)
+	net = nets.loadResNet(None, layers=layers, initscheme="he")        # (the reference's "gaussian" draws overflow 100+ layers deep)
+	assert net.name == "ResNet-%s" % layers
+	net.evalMode()
+	out = net(gpuarray.to_gpu(np.random.randn(1, 3, 224, 224).astype(np.float32))).get()
+	assert out.shape == (1, 1000) and np.isfinite(out).all() and abs(float(out.sum()) - 1.0) < 1e-4
+	del net
+	gpuarray.memoryPool.freeHeld()
 
 
 def test_checkpoint_round_trip_continues_bit_for_bit(bnd, mini_golden, tmp_path):

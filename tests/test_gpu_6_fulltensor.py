@@ -1,0 +1,250 @@
+"""
+Whole-tensor parity at BASELINE.json's own sizes (configs 2 and 4), the way the reference's per-op tests compare
+(Cuda/Wrappers/CuDnn.py:29-80 conv2dTest: np.allclose on the full outdata, ingrad and wgrad):
+
+* every distinct convolution of the reference's ResNet-50 at batch 256 — the 7x7/2 stem, the fifteen 1x1 layer shapes, the
+  four 3x3 layer shapes — and config 2's Conv2D(64 -> 128, 3x3, 56x56, batch 128): the launches the bench times (`auto`
+  algorithms, the lazy layer on), compared ELEMENT BY ELEMENT with the fp64 oracle over the WHOLE batch: forward,
+  backward-data (one host GEMM per chunk of 32 images) and the filter gradient — i.e. the b256 split-K / slab-reduce plan,
+  the XCD-remapped interior tiles and the k-sliced tail rounds themselves, not a sub-batch launch with a different plan.
+* one full-depth ResNet-50 training-mode step (53 convolutions, every fusion on) against the CPU network oracle: logits,
+  loss and all 161 parameter gradients.
+
+Tolerances (per element, stated where they are applied):
+  implicit GEMM / stem kernels   |err| <= 1e-5 s + 1e-4 |ref|,  s = the tensor's scale: max(1, rms(ref)) for y and dx (unit-
+                                 variance inputs, filters ~ 1/sqrt(fan-in)); sqrt(N P Q) for dw, the standard deviation of a
+                                 sum of N P Q unit-variance products — SURVEY.md section 8(c)'s bound on O(1) data
+  Winograd F(4x4) fwd / bwd-data |err| <= 6e-5 max|ref|      (test_winograd_convolution's stated bound)
+  Winograd F(2x2) bwd-filter     |err| <= 2e-5 max|ref| + 1e-5 sqrt(N P Q)
+"""
+import numpy as np
+import pytest
+
+import cpu_ref as R
+import cpu_net as N
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 32          # images per host GEMM (bounds the fp64 im2col: 32 x 3025 x 576 x 8 B = 446 MB for the widest 3x3 layer)
+
+
+def gpu(bnd, ary):
+	return bnd.GPUArray.toGpu(np.ascontiguousarray(ary))
+
+
+def dev_randn(bnd, shape, seed):
+	out = bnd.GPUArray.empty(shape, dtype=np.float32)
+	bnd.RandomNumberGenerator(seed=seed).fillNormal(out, mean=0.0, stddev=1.0)
+	return out
+
+
+def worst(got, ref, atol, rtol):
+	"""max over elements of |err| / (atol + rtol |ref|), chunked so that no fp64 copy of a whole tensor is made"""
+	assert got.shape == ref.shape, (got.shape, ref.shape)
+	g, r = got.reshape(-1), ref.reshape(-1)
+	top, step = 0.0, 1 << 24
+	for i in range(0, g.size, step):
+		gi, ri = g[i:i + step].astype(np.float64), r[i:i + step].astype(np.float64)
+		assert np.isfinite(gi).all(), "non-finite values in the device result"
+		top = max(top, float((np.abs(gi - ri) / (atol + rtol * np.abs(ri))).max()))
+	return top
+
+
+def rms(a):
+	return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+
+
+# (C, H, W) -> (K, size, stride, pad): Models/Nets/ResNet.py:23-121 on 224x224 inputs (55x55 stage-2 maps)
+R50_CONVS = [
+	((3, 224, 224), (64, 7, 2, 3)), ((64, 55, 55), (64, 1, 1, 0)), ((64, 55, 55), (64, 3, 1, 1)), ((64, 55, 55), (256, 1, 1, 0)),
+	((256, 55, 55), (64, 1, 1, 0)), ((256, 55, 55), (128, 1, 2, 0)), ((128, 28, 28), (128, 3, 1, 1)), ((128, 28, 28), (512, 1, 1, 0)),
+	((256, 55, 55), (512, 1, 2, 0)), ((512, 28, 28), (128, 1, 1, 0)), ((512, 28, 28), (256, 1, 2, 0)), ((256, 14, 14), (256, 3, 1, 1)),
+	((256, 14, 14), (1024, 1, 1, 0)), ((512, 28, 28), (1024, 1, 2, 0)), ((1024, 14, 14), (256, 1, 1, 0)),
+	((1024, 14, 14), (512, 1, 2, 0)), ((512, 7, 7), (512, 3, 1, 1)), ((512, 7, 7), (2048, 1, 1, 0)),
+	((1024, 14, 14), (2048, 1, 2, 0)), ((2048, 7, 7), (512, 1, 1, 0)),
+]
+CASES = [(256, ) + l for l in R50_CONVS] + [(128, (64, 56, 56), (128, 3, 1, 1))]          # + config 2
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "b%d_%dx%dx%d_to_%d_k%d_s%d" % ((c[0], ) + c[1] + c[2][:3]))
+def test_conv_whole_tensors_vs_fp64_oracle(bnd, case):
+	from puzzlelib_amd import lazy, lib
+	from puzzlelib_amd.surface import bound
+	Dnn, G = bound().Dnn, bnd.GPUArray
+	lazy.enabled, lazy.disabled = True, set()
+
+	n, (c, h, w), (k, size, stride, pad) = case
+	okw = dict(stride=(stride, stride), pad=(pad, pad), dilation=(1, 1), groups=1)
+	algos = Dnn.ConvFwdAlgo.auto, Dnn.ConvBwdDataAlgo.auto, Dnn.ConvBwdFilterAlgo.auto
+	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, size, size), stride, pad, 1, 1)
+	family = [bnd.dnn.convAlgoUsed(desc, which, -1) for which in (lib.CONV_FWD, lib.CONV_BWD_DATA, lib.CONV_BWD_FILTER)]
+	if size == 3:
+		assert family == [3, 3, 3], "3x3 layers run on the Winograd kernels under auto"
+
+	x = dev_randn(bnd, (n, c, h, w), 31)
+	wt = gpu(bnd, (np.random.RandomState(32).randn(k, c, size, size) / np.sqrt(c * size * size)).astype(np.float32))
+
+	# the launches the training step makes, back to back, before anything is read back
+	y = Dnn.convNd(x, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, algos[0])
+	p, q = y.shape[2:]
+	dy = dev_randn(bnd, (n, k, p, q), 33)
+	dx = Dnn.convNdBackwardData(dy, wt, x, okw["stride"], okw["pad"], okw["dilation"], 1, algos[1])
+	dw = G.zeros(wt.shape, dtype=np.float32)
+	Dnn.convNdBackwardParams(x, dy, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dw, None, 1.0, 1.0, algos[2])
+	dw_again = G.zeros(wt.shape, dtype=np.float32)
+	Dnn.convNdBackwardParams(x, dy, wt, None, okw["stride"], okw["pad"], okw["dilation"], 1, dw_again, None, 1.0, 1.0, algos[2])
+
+	xh, wh, dyh = x.get(), wt.get(), dy.get()
+	yh, dxh, dwh = y.get(), dx.get(), dw.get()
+	assert np.array_equal(dwh, dw_again.get()), "the filter gradient's slab reduction is not repeatable"
+	del x, dy, y, dx
+
+	images = np.arange(n)                                  # y and dx are compared over the whole batch
+	npix = n * p * q
+
+	def bounds(which, ref):
+		if family[which] == 3 and which < 2:
+			return 6e-5 * max(1.0, float(np.abs(ref).max())), 0.0
+		return 1e-5 * max(1.0, rms(ref)), 1e-4
+
+	ratios = {}
+	dw_ref = np.zeros(wh.shape, np.float64)
+	for c0 in range(0, n, CHUNK):
+		sel = slice(c0, min(n, c0 + CHUNK))
+		dw_ref += R.conv2d_bwd_filter(xh[sel], dyh[sel], wh.shape, withbias=False, acc=np.float64, **okw)
+		pick = images[(images >= sel.start) & (images < sel.stop)]
+		if len(pick) == 0:
+			continue
+		ref = R.conv2d_fwd(xh[pick], wh, None, acc=np.float64, **okw)
+		atol, rtol = bounds(0, ref)
+		ratios["forward"] = max(ratios.get("forward", 0.0), worst(yh[pick], ref, atol, rtol))
+		ref = R.conv2d_bwd_data(dyh[pick], wh, (len(pick), c, h, w), acc=np.float64, **okw)
+		atol, rtol = bounds(1, ref)
+		ratios["backward-data"] = max(ratios.get("backward-data", 0.0), worst(dxh[pick], ref, atol, rtol))
+
+	if family[2] == 3:
+		atol, rtol = 2e-5 * float(np.abs(dw_ref).max()) + 1e-5 * np.sqrt(npix), 0.0
+	else:
+		atol, rtol = 1e-5 * np.sqrt(npix), 1e-4
+	ratios["backward-filter"] = worst(dwh, dw_ref, atol, rtol)
+
+	print("whole-tensor error / bound:", {k_: round(v, 3) for k_, v in ratios.items()}, "kernel families", family)
+	for name, ratio in ratios.items():
+		assert ratio <= 1.0, "%s: an element is %.2f x its bound (families %s)" % (name, ratio, family)
+
+
+def adoptDeviceGatesNested(cnet, layers, spec, prefix=""):
+	"""test_gpu_5_nets.adoptDeviceGates for nested specs: the oracle's backward gates with the ReLU outputs / max-pool
+	operands the DEVICE produced (cache keys as oracle/cpu_net.py builds them: "<index>", "<index>.b.<index>", ...). Returns
+	(flipped gates, worst forward mismatch relative to the tensor's top)."""
+	flips, mism = 0, 0.0
+	for idx, layer in enumerate(layers):
+		key = "%s%d" % (prefix, idx)
+		if layer.kind == "act":
+			y = layer.y.get()
+			ref = cnet.cache[key]
+			mism = max(mism, float(np.abs(y - ref).max()) / max(1.0, float(np.abs(ref).max())))
+			flips += int(((y > 0) != (ref > 0)).sum())
+			cnet.cache[key] = y
+		elif layer.kind == "pool" and spec[idx][0] == "maxpool":
+			cnet.cache[key] = (layer.x.get(), layer.y.get())
+		elif layer.kind == "resid":
+			for tag, branch, sub in (("b", layer.branches[0], spec[idx][1]), ("s", layer.branches[1], spec[idx][2])):
+				if len(sub) > 0:
+					f, m = adoptDeviceGatesNested(cnet, branch, sub, "%s.%s." % (key, tag))
+					flips, mism = flips + f, max(mism, m)
+	return flips, mism
+
+
+@pytest.mark.parametrize("batch", [16])
+def test_resnet50_full_depth_training_step_vs_oracle(bnd, batch):
+	"""Config 4's network at full depth, training mode (batch statistics in all 53 batch norms), `auto` algorithms, every
+	fusion of the lazy layer on and the convolution epilogues' statistics in use (second pass of the adaptive policy):
+	logits, loss, cross-entropy gradient and ALL 161 parameter gradients against oracle/cpu_net.py on the same inputs and
+	initial values. The oracle's backward gates with the device's ReLU / max-pool decisions (a pre-activation within rounding
+	of zero may round to either side; see adoptDeviceGates in test_gpu_5_nets.py). Bound, per parameter gradient: relative L2
+	error against the oracle with fp64 sums inside every operator <= max(5e-5, 2 x the distance of the fp32-summing oracle from
+	that same yardstick) — 53 layers deep the order of fp32 sums alone moves the last block's gradients by ~1e-4 (two numpy
+	runs differing only in accumulation type), so a fixed 5e-5 would test numpy's summation order, not the kernels; median over
+	the 161 gradients <= 5e-5; every element within 1e-3 of its gradient's top."""
+	from puzzlelib_amd import nets, optim, lazy
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	lazy.enabled, lazy.disabled = True, set()
+
+	np.random.seed(4321)
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="he")
+	net.layers.pop()                                       # the trailing SoftMax: training runs on raw scores
+	spec = nets.resnet50_spec(softmax=False)
+	optimizer = optim.Adam(alpha=1e-3)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = optim.CrossEntropy()
+	rng = np.random.RandomState(99)
+	data = rng.randn(batch, 3, 224, 224).astype(np.float32)
+	labels = rng.randint(0, 1000, size=(batch, )).astype(np.int32)
+	gdata, glabels = gpuarray.to_gpu(data), gpuarray.to_gpu(labels)
+	params = {name: p.data.get() for name, p in net.namedParams().items()}
+	assert len(params) == 161
+	net.trainMode()
+
+	def devicePass():
+		for layer in net.walk():
+			if layer.kind == "bn":
+				layer.cfg["passes"] = 0
+				layer.attrs["mean"].fill(0.0)
+				layer.attrs["var"].fill(1.0)
+		lazy.counters.clear()
+		logits = net(gdata)
+		grad = cost(logits, glabels, queryError=False)
+		optimizer.zeroGradParams()
+		net.backward(grad, updGrad=False)
+		return logits, grad
+
+	devicePass()                                           # the adaptive policy learns which convolutions feed a batch norm
+	net.reset()
+	logits, grad = devicePass()
+	taken = dict(lazy.counters)
+	assert taken.get("bn_apply_add", 0) == 16 and taken.get("dgrad_bn_fold", 0) >= 1, taken
+
+	def oracle(acc):
+		attrs = {name: (np.zeros(a.shape, np.float32) if name.endswith(".mean") else np.ones(a.shape, np.float32))
+				 for name, a in net.namedAttrs().items()}      # running statistics as devicePass() resets them
+		cnet = N.CpuNet(spec, params, attrs, acc=acc)
+		cnet.train = True
+		ref_logits = cnet.forward(data)
+		err_ref, grad_ref = R.cross_entropy(ref_logits, labels)
+		flips, mism = adoptDeviceGatesNested(cnet, net.layers, spec)
+		cnet.zero_grads()
+		cnet.backward(grad_ref)
+		return cnet, ref_logits, err_ref, grad_ref, flips, mism
+
+	# the yardstick: every operator correctly rounded from fp64 sums ...
+	cnet, ref_logits, err_ref, grad_ref, flips, mism = oracle(np.float64)
+	got_logits = logits.get()
+	scale = float(np.abs(ref_logits).max())
+	assert np.abs(got_logits - ref_logits).max() <= 2e-4 * scale, "logits: %.3e of their top" % (np.abs(got_logits - ref_logits).max() / scale)
+	assert np.isclose(float(cost.devErr.get()), err_ref, rtol=1e-4), (float(cost.devErr.get()), err_ref)
+	assert np.abs(grad.get() - grad_ref).max() <= 1e-6 + 1e-3 * np.abs(grad_ref).max()
+	assert mism <= 2e-4, "a forward activation is %.3e of its top away from the oracle's" % mism
+	# ... and what fp32 summation itself is worth 53 layers deep: the oracle with fp32 sums (numpy's order) against the same
+	# yardstick. Two correctly working fp32 implementations are this far apart (measured: 1.15e-4 on the last block's filter
+	# gradients at batch 16, median 2e-5 — the device, Winograd or implicit GEMM alike, sits at 1.1e-4 / 2e-5).
+	c32 = oracle(np.float32)[0]
+
+	def rel(a, b):
+		return np.linalg.norm((a - b).astype(np.float64)) / (np.linalg.norm(b.astype(np.float64)) + 1e-30)
+
+	rels = []
+	for name, p in net.namedParams().items():
+		ref, got = cnet.grads[name], p.grad.get()
+		assert np.isfinite(got).all(), name
+		dev, own = rel(got, ref), rel(c32.grads[name], ref)
+		rels.append((dev, own, name))
+		assert dev <= max(5e-5, 2.0 * own), "grad %s: relative L2 error %.3e (the fp32 oracle's own: %.3e)" % (name, dev, own)
+		assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, "element of grad %s" % name
+	rels.sort(reverse=True)
+	median = rels[len(rels) // 2][0]
+	print("ResNet-50 b%d training step vs fp64-summing oracle: worst relative L2 gradient error %.3e (%s; fp32-summing oracle %.3e), "
+		  "median %.3e, %d flipped gates adopted, worst forward mismatch %.2e" % (batch, rels[0][0], rels[0][2], rels[0][1], median, flips, mism))
+	assert median <= 5e-5, "median relative L2 gradient error %.3e" % median
+	net.reset()

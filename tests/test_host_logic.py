@@ -165,6 +165,28 @@ def test_network_specs():
 	assert lp["7.W"] == (800, 1024) and lp["0.b"] == (1, 16, 1, 1)
 
 
+def test_resnet_variants_name_their_entries_as_the_reference_does():
+	"""Models/Nets/ResNet.py:69-121: ResNet-50 / -101 / -152. tests/golden/resnet_entry_names.json holds the link / attr entry
+	names (and shapes) the REFERENCE's networks save under assumeUniqueNames=True (oracle/make_checkpoint_fixture.py wrote it
+	from the imported reference): the specs here must produce exactly those, so that a reference checkpoint resolves."""
+	import json
+	from conftest import GOLDEN
+	from puzzlelib_amd import nets
+	want = json.load(open(os.path.join(GOLDEN, "resnet_entry_names.json")))
+	totals = {"50": 25557032, "101": 44549160, "152": 60192808}
+	for layers, entries in want.items():
+		names = nets.resnet_blocknames(layers)
+		stages = tuple((hmaps, len(names[level])) for level, hmaps in zip((2, 3, 4, 5), (64, 128, 256, 512)))
+		params, attrs = nets.spec_param_shapes(nets.resnet_spec(stages, blocknames=names))
+		got = {("links", "ResNet-%s.%s" % (layers, k)): list(v) for k, v in params.items()}
+		got.update({("attrs", "ResNet-%s.%s" % (layers, k)): list(v) for k, v in attrs.items()})
+		ref = {(grp, name): shape for grp, name, shape in entries}
+		assert got == ref, "ResNet-%s: %s" % (layers, sorted(set(got) ^ set(ref))[:6])
+		assert sum(int(np.prod(s)) for s in params.values()) == totals[layers]
+	with pytest.raises(ValueError, match="Unsupported ResNet layers mode"):
+		nets.resnet_blocknames("34")
+
+
 def test_settings_object():
 	from puzzlelib_amd.settings import Config, Backend, ConfigError
 	assert Config.backend == Backend.hip and Config.Backend.hip.value == 1
@@ -261,3 +283,24 @@ def test_convolution_family_resolution_without_device():
 
 	lib.pz_relu_mask_bytes(256, 256, 55 * 55, ctypes.byref(size))
 	assert size.value == 256 * 256 * (55 * 55 // 4 + 3)
+
+	# a pass that is handed its prepared filter operand needs no room for a second copy of it (round-3 advisor finding)
+	pre = ctypes.c_size_t()
+	for desc in (c1, c3):
+		for which in (lib.CONV_FWD, lib.CONV_BWD_DATA):
+			lib.pz_conv2d_workspace_bytes(ctypes.byref(desc), which, lib.CONV_ALGO_AUTO, ctypes.byref(size))
+			lib.pz_conv2d_workspace_bytes_pre(ctypes.byref(desc), which, lib.CONV_ALGO_AUTO, ctypes.byref(pre))
+			packed = ctypes.c_size_t()
+			lib.pz_conv2d_prepack_bytes(ctypes.byref(desc), which, lib.CONV_ALGO_AUTO, ctypes.byref(packed))
+			assert pre.value <= size.value and (packed.value == 0 or pre.value <= size.value - min(size.value, packed.value) + 256)
+	lib.pz_conv2d_workspace_bytes_pre(ctypes.byref(c3), lib.CONV_FWD, lib.CONV_ALGO_AUTO, ctypes.byref(pre))
+	assert pre.value == 0                                   # Winograd forward: everything it needs is the prepared operand
+
+	# one order of precedence everywhere (Winograd, thin backward-data, implicit GEMM, direct): a 3-map 3x3 / pad 1 layer is a
+	# thin backward-data problem under auto (reported as direct), a Winograd one on request — the workspace sizes follow
+	stemlike = ConvDesc(8, 3, 20, 20, 16, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+	if used(stemlike, lib.CONV_BWD_DATA, lib.CONV_ALGO_AUTO) == lib.CONV_ALGO_DIRECT:
+		lib.pz_conv2d_workspace_bytes(ctypes.byref(stemlike), lib.CONV_BWD_DATA, lib.CONV_ALGO_AUTO, ctypes.byref(size))
+		thin_bytes = size.value
+		lib.pz_conv2d_workspace_bytes(ctypes.byref(stemlike), lib.CONV_BWD_DATA, lib.CONV_ALGO_IMPLICIT_GEMM, ctypes.byref(size))
+		assert used(stemlike, lib.CONV_BWD_DATA, lib.CONV_ALGO_IMPLICIT_GEMM) == lib.CONV_ALGO_IMPLICIT_GEMM and size.value != thin_bytes
