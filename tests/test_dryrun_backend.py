@@ -52,8 +52,9 @@ def test_gradient_buckets_leave_progressively_for_resnet50():
 
 
 @pytest.mark.timeout(300)
-def test_bench_starts_its_own_ranks_and_runs_the_data_parallel_path():
-	"""`python bench.py --gpus 2` without a launcher (the shape of the driver's command): bench.py spawns the ranks itself,
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_starts_its_own_ranks_and_runs_the_data_parallel_path(ranks):
+	"""`python bench.py --gpus N` (N = 2, and the driver's full node: 8) without a launcher (the shape of the driver's command): bench.py spawns the ranks itself,
 	they find each other over the TCP host group, exchange the RCCL id, vote, create the communicator, broadcast the
 	parameters and run the bucketed, overlapped gradient exchange — all of it in dry-run mode here (both ranks pinned to the
 	one simulated device), so every host-side step of the multi-GPU path runs before hardware sees it."""
@@ -62,12 +63,13 @@ def test_bench_starts_its_own_ranks_and_runs_the_data_parallel_path():
 	for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
 		env.pop(key, None)
 	res = subprocess.run(
-		[sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+		[sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--batch", "2",
 		 "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=280
 	)
 	assert res.returncode == 0, res.stderr[-4000:]
 	lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
 	assert len(lines) == 1, "exactly one JSON line (rank 0's)"
 	out = json.loads(lines[0])
-	assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+	assert out["n_gpus"] == ranks and out["config"]["global_batch"] == 2 * ranks and out["scaling"] == "weak"
+	assert out["config"]["rccl_nranks"] == ranks and "comm" in out["config"] and "tolerance" in out
 	assert out["config"]["grad_allreduce"].startswith("RCCL")

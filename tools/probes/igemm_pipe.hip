@@ -176,6 +176,116 @@ loop(float *out, int ktiles, const float *src, unsigned plane, unsigned planes, 
 			for (int r = 0; r < 16; ++r) o[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
 }
 
+// ---- b64 fragment reads: LDS cells [group of 4 k][half][row]{2 floats}; lane (row, h) reads k = {4g+2h, 4g+2h+1} with one
+// ds_read_b64 and feeds two consecutive k2-steps. KT = k-tile depth (16: 16 KB per workgroup as production, 32: 64 KB, two
+// workgroups per CU). Production order otherwise (gathers spread over the tile, park + barrier + first read at its end).
+template <int KT, int WPE, bool STAGE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+loop64(float *out, int ksteps16, const float *src, unsigned plane, unsigned planes, const float *filt, unsigned kfilt) {
+	constexpr int G = KT / 4;                       // groups of 4 k per tile
+	__shared__ __attribute__((aligned(16))) float smem[2 * KT * (BM + BN)];
+	typedef float f32x2 __attribute__((ext_vector_type(2)));
+	auto cellA = [&](int buf, int g, int h, int row) { return reinterpret_cast<f32x2 *>(smem + ((size_t)(buf * G + g) * 2 + h) * BM * 2) + row; };
+	auto cellB = [&](int buf, int g, int h, int row) { return reinterpret_cast<f32x2 *>(smem + 2 * KT * BM + ((size_t)(buf * G + g) * 2 + h) * BN * 2) + row; };
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+	const unsigned tile = blockIdx.x;
+	const int ktiles = ksteps16 * 16 / KT;
+
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, plane * planes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)filt, 0, kfilt * BM * 4, 0x00020000);
+	constexpr int NB = KT / 2;                      // gathers per thread and tile (2 threads per pixel column)
+	constexpr int NA = KT * BM / 4 / 256;           // 16-byte filter loads per thread and tile
+	const int jb = tid % BN, kb0 = __builtin_amdgcn_readfirstlane(tid / BN);
+	const unsigned voffB = ((tile % 2048u) * BN + jb) * 4u;
+
+	f32x16 acc[2][2];
+	for (int i = 0; i < 2; ++i)
+		for (int j = 0; j < 2; ++j)
+			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+	f32x4 ra[NA];
+	float rb[NB];
+
+	auto load_one = [&](int kt, int j) {
+		const unsigned soffA = ((unsigned)(kt * KT) % kfilt) * BM * 4u;
+		const unsigned soffB = (((unsigned)(kt * KT) % planes) + kb0 * NB + j) * plane;
+		if (j < NA) ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, (unsigned)(tid + j * 256) * 16u, soffA, 0));
+		rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voffB, soffB, 0));
+	};
+	auto park = [&](int buf) {
+#pragma unroll
+		for (int i = 0; i < NA; ++i) reinterpret_cast<f32x4 *>(smem + (size_t)buf * KT * BM)[tid + i * 256] = ra[i];      // tile image = global order
+#pragma unroll
+		for (int i = 0; i < NB; i += 2) {
+			const int k = kb0 * NB + i;              // even: pair (k, k+1) = element pair of cell [k/4][(k/2)&1]
+			*cellB(buf, k / 4, (k / 2) & 1, jb) = f32x2{rb[i], rb[i + 1]};
+		}
+	};
+	f32x2 av[2][2], bv[2][2];
+	auto read_frag = [&](int buf, int g, int slot) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i) av[slot][i] = *cellA(buf, g, lhi, wm * 64 + i * 32 + l31);
+#pragma unroll
+		for (int j = 0; j < 2; ++j) bv[slot][j] = *cellB(buf, g, lhi, wn * 64 + j * 32 + l31);
+	};
+	auto compute_tile = [&](int buf, int kt_next, bool has_next) {
+		read_frag(buf, 0, 0);
+#pragma unroll
+		for (int g = 0; g < G; ++g) {
+			if (g + 1 < G) read_frag(buf, g + 1, (g + 1) & 1);
+			if (STAGE && has_next) {
+#pragma unroll
+				for (int q = 0; q < NB / G; ++q) load_one(kt_next, g * (NB / G) + q);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int e = 0; e < 2; ++e)
+#pragma unroll
+				for (int i = 0; i < 2; ++i)
+#pragma unroll
+					for (int jj = 0; jj < 2; ++jj)
+						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][i][e], bv[g & 1][jj][e], acc[i][jj], 0, 0, 0);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	};
+	if (STAGE) {
+#pragma unroll
+		for (int j = 0; j < NB; ++j) load_one(0, j);
+		park(0);
+	} else {
+		for (int i = tid; i < 2 * KT * (BM + BN); i += 256) smem[i] = (i * 2654435761u >> 8) * 1e-9f;
+	}
+	__syncthreads();
+	for (int kt = 0; kt + 1 < ktiles; ++kt) {
+		const int buf = kt & 1;
+		compute_tile(buf, kt + 1, true);
+		if (STAGE) park(buf ^ 1);
+		__syncthreads();
+	}
+	compute_tile((ktiles - 1) & 1, 0, false);
+
+	float *o = out + (size_t)tile * BM * BN;
+	for (int i = 0; i < 2; ++i)
+		for (int j = 0; j < 2; ++j)
+			for (int r = 0; r < 16; ++r) o[((i * 2 + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+}
+
+template <int KT, int WPE, bool STAGE>
+float timeit64(int blocks, int ksteps16, float *out, const float *src, const float *filt, int reps = 10) {
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0), hipEventCreate(&e1);
+	loop64<KT, WPE, STAGE><<<blocks, 256>>>(out, ksteps16, src, 1u << 20, 1024, filt, 4096);
+	hipEventRecord(e0);
+	for (int r = 0; r < reps; ++r) loop64<KT, WPE, STAGE><<<blocks, 256>>>(out, ksteps16, src, 1u << 20, 1024, filt, 4096);
+	hipEventRecord(e1);
+	hipEventSynchronize(e1);
+	float ms;
+	hipEventElapsedTime(&ms, e0, e1);
+	hipEventDestroy(e0), hipEventDestroy(e1);
+	return ms / reps;
+}
+
 __global__ void fill(float *p, size_t n, unsigned seed) {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
 		p[i] = (float)(((unsigned)i * 2654435761u + seed) >> 20) * (1.f / 4096.f) - 0.5f;
@@ -250,6 +360,20 @@ int main() {
 			const float t5 = timeit<5, 4>(nb, kt, out, src, filt);
 			printf("%5d (%5.2f/CU) x %3d        %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f %8.1f\n", nb, nb / 256.0, kt, gf / t0, gf / t1, gf / t2,
 			       gf / t3, gf / t33, gf / t4, gf / t5);
+		}
+	}
+
+	printf("\nb64 fragment reads (k pairs per lane), TFLOP/s: k-tile 16 / 32, staged (S) or fragment reads only (N); [2wpe] = two waves per SIMD allowed\n");
+	printf("%-28s %9s %9s %9s %9s %9s\n", "blocks x k-tiles(16)", "KT16 S", "KT16 N", "KT32 S", "KT32 N", "KT32 S 2wpe");
+	for (int nb : {256, 512, 768, 1024, 1536, 3072, 6144}) {
+		for (int kt : {16, 64}) {
+			const double gf = (double)nb * kt * 2.0 * BM * BN * BK / 1e9;
+			const float a = timeit64<16, 4, true>(nb, kt, out, src, filt);
+			const float b = timeit64<16, 4, false>(nb, kt, out, src, filt);
+			const float c = timeit64<32, 4, true>(nb, kt, out, src, filt);
+			const float d = timeit64<32, 4, false>(nb, kt, out, src, filt);
+			const float e = timeit64<32, 2, true>(nb, kt, out, src, filt);
+			printf("%5d (%5.2f/CU) x %3d        %9.1f %9.1f %9.1f %9.1f %9.1f\n", nb, nb / 256.0, kt, gf / a, gf / b, gf / c, gf / d, gf / e);
 		}
 	}
 	return 0;
