@@ -56,6 +56,9 @@
 #ifndef PZ_LB
 #define PZ_LB 4
 #endif
+#ifndef PZ_EPI_AUX
+#define PZ_EPI_AUX 0              // cache policy bits of the epilogue's 16-byte stores (2 = nt, 16 = sc1): experiment switch
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -444,7 +447,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 #else
 					const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u : kOOB;
 #endif
-					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, 0);
+					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, PZ_EPI_AUX);
 				} else {
 					auto store_one = [&](int e, float val) {
 						const int o = opix + e;
@@ -473,10 +476,17 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 
 // 4 waves (128x128, 64x256 tiles; 4 workgroups per CU) or 8 waves (256x128 tiles for >= 256 output rows: the gathered pixel
 // panel serves twice as many rows, half the gathers per MFMA; 2 workgroups per CU = the same 4 waves per SIMD)
-template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false>
-__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(BNX && WM * WN == 4 ? 3 : 4, 8)))
+// PF2: the next-but-one k-tile's global loads are in flight while a k-tile is multiplied (two register sets, the loop is
+// unrolled by two so that the sets stay static), the next tile is parked in LDS during k2-step 6, and the barrier sits
+// BETWEEN the MFMAs of k2-step 7 with the next tile's first fragments read behind it: no wave waits for a load it issued a
+// quarter of a tile ago, and the k-tile boundary (park, barrier, first fragment read) is in the shadow of MFMAs. Costs 16
+// registers (3 waves per SIMD instead of 4); tools/probes/igemm_pipe.hip variant V3 measured it at +4..6 % from 3 to 24
+// tiles per CU (profiles/r04_igemm_pipe_probe.txt). Same products in the same order: bit-identical results.
+template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false, bool PF2 = false>
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((BNX && WM * WN == 4) || PF2 ? 3 : 4, 8)))
 igemm_conv_kernel(IgemmArgs a) {
 	static_assert(!BNX || TAPMAJOR, "the BatchNorm-backward gather rides on the tap-major order");
+	static_assert(!PF2 || (TAPMAJOR && !BNX && WM * WN == 4), "two-tiles-ahead loads: tap-major, plain gathers, 4 waves");
 	constexpr int BK = 16, NT = 64 * WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
 	static_assert((WM * WN == 4 || WM * WN == 8) && TM >= 1 && TN >= 1, "4 or 8 waves per workgroup");
@@ -550,8 +560,9 @@ igemm_conv_kernel(IgemmArgs a) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-	f32x4 ra[NA];
-	float rb[NB];
+	constexpr int NSETS = PF2 ? 2 : 1;
+	f32x4 ra[NSETS][NA];
+	float rb[NSETS][NB];
 	float rb2[BNX ? NB : 1];                  // BNX: the BatchNorm input elements that go with the gradient elements
 	float4 bnc[BNX ? NB : 1];                 // ... and the coefficients of their channels (scalar loads)
 	const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
@@ -587,36 +598,40 @@ igemm_conv_kernel(IgemmArgs a) {
 		}
 	};
 
-	auto load_part = [&](int kt, int j) {
+	using Set0 = std::integral_constant<int, 0>;
+	using Set1 = std::integral_constant<int, NSETS - 1>;
+	auto load_part = [&](int kt, int j, auto set) {
+		constexpr int SET = decltype(set)::value;
 		constexpr int PER = NB >= BK / 2 ? NB / (BK / 2) : 1;          // gathers per k2-step (NB < 8: one every (BK/2)/NB steps)
 		constexpr int EVERY = NB >= BK / 2 ? 1 : (BK / 2) / NB;
 		if (j < NA)
-			ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[j], (unsigned)(kt * BK * a.mpad) * 4u, 0));
+			ra[SET][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, voffA[j], (unsigned)(kt * BK * a.mpad) * 4u, 0));
 		if (j % EVERY != 0) return;
 #pragma unroll
 		for (int t = 0; t < PER; ++t) {
 			const int i = (j / EVERY) * PER + t;
 			if constexpr (TAPMAJOR) {
-				rb[i] = buf_load_f32(xr, voff_tile, soff_tile + (unsigned)i * hw4);
+				rb[SET][i] = buf_load_f32(xr, voff_tile, soff_tile + (unsigned)i * hw4);
 				if constexpr (BNX) rb2[i] = buf_load_f32(x2r, voff_tile, soff_tile + (unsigned)i * hw4);
 			} else {
 				const bool ok = (tapmask >> e[i].y) & 1ull;
-				rb[i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
+				rb[SET][i] = buf_load_f32(xr, ok ? base_bytes + (unsigned)e[i].x : kOOB, 0);
 			}
 		}
 	};
 
-	auto store_tile = [&](int buf) {
+	auto store_tile = [&](int buf, auto set) {
+		constexpr int SET = decltype(set)::value;
 #pragma unroll
 		for (int i = 0; i < NA; ++i) {
 			const int f = tid + i * NT;
 			const int kk = f / (BM / 4), m4 = (f % (BM / 4)) * 4;
-			*reinterpret_cast<f32x4 *>(&As[buf][kk][m4]) = ra[i];
+			*reinterpret_cast<f32x4 *>(&As[buf][kk][m4]) = ra[SET][i];
 		}
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
-			float v = rb[i];
-			if constexpr (BNX) v = __builtin_fmaf(bnc[i].x, rb[i], __builtin_fmaf(bnc[i].y, rb2[i], bnc[i].z));
+			float v = rb[SET][i];
+			if constexpr (BNX) v = __builtin_fmaf(bnc[i].x, rb[SET][i], __builtin_fmaf(bnc[i].y, rb2[i], bnc[i].z));
 			Bs[buf][kb0 * NB + i][jb] = v;
 		}
 	};
@@ -640,7 +655,7 @@ igemm_conv_kernel(IgemmArgs a) {
 			if (j + 1 < BK / 2) read_frag(buf, 2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
 			if (has_next && j < PZ_IG_LOAD_STEPS) {
 #pragma unroll
-				for (int q = 0; q < (BK / 2) / PZ_IG_LOAD_STEPS; ++q) load_part(kt_next, j * ((BK / 2) / PZ_IG_LOAD_STEPS) + q);
+				for (int q = 0; q < (BK / 2) / PZ_IG_LOAD_STEPS; ++q) load_part(kt_next, j * ((BK / 2) / PZ_IG_LOAD_STEPS) + q, Set0{});
 			}
 			__builtin_amdgcn_sched_barrier(0);        // keep this step's LDS reads / gather ahead of its MFMAs ...
 #if PZ_ABL & 4
@@ -665,10 +680,74 @@ igemm_conv_kernel(IgemmArgs a) {
 		kt1 = (int)((long)nk_all * (kslice + 1) / a.tail_splits);
 	}
 
+	if constexpr (PF2) {
+		float av[2][TM], bv[2][TN];
+		// one k-tile out of LDS buffer `buf`; on entry the fragments of its k2-step 0 are in slot 0. lset: the register set
+		// this tile's loads (of tile kt_load, two ahead) go to; pset: the set parked into the other buffer during k2-step 6
+		auto tile_body = [&](int buf, auto lset, auto pset, int kt_load, bool do_load, bool do_park) {
+#pragma unroll
+			for (int j = 0; j < BK / 2; ++j) {
+				if (j + 1 < BK / 2) read_frag(buf, 2 * (j + 1), av[(j + 1) & 1], bv[(j + 1) & 1]);
+				if (do_load && j < 2) {
+					if (j == 0) load_tab(kt_load);
+#pragma unroll
+					for (int q = 0; q < BK / 4; ++q) load_part(kt_load, j * (BK / 4) + q, lset);
+				}
+				if (do_park && j == BK / 2 - 2) store_tile(buf ^ 1, pset);
+				__builtin_amdgcn_sched_barrier(0);
+				if (j == BK / 2 - 1 && do_park) {
+#pragma unroll
+					for (int jj = 0; jj < TN; ++jj) acc[0][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][0], bv[j & 1][jj], acc[0][jj], 0, 0, 0);
+					__builtin_amdgcn_sched_barrier(0);
+					__syncthreads();                     // everyone's park is visible, everyone is done reading `buf`
+					read_frag(buf ^ 1, 0, av[0], bv[0]);         // (slot 0; this k2-step's fragments are in slot 1)
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int i = 1; i < TM; ++i)
+#pragma unroll
+						for (int jj = 0; jj < TN; ++jj)
+							acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+				} else {
+#pragma unroll
+					for (int i = 0; i < TM; ++i)
+#pragma unroll
+						for (int jj = 0; jj < TN; ++jj)
+							acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
+				}
+				__builtin_amdgcn_sched_barrier(0);
+			}
+		};
+		static_assert((BK / 2) % 2 == 0, "k2-step BK/2 - 1 is odd: its fragments sit in slot 1, the next tile's first in slot 0");
+
+		const int nk = kt1 - kt0;
+		load_tab(kt0);
+#pragma unroll
+		for (int j = 0; j < BK / 2; ++j) load_part(kt0, j, Set0{});
+		store_tile(0, Set0{});
+		if (nk > 1) {
+			load_tab(kt0 + 1);
+#pragma unroll
+			for (int j = 0; j < BK / 2; ++j) load_part(kt0 + 1, j, Set1{});
+		}
+		__syncthreads();
+		read_frag(0, 0, av[0], bv[0]);
+
+		int t = 0;                                       // tile t: loads of tile t+2 into set t & 1, parks set (t+1) & 1
+		for (; t + 2 < nk; t += 2) {
+			tile_body(0, Set0{}, Set1{}, kt0 + t + 2, true, true);
+			tile_body(1, Set1{}, Set0{}, kt0 + t + 3, t + 3 < nk, true);
+		}
+		if (nk - t == 2) {
+			tile_body(0, Set0{}, Set1{}, 0, false, true);
+			tile_body(1, Set1{}, Set0{}, 0, false, false);
+		} else {
+			tile_body(0, Set0{}, Set1{}, 0, false, false);
+		}
+	} else {
 	load_tab(kt0);
 #pragma unroll
-	for (int j = 0; j < BK / 2; ++j) load_part(kt0, j);
-	store_tile(0);
+	for (int j = 0; j < BK / 2; ++j) load_part(kt0, j, Set0{});
+	store_tile(0, Set0{});
 	__syncthreads();
 
 	for (int kt = kt0; kt + 1 < kt1; ++kt) {
@@ -677,13 +756,14 @@ igemm_conv_kernel(IgemmArgs a) {
 		compute_tile(buf, kt + 1, false);
 #else
 		compute_tile(buf, kt + 1, true);
-		store_tile(buf ^ 1);
+		store_tile(buf ^ 1, Set0{});
 #endif
 #if !(PZ_ABL & 2)       // ablation: no barrier
 		__syncthreads();
 #endif
 	}
 	compute_tile((kt1 - 1 - kt0) & 1, 0, false);
+	}
 
 	if (kslice < 0) {
 #if PZ_ABL & 256        // ablation: no epilogue stores except one element per lane (timing only)
@@ -1856,6 +1936,18 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 	return PZ_OK;
 }
 
+// 128 x 128 tap-major launches with at least this many k-tiles take the two-tiles-ahead form of the kernel (PF2): measured on
+// the ResNet-50 census (profiles/r04_igemm_pf2_census.txt) -3..-8 % from 32 k-tiles up (the default), even at 16, +3..7 % at 8 (the longer
+// prologue and 3 instead of 4 waves per SIMD are not paid back by 8 tiles). PUZZLE_MI355_IG_PF2 = minimum (0: never) — A/B aid.
+static int ig_prefetch2_min_ktiles() {
+	static const int n = [] {
+		const char *e = getenv("PUZZLE_MI355_IG_PF2");
+		const int v = e ? atoi(e) : 32;
+		return v <= 0 ? (1 << 24) : v;
+	}();
+	return n;
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
 	constexpr int lds_pad = 0;
@@ -1878,7 +1970,10 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 		}
 		if (a.x2)
 			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
-		else if (a.tapmajor)
+		else if (a.tapmajor && BM == 128 && BN == 128 && a.kred_pad >= 16 * ig_prefetch2_min_ktiles()) {
+			if constexpr (BM == 128 && BN == 128 && WM * WN == 4)
+				igemm_conv_kernel<BM, BN, WM, WN, true, false, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+		} else if (a.tapmajor)
 			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else
 			igemm_conv_kernel<BM, BN, WM, WN, false><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);

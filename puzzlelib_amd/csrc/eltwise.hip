@@ -64,14 +64,19 @@ PZ_ELT(OpRbm, 3, 0b110, 0b001, const float p = 1.f / (1.f + expf(-v[1])); v[0] =
 // arena holding the SUM over ranks (Grid.py:126-133 divides inside its reduce; here the division rides in the update kernel
 // instead of a pass of its own over the arena — same rounding: one fp32 product per element)
 PZ_ELT(OpAdam, 4, 0b1111, 0b1101,                                                                     // :710-757
-       const float g = __fmul_rn(v[1], s[4]);        // (rounded on its own: never contracted into the sums below)
+       float g = v[1] * s[4];
+       asm volatile("" : "+v"(g));                   // the product is rounded on its own (never contracted into the sums below)
        v[2] += s[1] * (g - v[2]);
        v[3] += s[2] * (g * g - v[3]);
        v[0] += s[0] * v[2] / (sqrtf(v[3]) + s[3]);)
-PZ_ELT(OpClassicMomSGD, 3, 0b111, 0b101, const float g = __fmul_rn(v[1], s[2]); v[2] = s[1] * v[2] + s[0] * g; v[0] += v[2];)   // :760-806
+PZ_ELT(OpClassicMomSGD, 3, 0b111, 0b101,                                                              // :760-806
+       float g = v[1] * s[2];
+       asm volatile("" : "+v"(g));
+       v[2] = s[1] * v[2] + s[0] * g; v[0] += v[2];)
 PZ_ELT(OpNesterovMomSGD, 3, 0b111, 0b101,                                                             // :809-857
        const float m = v[2];
-       const float g = __fmul_rn(v[1], s[2]);
+       float g = v[1] * s[2];
+       asm volatile("" : "+v"(g));
        v[2] = s[1] * m + s[0] * g;
        v[0] += s[1] * s[1] * m + (1.f + s[1]) * s[0] * g;)
 PZ_ELT(OpRmsprop, 3, 0b111, 0b101,                                                                    // :860-905
