@@ -110,6 +110,16 @@ int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t
  * the launch itself needs (slabs of k-sliced tiles), not a second copy of the packed filters. */
 int pz_conv2d_workspace_bytes_pre(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
 /* y = conv(x, w) (+ bias[k] when bias != NULL) */
+/* Activation epilogues (backend-internal fusion behind Conv2D -> Activation(relu), Modules/Activation.py:52-70): is the pass
+ * served by a kernel that can apply them (implicit GEMM, output pixels contiguous per image)? */
+int pz_conv2d_epilogue_supported(const pz_conv_desc *d, int which, int algo, int *supported);
+/* y = max(conv(x, w) + bias, 0); w, or packed = a prepared operand (pz_conv2d_prepack) with w ignored */
+int pz_conv2d_fwd_relu(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y, int algo,
+                       void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* dx = bwd_data(dy, w) where gate > 0, else 0 (gate: dx's shape — the output of the ReLU in front of this convolution, whose
+ * reluDer follows; Modules/Activation.py:58-60) */
+int pz_conv2d_bwd_data_gate(const pz_conv_desc *d, const float *dy, const float *w, const float *gate, float *dx, int algo,
+                            void *workspace, size_t ws_bytes, pz_stream_t stream);
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                   int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* Forward convolution that also leaves, for a batch normalisation reading y next (Conv -> BatchNorm pairs of

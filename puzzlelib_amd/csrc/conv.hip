@@ -331,6 +331,10 @@ struct IgemmArgs {
 	const float4 *xcoef;
 	float4 *stats;                         // optional [OC_total][stat_strips] {shift, sum(v-shift), sum((v-shift)^2), -} per
 	int stat_strips;                       // (channel, 32*TN-pixel strip) for a following batch normalisation
+	// epilogue of contiguous outputs (pz_conv2d_fwd_relu / pz_conv2d_bwd_data_gate): y = max(y, 0) after the bias; y = 0 where
+	// gate <= 0 (gate: a tensor of y's shape — the output of the ReLU whose backward follows this backward-data pass)
+	int relu;
+	const float *gate;
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -428,6 +432,11 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 					v[0] += bv, v[1] += bv, v[2] += bv, v[3] += bv;
 				}
 
+				if (a.relu) {                    // x * (x > 0), the element-wise kernel's own form (csrc/eltwise.hip OpRelu): same bits, signed zeros included
+#pragma unroll
+					for (int e = 0; e < 4; ++e) v[e] = v[e] * (v[e] > 0.f ? 1.f : 0.f);
+				}
+
 				if (a.stats) {
 					if (j == 0) st_shift[k] = __shfl(v[0], lane & ~7);      // first pixel of the strip, same for the row's 8 lanes
 #pragma unroll
@@ -447,12 +456,22 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 #else
 					const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u : kOOB;
 #endif
+					if (a.gate) {                // (wave-uniform; out-of-range rows read zeros and are not stored)
+						const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gate, 0, a.y_bytes, 0x00020000);
+						const f32x4 gt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
+#pragma unroll
+						for (int e = 0; e < 4; ++e) v[e] = v[e] * (gt[e] > 0.f ? 1.f : 0.f);      // OpReluDer's form
+					}
 					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, PZ_EPI_AUX);
 				} else {
 					auto store_one = [&](int e, float val) {
 						const int o = opix + e;
 						const int n2 = o / PQ, pq2 = o - n2 * PQ;
 						const unsigned off = (row_ok && e < nvalid) ? (((unsigned)n2 * a.OC_total) * (unsigned)PQ + chan_off + pq2) * 4u : kOOB;
+						if (a.gate) {
+							const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gate, 0, a.y_bytes, 0x00020000);
+							val = val * (buf_load_f32(gr, off, 0) > 0.f ? 1.f : 0.f);
+						}
 						__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yr, off, 0, 0);
 					};
 					store_one(0, v[0]), store_one(1, v[1]), store_one(2, v[2]), store_one(3, v[3]);
@@ -2266,7 +2285,25 @@ static FwdPlan fwd_pack_args(const pz_conv_desc *d, int P, int Q, const float *w
 }
 
 static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
-                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu = 0);
+
+// Which passes can apply an activation in their epilogue (pz_conv2d_fwd_relu / pz_conv2d_bwd_data_gate): implicit-GEMM
+// launches whose output pixels are contiguous per image — every forward pass on that path, backward-data at unit stride.
+int pz_conv2d_epilogue_supported(const pz_conv_desc *d, int which, int algo, int *supported) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(supported != nullptr && (which == PZ_CONV_FWD || which == PZ_CONV_BWD_DATA), "pz_conv2d_epilogue_supported: bad arguments");
+	*supported = conv_path(d, which, P, Q, algo) == PATH_IGEMM && (which == PZ_CONV_FWD || (d->stride_h == 1 && d->stride_w == 1));
+	return PZ_OK;
+}
+
+int pz_conv2d_fwd_relu(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y, int algo,
+                       void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int ok = 0;
+	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_FWD, algo, &ok)) return rc;
+	PZ_REQUIRE(ok, "pz_conv2d_fwd_relu: this configuration has no activation epilogue (pz_conv2d_epilogue_supported)");
+	return conv2d_fwd_impl(d, x, packed ? nullptr : w, packed, bias, y, nullptr, algo, workspace, ws_bytes, stream, 1);
+}
 
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y, int algo,
                   void *workspace, size_t ws_bytes, pz_stream_t stream) {
@@ -2285,7 +2322,7 @@ int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed,
 }
 
 static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
-                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && (w || packed) && y, "pz_conv2d_fwd: null tensor");
@@ -2343,6 +2380,7 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 	a.OC_total = d->k, a.OH = P, a.OW = Q, a.os_h = 1, a.os_w = 1, a.oo_h = 0, a.oo_w = 0;
 	a.tapmajor = pa.tapmajor;
 	a.contig = 1, a.stats = reinterpret_cast<float4 *>(stats);
+	a.relu = relu;
 	a.stat_strips = pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	static_assert(PZ_CONV_STATS_STRIP == 64, "strip = 32 * TN pixels of both tile configurations");
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
@@ -2436,7 +2474,16 @@ int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported)
 }
 
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
-                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed = nullptr);
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed = nullptr,
+                                const float *gate = nullptr);
+
+int pz_conv2d_bwd_data_gate(const pz_conv_desc *d, const float *dy, const float *w, const float *gate, float *dx, int algo,
+                            void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int ok = 0;
+	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_BWD_DATA, algo, &ok)) return rc;
+	PZ_REQUIRE(ok && gate, "pz_conv2d_bwd_data_gate: this configuration has no gated epilogue (pz_conv2d_epilogue_supported)");
+	return conv2d_bwd_data_impl(d, dy, nullptr, nullptr, w, dx, algo, workspace, ws_bytes, stream, nullptr, gate);
+}
 
 int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
                            size_t ws_bytes, pz_stream_t stream) {
@@ -2459,7 +2506,8 @@ int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *b
 }
 
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
-                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed) {
+                                float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed,
+                                const float *gate) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(dy && (w || packed) && dx, "pz_conv2d_bwd_data: null tensor");
@@ -2551,6 +2599,8 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		a.tapmajor = pa.tapmajor;
 		a.contig = d->stride_h == 1 && d->stride_w == 1 && c.Pv == d->h && c.Qv == d->w && c.oo_h == 0 && c.oo_w == 0;
 		a.stats = nullptr;
+		a.gate = gate;
+		PZ_REQUIRE(gate == nullptr || a.contig, "pz_conv2d_bwd_data_gate: output pixels are not contiguous");
 		a.x2 = bnx, a.xcoef = reinterpret_cast<const float4 *>(bncoef);
 		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();

@@ -262,24 +262,17 @@ class DnnContext:
 			policy == "always" or (policy == "adaptive" and key[1] in self.statsWanted.get(wroot, ()))
 		)
 
+		# Conv2D(useBias) -> Activation(relu) (TestLib/CnnCifar10NIN.py:16-45): the launch waits for the ReLU that may follow
+		# and takes it into its epilogue (fusion.ConvFwd; kernels.absorbRelu). Whoever reads the tensor first runs it.
+		if bias is not None and not given and not want and lazy.on("convrelu") and lazy.whole(out) and \
+				self.epilogueSupported(desc, lib.CONV_FWD, algo):
+			lazy.attach(out, fusion.ConvFwd(self, desc, algo, data, W, bias))
+			return out
+
 		stats = None
 		if want and nstrips > 0:
 			stats = GPUArray.empty((W.shape[0], nstrips, 4), dtype=np.float32, allocator=allocator)
-		packed = self.prepared(W, desc, lib.CONV_FWD, algo)
-		if packed is not None:
-			wsbytes = self.workspaceWithPrepared(desc, lib.CONV_FWD, algo)
-		ws = self.workspace(wsbytes, allocator)
-		if packed is not None:
-			lib.pz_conv2d_fwd_pre(
-				byref(desc), data.rptr, packed, rptrOf(bias), out.optr, None if stats is None else stats.optr, algo, rptrOf(ws),
-				wsbytes, None
-			)
-		elif stats is None:
-			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, algo, rptrOf(ws), wsbytes, None)
-		else:
-			lib.pz_conv2d_fwd_stats(
-				byref(desc), data.rptr, W.rptr, rptrOf(bias), out.optr, stats.optr, algo, rptrOf(ws), wsbytes, None
-			)
+		self.launchForward(desc, algo, data, W, bias, out, False, stats=stats, allocator=allocator)
 		if stats is not None:
 			lazy.setFact(out, "convstats", (stats, outshape))
 			lazy.count("conv_stats")
@@ -287,6 +280,63 @@ class DnnContext:
 		if lazy.enabled and not given:
 			lazy.setFact(out, "fromconv", key)
 		return out
+
+
+	def launchForward(self, desc, algo, data, W, bias, out, relu, stats=None, allocator=None, prepared=True, settling=False):
+		"""the forward launch itself (out: the whole output, overwritten). prepared=False: W is not a live parameter (a snapshot):
+		its packed operand is made inside the call instead of being kept per parameter version. settling=True: called while
+		`out`'s own description runs (lazy.settle) — its address is taken without a write barrier (the barrier that led here
+		has done that work; another one would run `out`'s dependents BEFORE this launch wrote what they read)."""
+		optr = out.gpudata.ptr if settling else out.optr
+		wsbytes = self.convGeometry(desc, lib.CONV_FWD, algo)[2]
+		packed = self.prepared(W, desc, lib.CONV_FWD, algo) if prepared else None
+		if packed is not None:
+			wsbytes = self.workspaceWithPrepared(desc, lib.CONV_FWD, algo)
+		ws = self.workspace(wsbytes, allocator)
+		if relu:
+			assert stats is None
+			lib.pz_conv2d_fwd_relu(
+				byref(desc), data.rptr, None if packed is not None else W.rptr, packed, rptrOf(bias), optr, algo, rptrOf(ws),
+				wsbytes, None
+			)
+		elif packed is not None:
+			lib.pz_conv2d_fwd_pre(
+				byref(desc), data.rptr, packed, rptrOf(bias), optr, None if stats is None else stats.optr, algo, rptrOf(ws),
+				wsbytes, None
+			)
+		elif stats is None:
+			lib.pz_conv2d_fwd(byref(desc), data.rptr, W.rptr, rptrOf(bias), optr, algo, rptrOf(ws), wsbytes, None)
+		else:
+			lib.pz_conv2d_fwd_stats(
+				byref(desc), data.rptr, W.rptr, rptrOf(bias), optr, stats.optr, algo, rptrOf(ws), wsbytes, None
+			)
+
+
+	def launchBackwardData(self, desc, algo, grad, W, out, gate=None, allocator=None, prepared=True, settling=False):
+		optr = out.gpudata.ptr if settling else out.optr
+		wsbytes = self.convGeometry(desc, lib.CONV_BWD_DATA, algo)[2]
+		if gate is not None:
+			ws = self.workspace(wsbytes, allocator)
+			lib.pz_conv2d_bwd_data_gate(byref(desc), grad.rptr, W.rptr, gate.rptr, optr, algo, rptrOf(ws), wsbytes, None)
+			return
+		packed = self.prepared(W, desc, lib.CONV_BWD_DATA, algo) if prepared else None
+		if packed is not None:
+			wsbytes = self.workspaceWithPrepared(desc, lib.CONV_BWD_DATA, algo)
+			ws = self.workspace(wsbytes, allocator)
+			lib.pz_conv2d_bwd_data_pre(byref(desc), grad.rptr, packed, optr, algo, rptrOf(ws), wsbytes, None)
+		else:
+			ws = self.workspace(wsbytes, allocator)
+			lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, optr, algo, rptrOf(ws), wsbytes, None)
+
+
+	def epilogueSupported(self, desc, which, algo):
+		"""can this pass take an activation into its epilogue (pz_conv2d_fwd_relu / pz_conv2d_bwd_data_gate)?"""
+		hit = desc.geo.get((which, algo, "epi"))
+		if hit is None:
+			flag = c_int(0)
+			lib.pz_conv2d_epilogue_supported(byref(desc), which, algo, byref(flag))
+			hit = desc.geo[(which, algo, "epi")] = bool(flag.value)
+		return hit
 
 
 	def convAlgoUsed(self, desc, which, algo):
@@ -354,6 +404,7 @@ class DnnContext:
 		if (p, q) != grad.shape[2:]:
 			raise ValueError("gradient maps %s do not match the convolution geometry %s" % (grad.shape[2:], (p, q)))
 
+		given = out is not None
 		out = GPUArray.empty(inshape, dtype=grad.dtype, allocator=allocator) if out is None else out
 
 		# the gradient is the un-written input gradient of a BatchNorm (fusion.BnBwdApply): evaluate it while gathering
@@ -364,15 +415,15 @@ class DnnContext:
 				byref(desc), bn.dy.rptr, bn.x.rptr, fusion.raw(bn.coef), W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None
 			)
 			lazy.count("dgrad_bn_fold")
+		elif given is False and bias is None and data is not None and lazy.on("convgate") and lazy.whole(out) and \
+				isinstance(data, GPUArray) and self.epilogueSupported(desc, lib.CONV_BWD_DATA, algo) and (
+					lazy.fact(data, "convrelu") or getattr(lazy.pending(data, fusion.ConvFwd), "relu", False)):
+			# this convolution's input came out of a ReLU fused into the convolution in front: that ReLU's backward
+			# (reluDerKer on this very gradient) comes next and joins the launch as its epilogue (kernels.absorbReluDer)
+			lazy.attach(out, fusion.ConvBwdData(self, desc, algo, grad, W))
+			return out
 		else:
-			packed = self.prepared(W, desc, lib.CONV_BWD_DATA, algo)
-			if packed is not None:
-				wsbytes = self.workspaceWithPrepared(desc, lib.CONV_BWD_DATA, algo)
-				ws = self.workspace(wsbytes, allocator)
-				lib.pz_conv2d_bwd_data_pre(byref(desc), grad.rptr, packed, out.optr, algo, rptrOf(ws), wsbytes, None)
-			else:
-				ws = self.workspace(wsbytes, allocator)
-				lib.pz_conv2d_bwd_data(byref(desc), grad.rptr, W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None)
+			self.launchBackwardData(desc, algo, grad, W, out, allocator=allocator)
 
 		if bias is not None:           # deconvolution forward: bias over the produced maps, rows of the (n*maps, pixels) view
 			assert bias.size == out.shape[1]

@@ -19,6 +19,10 @@ backend.py create and consume these.
                                                                                       pz_conv2d_bwd_{data,filter}_bn
   Up2(compact)           convNdBackwardData of a stride-2 pointwise convolution       zero fill + strided copy; folded into
                                                                                       pz_bn_gate_stats_up2
+  ConvFwd(x, W, b)       convNd with a bias and no BatchNorm behind it (Conv2D ->   one convolution launch; + reluKer: the ReLU
+    .relu                Activation(relu), TestLib/CnnCifar10NIN.py:16-45)            in its epilogue (pz_conv2d_fwd_relu)
+  ConvBwdData(dy, W)     convNdBackwardData into the output of such a ReLU           one launch; + reluDerKer: the gate in its
+    .gate = y                                                                         epilogue (pz_conv2d_bwd_data_gate)
   Scaled(1/N)            nodeinfo.sumTensor on the gradient arena (the mean of the    linear kernel in place; folded into the
                          data-parallel exchange, Optimizers/Optimizer.py:166-167)     Adam / momentum-SGD update kernels
 """
@@ -109,6 +113,59 @@ class Gate(Thunk):
 		ptrs = (ctypes.c_void_p * 3)(out.gpudata.ptr, out.gpudata.ptr, self.y.rptr)
 		lib.pz_eltwise(lib.OP_RELU_DER, out.size, ptrs, 3, None, 0, 0, out.size, 1, None)
 		lazy.count("gate")
+
+
+class ConvFwd(Thunk):
+	"""y = conv(x, W) + b, optionally through ReLU (x * (x > 0), the element-wise kernel's form) in the kernel's epilogue.
+	Modules/Activation.py:52-55 is out of place by default: the ReLU's output then gets the activated launch and THIS
+	description stays on the convolution's own output, which nobody reads in a training step — `detach()` moves it onto a
+	snapshot of the parameters so that the optimizer's update does not have to materialise it."""
+
+	def __init__(self, dnn, desc, algo, x, W, bias, relu=False):
+		self.dnn, self.desc, self.algo, self.x, self.W, self.bias, self.relu = dnn, desc, algo, x, W, bias, relu
+		self.detached = False
+
+	def inputs(self):
+		return (self.x, self.W, self.bias)
+
+	def dependsOn(self, root):
+		return any(t.gpudata.root is root for t in self.inputs())
+
+	def twin(self, relu):
+		return ConvFwd(self.dnn, self.desc, self.algo, self.x, self.W, self.bias, relu)
+
+	def detach(self):
+		self.W, self.bias, self.detached = lazy.snapshot(self.W), lazy.snapshot(self.bias), True
+
+	def run(self, out):
+		self.dnn.launchForward(self.desc, self.algo, self.x, self.W, self.bias, out, self.relu, prepared=not self.detached, settling=True)
+		lazy.count("conv_relu" if self.relu else "conv_deferred")
+		return {"convrelu": True} if self.relu else None
+
+
+class ConvBwdData(Thunk):
+	"""dx = bwd_data(dy, W), optionally gated by `gate` > 0 (reluDerKer's form g * (y > 0)) in the kernel's epilogue; see ConvFwd
+	for `detach`."""
+
+	def __init__(self, dnn, desc, algo, dy, W, gate=None):
+		self.dnn, self.desc, self.algo, self.dy, self.W, self.gate = dnn, desc, algo, dy, W, gate
+		self.detached = False
+
+	def inputs(self):
+		return (self.dy, self.W) + ((self.gate, ) if self.gate is not None else ())
+
+	def dependsOn(self, root):
+		return any(t.gpudata.root is root for t in self.inputs())
+
+	def twin(self, gate):
+		return ConvBwdData(self.dnn, self.desc, self.algo, self.dy, self.W, gate)
+
+	def detach(self):
+		self.W, self.detached = lazy.snapshot(self.W), True
+
+	def run(self, out):
+		self.dnn.launchBackwardData(self.desc, self.algo, self.dy, self.W, out, self.gate, prepared=not self.detached, settling=True)
+		lazy.count("dgrad_gate" if self.gate is not None else "dgrad_deferred")
 
 
 class Scaled(Thunk):

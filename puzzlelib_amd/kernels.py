@@ -35,7 +35,21 @@ def absorbRelu(arrays, scalars):
 		if isinstance(waiting, fusion.Sum) and not waiting.relu and waiting.gate is None and lazy.on("addrelu"):
 			waiting.relu = True
 			return True
+		if isinstance(waiting, fusion.ConvFwd) and not waiting.relu and lazy.on("convrelu"):
+			waiting.relu = True
+			return True
 		return False
+
+	if isinstance(waiting, fusion.ConvFwd) and not waiting.relu and lazy.on("convrelu") and lazy.whole(out) and \
+			out.shape == inp.shape and lazy.pending(out) is None:
+		# out of place (Modules/Activation.py:52-55 default): ONE launch writes relu(conv) into `out`; the convolution's own
+		# output keeps its description, moved onto a snapshot of the parameters (nobody reads it in a training step, and the
+		# optimizer's update must not force it)
+		out.optr
+		facts = waiting.twin(True).run(out)
+		lazy.setFact(out, "convrelu", facts["convrelu"])
+		waiting.detach()
+		return True
 
 	if isinstance(waiting, fusion.BnApply) and not waiting.relu and lazy.on("bnrelu") and lazy.whole(out) and \
 			out.shape == inp.shape and lazy.pending(out) is None:
@@ -50,12 +64,25 @@ def absorbReluDer(arrays, scalars):
 	joins a described fan-in, or becomes a description of its own on a written gradient — the batch-norm backward that
 	reads it next applies it while loading."""
 	ingrad, outgrad, outdata = arrays
-	if not lazy.sameBuffer(ingrad, outgrad) or not lazy.whole(ingrad) or ingrad.shape != outdata.shape or \
-			lazy.sameBuffer(ingrad, outdata):
+	if not lazy.sameBuffer(ingrad, outgrad):
+		# out of place: a backward-data launch that is still only described takes the gate into its epilogue and writes `ingrad`
+		waiting = lazy.pending(outgrad, fusion.ConvBwdData) if lazy.on("convgate") else None
+		if waiting is None or waiting.gate is not None or not lazy.whole(ingrad) or ingrad.shape != outgrad.shape or \
+				ingrad.shape != outdata.shape or lazy.pending(ingrad) is not None or lazy.sameBuffer(ingrad, outdata):
+			return False
+		ingrad.optr
+		waiting.twin(outdata).run(ingrad)
+		waiting.detach()
+		return True
+	if not lazy.whole(ingrad) or ingrad.shape != outdata.shape or lazy.sameBuffer(ingrad, outdata):
 		return False
 
 	waiting = lazy.editable(ingrad)
 	root = ingrad.gpudata.root
+	if isinstance(waiting, fusion.ConvBwdData) and waiting.gate is None and lazy.on("convgate"):
+		waiting.gate = outdata
+		lazy.depend(outdata, root)
+		return True
 	if isinstance(waiting, fusion.Sum) and not waiting.relu and waiting.gate is None and lazy.on("addgate"):
 		waiting.gate = outdata
 		lazy.depend(outdata, root)

@@ -47,13 +47,14 @@ def on(pattern):
 class State:
 	"""thunk: pending contents; deps: weak references to allocations whose thunk / facts derive from this one's contents;
 	meta: facts about the contents; wev / rev: [(event, stream, lo, hi)] — byte ranges a foreign stream still writes / reads"""
-	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small", "version")
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small", "version", "snap")
 
 	def __init__(self, base):
 		self.thunk, self.deps, self.meta, self.wev, self.rev, self.base = None, None, None, None, None, base
 		self.small = None         # [(lo, hi, written)] byte ranges that queued small adds (deferAdd) will write / read
 		self.version = 0          # bumped by every write barrier: what was derived from the contents (prepared filter
 		                          # operands, DnnContext.prepared) is current while the number stands
+		self.snap = None          # (version, Buffer): a copy of the allocation as of that version (lazy.snapshot)
 
 
 def stateOf(root):
@@ -73,6 +74,10 @@ class Thunk:
 
 	def run(self, out):
 		raise NotImplementedError()
+
+	def dependsOn(self, root):
+		"""does the description (still) read allocation `root`? (a description may have moved to a snapshot of it)"""
+		return True
 
 
 def attach(ary, thunk):
@@ -193,7 +198,7 @@ def settleDependents(root):
 	for ref in deps:
 		other = ref()
 		if other is not None and other.lz is not None and other is not root:
-			if other.lz.thunk is not None:
+			if other.lz.thunk is not None and other.lz.thunk.dependsOn(root):
 				settle(other)
 			other.lz.meta = None
 	lz.deps = None                            # (a dependent that settled re-registered its facts: they were just dropped)
@@ -372,6 +377,25 @@ def whole(ary):
 	buf = ary.gpudata
 	root = buf.root
 	return ary.contiguous and buf.ptr == root.ptr and ary.nbytes == root.size
+
+
+def snapshot(ary):
+	"""A view like `ary` over a COPY of its allocation as it stands now. One copy per allocation and write-version: with the
+	parameters in one flat arena, every description of a step that has to outlive the optimizer's update (fusion.ConvFwd /
+	ConvBwdData twins whose activated version was written instead) shares a single device-to-device copy."""
+	from puzzlelib_amd.gpuarray import GPUArray
+	from puzzlelib_amd import driver
+	buf = ary.gpudata
+	root = buf.root
+	lz = stateOf(root)
+	readBarrier(root)
+	if lz.snap is None or lz.snap[0] != lz.version:
+		copy = GPUArray.defaultAllocator.allocate(root.size) if GPUArray.defaultAllocator is not None else driver.Buffer.allocate(root.size)
+		lib.pz_memcpy_d2d(copy.ptr, root.ptr, root.size, None)
+		lz.snap = (lz.version, copy)
+		count("param_snapshot")
+	offset = buf.ptr - root.ptr
+	return GPUArray(ary.shape, ary.dtype, gpudata=lz.snap[1][offset:offset + buf.size])
 
 
 def sameBuffer(a, b):

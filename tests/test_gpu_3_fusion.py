@@ -541,6 +541,64 @@ def test_prepared_filter_operands_follow_every_write_of_the_filter(surf):
 		g.streamManager.give([stream])
 
 
+@pytest.mark.parametrize("inplace", [False, True])
+def test_relu_and_its_gate_ride_in_the_convolution_epilogues(surf, inplace):
+	"""Conv2D(bias) -> Activation(relu) (TestLib/CnnCifar10NIN.py:16-45; Modules/Activation.py:52-60, out of place by default):
+	the forward launch takes the ReLU into its epilogue, the next layer's backward-data launch takes the ReLU's gate. Bit-identical
+	to the literal sequence (same products, `x * (x > 0)` / `g * (y > 0)` as the element-wise kernels compute them); the
+	convolution's own (pre-activation) output and the ungated gradient stay readable and keep the values of the call's time even
+	after the parameters were updated."""
+	from puzzlelib_amd import lazy
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	rng = np.random.RandomState(41)
+	x = rng.randn(5, 24, 9, 11).astype(np.float32)
+	w1, b1 = (rng.randn(40, 24, 3, 3) / 15).astype(np.float32), rng.randn(1, 40, 1, 1).astype(np.float32)
+	w2, b2 = (rng.randn(16, 40, 1, 1) / 6).astype(np.float32), rng.randn(1, 16, 1, 1).astype(np.float32)
+	dy2 = rng.randn(5, 16, 9, 11).astype(np.float32)
+	igemm = Dnn.ConvFwdAlgo.implicitGemm, Dnn.ConvBwdDataAlgo.implicitGemm
+
+	def run(fused):
+		lazy.enabled = fused
+		lazy.counters.clear()
+		arena = g.to_gpu(np.concatenate([w1.ravel(), b1.ravel(), w2.ravel(), b2.ravel()]))
+		cuts = np.cumsum([0, w1.size, b1.size, w2.size, b2.size])
+		gw1, gb1, gw2, gb2 = (arena[cuts[i]:cuts[i + 1]].reshape(t.shape) for i, t in enumerate((w1, b1, w2, b2)))
+		gx = g.to_gpu(x)
+		c1 = Dnn.convNd(gx, gw1, gb1, 1, 1, 1, 1, igemm[0])
+		y1 = c1 if inplace else g.empty(c1.shape, dtype=np.float32)
+		El.reluKer(np.float32)(y1, c1)
+		c2 = Dnn.convNd(y1, gw2, gb2, 1, 0, 1, 1, igemm[0])
+		# backward of the second convolution, then of the ReLU
+		d1 = Dnn.convNdBackwardData(g.to_gpu(dy2), gw2, y1, 1, 0, 1, 1, igemm[1])
+		g1 = d1 if inplace else g.empty(d1.shape, dtype=np.float32)
+		El.reluDerKer(np.float32)(g1, d1, y1)
+		counts = dict(lazy.counters)
+		# the optimizer touches the parameters while the pre-activation tensors are still only described
+		El.linearKer(np.float32)(arena, arena, 0.5, 0.125)
+		out = {"y1": y1.get(), "c2": c2.get(), "g1": g1.get()}
+		if not inplace:
+			out["c1"], out["d1"] = c1.get(), d1.get()
+		return out, counts, dict(lazy.counters)
+
+	try:
+		fused, taken, after = run(True)
+		literal, _, _ = run(False)
+	finally:
+		lazy.enabled = True
+	assert after.get("conv_relu", 0) == 1 and after.get("dgrad_gate", 0) == 1 and "relu" not in after and "gate" not in after, after
+	if inplace:
+		assert not taken, "in place everything up to the optimizer is only described: %s" % taken
+	else:
+		# out of place the activated launches run at once; ONE copy of the parameter arena serves both detached descriptions;
+		# c1, c2 and d1 are materialised by .get() only (from the copy: the arena has been updated by then)
+		assert taken.get("conv_relu", 0) == 1 and taken.get("dgrad_gate", 0) == 1 and taken.get("param_snapshot", 0) == 1, taken
+		assert after.get("conv_deferred", 0) == 2 and after.get("dgrad_deferred", 0) == 1, after
+	for key in literal:
+		assert np.array_equal(fused[key], literal[key]), "%s differs from the literal call sequence" % key
+	ref = R.conv2d_fwd(x, w1, b1.ravel(), 1, 1, acc=np.float64)
+	assert_close(fused["y1"], R.relu(ref), atol=1e-4, rtol=1e-4, what="relu(conv + bias)")
+
+
 @pytest.mark.parametrize("rule", ["adam", "classicMomSGD", "nesterovMomSGD"])
 def test_gradient_mean_rides_in_the_update_kernel(surf, rule):
 	"""The data-parallel mean (Optimizers/Optimizer.py:166-167 -> Grid.py:126-133 sums and divides in one pass): the exchange
