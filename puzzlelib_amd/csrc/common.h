@@ -34,7 +34,10 @@ inline int stream_grid(size_t work_items, int per_block) {
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats = nullptr, bool filters_ready = false);
+              void *workspace, hipStream_t st, float *stats = nullptr, bool filters_ready = false, void *vscratch = nullptr);
+// scratch for the transformed input of a forward / backward-data launch (0: the launch transforms its patches itself); passed
+// as `vscratch`
+size_t wino_input_bytes(const pz_conv_desc *d, int which, int P, int Q);
 // transformed filters of up to kWinoBatch (layer, pass) pairs in one launch; u[i] = what wino_conv expects at `workspace`
 constexpr int kWinoBatch = 40;
 int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st);
@@ -50,7 +53,8 @@ size_t wino4_workspace_bytes(const pz_conv_desc *d, int which);
 int wino4_stats_strips(const pz_conv_desc *d, int P, int Q);
 int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st);
 int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-               void *workspace, hipStream_t st, float *stats, bool filters_ready);
+               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch);
+size_t wino4_input_bytes(const pz_conv_desc *d, int which, int P, int Q);
 
 // direct backward-data for stride-2 convolutions with <= 4 input maps (thin.hip): the stem layer
 bool thin_dgrad_eligible(const pz_conv_desc *d, int P, int Q);

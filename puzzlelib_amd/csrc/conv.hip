@@ -2215,9 +2215,10 @@ static int conv_workspace_bytes(const pz_conv_desc *d, int which, int algo, bool
 	*nbytes = 0;
 	const ConvPath path = conv_path(d, which, P, Q, algo);
 	if (path == PATH_WINOGRAD) {
+		// forward / backward-data: [transformed filters unless prepared | transformed input where the launch takes it from a pass of its own]
 		*nbytes = which == PZ_CONV_BWD_FILTER
 		              ? align256(pz::wino_wgrad_workspace_bytes(d, P, Q)) + align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float))
-		              : prepared ? 0 : pz::wino_workspace_bytes(d, which, P, Q);
+		              : (prepared ? 0 : align256(pz::wino_workspace_bytes(d, which, P, Q))) + pz::wino_input_bytes(d, which, P, Q);
 		return PZ_OK;
 	}
 	if (path == PATH_THIN) {
@@ -2330,10 +2331,14 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 
 	if (uses_winograd(d, PZ_CONV_FWD, P, Q, algo)) {
 		PZ_REQUIRE(stats == nullptr || pz::wino_stats_strips(d, P, Q) > 0, "pz_conv2d_fwd_stats: this Winograd build does not produce statistics");
-		size_t need = packed ? 0 : pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q);
-		PZ_REQUIRE(packed || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+		size_t need;
+		conv_workspace_bytes(d, PZ_CONV_FWD, algo, packed != nullptr, &need);
+		PZ_REQUIRE(need == 0 || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
+		const size_t fbytes = packed ? 0 : align256(pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q));
+		void *vscratch = pz::wino_input_bytes(d, PZ_CONV_FWD, P, Q) > 0 ? (char *)workspace + fbytes : nullptr;
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
-		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, packed ? const_cast<void *>(packed) : workspace, st, stats, packed != nullptr);
+		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, packed ? const_cast<void *>(packed) : workspace, st, stats, packed != nullptr,
+		                     vscratch);
 	}
 	PZ_REQUIRE(packed == nullptr || (algo != PZ_CONV_ALGO_DIRECT && igemm_eligible(d, P, Q)), "pz_conv2d_fwd_pre: this configuration takes no prepared operand");
 
@@ -2514,11 +2519,14 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 	hipStream_t st = pz::as_stream(stream);
 
 	if (bnx == nullptr && uses_winograd(d, PZ_CONV_BWD_DATA, P, Q, algo)) {
-		size_t need = packed ? 0 : pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q);
-		PZ_REQUIRE(packed || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		size_t need;
+		conv_workspace_bytes(d, PZ_CONV_BWD_DATA, algo, packed != nullptr, &need);
+		PZ_REQUIRE(need == 0 || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
+		const size_t fbytes = packed ? 0 : align256(pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q));
+		void *vscratch = pz::wino_input_bytes(d, PZ_CONV_BWD_DATA, P, Q) > 0 ? (char *)workspace + fbytes : nullptr;
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
 		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st, nullptr,
-		                     packed != nullptr);
+		                     packed != nullptr, vscratch);
 	}
 	// (only the Winograd form of backward-data takes a prepared operand: the pointwise layers read the filter tensor itself)
 	PZ_REQUIRE(packed == nullptr, "pz_conv2d_bwd_data_pre: this configuration takes no prepared operand");

@@ -1558,9 +1558,11 @@ int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const 
 	return PZ_OK;
 }
 
+size_t wino_input_bytes(const pz_conv_desc *d, int which, int P, int Q) { return wino4_input_bytes(d, which, P, Q); }
+
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats, bool filters_ready) {
-	if (wino4_pick(d, which, P, Q)) return wino4_conv(d, which, P, Q, in, w, bias, out, workspace, st, stats, filters_ready);
+              void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch) {
+	if (wino4_pick(d, which, P, Q)) return wino4_conv(d, which, P, Q, in, w, bias, out, workspace, st, stats, filters_ready, vscratch);
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 

@@ -141,6 +141,7 @@ struct W4Args {
 	int chunks, tblocks, kblocks;
 	unsigned x_bytes, y_bytes;
 	float4 *stats;           // optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count}
+	const float *v;          // PRE: transformed patches [tblocks][chunks][kV] in the order of an LDS stage (wino4_input_kernel)
 };
 
 template <int V>
@@ -172,6 +173,64 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&o)[4]) {
 	o[1] = __builtin_fmaf(2.f, d34, d12);
 	o[2] = __builtin_fmaf(4.f, p34, p12);
 	o[3] = __builtin_fmaf(8.f, d34, d12) + m[5];
+}
+
+// ---- the patches' transform as a pass of its own (PRE): V = B^T d B of every (tile, channel), written once in the order of
+// the main kernel's LDS stages — [tile block][chunk]{[position][channel pair][tile][channel of the pair]} — so that the main
+// kernel's workgroups (one per 32 produced channels: 8-16 of them share a tile block) COPY a chunk instead of each gathering
+// and transforming it: the main loop sheds its ~90 vector and ~30 LDS instructions per wave and chunk, which at two waves per
+// SIMD do not hide behind the MFMAs. An experiment that did NOT pay (see wino4_input_bytes: off by default).
+// Same operations in the same order as the fused kernel's row / column passes: bit-identical results.
+// Block = 256 threads = 32 tiles x 4 channels x 2 chunks; lane = (tile, channel parity): a wave stores 256 contiguous bytes.
+__global__ void __launch_bounds__(256) wino4_input_kernel(W4Args a, float *__restrict__ vout) {
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int pairs = (a.chunks + 1) / 2;
+	const int tb = blockIdx.x / pairs, chunk = (blockIdx.x % pairs) * 2 + (wave >> 1);
+	if (chunk >= a.chunks) return;
+	const int chalf = wave & 1, j = lane >> 1, cpar = lane & 1;
+	const int ch = chunk * BC + chalf * 2 + cpar;
+
+	const int t = tb * TB + j;
+	const bool tv = t < a.tiles;
+	const int n = t / (a.TY * a.TX), r0 = t - n * (a.TY * a.TX);
+	const int ty = r0 / a.TX, tx = r0 - ty * a.TX;
+	const int row0 = 4 * ty - a.pad_h, col0 = 4 * tx - a.pad_w;
+	const bool inner = col0 >= 0 && col0 + 5 < a.W;
+	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
+
+	float rt[6][6];                             // rt[e][jj] = (d B)[e][jj]: row e of the patch through B^T along the row
+#pragma unroll
+	for (int e = 0; e < 6; ++e) {
+		const int row = row0 + e;
+		const bool ok = tv && (unsigned)row < (unsigned)a.H;
+		float d[6];
+		if (inner) {
+			const unsigned off = ok ? (unsigned)(((((long)n * a.C + ch) * a.H + row) * a.W + col0) * 4) : kOOB;
+			const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+			const f32x2 hi = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, off + 16u, 0, 0));
+			d[0] = lo[0], d[1] = lo[1], d[2] = lo[2], d[3] = lo[3], d[4] = hi[0], d[5] = hi[1];
+		} else {
+#pragma unroll
+			for (int c = 0; c < 6; ++c) {
+				const int col = col0 + c;
+				const bool cok = ok && (unsigned)col < (unsigned)a.W;
+				const unsigned off = cok ? (unsigned)(((((long)n * a.C + ch) * a.H + row) * a.W + col) * 4) : kOOB;
+				d[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+			}
+		}
+		w4_bt(d, rt[e]);
+	}
+
+	float *dst = vout + ((size_t)tb * a.chunks + chunk) * kV + (chalf * TB + j) * 2 + cpar;
+#pragma unroll
+	for (int c = 0; c < 6; ++c) {
+		const float col[6] = {rt[0][c], rt[1][c], rt[2][c], rt[3][c], rt[4][c], rt[5][c]};
+		float o[6];
+		w4_bt(col, o);
+#pragma unroll
+		for (int i = 0; i < 6; ++i) dst[(i * 6 + c) * (TB * BC)] = o[i];
+	}
 }
 
 __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], float *Ms, int kb, int tb, int tid, int pbase, int lane) {
@@ -256,6 +315,7 @@ __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], f
 	}
 }
 
+template <bool PRE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) wino4_conv_kernel(W4Args a) {
 	// two stages of V, then the waves' private blocks of row-transformed patches; the epilogue's block reuses all of it
 	__shared__ __attribute__((aligned(16))) float smem[3 * kV];                  // 54 KB
@@ -311,6 +371,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	f32x4 sa[3];
 	f32x2 sb[3];                                // staged patch rows (6 floats each)
 	float rt[6];                                // a transformed row / column on its way to LDS
+
+	// PRE: a chunk of transformed patches is a plain 18 KB copy: four 16-byte and one 8-byte piece per thread
+	f32x4 pv[4];
+	f32x2 pt;
+	const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+	    (void *)(PRE ? a.v + (size_t)tb * a.chunks * kV : a.x), 0, PRE ? (unsigned)a.chunks * (kV * 4u) : 0u, 0x00020000);
+	auto pre_load = [&](int chunk) {
+		const unsigned soff = (unsigned)chunk * (kV * 4u);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, (unsigned)(tid + 256 * i) * 16u, soff, 0));
+		pt = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(vr, 16384u + (unsigned)tid * 8u, soff, 0));
+	};
+	auto pre_park = [&](float *stg) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) reinterpret_cast<f32x4 *>(stg)[tid + 256 * i] = pv[i];
+		reinterpret_cast<f32x2 *>(stg + 4096)[tid] = pt;
+	};
+	static_assert(kV == 4 * 256 * 4 + 256 * 2, "the copy covers a stage exactly");
 
 	// row `r` of the next but two chunk. The one workgroup whose first patch starts in front of the tensor loads word by word
 	// and turns offsets below zero into out-of-range ones: they read as the padding they are.
@@ -408,9 +486,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 		// ---- prologue: V(0), V(1) into the two stages, the fragments of chunk 0 into registers
 		static_for<5>([&](auto sc) { load_a(sc, 0); });
-		static_for<3>([&](auto rc) { issue_row(fixed, rc, 0); });
-		static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem, min(1, last)); });
-		static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem + kV, min(2, last)); });
+		if constexpr (PRE) {
+			pre_load(0);
+			pre_park(smem);
+			pre_load(min(1, last));
+			pre_park(smem + kV);
+		} else {
+			static_for<3>([&](auto rc) { issue_row(fixed, rc, 0); });
+			static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem, min(1, last)); });
+			static_for<15>([&](auto sc) { patch_slot(fixed, sc, smem + kV, min(2, last)); });
+		}
 #pragma unroll
 		for (int i = 0; i < 9; ++i)
 #pragma unroll
@@ -437,7 +522,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 					__builtin_amdgcn_s_setprio(0);
 #endif
 #endif
-					patch_slot(fixed, IC<6 * G + J>{}, wr, reload);
+					if constexpr (PRE) {
+						// V(ch + 2): requested behind the chunk's first MFMA, parked behind its last (a chunk of MFMAs covers the latency)
+						if constexpr (6 * G + J == 0) pre_load(min(ch + 2, last));
+						if constexpr (6 * G + J == 17) pre_park(wr);
+					} else {
+						patch_slot(fixed, IC<6 * G + J>{}, wr, reload);
+					}
 #ifdef W4_DUMMY_VALU      // measurement aid: N extra vector instructions behind every MFMA (experiment 12: they cost their full issue time)
 #pragma unroll
 					for (int dv = 0; dv < W4_DUMMY_VALU; ++dv) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
@@ -475,10 +566,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 		w4_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
 	};
 
-	if (anyfix)
-		run(IC<1>{});
-	else
+	if constexpr (PRE) {
 		run(IC<0>{});
+	} else {
+		if (anyfix)
+			run(IC<1>{});
+		else
+			run(IC<0>{});
+	}
 }
 
 
@@ -508,6 +603,23 @@ bool wino4_pick(const pz_conv_desc *d, int which, int P, int Q) {
 	w4_dims(d, which, &prod, &red);
 	const long wgs = (long)ceil_div((long)d->n * ((OP + 3) / 4) * ((OQ + 3) / 4), TB) * ceil_div(prod, KB);
 	return wgs >= kNumCU;
+}
+
+// The patches' transform as its own pass (PRE), for launches whose transformed input is at most PUZZLE_MI355_WINO_PRE_MB
+// megabytes. OFF by default (0): measured on the four ResNet-50 3x3 layers at batch 256 (profiles/r04_wino4_pretransform_ab.txt,
+// ms per launch fused -> PRE, forward | backward-data): 55x55 0.244 -> 0.410 | 0.228 -> 0.398 (V = 462 MB), 28x28 0.204 -> 0.297 |
+// 0.186 -> 0.286 (231 MB), 14x14 0.221 -> 0.256 | 0.202 -> 0.226 (151 MB), 7x7 0.220 -> 0.227 | 0.206 -> 0.209 (75 MB). Results are
+// bit-identical (the Winograd and whole-tensor suites passed with the limit at 200), but 2.25 x the input through HBM / L2 and
+// a second launch cost more than the vector work they take out of the main loop — the fused kernel stays.
+size_t wino4_input_bytes(const pz_conv_desc *d, int which, int P, int Q) {
+	static const long limit_mb = [] { const char *e = getenv("PUZZLE_MI355_WINO_PRE_MB"); return e ? atol(e) : 0L; }();
+	if (!wino4_pick(d, which, P, Q)) return 0;
+	int prod, red;
+	w4_dims(d, which, &prod, &red);
+	const int OP = which == PZ_CONV_FWD ? P : d->h, OQ = which == PZ_CONV_FWD ? Q : d->w;
+	const long tiles = (long)d->n * ((OP + 3) / 4) * ((OQ + 3) / 4);
+	const size_t bytes = (size_t)ceil_div(tiles, TB) * (red / BC) * kV * sizeof(float);
+	return bytes <= (size_t)limit_mb << 20 ? bytes : 0;
 }
 
 size_t wino4_workspace_bytes(const pz_conv_desc *d, int which) {
@@ -543,7 +655,7 @@ int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const
 }
 
 int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-               void *workspace, hipStream_t st, float *stats, bool filters_ready) {
+               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch) {
 	W4FilterArgs fa = w4_filter_args(d, which, w, (float *)workspace);
 	if (!filters_ready) {
 		const long ftotal = (long)fa.kblocks * fa.chunks * KB * BC;
@@ -564,7 +676,14 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
 	a.stats = reinterpret_cast<float4 *>(stats);
-	wino4_conv_kernel<<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
+	if (vscratch != nullptr && wino4_input_bytes(d, which, P, Q) > 0) {
+		a.v = (const float *)vscratch;
+		wino4_input_kernel<<<a.tblocks * ((a.chunks + 1) / 2), 256, 0, st>>>(a, (float *)vscratch);
+		PZ_LAUNCH_CHECK();
+		wino4_conv_kernel<true><<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
+	} else {
+		wino4_conv_kernel<false><<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
+	}
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }
