@@ -101,6 +101,16 @@ def test_rccl_single_rank_roundtrip(bnd):
 
 	node.broadcastBuffer("data", g.gpudata)
 	assert np.array_equal(g.get(), host)
+
+	# what the exchange reports about itself (bench.py: config.comm): the step above, read back after the fact
+	for _ in range(3):
+		reducer.variableReady("b")
+		reducer.variableReady("a")
+		node.sumTensor("grad", g)
+	assert np.array_equal(g.get(), host)
+	summary = node.commSummary()
+	assert summary["steps_measured"] == 4 and summary["exposed_ms_per_step"] >= 0.0
+	assert [round(b["mbytes"], 3) for b in summary["buckets"]] == [0.262] and summary["buckets"][0]["ms"] > 0.0
 	node.close()
 
 
