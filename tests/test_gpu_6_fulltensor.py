@@ -234,13 +234,16 @@ def test_resnet50_full_depth_training_step_vs_oracle(bnd, batch):
 	def rel(a, b):
 		return np.linalg.norm((a - b).astype(np.float64)) / (np.linalg.norm(b.astype(np.float64)) + 1e-30)
 
+	# (the opt-in split math modes, PUZZLE_MI355_MATH=split6 / split9, sum 6 / 9 partial products per fp32 product: measured up to
+	# 7.3e-5 on the first layer's BatchNorm bias gradient, whose value collects every layer's rounding — their floor is 1e-4)
+	floor = 5e-5 if bnd.dnn.convMath == "f32" else 1e-4
 	rels = []
 	for name, p in net.namedParams().items():
 		ref, got = cnet.grads[name], p.grad.get()
 		assert np.isfinite(got).all(), name
 		dev, own = rel(got, ref), rel(c32.grads[name], ref)
 		rels.append((dev, own, name))
-		assert dev <= max(5e-5, 2.0 * own), "grad %s: relative L2 error %.3e (the fp32 oracle's own: %.3e)" % (name, dev, own)
+		assert dev <= max(floor, 2.0 * own), "grad %s: relative L2 error %.3e (the fp32 oracle's own: %.3e)" % (name, dev, own)
 		assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, "element of grad %s" % name
 	rels.sort(reverse=True)
 	median = rels[len(rels) // 2][0]
