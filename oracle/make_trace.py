@@ -28,6 +28,9 @@ CASES = {
 	# name: (builder of the reference network, input shape, classes)
 	"resnet50_b8": (lambda: refResNet(), (8, 3, 224, 224), 1000),
 	"lenet_b16": (lambda: refLeNet(), (16, 1, 28, 28), 10),
+	# config 3: TestLib/CnnCifar10NIN.py's own buildNet, optimizer and hook (:13-49, :68-70) — Conv2D(bias) -> Activation(relu)
+	# out of place, Dropout, both pooling modes
+	"nin_b8": (lambda: refNiN(), (8, 3, 32, 32), 10),
 }
 SKIP = ("pz_pool_", "pz_event_", "pz_stream_", "pz_malloc", "pz_free", "pz_device_", "pz_init")
 
@@ -42,6 +45,17 @@ def refResNet():
 def refLeNet():
 	from PuzzleLib.Models.Nets.LeNet import loadLeNet
 	return loadLeNet(None, initscheme="none")
+
+
+def refNiN():
+	# the script pulls in its dataset loader and matplotlib-based visualisation at import time; only buildNet is wanted
+	src = open("/root/reference/TestLib/CnnCifar10NIN.py").read()
+	head = src[:src.index("def main():")]
+	head = "\n".join(l for l in head.splitlines() if "Datasets" not in l and "Visual" not in l)
+	mod = types.ModuleType("nin_buildnet")
+	exec(compile(head, "CnnCifar10NIN.py (buildNet only)", "exec"), mod.__dict__)
+	np.random.seed(1234)
+	return mod.buildNet()
 
 
 def compute(trace):
@@ -75,9 +89,15 @@ def record(case):
 	data = gpuarray.to_gpu(np.zeros(shape, np.float32))
 	labels = gpuarray.to_gpu(np.zeros(shape[:1], np.int32))
 
-	optimizer = Adam(alpha=1e-3)
+	if case.startswith("nin"):
+		from PuzzleLib.Optimizers.MomentumSGD import MomentumSGD
+		from PuzzleLib.Optimizers import Hooks
+		optimizer = MomentumSGD(learnRate=0.1, momRate=0.9)
+		optimizer.addHook(Hooks.WeightDecay(0.0001))
+	else:
+		optimizer = Adam(alpha=1e-3)
 	optimizer.setupOn(net, useGlobalState=True)
-	trainer = Trainer(net, CrossEntropy(), optimizer, batchsize=shape[0])
+	trainer = Trainer(net, CrossEntropy(maxlabels=classes) if case.startswith("nin") else CrossEntropy(), optimizer, batchsize=shape[0])
 
 	steps = []
 	for _ in range(2):

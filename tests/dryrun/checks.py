@@ -34,9 +34,18 @@ def executor_trace(case):
 		net = nets.loadResNet(None, "50", actInplace=True, initscheme="none")
 		net.layers.pop()                                   # the trailing SoftMax (training on raw scores)
 		shape = (8, 3, 224, 224)
+	elif case == "nin_b8":
+		np.random.seed(1234)
+		net, shape = nets.buildNiN(), (8, 3, 32, 32)
 	else:
 		net, shape = nets.loadLeNet(None), (16, 1, 28, 28)
-	trainer, _ = trainerFor(net, shape[0])
+	if case == "nin_b8":                                   # TestLib/CnnCifar10NIN.py:68-72
+		opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9)
+		opt.addHook(optim.WeightDecay(0.0001))
+		opt.setupOn(net, useGlobalState=True)
+		trainer = optim.Trainer(net, optim.CrossEntropy(maxlabels=10), opt, batchsize=shape[0])
+	else:
+		trainer, _ = trainerFor(net, shape[0])
 	data, labels = g.to_gpu(np.zeros(shape, np.float32)), g.to_gpu(np.zeros(shape[:1], np.int32))
 	steps = []
 	for _ in range(2):
@@ -63,6 +72,10 @@ def trace_resnet50():
 
 def trace_lenet():
 	check_trace("lenet_b16")
+
+
+def trace_nin():
+	check_trace("nin_b8")
 
 
 # ------------------------------------------------------------------------------------------------ lazy-buffer semantics
