@@ -601,6 +601,47 @@ def test_relu_and_its_gate_ride_in_the_convolution_epilogues(surf, inplace):
 	assert_close(fused["y1"], R.relu(ref), atol=1e-4, rtol=1e-4, what="relu(conv + bias)")
 
 
+def test_described_convolutions_survive_writes_to_what_they_read(surf):
+	"""A convolution that waits for its ReLU (fusion.ConvFwd) or a backward-data launch that waits for its gate
+	(fusion.ConvBwdData) is a tensor captured by reference: overwriting ANY of its operands — input, filter, bias, incoming
+	gradient, gate — before it ran must leave it with the values of the call's time."""
+	from puzzlelib_amd import lazy
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	rng = np.random.RandomState(43)
+	x = rng.randn(3, 16, 7, 9).astype(np.float32)
+	w, b = (rng.randn(24, 16, 1, 1) / 4).astype(np.float32), rng.randn(1, 24, 1, 1).astype(np.float32)
+	dy = rng.randn(3, 24, 7, 9).astype(np.float32)
+	algo = Dnn.ConvFwdAlgo.implicitGemm, Dnn.ConvBwdDataAlgo.implicitGemm
+	ref = R.conv2d_fwd(x, w, b.ravel(), 1, 0, acc=np.float64)
+	other = lambda a: g.to_gpu(rng.randn(*a.shape).astype(np.float32))
+
+	for victim in ("x", "w", "b"):
+		for relu in (False, True):
+			gx, gw, gb = g.to_gpu(x), g.to_gpu(w), g.to_gpu(b)
+			c = Dnn.convNd(gx, gw, gb, 1, 0, 1, 1, algo[0])
+			assert lazy.pending(c) is not None, "the launch waits for a ReLU that may follow"
+			y = g.empty(c.shape, dtype=np.float32)
+			if relu:
+				El.reluKer(np.float32)(y, c)                         # runs the activated launch, detaches c onto a snapshot
+			{"x": gx, "w": gw, "b": gb}[victim].set(other({"x": x, "w": w, "b": b}[victim]).get())
+			assert_close(c.get(), ref, atol=1e-4, rtol=1e-4, what="pre-activation after %s was overwritten (relu taken: %s)" % (victim, relu))
+			if relu:
+				assert_close(y.get(), R.relu(ref), atol=1e-4, rtol=1e-4, what="activated output")
+
+	# backward: the gate tensor and the incoming gradient are overwritten while the launch is still only described
+	dref = R.conv2d_bwd_data(dy, w, x.shape, 1, 0, acc=np.float64)
+	yact = R.relu(ref).astype(np.float32)[:, :16]             # any tensor of dx's shape serves as a gate
+	for victim in ("dy", "gate", "w"):
+		gw, gdy, gate = g.to_gpu(w), g.to_gpu(dy), g.to_gpu(np.ascontiguousarray(yact))
+		lazy.setFact(gate, "convrelu", True)                      # as a fused forward launch leaves it
+		d = Dnn.convNdBackwardData(gdy, gw, gate, 1, 0, 1, 1, algo[1])
+		assert lazy.pending(d) is not None
+		El.reluDerKer(np.float32)(d, d, gate)                     # in place: the gate joins the description
+		assert lazy.pending(d) is not None
+		{"dy": gdy, "gate": gate, "w": gw}[victim].set(other({"dy": dy, "gate": yact, "w": w}[victim]).get())
+		assert_close(d.get(), dref * (yact > 0), atol=1e-4, rtol=1e-4, what="gated input gradient after %s was overwritten" % victim)
+
+
 @pytest.mark.parametrize("rule", ["adam", "classicMomSGD", "nesterovMomSGD"])
 def test_gradient_mean_rides_in_the_update_kernel(surf, rule):
 	"""The data-parallel mean (Optimizers/Optimizer.py:166-167 -> Grid.py:126-133 sums and divides in one pass): the exchange
