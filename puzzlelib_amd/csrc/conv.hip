@@ -381,51 +381,55 @@ __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int
 
 // Epilogue through LDS for outputs whose pixel index is contiguous inside an image (forward, stride-1 backward-data).
 // The MFMA result layout gives a lane one pixel of 16 scattered channel rows: stored directly that is 64 four-byte stores
-// per lane and the texture-address unit, not HBM, bounds short-K layers. Each wave parks a 32x32 sub-tile in its own
-// 4.5 KB of LDS ([row][36]) and reads it back as [8 rows][8 x 4 pixels]: 16 B per lane, 128 contiguous bytes per channel
-// row, 4 stores per sub-tile instead of 16. Groups that straddle two images or the end of the tensor fall back to
-// 4-byte stores. With a.stats the same pass accumulates, per channel row and 32*TN-pixel strip, shifted sums for the
-// batch normalisation that follows (saves its statistics pass over y).
-constexpr int kEpiStride = 36;
-constexpr int kEpiFloatsPerWave = 32 * kEpiStride;
+// per lane and the texture-address unit, not HBM, bounds short-K layers. Each wave parks HALF a 32-row band of its
+// 32*TN = 64 pixel strip in its own 4.25 KB of LDS ([16 rows][68]) and reads it back as [4 rows][16 x 4 pixels]: 16 B per
+// lane, 256 contiguous bytes per channel row and store instruction. The length of that run is what the write path is
+// sensitive to: planes of 55x55 / 14x14 / 7x7 floats start at 4- or 16-byte phases, so NO run is made of whole 128-byte
+// lines, and tools/probes/mfma_store.hip (profiles/r04_store_alignment_probe.txt) times the 793 MB of the 64 -> 256 layer
+// at 0.147 ms for line-aligned rows, 0.315 ms for 128-byte runs at 4-byte phase (every run is two partial lines) and
+// 0.265 ms for 256-byte runs (head, one whole line, tail) — with 128 MFMAs per wave in front 0.242 / 0.369 / 0.290 ms.
+// Groups that straddle two images or the end of the tensor fall back to 4-byte stores. With a.stats the same pass
+// accumulates, per channel row and 64-pixel strip, shifted sums for the batch normalisation that follows (saves its
+// statistics pass over y).
+constexpr int kEpiStride = 68;
+constexpr int kEpiFloatsPerWave = 16 * kEpiStride;
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm, int tn, int g, int wm, int wn, int wave, int lane,
                                                      f32x16 (&acc)[TM][TN], float *smem, int only_i = -1) {
+	static_assert(TN == 2, "a wave's strip is two 32-pixel MFMA tiles wide");
 	const int l31 = lane & 31, lhi = lane >> 5;
-	const int rr = lane >> 3, c4 = lane & 7;
+	const int r4 = lane >> 4, c16 = lane & 15;
 	float *scr = smem + wave * kEpiFloatsPerWave;
 	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
 	const int PQ = a.OH * a.OW;
-	const int strip0 = tn * BN + wn * (32 * TN);                  // first pixel of this wave's strip
+	const int strip0 = tn * BN + wn * 64;                         // first pixel of this wave's strip
+
+	const int opix = strip0 + c16 * 4;                            // this lane's 4 pixels
+	const int n_img = opix / PQ, pq = opix - n_img * PQ;
+	const int nvalid = min(4, a.npix - opix);                     // <= 0: beyond the tensor
+#ifdef PZ_EPI_FORCE_SCALAR
+	const bool whole = false;
+#else
+	const bool whole = nvalid == 4 && pq + 3 < PQ;
+#endif
 
 #pragma unroll
 	for (int i = 0; i < TM; ++i) {
 		if (only_i >= 0 && i != only_i) continue;
-		const int row_base = tm * BM + wm * (32 * TM) + i * 32;      // first channel row of this sub-tile row
-		float st_shift[4], st_s1[4], st_s2[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) st_shift[k] = 0.f, st_s1[k] = 0.f, st_s2[k] = 0.f;
-
+		for (int h = 0; h < 2; ++h) {
+			const int row_base = tm * BM + wm * (32 * TM) + i * 32 + 16 * h;      // first channel row of this half band
 #pragma unroll
-		for (int j = 0; j < TN; ++j) {
+			for (int j = 0; j < 2; ++j)
 #pragma unroll
-			for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lhi) * kEpiStride + l31] = acc[i][j][r];
-
-			const int opix = strip0 + j * 32 + c4 * 4;                // this lane's 4 pixels
-			const int n_img = opix / PQ, pq = opix - n_img * PQ;
-			const int nvalid = min(4, a.npix - opix);                 // <= 0: beyond the tensor
-#ifdef PZ_EPI_FORCE_SCALAR
-			const bool whole = false;
-#else
-			const bool whole = nvalid == 4 && pq + 3 < PQ;
-#endif
+				for (int r = 8 * h; r < 8 * h + 8; ++r) scr[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi) * kEpiStride + j * 32 + l31] = acc[i][j][r];
 
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const int ch = row_base + rr + 8 * k;
+				const int ch = row_base + 4 * k + r4;
 				typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));      // written as scalars, read as vectors
-				f32x4 v = *reinterpret_cast<const f32x4_alias *>(&scr[(rr + 8 * k) * kEpiStride + c4 * 4]);
+				f32x4 v = *reinterpret_cast<const f32x4_alias *>(&scr[(4 * k + r4) * kEpiStride + c16 * 4]);
 				const bool row_ok = ch < a.M;
 				if (a.bias) {
 					const float bv = a.bias[g * a.M + min(ch, a.M - 1)];
@@ -437,14 +441,19 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 					for (int e = 0; e < 4; ++e) v[e] = v[e] * (v[e] > 0.f ? 1.f : 0.f);
 				}
 
-				if (a.stats) {
-					if (j == 0) st_shift[k] = __shfl(v[0], lane & ~7);      // first pixel of the strip, same for the row's 8 lanes
+				if (a.stats) {                   // (wave-uniform)
+					const float shift = __shfl(v[0], lane & ~15);      // first pixel of the strip, same for the row's 16 lanes
+					float s1 = 0.f, s2 = 0.f;
 #pragma unroll
 					for (int e = 0; e < 4; ++e) {
-						const float dlt = e < nvalid ? v[e] - st_shift[k] : 0.f;
-						st_s1[k] += dlt;
-						st_s2[k] = __builtin_fmaf(dlt, dlt, st_s2[k]);
+						const float dlt = e < nvalid ? v[e] - shift : 0.f;
+						s1 += dlt;
+						s2 = __builtin_fmaf(dlt, dlt, s2);
 					}
+#pragma unroll
+					for (int d = 1; d < 16; d <<= 1) s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
+					if (c16 == 0 && row_ok && strip0 < a.npix)
+						a.stats[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / 64] = make_float4(shift, s1, s2, 0.f);
 				}
 
 				const unsigned chan_off = (unsigned)(g * a.M + ch) * (unsigned)PQ;
@@ -476,18 +485,6 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 					};
 					store_one(0, v[0]), store_one(1, v[1]), store_one(2, v[2]), store_one(3, v[3]);
 				}
-			}
-		}
-
-		if (a.stats) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				float s1 = st_s1[k], s2 = st_s2[k];
-#pragma unroll
-				for (int d = 1; d < 8; d <<= 1) s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
-				const int ch = row_base + rr + 8 * k;
-				if (c4 == 0 && ch < a.M && strip0 < a.npix)
-					a.stats[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / (32 * TN)] = make_float4(st_shift[k], s1, s2, 0.f);
 			}
 		}
 	}
