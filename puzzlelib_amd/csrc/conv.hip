@@ -56,6 +56,10 @@
 #ifndef PZ_LB
 #define PZ_LB 4
 #endif
+#ifndef PZ_IG_PRIO
+#define PZ_IG_PRIO 0             // experiment switch: 1 = the implicit GEMM's waves raise their priority as their k-loop advances
+                                 // (progress_prio), 2 = for the epilogue only, 3 = from their last k-tile on
+#endif
 #ifndef PZ_EPI_AUX
 #define PZ_EPI_AUX 0              // cache policy bits of the epilogue's 16-byte stores (2 = nt, 16 = sc1): experiment switch
 #endif
@@ -696,6 +700,24 @@ igemm_conv_kernel(IgemmArgs a) {
 		kt1 = (int)((long)nk_all * (kslice + 1) / a.tail_splits);
 	}
 
+	// Progress priority. The waves that share a SIMD belong to different workgroups doing the same work at the same fair
+	// share of the matrix pipe, so the resident workgroups finish — and wait for their stores to land — all at the same
+	// time, and the pipe idles through every such drain (tools/probes/mfma_store.hip: MFMAs 0.687 ms, stores 0.131 ms,
+	// both 0.745 ms; with this 0.691 ms). A wave raises its own priority at each quarter of its k-loop: whoever is ahead is
+	// issued first and gets further ahead, the workgroups of a CU spread out over the phases and one's epilogue runs
+	// under the others' MFMAs.
+	const int nk_mine = kt1 - kt0;
+	const int prio_q1 = (nk_mine + 3) >> 2, prio_q2 = (nk_mine + 1) >> 1, prio_q3 = (3 * nk_mine + 3) >> 2;
+	auto progress_prio = [&](int t) {          // called before k-tile t (0-based) of this workgroup's nk_mine
+#if PZ_IG_PRIO == 1
+		if (t == prio_q1) __builtin_amdgcn_s_setprio(1);
+		if (t == prio_q2) __builtin_amdgcn_s_setprio(2);
+		if (t == prio_q3) __builtin_amdgcn_s_setprio(3);
+#elif PZ_IG_PRIO == 3
+		if (t == nk_mine - 1) __builtin_amdgcn_s_setprio(3);
+#endif
+	};
+
 	if constexpr (PF2) {
 		float av[2][TM], bv[2][TN];
 		// one k-tile out of LDS buffer `buf`; on entry the fragments of its k2-step 0 are in slot 0. lset: the register set
@@ -750,11 +772,15 @@ igemm_conv_kernel(IgemmArgs a) {
 
 		int t = 0;                                       // tile t: loads of tile t+2 into set t & 1, parks set (t+1) & 1
 		for (; t + 2 < nk; t += 2) {
+			progress_prio(t);
 			tile_body(0, Set0{}, Set1{}, kt0 + t + 2, true, true);
+			progress_prio(t + 1);
 			tile_body(1, Set1{}, Set0{}, kt0 + t + 3, t + 3 < nk, true);
 		}
+		progress_prio(t);
 		if (nk - t == 2) {
 			tile_body(0, Set0{}, Set1{}, 0, false, true);
+			progress_prio(t + 1);
 			tile_body(1, Set1{}, Set0{}, 0, false, false);
 		} else {
 			tile_body(0, Set0{}, Set1{}, 0, false, false);
@@ -768,6 +794,7 @@ igemm_conv_kernel(IgemmArgs a) {
 
 	for (int kt = kt0; kt + 1 < kt1; ++kt) {
 		const int buf = (kt - kt0) & 1;
+		progress_prio(kt - kt0);
 #if PZ_ABL & 1          // ablation: no global loads / LDS stores in the loop (wrong results, timing only)
 		compute_tile(buf, kt + 1, false);
 #else
@@ -778,9 +805,13 @@ igemm_conv_kernel(IgemmArgs a) {
 		__syncthreads();
 #endif
 	}
+	progress_prio(kt1 - 1 - kt0);
 	compute_tile((kt1 - 1 - kt0) & 1, 0, false);
 	}
 
+#if PZ_IG_PRIO == 2
+	__builtin_amdgcn_s_setprio(3);
+#endif
 	if (kslice < 0) {
 #if PZ_ABL & 256        // ablation: no epilogue stores except one element per lane (timing only)
 		a.y[(size_t)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15];

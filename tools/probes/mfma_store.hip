@@ -21,7 +21,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Args {
 	float *y;
 	unsigned y_bytes;
-	int nmfma, store, pat, PQ, OC, npix, mtiles, load, remap, blocks;
+	int nmfma, store, pat, PQ, OC, npix, mtiles, load, remap, blocks, prio;
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) probe(Args a) {
@@ -36,7 +36,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 			for (int r = 0; r < 16; ++r) acc[i][j][r] = (float)(lane + r);
 	float fa[2] = {1.f + lane * 1e-3f, 2.f - lane * 1e-3f}, fb[2] = {0.5f + lane * 1e-3f, 0.25f};
 
-	for (int it = 0; it < a.nmfma / 4; ++it) {
+	const int n_it = a.nmfma / 4;
+	// prio 2: the first generation of workgroups (4 per CU) starts a quarter of a workgroup's life apart: slot = blockIdx / 256
+	if (a.prio == 2 && blockIdx.x < 1024) {
+		const long long until = __builtin_readcyclecounter() + (long long)(blockIdx.x >> 8) * a.nmfma * 64;      // 4 waves x nmfma x 64 cycles / 4
+		while (__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
+	}
+	for (int it = 0; it < n_it; ++it) {
+		// prio 1: a wave raises its own priority as it advances (quarters of the loop): whoever is ahead gets the matrix pipe
+		// first, the resident workgroups stop finishing — and draining their stores — all at the same time
+		if (a.prio == 1) {
+			if (it == n_it / 4) __builtin_amdgcn_s_setprio(1);
+			if (it == n_it / 2) __builtin_amdgcn_s_setprio(2);
+			if (it == 3 * n_it / 4) __builtin_amdgcn_s_setprio(3);
+		}
 #pragma unroll
 		for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -99,22 +112,27 @@ int main() {
 	printf("%-10s %6s | %8s %8s %8s | %8s %8s  (ms; %d x %d x PQ tensor, 128x128 tiles)\n", "pattern", "nmfma", "mfma", "store", "both", "sum", "max", N, OC);
 	const char *names[9] = {"pq3025", "pq3072", "linear", "pq3028", "pq3025cut", "pq3025wide", "pq3028wide", "pq3056", "pq3032"};
 	const int pqs[9] = {3025, 3072, 3072, 3028, 3025, 3025, 3028, 3056, 3032};
-	for (int remap = 0; remap < 2; ++remap)
+	for (int remap = 1; remap < 2; ++remap)
 	for (int pat = 0; pat < 9; ++pat) {
 		const int PQ = pqs[pat];
 		const int npix = N * PQ;
 		const int ntiles = (npix + 127) / 128, mtiles = OC / 128;
 		const int blocks = ntiles * mtiles;
-		for (int nm : {128}) {
-			Args a = {y, (unsigned)((size_t)N * OC * PQ * 4), nm, 0, pat, PQ, OC, npix, mtiles, 0, remap, blocks & ~7};
+		for (int nm : {128, 512}) {
+			Args a = {y, (unsigned)((size_t)N * OC * PQ * 4), nm, 0, pat, PQ, OC, npix, mtiles, 0, remap, blocks & ~7, 0};
 			const float tm = run(a, blocks, 20);
 			a.store = 1; a.nmfma = 0;
 			const float ts = run(a, blocks, 20);
 			a.nmfma = nm;
 			const float tb = run(a, blocks, 20);
+			a.prio = 1;
+			const float tp = run(a, blocks, 20);
+			a.prio = 2;
+			const float tq = run(a, blocks, 20);
+			a.prio = 0;
 			a.nmfma = 0; a.load = 1;
 			const float tl = run(a, blocks, 20);
-			printf("%-10s%s %6d | %8.3f %8.3f %8.3f | %8.3f %8.3f   %.0f MB   loads alone %.3f\n", names[pat], remap ? "/x" : "  ", nm, tm, ts, tb, tm + ts, tm > ts ? tm : ts, blocks * 65536e-6, tl);
+			printf("%-10s%s %6d | %8.3f %8.3f %8.3f | %8.3f %8.3f   %.0f MB   loads alone %.3f   both with progress priority %.3f, staggered start %.3f\n", names[pat], remap ? "/x" : "  ", nm, tm, ts, tb, tm + ts, tm > ts ? tm : ts, blocks * 65536e-6, tl, tp, tq);
 		}
 	}
 	return 0;
