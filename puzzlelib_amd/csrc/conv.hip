@@ -395,6 +395,19 @@ __device__ __forceinline__ void igemm_store_tile(const IgemmArgs &a, int tm, int
 // Groups that straddle two images or the end of the tensor fall back to 4-byte stores. With a.stats the same pass
 // accumulates, per channel row and 64-pixel strip, shifted sums for the batch normalisation that follows (saves its
 // statistics pass over y).
+// sum over the 16 lanes of a DPP row, left in every lane: four v_add_f32 with lane-permuting operands (the vector pipe alone —
+// __shfl_xor goes through the LDS pipe); fixed tree, deterministic
+__device__ __forceinline__ float row16_sum(float v) {
+	auto dpp = [](float x, auto ctrl) {
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+	};
+	v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+	v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+	v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror: the other quad of the half
+	v += dpp(v, std::integral_constant<int, 0x140>{});      // row_mirror: the other half
+	return v;
+}
+
 constexpr int kEpiStride = 68;
 constexpr int kEpiFloatsPerWave = 16 * kEpiStride;
 
@@ -429,6 +442,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 #pragma unroll
 				for (int r = 8 * h; r < 8 * h + 8; ++r) scr[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi) * kEpiStride + j * 32 + l31] = acc[i][j][r];
 
+			float st_shift[4], st_s1[4], st_s2[4];
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				const int ch = row_base + 4 * k + r4;
@@ -454,10 +468,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 						s1 += dlt;
 						s2 = __builtin_fmaf(dlt, dlt, s2);
 					}
-#pragma unroll
-					for (int d = 1; d < 16; d <<= 1) s1 += __shfl_xor(s1, d), s2 += __shfl_xor(s2, d);
-					if (c16 == 0 && row_ok && strip0 < a.npix)
-						a.stats[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / 64] = make_float4(shift, s1, s2, 0.f);
+					st_shift[k] = shift, st_s1[k] = row16_sum(s1), st_s2[k] = row16_sum(s2);      // (every lane of the row holds them)
 				}
 
 				const unsigned chan_off = (unsigned)(g * a.M + ch) * (unsigned)PQ;
@@ -489,6 +500,16 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 					};
 					store_one(0, v[0]), store_one(1, v[1]), store_one(2, v[2]), store_one(3, v[3]);
 				}
+			}
+
+			if (a.stats) {                   // one store for the half band's 16 rows: lane (r4, c16 = k) writes row 4 k + r4
+				float sh = st_shift[0], q1 = st_s1[0], q2 = st_s2[0];
+#pragma unroll
+				for (int k = 1; k < 4; ++k)
+					if (c16 == k) sh = st_shift[k], q1 = st_s1[k], q2 = st_s2[k];
+				const int ch = row_base + 4 * c16 + r4;
+				if (c16 < 4 && ch < a.M && strip0 < a.npix)
+					a.stats[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / 64] = make_float4(sh, q1, q2, 0.f);
 			}
 		}
 	}
