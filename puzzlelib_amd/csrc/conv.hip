@@ -1178,6 +1178,9 @@ struct WgradArgs {
 	// gradient, bnx = this convolution's output / the BN's input, same shape)
 	const float *bnx;
 	const float4 *bncoef;
+	// BIAS kernels: the bias gradient db[k] = sum over (image, pixel) of dy rides on the operand-A runs the workgroups of
+	// tile column 0 park anyway (no pass of its own over dy): db (direct) or per-split partials [split][K_total]
+	float *db_out;
 };
 
 // The reduction axis is enumerated in RUNS of 4 consecutive output pixels of one output row (rows padded to a multiple
@@ -1191,9 +1194,10 @@ struct WgradArgs {
 // WM x WN = 4 or 8 waves. With 8 (PZ_WG_WAVES=8, tiles of at least 8 MFMA tiles) a wave owns half as many accumulators
 // and gathers half as many runs, so two workgroups per CU (the LDS limit) put 4 waves on every SIMD instead of 2 — what
 // gave the Winograd kernels 6-11 % changes nothing here (every census layer within +-2 %), so 4 stays the default.
-template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false>
+template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false, bool BIAS = false>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(RUNS == 8 ? WM * WN / 2 : 4, 8)))
 wgrad_conv_kernel(WgradArgs a) {
+	static_assert(!(BNX && BIAS), "a convolution in front of a BatchNorm has no bias gradient of its own to fold");
 	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
 	constexpr int NT = 64 * WM * WN;
 	constexpr int RP = NT / RUNS;                // tile rows loaded per pass (one 16-byte run per thread)
@@ -1242,6 +1246,9 @@ wgrad_conv_kernel(WgradArgs a) {
 	f32x4 ra2[SETS][BNX ? NA : 1];           // BNX: the BatchNorm input runs that go with the dy runs
 	unsigned mb[SETS][NB];         // valid-pixel masks of the operand-B runs in flight
 	int x_img_of[SETS] = {};       // x_img of the step held by each set (the rare far-left fix-up in store_step needs it)
+	int nq_of[SETS] = {};          // BIAS: real pixels of the dy run held by each set
+	float bsum[BIAS ? NA : 1] = {};        // BIAS: this thread's share of the bias gradient of its NA rows
+	const bool bias_here = BIAS && tn == 0;
 	const int PQ = a.P * a.Q;
 
 	__syncthreads();   // tabs visible
@@ -1332,6 +1339,7 @@ wgrad_conv_kernel(WgradArgs a) {
 			}
 		}
 		if (j == NA + NB - 1) x_img_of[set] = x_img;
+		if (BIAS && j == 0) nq_of[set] = nq;
 	};
 
 	auto store_step = [&](int set, int buf) {
@@ -1344,6 +1352,15 @@ wgrad_conv_kernel(WgradArgs a) {
 					v[q] = __builtin_fmaf(bnc[i].x, (float)ra[set][i][q], __builtin_fmaf(bnc[i].y, (float)ra2[set][i][q], bnc[i].z));
 			}
 			As[buf][run >> 1][run & 1][row0 + RP * i] = v;
+			if constexpr (BIAS) {
+				if (bias_here) {              // pixels past the row end hold the next row's data (they meet zeros in operand B)
+					const int m = (1 << nq_of[set]) - 1;
+					float t[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) t[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)v[q]) & __builtin_amdgcn_sbfe(m, q, 1));
+					bsum[i] += (t[0] + t[1]) + (t[2] + t[3]);
+				}
+			}
 		}
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
@@ -1466,6 +1483,29 @@ wgrad_conv_kernel(WgradArgs a) {
 			__syncthreads();
 		}
 		compute_step((s_end - 1 - s_begin) & 1, 0, 0, false);
+	}
+
+	if constexpr (BIAS) {
+		if (bias_here) {
+			// the RUNS threads of a row are consecutive lanes: butterfly over them (fixed order), lane `run == 0` stores
+			static_assert(RUNS == 8, "bias gradient: eight lanes per row");
+#pragma unroll
+			for (int i = 0; i < NA; ++i) {
+				float v = bsum[i];
+				v += __shfl_xor(v, 1);
+				v += __shfl_xor(v, 2);
+				v += __shfl_xor(v, 4);
+				const int m = tm * BM + row0 + RP * i;
+				if (run == 0 && m < a.Kg) {
+					if (a.direct) {
+						float *o = a.db_out + g * a.Kg + m;
+						*o = (a.beta == 0.f ? 0.f : a.beta * *o) + a.alpha * v;
+					} else {
+						a.db_out[(size_t)split * a.K_total + g * a.Kg + m] = v;
+					}
+				}
+			}
+		}
 	}
 
 	float *outb = a.out + (a.direct ? 0 : (size_t)split * a.slab) + (size_t)g * a.Kg * a.ncrs;
@@ -1722,11 +1762,23 @@ wgrad_split_kernel(WgradArgs a) {
 // waves each sum a contiguous range of the slabs (in order, eight loads in flight) and wave 0 adds the W range sums in
 // order. W follows the split count (small filters have up to 512 slabs: one thread walking them was a chain of 128
 // dependent memory round trips), W = 1 is the plain in-order sum.
+// Workgroups from `dw_blocks` on (only launched with a folded bias gradient) add the per-split bias partials
+// bpart[split][K] the same way, one thread per channel.
 template <int W>
 __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
-                                                              int splits, float alpha, float beta) {
+                                                              int splits, float alpha, float beta, int dw_blocks,
+                                                              const float *__restrict__ bpart, float *__restrict__ db, int K) {
 	typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
 	__shared__ f4 sh[W > 1 ? W : 1][64];
+	if ((int)blockIdx.x >= dw_blocks) {
+		const int k = ((int)blockIdx.x - dw_blocks) * (64 * W) + (int)threadIdx.x;
+		if (k < K) {
+			float r = 0.f;
+			for (int sp = 0; sp < splits; ++sp) r += bpart[(size_t)sp * K + k];
+			db[k] = (beta == 0.f ? 0.f : beta * db[k]) + alpha * r;
+		}
+		return;
+	}
 	const size_t n4 = n >> 2;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 	const size_t i = (size_t)blockIdx.x * 64 + lane;
@@ -1765,14 +1817,17 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 	}
 }
 
-inline void launch_wgrad_reduce(float *dw, const float *slabs, size_t n, int splits, float alpha, float beta, hipStream_t st) {
+inline void launch_wgrad_reduce(float *dw, const float *slabs, size_t n, int splits, float alpha, float beta, hipStream_t st,
+                                const float *bpart = nullptr, float *db = nullptr, int K = 0) {
 	const int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
-	if (splits >= 128)
-		wgrad_reduce_kernel<16><<<blocks, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta);
-	else if (splits >= 32)
-		wgrad_reduce_kernel<4><<<blocks, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta);
+	const int W = splits >= 128 ? 16 : splits >= 32 ? 4 : 1;
+	const int extra = db ? pz::ceil_div(K, 64 * W) : 0;
+	if (W == 16)
+		wgrad_reduce_kernel<16><<<blocks + extra, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
+	else if (W == 4)
+		wgrad_reduce_kernel<4><<<blocks + extra, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 	else
-		wgrad_reduce_kernel<1><<<blocks, 64, 0, st>>>(dw, slabs, n, splits, alpha, beta);
+		wgrad_reduce_kernel<1><<<blocks + extra, 64, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 }
 
 // db[k] = beta*db[k] + alpha * sum_{n,pq} dy[n,k,pq], two deterministic stages: workgroup (k, s) sums the images
@@ -1825,6 +1880,13 @@ inline int bias_grad_splits(int n, int k) {
 	int s = pz::ceil_div(8 * pz::kNumCU, k);
 	s = s > n ? n : s;
 	return s > 64 ? 64 : (s < 1 ? 1 : s);
+}
+
+// last block of a backward-filter workspace: the bias-gradient partials, of the two-stage kernels above or (one row per
+// split of the filter-gradient launch) of the form folded into wgrad_conv_kernel
+inline size_t bias_part_bytes(const pz_conv_desc *d, int wgrad_splits) {
+	const int s = bias_grad_splits(d->n, d->k);
+	return (((size_t)d->k * (s > wgrad_splits ? s : wgrad_splits) * sizeof(float)) + 255) & ~(size_t)255;
 }
 
 // single-stage variant (one workgroup per channel) for callers without workspace
@@ -2296,7 +2358,7 @@ static int conv_workspace_bytes(const pz_conv_desc *d, int which, int algo, bool
 	} else {
 		WgradPlan p = wgrad_split_eligible(d) ? plan_wgrad_split(d, P, Q) : plan_wgrad(d, P, Q);
 		*nbytes = p.tab_bytes + (p.splits > 1 ? align256(p.slab_elems * p.splits * sizeof(float)) : 0) +
-		          align256((size_t)d->k * bias_grad_splits(d->n, d->k) * sizeof(float));       // bias-gradient partials
+		          bias_part_bytes(d, p.splits);                                                 // bias-gradient partials
 	}
 	return PZ_OK;
 }
@@ -2694,9 +2756,15 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	const int Kg = d->k / d->groups, Cg = d->c / d->groups;
 	const bool gemm_path = !(algo == PZ_CONV_ALGO_DIRECT || !igemm_eligible(d, P, Q));
 
-	if (db) {
-		size_t need_all = 0;
-		if (gemm_path) pz_conv2d_workspace_bytes(d, PZ_CONV_BWD_FILTER, algo, &need_all);
+	// The bias gradient rides in the filter-gradient kernel (wgrad_conv_kernel<..., BIAS>) when that kernel runs on fp32
+	// operands and the workspace has the partials' block (PUZZLE_MI355_BIAS_FOLD=0: the two-stage kernels, A/B aid)
+	size_t need_all = 0;
+	if (db && gemm_path) pz_conv2d_workspace_bytes(d, PZ_CONV_BWD_FILTER, algo, &need_all);
+	static const bool fold_allowed = [] { const char *e = getenv("PUZZLE_MI355_BIAS_FOLD"); return !e || atoi(e) != 0; }();
+	const bool fold_bias = db && gemm_path && fold_allowed && bnx == nullptr && !uses_winograd(d, PZ_CONV_BWD_FILTER, P, Q, algo) &&
+	                       !wgrad_split_eligible(d) && workspace && ws_bytes >= need_all;
+
+	if (db && !fold_bias) {
 		const int S = bias_grad_splits(d->n, d->k);
 		const size_t part_bytes = align256((size_t)d->k * S * sizeof(float));
 
@@ -2767,6 +2835,8 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	a.out = a.direct ? dw : slabs;
 	a.slab = p.slab_elems;
 	a.bnx = bnx, a.bncoef = reinterpret_cast<const float4 *>(bncoef);
+	float *bpart = fold_bias ? (float *)((char *)workspace + need_all - bias_part_bytes(d, p.splits)) : nullptr;
+	a.db_out = fold_bias ? (a.direct ? db : bpart) : nullptr;
 
 	dim3 grid(p.tiles_m * p.tiles_n * p.splits, 1, d->groups);
 	if (split_math) {
@@ -2789,6 +2859,9 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 #define PZ_WGRAD_LAUNCH(BM_, BN_, WM_, WN_) \
 	(a.bnx     ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
 	                        : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a)) \
+	 : a.db_out ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	               : unit_w  ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 1, PZ_WG_RUNS, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	                         : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a)) \
 	 : pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
 	 : unit_w  ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 1, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
 	           : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS><<<grid, 64 * WM_ * WN_, 0, st>>>(a))
@@ -2800,7 +2873,10 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128, 2, 2);
 	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64, 2, 2);
 	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128, 2, 2);
-	else if (p.bm == 64 && p.bn == 192) wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a);      // plan_wgrad: strided gathers only
+	else if (p.bm == 64 && p.bn == 192) {      // plan_wgrad: strided gathers only
+		if (a.db_out) wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS, false, true><<<grid, 256, 0, st>>>(a);
+		else wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a);
+	}
 #endif
 	else PZ_WGRAD_LAUNCH(64, 64, 2, 2);
 #undef PZ_WGRAD_LAUNCH
@@ -2808,7 +2884,7 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	PZ_LAUNCH_CHECK();
 
 	if (!a.direct) {
-		launch_wgrad_reduce(dw, slabs, p.slab_elems, p.splits, alpha, beta, st);
+		launch_wgrad_reduce(dw, slabs, p.slab_elems, p.splits, alpha, beta, st, bpart, fold_bias ? db : nullptr, d->k);
 		PZ_LAUNCH_CHECK();
 	}
 	return PZ_OK;
