@@ -462,3 +462,44 @@ def test_resnet50_b256_step_fused_equals_literal_and_matches_oracle(bnd):
 	cnet.train = False
 	ref = cnet.forward(data[:2].get())
 	assert_close(dev, ref, atol=2e-3 * np.abs(ref).max() + 1e-4, rtol=2e-3, what="ResNet-50 logits vs oracle, 2 images")
+
+
+# config 3 (TestLib/CnnCifar10NIN.py:13-49): the nine convolutions of the CIFAR-10 NiN at batch 128, all with a bias
+NIN_LAYERS = [
+	((3, 32, 32), (192, 5, 1, 2)), ((192, 32, 32), (160, 1, 1, 0)), ((160, 32, 32), (96, 1, 1, 0)),
+	((96, 16, 16), (192, 5, 1, 2)), ((192, 16, 16), (192, 1, 1, 0)), ((192, 8, 8), (192, 3, 1, 1)),
+	((192, 8, 8), (192, 1, 1, 0)), ((192, 8, 8), (10, 1, 1, 0)),
+]
+
+
+@pytest.mark.parametrize("layer", NIN_LAYERS, ids=lambda l: "%dx%dx%d_to_%d_k%d" % (l[0] + l[1][:2]))
+def test_nin_layers_bias_gradient_rides_in_the_filter_gradient(bnd, layer):
+	"""Backend/Dnn.py convNdBackwardParams(withbias=True) at config 3's sizes: the bias gradient is the sum of the output
+	gradient over images and pixels (Hip/Wrappers/MIOpen.py:435-455), whichever kernel produced it — folded into the
+	implicit-GEMM filter-gradient kernel (whole tensors against fp64 sums, |err| <= 1e-5 + 1e-4 |ref| scaled by the sum's
+	length), and the accumulate form bgrad <- momentum * bgrad + scale * db on the same launch."""
+	(c, h, w), (k, size, stride, pad) = layer
+	n = 128
+	rng = np.random.RandomState(k * 31 + c)
+	x = dev_randn(bnd, (n, c, h, w), seed=11 + c)
+	wt = gpu(bnd, (rng.randn(k, c, size, size) / np.sqrt(c * size * size)).astype(np.float32))
+	oh, ow = (h + 2 * pad - size) // stride + 1, (w + 2 * pad - size) // stride + 1
+	dy = dev_randn(bnd, (n, k, oh, ow), seed=23 + k)
+	kw = dict(stride=stride, pad=pad)
+
+	dw, db = bnd.dnn.convNdBackwardParams(x, dy, wt, withbias=True, **kw)
+	dyh = dy.get().astype(np.float64)
+	db_ref = dyh.sum(axis=(0, 2, 3))
+	tol = np.sqrt(n * oh * ow)
+	assert_close(db.get(), db_ref, atol=1e-5 * tol, rtol=1e-4, what="bias gradient")
+
+	# the filter gradient next to it is the one the call without a bias gives, bit for bit
+	dw_plain = bnd.dnn.convNdBackwardParams(x, dy, wt, withbias=False, **kw)
+	assert np.array_equal(dw.get(), dw_plain.get()), "filter gradient changed by the folded bias gradient"
+
+	# accumulate contract on both destinations
+	wg0, bg0 = rng.randn(*wt.shape).astype(np.float32), rng.randn(k).astype(np.float32)
+	wg, bg = gpu(bnd, wg0), gpu(bnd, bg0)
+	bnd.dnn.convNdBackwardParams(x, dy, wt, withbias=True, wgrad=wg, bgrad=bg, scale=0.5, momentum=0.9, **kw)
+	assert_close(bg.get(), 0.9 * bg0 + 0.5 * db_ref, atol=1e-5 * tol, rtol=1e-4, what="accumulated bias gradient")
+	assert_close(wg.get(), 0.9 * wg0 + 0.5 * dw_plain.get().astype(np.float64), atol=1e-5 * tol, rtol=1e-4, what="accumulated filter gradient")
