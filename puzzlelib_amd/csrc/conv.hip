@@ -1195,7 +1195,7 @@ struct WgradArgs {
 // and gathers half as many runs, so two workgroups per CU (the LDS limit) put 4 waves on every SIMD instead of 2 — what
 // gave the Winograd kernels 6-11 % changes nothing here (every census layer within +-2 %), so 4 stays the default.
 template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false, bool BIAS = false>
-__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(RUNS == 8 ? WM * WN / 2 : 4, 8)))
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(RUNS == 8 || BM > 128 ? WM * WN / 2 : 4, 8)))
 wgrad_conv_kernel(WgradArgs a) {
 	static_assert(!(BNX && BIAS), "a convolution in front of a BatchNorm has no bias gradient of its own to fold");
 	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
@@ -1488,13 +1488,12 @@ wgrad_conv_kernel(WgradArgs a) {
 	if constexpr (BIAS) {
 		if (bias_here) {
 			// the RUNS threads of a row are consecutive lanes: butterfly over them (fixed order), lane `run == 0` stores
-			static_assert(RUNS == 8, "bias gradient: eight lanes per row");
+			static_assert(RUNS == 8 || RUNS == 4, "bias gradient: a row's lanes are a power of two");
 #pragma unroll
 			for (int i = 0; i < NA; ++i) {
 				float v = bsum[i];
-				v += __shfl_xor(v, 1);
-				v += __shfl_xor(v, 2);
-				v += __shfl_xor(v, 4);
+#pragma unroll
+				for (int o = 1; o < RUNS; o <<= 1) v += __shfl_xor(v, o);
 				const int m = tm * BM + row0 + RP * i;
 				if (run == 0 && m < a.Kg) {
 					if (a.direct) {
@@ -1762,14 +1761,18 @@ wgrad_split_kernel(WgradArgs a) {
 // waves each sum a contiguous range of the slabs (in order, eight loads in flight) and wave 0 adds the W range sums in
 // order. W follows the split count (small filters have up to 512 slabs: one thread walking them was a chain of 128
 // dependent memory round trips), W = 1 is the plain in-order sum.
+// SUB = 4 (small filter gradients: fewer than a workgroup per CU otherwise — NiN's 192 x 75 gradient in 170 slabs was 57
+// workgroups walking 10 MB): a wave owns 16 elements and its four lane quarters sum a quarter of the wave's slab range each;
+// the W x SUB range sums are added in range order.
 // Workgroups from `dw_blocks` on (only launched with a folded bias gradient) add the per-split bias partials
 // bpart[split][K] the same way, one thread per channel.
-template <int W>
+template <int W, int SUB = 1>
 __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
                                                               int splits, float alpha, float beta, int dw_blocks,
                                                               const float *__restrict__ bpart, float *__restrict__ db, int K) {
 	typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
-	__shared__ f4 sh[W > 1 ? W : 1][64];
+	constexpr int E = 64 / SUB;            // elements (of 16 bytes) per workgroup
+	__shared__ f4 sh[W * SUB > 1 ? W : 1][64];
 	if ((int)blockIdx.x >= dw_blocks) {
 		const int k = ((int)blockIdx.x - dw_blocks) * (64 * W) + (int)threadIdx.x;
 		if (k < K) {
@@ -1781,8 +1784,8 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 	}
 	const size_t n4 = n >> 2;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const size_t i = (size_t)blockIdx.x * 64 + lane;
-	const int per = (splits + W - 1) / W, k0 = w * per, k1 = min(k0 + per, splits);
+	const size_t i = (size_t)blockIdx.x * E + lane % E;
+	const int per = (splits + W * SUB - 1) / (W * SUB), k0 = (w * SUB + lane / E) * per, k1 = min(k0 + per, splits);
 
 	f4 s = {0.f, 0.f, 0.f, 0.f};
 	if (i < n4) {
@@ -1795,13 +1798,13 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 				if (k + q < k1) s += v[q];
 		}
 	}
-	if (W > 1) {
+	if (W * SUB > 1) {
 		sh[w][lane] = s;
 		__syncthreads();
-		if (w != 0) return;
+		if (w != 0 || lane >= E) return;
 		s = sh[0][lane];
 #pragma unroll
-		for (int q = 1; q < W; ++q) s += sh[q][lane];
+		for (int q = 1; q < W * SUB; ++q) s += sh[q / SUB][(q % SUB) * E + lane];
 	}
 	if (i < n4) {
 		f4 *o = reinterpret_cast<f4 *>(dw + 4 * i);
@@ -1819,11 +1822,18 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 
 inline void launch_wgrad_reduce(float *dw, const float *slabs, size_t n, int splits, float alpha, float beta, hipStream_t st,
                                 const float *bpart = nullptr, float *db = nullptr, int K = 0) {
-	const int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
+	int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
 	const int W = splits >= 128 ? 16 : splits >= 32 ? 4 : 1;
 	const int extra = db ? pz::ceil_div(K, 64 * W) : 0;
-	if (W == 16)
+	// many slabs of a small gradient: four times the workgroups, each lane quarter a quarter of the slab range
+	const bool narrow = W >= 4 && blocks < pz::kNumCU && (n >> 2) > 0;
+	if (narrow) blocks = (int)(((n >> 2) + 15) / 16);
+	if (W == 16 && narrow)
+		wgrad_reduce_kernel<16, 4><<<blocks + extra, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
+	else if (W == 16)
 		wgrad_reduce_kernel<16><<<blocks + extra, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
+	else if (W == 4 && narrow)
+		wgrad_reduce_kernel<4, 4><<<blocks + extra, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 	else if (W == 4)
 		wgrad_reduce_kernel<4><<<blocks + extra, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 	else
@@ -2172,6 +2182,7 @@ bool dgrad_uses_igemm(const pz_conv_desc *d) {
 
 struct WgradPlan {
 	int bm, bn, tiles_m, tiles_n, ncrs, ncrs_pad, steps_total, steps_per_split, splits;
+	int runs;             // 4-pixel runs per k-step of the kernel instantiation the plan is for
 	size_t tab_bytes, slab_elems;
 };
 
@@ -2196,15 +2207,23 @@ WgradPlan plan_wgrad(const pz_conv_desc *d, int P, int Q) {
 	// instead of once per 64-column tile, and a wave's 32 x 96 share does 3 MFMAs per 4 fragment reads instead of 1 per 2
 	if (p.bm == 64 && Kg <= 64 && p.ncrs > 128 && p.ncrs <= 192 && d->stride_w > 1 && d->r * d->s > 1 && PZ_WG_RUNS == 8 && PZ_WG_WAVES == 4)
 		p.bn = 192;      // (not a pointwise filter: those may arrive with a BatchNorm fold, which this instantiation does not carry)
+	p.runs = PZ_WG_RUNS;
+	// 129..192 output maps under a filter with taps (NiN's 5x5 layers: 192 maps, 2 400 gathered columns): ONE 192-row tile
+	// instead of three 64-row ones — the x runs, which every tap gathers again, are fetched once instead of three times and a
+	// wave's 96 x 64 share does 6 MFMAs per 5 fragment reads instead of 2 per 3; 16-pixel k-steps keep two such workgroups
+	// on a CU (82 KB of LDS each otherwise). Only where the gathered side is wide (>= 4 column tiles): a 192 x 75 gradient would
+	// be ONE tile cut into 512 slabs, whose reduce costs more than the tile saves.
+	if (Kg > 128 && Kg <= 192 && p.bn == 128 && p.ncrs >= 512 && d->r * d->s > 1 && d->stride_w == 1 && PZ_WG_WAVES == 4) p.bm = 192, p.runs = 4;
 	p.tiles_m = pz::ceil_div(Kg, p.bm);
 	p.tiles_n = pz::ceil_div(p.ncrs, p.bn);
 	p.ncrs_pad = p.tiles_n * p.bn;
 	const long nruns = (long)d->n * P * ((Q + 3) / 4);         // reduction axis in runs of 4 pixels (rows padded to 4)
-	p.steps_total = pz::ceil_div(nruns, PZ_WG_RUNS);
+	p.steps_total = pz::ceil_div(nruns, p.runs);
 
 	const int tiles = p.tiles_m * p.tiles_n * d->groups;
-	int splits = (PZ_WG_RUNS == 8 ? 2 : 4) * pz::kNumCU / tiles;       // workgroups that fit a CU (LDS): one balanced round
-	const int max_by_work = p.steps_total / 8 > 0 ? p.steps_total / 8 : 1;   // >= 8 k-steps (256 pixels) per split
+	int splits = (PZ_WG_RUNS == 8 || p.bm == 192 ? 2 : 4) * pz::kNumCU / tiles;       // workgroups that fit a CU (LDS): one balanced round
+	const int min_steps = 8 * 8 / p.runs;                                             // >= 256 pixels per split
+	const int max_by_work = p.steps_total / min_steps > 0 ? p.steps_total / min_steps : 1;
 	if (splits > max_by_work) splits = max_by_work;
 	if (splits < 1) splits = 1;
 	p.steps_per_split = pz::ceil_div(p.steps_total, splits);
@@ -2242,6 +2261,7 @@ WgradPlan plan_wgrad_split(const pz_conv_desc *d, int P, int Q) {
 	p.steps_per_split = pz::ceil_div(p.steps_total, splits);
 	p.splits = pz::ceil_div(p.steps_total, p.steps_per_split);
 	p.tab_bytes = 0;
+	p.runs = 0;
 	p.slab_elems = (size_t)d->groups * Kg * p.ncrs;
 	return p;
 }
@@ -2873,7 +2893,10 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	if (p.bm == 128 && p.bn == 128) PZ_WGRAD_LAUNCH(128, 128, 2, 2);
 	else if (p.bm == 128 && p.bn == 64) PZ_WGRAD_LAUNCH(128, 64, 2, 2);
 	else if (p.bm == 64 && p.bn == 128) PZ_WGRAD_LAUNCH(64, 128, 2, 2);
-	else if (p.bm == 64 && p.bn == 192) {      // plan_wgrad: strided gathers only
+	else if (p.bm == 192) {                    // plan_wgrad: unit-stride gathers under a filter with taps, 16-pixel k-steps
+		if (a.db_out) wgrad_conv_kernel<192, 128, 2, 2, 1, 4, false, true><<<grid, 256, 0, st>>>(a);
+		else wgrad_conv_kernel<192, 128, 2, 2, 1, 4><<<grid, 256, 0, st>>>(a);
+	} else if (p.bm == 64 && p.bn == 192) {      // plan_wgrad: strided gathers only
 		if (a.db_out) wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS, false, true><<<grid, 256, 0, st>>>(a);
 		else wgrad_conv_kernel<64, 192, 2, 2, 0, PZ_WG_RUNS><<<grid, 256, 0, st>>>(a);
 	}

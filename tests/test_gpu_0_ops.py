@@ -153,6 +153,11 @@ FRESH = [
 	# pointwise with both channel counts in whole tiles: backward-data reads the filter tensor as its packed operand
 	dict(n=3, c=128, h=9, w=11, k=64, r=1, s=1, stride=1, pad=0, dil=1, groups=1),
 	dict(n=2, c=64, h=10, w=10, k=256, r=1, s=1, stride=2, pad=0, dil=1, groups=1),
+	# 129..192 output maps under a filter with taps: the filter gradient's 192 x 128 tile (16-pixel k-steps), whole and partial
+	# in both directions, with the bias gradient folded in; odd maps so that runs cross row ends
+	dict(n=5, c=20, h=13, w=11, k=192, r=5, s=5, stride=1, pad=2, dil=1, groups=1),
+	dict(n=3, c=3, h=18, w=18, k=160, r=5, s=5, stride=1, pad=2, dil=1, groups=1),
+	dict(n=2, c=40, h=9, w=10, k=130, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
 	# the stem's filter gradient (64 x 147) on the 64 x 192 tile, here with fewer than 64 output maps and an odd map
 	dict(n=3, c=3, h=45, w=39, k=48, r=7, s=7, stride=2, pad=3, dil=1, groups=1),
 ]
