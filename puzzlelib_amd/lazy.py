@@ -325,13 +325,28 @@ def prune(block=False):
 			spare.append(objects[0])              # the launch's `ready` event
 
 
-def foreignBegin(stream):
-	"""Everything issued on the main stream so far happens before what `stream` is given next."""
+def foreignBegin(stream, ready=None):
+	"""Everything issued on the main stream so far — or up to `ready`, an event the caller recorded on it earlier and knows
+	to lie behind every write of what the launch reads — happens before what `stream` is given next."""
 	prune()
-	ready = newEvent()
-	ready.record(None)
+	if ready is None:
+		ready = newEvent()
+		ready.record(None)
 	stream.waitEvent(ready)
 	return ready
+
+
+def quiet(ary):
+	"""touching `ary` (read or write) launches nothing on the main stream: no pending contents, no dependents to settle, no
+	queued small adds over its allocation (events of foreign streams do not count: the toucher waits for those itself)"""
+	lz = ary.gpudata.root.lz
+	return lz is None or (lz.thunk is None and not lz.deps and lz.small is None)
+
+
+def cleanSince(root, version):
+	"""nothing pending on allocation `root` and no write barrier passed since its version counter read `version`"""
+	lz = root.lz
+	return lz is not None and lz.thunk is None and lz.version == version
 
 
 def foreignEnd(stream, ready, reads=(), writes=(), keep=()):

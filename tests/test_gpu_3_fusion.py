@@ -332,6 +332,56 @@ def test_filter_gradients_on_the_side_stream(surf):
 	assert_close(with_side[wt.size:].reshape(wt.shape), 1.0 * dw, atol=2e-4 * scale, rtol=2e-4, what="2 x 0.5 dw")
 
 
+def test_filter_gradient_follows_the_mark_in_front_of_backward_data_only_over_untouched_operands(surf):
+	"""Modules/ConvND.py:84-95 calls backward-data, then backward-filter on the same gradient. On the filter-gradient stream the
+	second has to wait for the producers of its operands, not for the first: it follows the main stream from a mark recorded
+	in front of the backward-data launch (DnnContext.markBeforeBackwardData) — but only if neither operand was written since
+	and its destination holds nothing pending. Values against the fp64 oracle in every case (the test allocator poisons the
+	workspace with NaNs on whichever stream the launch runs on), bit-identical to the one-stream run."""
+	from puzzlelib_amd import lazy
+	g, Dnn = surf.gpuarray, surf.Dnn
+	dnn = surf.backend.dnn
+	if dnn.convMath != "f32" or dnn.sideStreamMaxGflop <= 1.0:
+		pytest.skip("one stream by configuration")
+	rng = np.random.RandomState(11)
+	n, c, k, h = 32, 96, 160, 16
+	x, dy = rng.randn(n, c, h, h).astype(np.float32), rng.randn(n, k, h, h).astype(np.float32)
+	x2, dy2 = rng.randn(*x.shape).astype(np.float32), rng.randn(*dy.shape).astype(np.float32)
+	wt = (rng.randn(k, c, 5, 5) / 50.0).astype(np.float32)
+	kw = dict(stride=(1, 1), pad=(2, 2), dilation=(1, 1), groups=1)
+	args = ((1, 1), (2, 2), (1, 1))
+
+	def run(between):
+		gx, gdy, gw = g.to_gpu(x), g.to_gpu(dy), g.to_gpu(wt)
+		wg, bg = g.zeros(wt.shape, dtype=np.float32), g.zeros((k, ), dtype=np.float32)
+		wg.get(), bg.get()                                             # (the zero fills are written, not pending)
+		dx = Dnn.convNdBackwardData(gdy, gw, gx, *args, 1, Dnn.ConvBwdDataAlgo.auto)
+		between(gx, gdy)
+		Dnn.convNdBackwardParams(gx, gdy, gw, bg, *args, 1, wg, bg, 1.0, 0.0, Dnn.ConvBwdFilterAlgo.auto)
+		return dx.get(), wg.get(), bg.get()
+
+	cases = {
+		"untouched": (lambda gx, gdy: None, x, dy, 1),
+		"gradient rewritten": (lambda gx, gdy: gdy.set(dy2), x, dy2, 0),
+		"input rewritten": (lambda gx, gdy: gx.set(x2), x2, dy, 0),
+	}
+	for name, (between, xr, dyr, marks) in cases.items():
+		dnn.sideWorkMean = 0.0
+		lazy.disabled = set()
+		lazy.counters.clear()
+		dx, dw, db = run(between)
+		assert lazy.counters.get("wgrad_early_start", 0) == marks, name
+		lazy.disabled = {"sidestream"}
+		dx1, dw1, db1 = run(between)
+		lazy.disabled = set()
+		assert np.array_equal(dx, dx1) and np.array_equal(dw, dw1) and np.array_equal(db, db1), name
+		dw_ref, db_ref = R.conv2d_bwd_filter(xr, dyr, wt.shape, withbias=True, acc=np.float64, **kw)
+		scale = np.sqrt(n * h * h)
+		assert_close(dw, dw_ref, atol=1e-5 * scale, rtol=1e-4, what=name + ": filter gradient")
+		assert_close(db, db_ref, atol=1e-5 * scale, rtol=1e-4, what=name + ": bias gradient")
+		assert_close(dx, R.conv2d_bwd_data(dy, wt, x.shape, acc=np.float64, **kw), atol=1e-4, rtol=1e-4, what=name + ": input gradient")
+
+
 def test_borrowed_streams_are_ordered_by_the_buffers(surf):
 	"""Optimizer.update(useStreams=True) (Optimizers/Optimizer.py:176-196): per-parameter updates on borrowed streams. The
 	reference's streams are blocking ones; here ordering is carried by events on the buffers (updates raced

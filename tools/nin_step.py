@@ -31,4 +31,6 @@ for _ in range(steps):
 t1 = time.perf_counter()
 lib.pz_device_sync()
 t2 = time.perf_counter()
+from puzzlelib_amd import lazy
+print("filter gradients started from the mark in front of their layer's backward-data: %.1f per step" % (lazy.counters.get("wgrad_early_start", 0) / (steps + 20.0)))
 print("NiN b128: %.3f ms/step wall (host issue %.3f ms/step), %.0f img/s" % ((t2 - t0) / steps * 1e3, (t1 - t0) / steps * 1e3, 128 * steps / (t2 - t0)))
