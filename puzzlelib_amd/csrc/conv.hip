@@ -1761,18 +1761,14 @@ wgrad_split_kernel(WgradArgs a) {
 // waves each sum a contiguous range of the slabs (in order, eight loads in flight) and wave 0 adds the W range sums in
 // order. W follows the split count (small filters have up to 512 slabs: one thread walking them was a chain of 128
 // dependent memory round trips), W = 1 is the plain in-order sum.
-// SUB = 4 (small filter gradients: fewer than a workgroup per CU otherwise — NiN's 192 x 75 gradient in 170 slabs was 57
-// workgroups walking 10 MB): a wave owns 16 elements and its four lane quarters sum a quarter of the wave's slab range each;
-// the W x SUB range sums are added in range order.
 // Workgroups from `dw_blocks` on (only launched with a folded bias gradient) add the per-split bias partials
 // bpart[split][K] the same way, one thread per channel.
-template <int W, int SUB = 1>
+template <int W>
 __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict__ dw, const float *__restrict__ slabs, size_t n,
                                                               int splits, float alpha, float beta, int dw_blocks,
                                                               const float *__restrict__ bpart, float *__restrict__ db, int K) {
 	typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
-	constexpr int E = 64 / SUB;            // elements (of 16 bytes) per workgroup
-	__shared__ f4 sh[W * SUB > 1 ? W : 1][64];
+	__shared__ f4 sh[W > 1 ? W : 1][64];
 	if ((int)blockIdx.x >= dw_blocks) {
 		const int k = ((int)blockIdx.x - dw_blocks) * (64 * W) + (int)threadIdx.x;
 		if (k < K) {
@@ -1784,8 +1780,8 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 	}
 	const size_t n4 = n >> 2;
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const size_t i = (size_t)blockIdx.x * E + lane % E;
-	const int per = (splits + W * SUB - 1) / (W * SUB), k0 = (w * SUB + lane / E) * per, k1 = min(k0 + per, splits);
+	const size_t i = (size_t)blockIdx.x * 64 + lane;
+	const int per = (splits + W - 1) / W, k0 = w * per, k1 = min(k0 + per, splits);
 
 	f4 s = {0.f, 0.f, 0.f, 0.f};
 	if (i < n4) {
@@ -1798,13 +1794,13 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 				if (k + q < k1) s += v[q];
 		}
 	}
-	if (W * SUB > 1) {
+	if (W > 1) {
 		sh[w][lane] = s;
 		__syncthreads();
-		if (w != 0 || lane >= E) return;
+		if (w != 0) return;
 		s = sh[0][lane];
 #pragma unroll
-		for (int q = 1; q < W * SUB; ++q) s += sh[q / SUB][(q % SUB) * E + lane];
+		for (int q = 1; q < W; ++q) s += sh[q][lane];
 	}
 	if (i < n4) {
 		f4 *o = reinterpret_cast<f4 *>(dw + 4 * i);
@@ -1822,18 +1818,11 @@ __global__ void __launch_bounds__(64 * W) wgrad_reduce_kernel(float *__restrict_
 
 inline void launch_wgrad_reduce(float *dw, const float *slabs, size_t n, int splits, float alpha, float beta, hipStream_t st,
                                 const float *bpart = nullptr, float *db = nullptr, int K = 0) {
-	int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
+	const int blocks = (int)(((n >> 2) + 63) / 64) + ((n >> 2) == 0 ? 1 : 0);
 	const int W = splits >= 128 ? 16 : splits >= 32 ? 4 : 1;
 	const int extra = db ? pz::ceil_div(K, 64 * W) : 0;
-	// many slabs of a small gradient: four times the workgroups, each lane quarter a quarter of the slab range
-	const bool narrow = W >= 4 && blocks < pz::kNumCU && (n >> 2) > 0;
-	if (narrow) blocks = (int)(((n >> 2) + 15) / 16);
-	if (W == 16 && narrow)
-		wgrad_reduce_kernel<16, 4><<<blocks + extra, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
-	else if (W == 16)
+	if (W == 16)
 		wgrad_reduce_kernel<16><<<blocks + extra, 1024, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
-	else if (W == 4 && narrow)
-		wgrad_reduce_kernel<4, 4><<<blocks + extra, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 	else if (W == 4)
 		wgrad_reduce_kernel<4><<<blocks + extra, 256, 0, st>>>(dw, slabs, n, splits, alpha, beta, blocks, bpart, db, K);
 	else
