@@ -449,7 +449,7 @@ class DnnContext:
 		filter-gradient call uses the mark if nothing touched them since (convNdBackwardParams). NiN b128: the 5x5 layer's
 		filter gradient no longer starts 0.38 ms late, the first layer's not behind its input gradient."""
 		self.earlyReady = None
-		if data is None or not lazy.on("sidestream") or not lazy.on("earlyready") or self.convMath != "f32" or \
+		if not isinstance(data, GPUArray) or not lazy.on("sidestream") or not lazy.on("earlyready") or self.convMath != "f32" or \
 				self.sideWorkMean > self.sideStreamMaxGflop:
 			return
 		grad.rptr, W.rptr                                    # whatever is pending is launched in FRONT of the mark
