@@ -152,7 +152,9 @@ int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed,
 int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
                            size_t ws_bytes, pz_stream_t stream);
 /* dw <- beta*dw + alpha*sum(x (x) dy); db (optional) <- beta*db + alpha*sum(dy): the accumulate contract of
- * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue.         */
+ * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue. With the workspace of
+ * pz_conv2d_workspace_bytes the bias gradient is summed inside the filter-gradient kernel (from the dy runs it stages
+ * anyway) and reduced with the filter gradient's slabs; without a workspace a one-stage kernel sums it.            */
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
                          float alpha, float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 
