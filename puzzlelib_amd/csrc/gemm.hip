@@ -2,14 +2,21 @@
 // Serves Linear forward (NN), dx (NT) and dW (TN with alpha=scale, beta=momentum) — Modules/Linear.py:36-54 via
 // Blas.mulMatrixOnMatrix (Backend/Blas.py:60-61). Replaces BlasContext.gemm — Cuda/Source/Libs/CuBlas.c:327-402.
 //
-// Workgroup = 4 waves (2 x 2), tile BM x BN in {64, 128}^2, each wave (BM/2) x (BN/2) = TM x TN tiles of
-// v_mfma_f32_32x32x2_f32; BK = 16, LDS double buffer, one barrier per k-tile, the next tile's global loads in flight
-// while the current one is multiplied.
+// Workgroup = WM x WN waves, each wave (BM / WM) x (BN / WN) = TM x TN tiles of v_mfma_f32_32x32x2_f32: tiles {64, 128}^2 on 4
+// waves (2 x 2), and 256 x 256 on 16 waves (4 x 4; a launch with at least one such tile per CU and K >= 256 — 137 instead of
+// 126 TFLOP/s at 4096^3: half the operand bytes per MFMA through L2 and LDS). BK = 16, LDS double buffer, one barrier per
+// k-tile, the next tile's global loads in flight while the current one is multiplied.
 // LDS holds both operands reduction-major, As[k][m] and Bs[k][n] with a row stride of BM + 32 floats: a fragment read
 // (lane l -> column l & 31 of row k + (l >> 5)) touches 64 distinct banks. Global reads always run along the
 // contiguous axis of the source, 16 bytes per lane: an operand whose contiguous axis is m (or n) is parked with one
-// ds_write_b128, one whose contiguous axis is k with four ds_write_b32 (lanes along m: conflict-free). Operands that
-// are not 16-byte aligned / whose K is not a multiple of 4 take the 4-byte loader.
+// ds_write_b128, one whose contiguous axis is k with four ds_write_b32 (lanes along m: conflict-free).
+// The 16-byte loads are BUFFER loads without a branch around them (round 4, session 6): the per-lane bounds tests of the
+// first version (`if (row < rows) x = *p; else x = 0`) made the compiler wait for every load right behind its issue — the
+// software pipeline never overlapped anything, 106 TFLOP/s at 4096^3 where tools/probes/gemm_variants.hip measured 126 for the
+// same structure with unconditional loads. Now the descriptor covers exactly the matrix: rows beyond it read as zero (and
+// rows >= M / columns >= N only feed outputs nobody stores), a quad beyond the reduction range takes an out-of-range
+// offset (one v_cndmask per load). Operands that are not 16-byte aligned, whose K is not a multiple of 4 or that reach
+// beyond 4 GiB take the 4-byte loader with explicit tests.
 // Small outputs with long reductions (the 256 x 1000 x 2048 classifier of ResNet-50 is 16 tiles on 256 CUs) are split
 // along K over blockIdx.z; partial tiles go to slabs and gemm_reduce_kernel adds them in slab order with the alpha / beta
 // epilogue — deterministic, no atomics. 2*M*N*K FLOP; MFMA-bound above ~128 x 128 x 1k.
@@ -26,22 +33,51 @@ struct GemmArgs {
 	int m, n, k, lda, ldb, ldc;
 	float alpha, beta;
 	int tiles_m, tiles_n, splits, ksteps_per_split;
+	unsigned a_bytes, b_bytes;      // extents for the buffer descriptors of the 16-byte path
 };
 
 constexpr int BK = 16;
+constexpr unsigned kOOB = 0xfffffff0u;      // buffer-load byte offset beyond every matrix: the hardware returns 0
 
 // Loads one operand tile (ROWS x BK, ROWS = BM or BN) into registers and parks it in LDS as [k][row].
-// KMAJOR: the source is stored [k][row] (row contiguous); else [row][k] (k contiguous). VEC: 16-byte accesses.
-template <int ROWS, bool KMAJOR, bool VEC>
+// KMAJOR: the source is stored [k][row] (row contiguous); else [row][k] (k contiguous). VEC: 16-byte buffer loads.
+template <int NT, int ROWS, bool KMAJOR, bool VEC>
 struct Loader {
 	static constexpr int LD = ROWS + 32;
-	static constexpr int NV = ROWS * BK / 4 / 256;            // float4 per thread per tile (2 for 128 rows, 1 for 64)
+	static constexpr int NV = ROWS * BK / 4 / NT;             // float4 per thread per tile
+	static_assert(NV >= 1 && NV * NT * 4 == ROWS * BK, "operand tile / thread count");
 	f32x4 reg[NV];
+	unsigned voff[NV];               // VEC: byte offset of this thread's quad in k-tile 0 of the launch (kOOB: row outside)
+	int kq[NV];                      // VEC: its first k inside a k-tile
 
-	__device__ __forceinline__ void load(const float *__restrict__ src, int ld, int row0, int nrows, int k0, int kend, int tid) {
+	__device__ __forceinline__ void init(int ld, int row0, int nrows, int kbeg, int tid) {
+		if (!VEC) return;
 #pragma unroll
 		for (int i = 0; i < NV; ++i) {
-			const int v = tid + 256 * i;
+			const int v = tid + NT * i;
+			int r, k;
+			if (KMAJOR) { r = (v % (ROWS / 4)) * 4, k = v / (ROWS / 4); }
+			else        { r = v % ROWS, k = (v / ROWS) * 4; }
+			const int gr = row0 + r;
+			kq[i] = k;
+			// a quad that starts inside the matrix and runs over its edge (KMAJOR, rows not a multiple of 4) reads the next
+			// k-row's first elements or zeros beyond the descriptor: rows >= nrows only meet outputs that are not stored
+			const size_t e = KMAJOR ? (size_t)(kbeg + k) * ld + gr : (size_t)gr * ld + kbeg + k;
+			voff[i] = gr < nrows ? (unsigned)(e * 4) : kOOB;
+		}
+	}
+
+	__device__ __forceinline__ void load(const float *__restrict__ src, __amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0,
+	                                     int kend, int tid) {
+#pragma unroll
+		for (int i = 0; i < NV; ++i) {
+			if (VEC) {
+				const unsigned vo = k0 + kq[i] < kend ? voff[i] : kOOB;
+				reg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+				voff[i] += KMAJOR ? (unsigned)(BK * ld) * 4u : (unsigned)BK * 4u;      // (kOOB stays beyond every matrix < 4 GiB - 64 K)
+				continue;
+			}
+			const int v = tid + NT * i;
 			int r, k;
 			if (KMAJOR) { r = (v % (ROWS / 4)) * 4, k = v / (ROWS / 4); }       // 4 consecutive rows of one k
 			else        { r = v % ROWS, k = (v / ROWS) * 4; }                     // 4 consecutive k of one row
@@ -50,20 +86,14 @@ struct Loader {
 			if (KMAJOR) {
 				if (gk < kend) {
 					const float *p = src + (size_t)gk * ld + gr;
-					if (VEC && gr + 3 < nrows) x = *reinterpret_cast<const f32x4 *>(p);
-					else {
 #pragma unroll
-						for (int e = 0; e < 4; ++e) if (gr + e < nrows) x[e] = p[e];
-					}
+					for (int e = 0; e < 4; ++e) if (gr + e < nrows) x[e] = p[e];
 				}
 			} else {
 				if (gr < nrows) {
 					const float *p = src + (size_t)gr * ld + gk;
-					if (VEC && gk + 3 < kend) x = *reinterpret_cast<const f32x4 *>(p);
-					else {
 #pragma unroll
-						for (int e = 0; e < 4; ++e) if (gk + e < kend) x[e] = p[e];
-					}
+					for (int e = 0; e < 4; ++e) if (gk + e < kend) x[e] = p[e];
 				}
 			}
 			reg[i] = x;
@@ -73,7 +103,7 @@ struct Loader {
 	__device__ __forceinline__ void park(float *lds, int tid) const {
 #pragma unroll
 		for (int i = 0; i < NV; ++i) {
-			const int v = tid + 256 * i;
+			const int v = tid + NT * i;
 			if (KMAJOR) {
 				const int r = (v % (ROWS / 4)) * 4, k = v / (ROWS / 4);
 				*reinterpret_cast<f32x4 *>(&lds[k * LD + r]) = reg[i];
@@ -86,23 +116,26 @@ struct Loader {
 	}
 };
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
-	constexpr int TM = BM / 64, TN = BN / 64;
-	using LA = Loader<BM, TA, VEC>;             // A stored [k][m] when transposed
-	using LB = Loader<BN, !TB, VEC>;            // B stored [k][n] unless transposed
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
+__global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(GemmArgs g) {
+	constexpr int NT = 64 * WM * WN, TM = BM / (32 * WM), TN = BN / (32 * WN);
+	using LA = Loader<NT, BM, TA, VEC>;         // A stored [k][m] when transposed
+	using LB = Loader<NT, BN, !TB, VEC>;        // B stored [k][n] unless transposed
 	__shared__ __attribute__((aligned(16))) float As[2][BK * LA::LD];
 	__shared__ __attribute__((aligned(16))) float Bs[2][BK * LB::LD];
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int wm = wave >> 1, wn = wave & 1;
+	const int wm = wave / WN, wn = wave % WN;
 	const int tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;
 	const int m0 = tm * BM, n0 = tn * BN;
 	const int split = blockIdx.z;
 	const int kbeg = split * g.ksteps_per_split * BK;
 	const int kend = min(g.k, kbeg + g.ksteps_per_split * BK);
 	const int l31 = lane & 31, lhi = lane >> 5;
+
+	const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void *)g.a, 0, g.a_bytes, 0x00020000);
+	const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc((void *)g.b, 0, g.b_bytes, 0x00020000);
 
 	f32x16 acc[TM][TN];
 #pragma unroll
@@ -114,8 +147,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 
 	LA la;
 	LB lb;
-	la.load(g.a, g.lda, m0, g.m, kbeg, kend, tid);
-	lb.load(g.b, g.ldb, n0, g.n, kbeg, kend, tid);
+	la.init(g.lda, m0, g.m, kbeg, tid);
+	lb.init(g.ldb, n0, g.n, kbeg, tid);
+	la.load(g.a, ar, g.lda, m0, g.m, kbeg, kend, tid);
+	lb.load(g.b, br, g.ldb, n0, g.n, kbeg, kend, tid);
 	la.park(As[0], tid);
 	lb.park(Bs[0], tid);
 	__syncthreads();
@@ -124,11 +159,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 	for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
 		const bool more = k0 + BK < kend;
 		if (more) {
-			la.load(g.a, g.lda, m0, g.m, k0 + BK, kend, tid);
-			lb.load(g.b, g.ldb, n0, g.n, k0 + BK, kend, tid);
+			la.load(g.a, ar, g.lda, m0, g.m, k0 + BK, kend, tid);
+			lb.load(g.b, br, g.ldb, n0, g.n, k0 + BK, kend, tid);
 		}
 
-		const float *as = As[buf] + wm * (BM / 2) + l31, *bs = Bs[buf] + wn * (BN / 2) + l31;
+		const float *as = As[buf] + wm * (BM / WM) + l31, *bs = Bs[buf] + wn * (BN / WN) + l31;
 #pragma unroll
 		for (int ks = 0; ks < BK; ks += 2) {
 			float av[TM], bv[TN];
@@ -155,13 +190,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 	const int ldo = direct ? g.ldc : g.n;
 #pragma unroll
 	for (int j = 0; j < TN; ++j) {
-		const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+		const int n = n0 + wn * (BN / WN) + j * 32 + l31;
 		if (n >= g.n) continue;
 #pragma unroll
 		for (int i = 0; i < TM; ++i)
 #pragma unroll
 			for (int r = 0; r < 16; ++r) {
-				const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+				const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
 				if (m < g.m) {
 					float *o = out + (size_t)m * ldo + n;
 					*o = direct ? (g.beta == 0.f ? 0.f : g.beta * *o) + g.alpha * acc[i][j][r] : acc[i][j][r];
@@ -185,13 +220,16 @@ struct GemmPlan {
 	int bm, bn, tiles_m, tiles_n, splits, ksteps_per_split;
 };
 
-GemmPlan plan_gemm(int m, int n, int k) {
+GemmPlan plan_gemm(int m, int n, int k, bool vec = true) {
 	GemmPlan p;
 	p.bm = m > 64 ? 128 : 64;
 	p.bn = n > 64 ? 128 : 64;
 	// prefer the smaller tile when the larger one leaves the chip mostly idle and pads a lot
 	if (p.bm == 128 && pz::ceil_div(m, 128) * pz::ceil_div(n, p.bn) < pz::kNumCU / 2 && m % 128 != 0 && m % 128 <= 64) p.bm = 64;
 	if (p.bn == 128 && pz::ceil_div(m, p.bm) * pz::ceil_div(n, 128) < pz::kNumCU / 2 && n % 128 != 0 && n % 128 <= 64) p.bn = 64;
+	// one 256 x 256 tile per CU or more, and a reduction that pays its longer prologue: 16 waves per workgroup
+	// (never split along K, with either tiling: the workspace does not depend on `vec`)
+	if (vec && k >= 256 && (long)pz::ceil_div(m, 256) * pz::ceil_div(n, 256) >= pz::kNumCU) p.bm = p.bn = 256;
 	p.tiles_m = pz::ceil_div(m, p.bm), p.tiles_n = pz::ceil_div(n, p.bn);
 	const int tiles = p.tiles_m * p.tiles_n, ksteps = pz::ceil_div(k, BK);
 	int splits = 1;
@@ -209,10 +247,12 @@ GemmPlan plan_gemm(int m, int n, int k) {
 template <bool TA, bool TB, bool VEC>
 void launch(const GemmPlan &p, const GemmArgs &g, hipStream_t st) {
 	const dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
-	if (p.bm == 128 && p.bn == 128) gemm_kernel<128, 128, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
-	else if (p.bm == 128) gemm_kernel<128, 64, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
-	else if (p.bn == 128) gemm_kernel<64, 128, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
-	else gemm_kernel<64, 64, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
+	if (p.bm == 256) {
+		if constexpr (VEC) gemm_kernel<256, 256, 4, 4, TA, TB, true><<<grid, 1024, 0, st>>>(g);
+	} else if (p.bm == 128 && p.bn == 128) gemm_kernel<128, 128, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
+	else if (p.bm == 128) gemm_kernel<128, 64, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
+	else if (p.bn == 128) gemm_kernel<64, 128, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
+	else gemm_kernel<64, 64, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
 }
 
 }  // namespace
@@ -233,14 +273,19 @@ int pz_gemm_ws(int trans_a, int trans_b, int m, int n, int k, float alpha, const
 	PZ_REQUIRE(a && b && c, "pz_gemm: null matrix");
 	PZ_REQUIRE(lda >= (trans_a ? m : k) && ldb >= (trans_b ? k : n) && ldc >= n, "pz_gemm: leading dimension too small");
 
-	GemmPlan p = plan_gemm(m, n, k);
+	// 16-byte buffer loads: aligned operands, whole quads along K, extents a 32-bit byte offset can address
+	const size_t a_ext = (trans_a ? (size_t)(k - 1) * lda + m : (size_t)(m - 1) * lda + k) * sizeof(float);
+	const size_t b_ext = (trans_b ? (size_t)(n - 1) * ldb + k : (size_t)(k - 1) * ldb + n) * sizeof(float);
+	const bool vec = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0 && k % 4 == 0 &&
+	                 a_ext < 0xffff0000ull && b_ext < 0xffff0000ull;
+
+	GemmPlan p = plan_gemm(m, n, k, vec);
 	const size_t need = p.splits > 1 ? (size_t)p.splits * m * n * sizeof(float) : 0;
 	if (ws_bytes < need || (need > 0 && workspace == nullptr)) p.splits = 1, p.ksteps_per_split = pz::ceil_div(k, BK);   // no scratch: one pass over K
 
 	GemmArgs g{a, b, p.splits > 1 ? (float *)workspace : c, m, n, k, lda, ldb, ldc, alpha, beta, p.tiles_m, p.tiles_n, p.splits,
-	           p.ksteps_per_split};
+	           p.ksteps_per_split, vec ? (unsigned)a_ext : 0u, vec ? (unsigned)b_ext : 0u};
 	hipStream_t st = pz::as_stream(stream);
-	const bool vec = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && lda % 4 == 0 && ldb % 4 == 0;
 
 	if (trans_a) vec ? launch<true, false, true>(p, g, st) : launch<true, false, false>(p, g, st);
 	else if (trans_b) vec ? launch<false, true, true>(p, g, st) : launch<false, true, false>(p, g, st);

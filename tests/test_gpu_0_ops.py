@@ -836,11 +836,14 @@ def lib_bwd_data():
 	return lib.CONV_BWD_DATA
 
 
-@pytest.mark.parametrize("shape", [(256, 2048, 1000), (64, 800, 1024), (130, 70, 190), (5, 3, 7), (300, 4097, 65), (129, 16, 129)])
+@pytest.mark.parametrize("shape", [(256, 2048, 1000), (64, 800, 1024), (130, 70, 190), (5, 3, 7), (300, 4097, 65), (129, 16, 129),
+								   (4096, 256, 4096), (4100, 260, 4090), (132, 36, 250), (4100, 258, 4092)])
 def test_gemm_tiles_split_k_and_unaligned_operands(bnd, shape):
-	"""The MFMA GEMM over its tile shapes (64 / 128 on either side), the split along K for small outputs with long
-	reductions (deterministic: slabs added in order), operands whose rows are not 16-byte multiples (4-byte loader), all
-	three layouts with the alpha / beta epilogue, against an fp64 product."""
+	"""The MFMA GEMM over its tile shapes (64 / 128 on either side on 4 waves, 256 x 256 on 16 waves from one such tile per CU
+	up — whole and ragged at both edges), the split along K for small outputs with long reductions (deterministic: slabs added
+	in order), the 16-byte buffer loader (rows that end inside a quad, reductions that end inside a k-tile) and the 4-byte
+	loader (rows that are not 16-byte multiples, K not a multiple of 4), all three layouts with the alpha / beta epilogue,
+	against an fp64 product."""
 	m, k, n = shape
 	rng = np.random.RandomState(m + k + n)
 	a, b = rng.randn(m, k).astype(np.float32), rng.randn(k, n).astype(np.float32)

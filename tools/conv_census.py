@@ -28,6 +28,8 @@ def main():
 	ap.add_argument("--batch", type=int, default=256)
 	ap.add_argument("--reps", type=int, default=5)
 	ap.add_argument("--only", type=int, default=-1)
+	ap.add_argument("--rotate", type=int, default=1, help="cycle over this many input tensors (and their fresh outputs): with 1 the "
+					"launches of a long run re-read an Infinity-Cache-resident input; a training step never does")
 	ap.add_argument("--passes", default="fwd,dgrad,wgrad")
 	ap.add_argument("--config2", action="store_true", help="BASELINE.json config 2: Conv2D 3x3, 64 -> 128, 56x56, batch 128")
 	ap.add_argument("--nin", action="store_true", help="BASELINE.json config 3: the nine convolutions of the CIFAR-10 NiN, batch 128, with bias")
@@ -76,9 +78,26 @@ def main():
 		gflop = 2.0 * n * k * p * q * c * size * size / 1e9
 
 		passes = args.passes.split(",")
-		tf = timed(lambda: bnd.dnn.convNd(x, W, None, stride, pad, allocator=bnd.memoryPool)) if "fwd" in passes else 1e9
-		td = timed(lambda: bnd.dnn.convNdBackwardData(dy, W, None, x, stride, pad, allocator=bnd.memoryPool)) \
-			if "dgrad" in passes else 1e9
+		if args.rotate > 1:
+			xs = [x] + [G.toGpu(rng.randn(n, c, h, w).astype(np.float32)) for _ in range(args.rotate - 1)]
+			dys = [dy] + [G.toGpu(rng.randn(*y.shape).astype(np.float32)) for _ in range(args.rotate - 1)]
+			outs, state = [None] * args.rotate, [0]
+
+			def fwd_rot():
+				i = state[0] = (state[0] + 1) % args.rotate
+				outs[i] = bnd.dnn.convNd(xs[i], W, None, stride, pad, allocator=bnd.memoryPool)
+
+			def dgrad_rot():
+				i = state[0] = (state[0] + 1) % args.rotate
+				outs[i] = bnd.dnn.convNdBackwardData(dys[i], W, None, xs[i], stride, pad, allocator=bnd.memoryPool)
+			tf = timed(fwd_rot) if "fwd" in passes else 1e9
+			outs = [None] * args.rotate
+			td = timed(dgrad_rot) if "dgrad" in passes else 1e9
+			del xs, dys, outs
+		else:
+			tf = timed(lambda: bnd.dnn.convNd(x, W, None, stride, pad, allocator=bnd.memoryPool)) if "fwd" in passes else 1e9
+			td = timed(lambda: bnd.dnn.convNdBackwardData(dy, W, None, x, stride, pad, allocator=bnd.memoryPool)) \
+				if "dgrad" in passes else 1e9
 		tw = timed(lambda: bnd.dnn.convNdBackwardParams(x, dy, W, stride, pad, wgrad=wg, scale=1.0, momentum=1.0,
 													  allocator=bnd.memoryPool)) if "wgrad" in passes else 1e9
 

@@ -11,6 +11,7 @@ rng = np.random.RandomState(0)
 ap = argparse.ArgumentParser()
 ap.add_argument("--data", default="randn", help="randn | uniform | q12 (12 significant bits) | zeros | ones: operand values (power / clock sensitivity)")
 ap.add_argument("--big", action="store_true", help="only the MFMA-bound shapes")
+ap.add_argument("--loop", type=int, default=20, help="launches per timing (>= 300: clocks settled under the kernel's own load; 20-launch bursts read up to 10 %% off either way)")
 args = ap.parse_args()
 
 
@@ -33,6 +34,6 @@ for m, k, n in SHAPES:
 		B = G.toGpu(values(*((n, k) if tb else (k, n))))
 		out = G.empty((m, n), dtype=np.float32)
 		fn = lambda: bnd.blas.gemm(A, B, out, ta, tb, 1.0, 0.0, bnd.memoryPool)
-		secs, _ = bnd.timeKernel(fn, (), looplength=20, log=False, normalize=True)
+		secs, _ = bnd.timeKernel(fn, (), looplength=args.loop, log=False, normalize=True)
 		tf = 2.0 * m * n * k / secs / 1e12
 		print("%-22s %-3s %10.1f %9.1f %6.0f%%" % ("%d x %d x %d" % (m, k, n), tag, secs * 1e6, tf, tf / 157.3 * 100))
