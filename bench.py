@@ -203,6 +203,18 @@ def sideConfigs(gpuarray, lib, optim, nets, bnd):
 		"note": "host time to issue a step next to its wall time (the bound on outstanding filter-gradient launches ties the "
 				"host to the device's pace: tools/nin_trace.sh shows the two streams)"
 	}
+	# the gather-free test bed of the MFMA loops (csrc/gemm.hip): one 4096^3 fp32 GEMM, uniform operands, 300 launches behind 60
+	# warm ones (steady state; 20-launch bursts read up to 10 % off either way, profiles/r04_gemm_variants_probe.txt)
+	m = 4096
+	A = gpuarray.to_gpu(np.random.uniform(-1, 1, (m, m)).astype(np.float32))
+	B = gpuarray.to_gpu(np.random.uniform(-1, 1, (m, m)).astype(np.float32))
+	C = gpuarray.empty((m, m), dtype=np.float32)
+	for _ in range(60):
+		bnd.blas.gemm(A, B, C, False, False, 1.0, 0.0, bnd.memoryPool)
+	secs, _ = bnd.timeKernel(lambda: bnd.blas.gemm(A, B, C, False, False, 1.0, 0.0, bnd.memoryPool), (), looplength=300, log=False,
+							 normalize=True)
+	out["gemm_testbed_4096_nn"] = {"us": secs * 1e6, "tflops": 2.0 * m ** 3 / secs / 1e12, "frac_of_f32_mfma_peak": 2.0 * m ** 3 / secs / 1e12 / PEAK_F32_MFMA_TFLOPS,
+								   "operands": "uniform[-1,1)", "launches": 300}
 	return out
 
 
