@@ -198,6 +198,79 @@ __global__ void __launch_bounds__(64 * WM * WN) gv_kernel(const float *__restric
 	}
 }
 
+// The same 128 x 128 / 4-wave / BK 16 / PIPE 1 structure on v_mfma_f32_16x16x4_f32 (16 MFMAs of 32 cycles per wave and 4 reduction
+// elements instead of 8 of 64 cycles per 2): same FLOP per cycle, half the accumulator registers read and written per MAC, twice
+// the operand registers — a power question on a chip that runs these loops at its power limit.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <int SWZ, int XLDS = 0>
+__global__ void __launch_bounds__(256) gv16_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K) {
+	constexpr int NT = 256, BM = 128, BN = 128, BK = 16;
+	using LA = Loader<NT, BM, BK, false, 16>;        // row stride 144: the four k rows of a fragment read sit 16 banks apart
+	using LB = Loader<NT, BN, BK, true, 16>;
+	__shared__ __attribute__((aligned(16))) float As[2][BK * LA::LD];
+	__shared__ __attribute__((aligned(16))) float Bs[2][BK * LB::LD];
+	__shared__ float ballast[XLDS > 0 ? XLDS : 1];          // XLDS floats of unused LDS: fewer resident workgroups per CU at the same code
+	if (XLDS > 0 && K < 0) ballast[threadIdx.x % XLDS] = 1.f;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wm = wave >> 1, wn = wave & 1;
+	const int l15 = lane & 15, lq = lane >> 4;
+	const int tiles_m = M / BM, tiles_n = N / BN, tiles = tiles_m * tiles_n;
+	int t = blockIdx.x;
+	if (SWZ) {
+		const int per = tiles / 8, rem = tiles % 8, x = blockIdx.x % 8;
+		t = x * per + min(x, rem) + blockIdx.x / 8;
+	}
+	const int tm = t % tiles_m, tn = t / tiles_m;
+	const int m0 = tm * BM, n0 = tn * BN;
+	f32x4acc acc[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+#pragma unroll
+		for (int j = 0; j < 4; ++j) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+	LA la;
+	LB lb;
+	la.load(A, K, m0, 0, tid);
+	lb.load(B, N, n0, 0, tid);
+	la.park(As[0], tid);
+	lb.park(Bs[0], tid);
+	__syncthreads();
+	int buf = 0;
+	for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+		const bool more = k0 + BK < K;
+		if (more) {
+			la.load(A, K, m0, k0 + BK, tid);
+			lb.load(B, N, n0, k0 + BK, tid);
+		}
+		const float *as = As[buf] + wm * 64 + l15, *bs = Bs[buf] + wn * 64 + l15;
+#pragma unroll
+		for (int ks = 0; ks < BK; ks += 4) {
+			float av[4], bv[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) av[i] = as[(ks + lq) * LA::LD + i * 16];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) bv[j] = bs[(ks + lq) * LB::LD + j * 16];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+		}
+		if (more) {
+			la.park(As[buf ^ 1], tid);
+			lb.park(Bs[buf ^ 1], tid);
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int n = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) C[(size_t)(m0 + wm * 64 + i * 16 + 4 * lq + r) * N + n] = acc[i][j][r];
+	}
+}
+
 // the k-ordered fmaf chain the MFMA result must equal bit for bit
 __global__ void __launch_bounds__(256) ref_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K) {
 	const int n = blockIdx.x * 64 + (threadIdx.x & 63), m = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -251,6 +324,36 @@ void run(const Ctx &c) {
 	CK(hipEventDestroy(e1));
 }
 
+template <int SWZ, int XLDS = 0>
+void run16(const Ctx &c) {
+	if (c.M % 128 || c.N % 128 || c.K % 16) return;
+	auto kern = gv16_kernel<SWZ, XLDS>;
+	hipFuncAttributes fa;
+	CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+	const dim3 grid((c.M / 128) * (c.N / 128));
+	CK(hipMemset(c.C, 0xff, (size_t)c.M * c.N * 4));
+	kern<<<grid, 256>>>(c.A, c.B, c.C, c.M, c.N, c.K);
+	CK(hipGetLastError());
+	CK(hipMemset(c.cnt, 0, 4));
+	diff_kernel<<<(unsigned)(((size_t)c.M * c.N + 255) / 256), 256>>>(c.C, c.R, (size_t)c.M * c.N, c.cnt);
+	unsigned bad = 0;
+	CK(hipMemcpy(&bad, c.cnt, 4, hipMemcpyDeviceToHost));
+	for (int i = 0; i < 2 + c.reps / 4; ++i) kern<<<grid, 256>>>(c.A, c.B, c.C, c.M, c.N, c.K);
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0));
+	for (int i = 0; i < c.reps; ++i) kern<<<grid, 256>>>(c.A, c.B, c.C, c.M, c.N, c.K);
+	CK(hipEventRecord(e1));
+	CK(hipEventSynchronize(e1));
+	float ms;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	const double us = ms * 1e3 / c.reps, tf = 2.0 * c.M * c.N * c.K / (us * 1e-6) / 1e12;
+	printf("128x128 2x2 waves of 64x64  BK 16  PIPE 1  SWZ %d on v_mfma_f32_16x16x4_f32 | %3d vgpr %6zu B lds | %8.1f us %6.1f TF %5.3f | %s\n", SWZ, fa.numRegs,
+	       (size_t)fa.sharedSizeBytes, us, tf, tf / 157.3, bad ? "DIFFERS" : "bit-identical");
+	fflush(stdout);
+}
+
 template <int WM, int WN, int TM, int TN>
 void family(const Ctx &c) {
 	run<WM, WN, TM, TN, 16, 1, 0>(c);
@@ -292,6 +395,15 @@ int main(int argc, char **argv) {
 		run<2, 2, 2, 2, 16, 1, 1, 0, 0>(c);
 		run<2, 2, 2, 2, 16, 1, 1, 32, 1>(c);
 		run<2, 2, 2, 2, 16, 1, 1, 0, 1>(c);
+		return 0;
+	}
+	if (argc > 6 && !strcmp(argv[6], "mfma16")) {      // instruction shape at equal structure, A B A B
+		for (int rep = 0; rep < 2; ++rep) {
+			run<2, 2, 2, 2, 16, 1, 1>(c);
+			run16<1>(c);
+			run16<1, 4096>(c);        // 52 KB: three workgroups per CU, as the 32x32x2 variant's 132 registers allow
+			run16<1, 12288>(c);       // 84 KB: one workgroup per CU
+		}
 		return 0;
 	}
 	if (argc > 6 && !strcmp(argv[6], "key")) {         // the candidates, for long runs (reps >= 300: 20-launch bursts read 10 % off either way)
