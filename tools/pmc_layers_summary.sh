@@ -4,7 +4,7 @@
 # dispatch, matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x active cycles), VALU per MFMA.
 # Usage: tools/pmc_layers_summary.sh > gpurun_out/pmc_layers.txt
 cd "$(dirname "$0")/.."
-for spec in "3 fwd" "7 fwd" "12 fwd" "14 fwd" "14 dgrad" "12 wgrad" "6 fwd" "6 wgrad"; do
+for spec in "3 fwd" "7 fwd" "12 fwd" "14 fwd" "14 dgrad" "12 wgrad" "2 fwd" "6 fwd" "11 fwd" "16 fwd" "6 wgrad"; do
 	set -- $spec
 	PMC_GROUPS="1 2 3" bash tools/pmc_layer.sh $1 $2 s3_l$1_$2 > gpurun_out/pmc_s3_l$1_$2.txt 2>&1
 	python - "$1" "$2" gpurun_out/pmc_s3_l$1_$2.txt <<'PY'
