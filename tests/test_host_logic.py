@@ -304,3 +304,27 @@ def test_convolution_family_resolution_without_device():
 		thin_bytes = size.value
 		lib.pz_conv2d_workspace_bytes(ctypes.byref(stemlike), lib.CONV_BWD_DATA, lib.CONV_ALGO_IMPLICIT_GEMM, ctypes.byref(size))
 		assert used(stemlike, lib.CONV_BWD_DATA, lib.CONV_ALGO_IMPLICIT_GEMM) == lib.CONV_ALGO_IMPLICIT_GEMM and size.value != thin_bytes
+
+
+def test_gemm_workspace_planning_without_device():
+	"""pz_gemm_workspace_bytes is host logic: only outputs of fewer tiles than CUs are split along K (slabs of m x n floats,
+	at least 8 k-tiles per slab, one balanced round); a problem big enough for 256 x 256 tiles — which the library takes only
+	with 16-byte-loadable operands — needs no workspace under either tiling, so the size cannot depend on operand alignment
+	(Cuda/Source/Libs/CuBlas.c:327-402 takes no workspace at all: this is the backend's own scratch)."""
+	import ctypes
+	from puzzlelib_amd import lib
+
+	def ws(m, n, k):
+		size = ctypes.c_size_t(1)
+		lib.pz_gemm_workspace_bytes(m, n, k, ctypes.byref(size))
+		return size.value
+
+	for shape in ((4096, 4096, 4096), (8192, 8192, 1024), (4096, 4096, 256), (2048, 2048, 4096), (4100, 4090, 258)):
+		assert ws(*shape) == 0, shape                        # at least one tile per CU: never split
+	fc = ws(256, 1000, 2048)                                 # the ResNet-50 classifier: 2 x 8 tiles on 256 CUs
+	assert fc > 0 and fc % (256 * 1000 * 4) == 0
+	splits = fc // (256 * 1000 * 4)
+	assert 2 <= splits <= 2048 // 16 // 8, splits            # >= 8 k-tiles of 16 per slab
+	assert ws(64, 64, 32) == 0                               # too short a reduction to split
+	with pytest.raises(ValueError):                          # PZ_ERR_INVALID maps to ValueError (lib.py)
+		lib.pz_gemm_workspace_bytes(0, 4, 4, ctypes.byref(ctypes.c_size_t()))
