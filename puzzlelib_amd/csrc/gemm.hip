@@ -3,8 +3,8 @@
 // Blas.mulMatrixOnMatrix (Backend/Blas.py:60-61). Replaces BlasContext.gemm — Cuda/Source/Libs/CuBlas.c:327-402.
 //
 // Workgroup = WM x WN waves, each wave (BM / WM) x (BN / WN) = TM x TN tiles of v_mfma_f32_32x32x2_f32: tiles {64, 128}^2 on 4
-// waves (2 x 2), and 256 x 256 on 16 waves (4 x 4; a launch with at least one such tile per CU and K >= 256 — 137 instead of
-// 126 TFLOP/s at 4096^3: half the operand bytes per MFMA through L2 and LDS). BK = 16, LDS double buffer, one barrier per
+// waves (2 x 2; 98-104 registers: four workgroups per CU, +4 % over three), and 256 x 256 on 16 waves (4 x 4; a launch with at
+// least one such tile per CU and K >= 1024 — 137 instead of 126 TFLOP/s at 4096^3: half the operand bytes per MFMA through L2 and LDS). BK = 16, LDS double buffer, one barrier per
 // k-tile, the next tile's global loads in flight while the current one is multiplied.
 // LDS holds both operands reduction-major, As[k][m] and Bs[k][n] with a row stride of BM + 32 floats: a fragment read
 // (lane l -> column l & 31 of row k + (l >> 5)) touches 64 distinct banks. Global reads always run along the
@@ -117,7 +117,7 @@ struct Loader {
 };
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN) gemm_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(4, 8))) gemm_kernel(GemmArgs g) {
 	constexpr int NT = 64 * WM * WN, TM = BM / (32 * WM), TN = BN / (32 * WN);
 	using LA = Loader<NT, BM, TA, VEC>;         // A stored [k][m] when transposed
 	using LB = Loader<NT, BN, !TB, VEC>;        // B stored [k][n] unless transposed
@@ -227,9 +227,11 @@ GemmPlan plan_gemm(int m, int n, int k, bool vec = true) {
 	// prefer the smaller tile when the larger one leaves the chip mostly idle and pads a lot
 	if (p.bm == 128 && pz::ceil_div(m, 128) * pz::ceil_div(n, p.bn) < pz::kNumCU / 2 && m % 128 != 0 && m % 128 <= 64) p.bm = 64;
 	if (p.bn == 128 && pz::ceil_div(m, p.bm) * pz::ceil_div(n, 128) < pz::kNumCU / 2 && n % 128 != 0 && n % 128 <= 64) p.bn = 64;
-	// one 256 x 256 tile per CU or more, and a reduction that pays its longer prologue: 16 waves per workgroup
+	// one 256 x 256 tile per CU or more over a reduction of >= 1024 (eight per CU from 256): 16 waves per workgroup
 	// (never split along K, with either tiling: the workspace does not depend on `vec`)
-	if (vec && k >= 256 && (long)pz::ceil_div(m, 256) * pz::ceil_div(n, 256) >= pz::kNumCU) p.bm = p.bn = 256;
+	// (on short reductions the big tile needs many rounds to pay: 1024 x 256 x 50176 = 3 tiles per CU runs 94 TFLOP/s on it, 114 on 128 x 128)
+	const long tiles256 = (long)pz::ceil_div(m, 256) * pz::ceil_div(n, 256);
+	if (vec && (k >= 1024 ? tiles256 >= pz::kNumCU : k >= 256 && tiles256 >= 8 * pz::kNumCU)) p.bm = p.bn = 256;
 	p.tiles_m = pz::ceil_div(m, p.bm), p.tiles_n = pz::ceil_div(n, p.bn);
 	const int tiles = p.tiles_m * p.tiles_n, ksteps = pz::ceil_div(k, BK);
 	int splits = 1;

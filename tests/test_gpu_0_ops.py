@@ -837,7 +837,7 @@ def lib_bwd_data():
 
 
 @pytest.mark.parametrize("shape", [(256, 2048, 1000), (64, 800, 1024), (130, 70, 190), (5, 3, 7), (300, 4097, 65), (129, 16, 129),
-								   (4096, 256, 4096), (4100, 260, 4090), (132, 36, 250), (4100, 258, 4092), (4096, 1028, 4096)])
+								   (4096, 256, 4096), (4100, 260, 4090), (132, 36, 250), (4100, 258, 4092), (4096, 1028, 4096), (4100, 1032, 4090)])
 def test_gemm_tiles_split_k_and_unaligned_operands(bnd, shape):
 	"""The MFMA GEMM over its tile shapes (64 / 128 on either side on 4 waves, 256 x 256 on 16 waves from one such tile per CU
 	up — whole and ragged at both edges), the split along K for small outputs with long reductions (deterministic: slabs added

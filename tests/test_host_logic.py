@@ -319,7 +319,7 @@ def test_gemm_workspace_planning_without_device():
 		lib.pz_gemm_workspace_bytes(m, n, k, ctypes.byref(size))
 		return size.value
 
-	for shape in ((4096, 4096, 4096), (8192, 8192, 1024), (4096, 4096, 256), (2048, 2048, 4096), (4100, 4090, 258)):
+	for shape in ((4096, 4096, 4096), (8192, 8192, 1024), (4096, 4096, 256), (2048, 2048, 4096), (4100, 4090, 258), (1024, 50176, 256)):
 		assert ws(*shape) == 0, shape                        # at least one tile per CU: never split
 	fc = ws(256, 1000, 2048)                                 # the ResNet-50 classifier: 2 x 8 tiles on 256 CUs
 	assert fc > 0 and fc % (256 * 1000 * 4) == 0

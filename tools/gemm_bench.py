@@ -25,7 +25,7 @@ def values(*shape):
 
 SHAPES = [(256, 2048, 1000), (64, 800, 1024), (256, 1000, 2048), (2048, 256, 1000), (1024, 1024, 1024), (4096, 4096, 4096),
 		  (8192, 1024, 8192), (128, 25088, 4096)]
-if args.big: SHAPES = [(4096, 4096, 4096), (8192, 1024, 8192)]
+if args.big: SHAPES = [(4096, 4096, 4096), (8192, 1024, 8192), (2048, 2048, 2048), (1024, 256, 50176), (512, 128, 200704)]
 print("data: %s" % args.data)
 print("%-22s %-3s %10s %9s %7s" % ("M x K x N", "op", "us", "TFLOP/s", "of peak"))
 for m, k, n in SHAPES:
