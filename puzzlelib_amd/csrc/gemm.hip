@@ -22,6 +22,8 @@
 // epilogue — deterministic, no atomics. 2*M*N*K FLOP; MFMA-bound above ~128 x 128 x 1k.
 #include "common.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -184,25 +186,40 @@ __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_
 		__syncthreads();
 	}
 
-	// epilogue: lane = column, 16 rows per MFMA tile; split-K partials go to their slab untouched
+	// epilogue: lane = column, 16 rows per MFMA tile; split-K partials go to their slab untouched. The three cases (slab, beta = 0,
+	// beta != 0) and whole / ragged tiles are told apart ONCE, outside the 64 stores of a lane (on short reductions the epilogue is a
+	// fifth of the launch); same arithmetic as before: (beta == 0 ? 0 : beta * c) + alpha * acc
 	const bool direct = g.splits == 1;
 	float *out = direct ? g.c : g.c + (size_t)split * g.m * g.n;
 	const int ldo = direct ? g.ldc : g.n;
+	const bool whole = m0 + BM <= g.m && n0 + BN <= g.n;
+	auto store_all = [&](auto mode, auto full) {
+		constexpr int MODE = decltype(mode)::value;
+		constexpr bool FULL = decltype(full)::value;
 #pragma unroll
-	for (int j = 0; j < TN; ++j) {
-		const int n = n0 + wn * (BN / WN) + j * 32 + l31;
-		if (n >= g.n) continue;
+		for (int j = 0; j < TN; ++j) {
+			const int n = n0 + wn * (BN / WN) + j * 32 + l31;
+			if (!FULL && n >= g.n) continue;
 #pragma unroll
-		for (int i = 0; i < TM; ++i)
+			for (int i = 0; i < TM; ++i)
 #pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-				if (m < g.m) {
-					float *o = out + (size_t)m * ldo + n;
-					*o = direct ? (g.beta == 0.f ? 0.f : g.beta * *o) + g.alpha * acc[i][j][r] : acc[i][j][r];
+				for (int r = 0; r < 16; ++r) {
+					const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+					if (FULL || m < g.m) {
+						float *o = out + (size_t)m * ldo + n;
+						if (MODE == 0) *o = acc[i][j][r];
+						else if (MODE == 1) *o = 0.f + g.alpha * acc[i][j][r];
+						else *o = g.beta * *o + g.alpha * acc[i][j][r];
+					}
 				}
-			}
-	}
+		}
+	};
+	using M0 = std::integral_constant<int, 0>;
+	using M1 = std::integral_constant<int, 1>;
+	using M2 = std::integral_constant<int, 2>;
+	if (!direct) whole ? store_all(M0{}, std::true_type{}) : store_all(M0{}, std::false_type{});
+	else if (g.beta == 0.f) whole ? store_all(M1{}, std::true_type{}) : store_all(M1{}, std::false_type{});
+	else whole ? store_all(M2{}, std::true_type{}) : store_all(M2{}, std::false_type{});
 }
 
 // C = beta*C + alpha * (slab_0 + slab_1 + ...), slabs added in order
