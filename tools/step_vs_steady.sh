@@ -9,7 +9,7 @@ rm -rf $OUT && mkdir -p $OUT/a $OUT/b
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/a -- python $ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > $OUT/a.log 2>&1
 for i in 1 3 4 7 9 12 14 17 19; do
-	rocprofv3 --kernel-trace --output-format csv -d $OUT/b/$i -- python $ROOT/tools/conv_census.py --reps 300 --passes fwd,dgrad --only $i > $OUT/b/$i.log 2>&1
+	rocprofv3 --kernel-trace --output-format csv -d $OUT/b/$i -- python $ROOT/tools/conv_census.py --reps 300 --passes fwd,dgrad,wgrad --only $i > $OUT/b/$i.log 2>&1
 done
 python - $OUT <<'PY' > $ROOT/gpurun_out/step_vs_steady.txt
 import csv, glob, re, sys, collections
