@@ -255,6 +255,10 @@ def main():
 
 	surf = bound()
 	gpuarray, bnd = surf.gpuarray, surf.backend
+	# a variant library (measurement rig, experiment switches: anything but csrc/Makefile's default flags) or one older than
+	# the sources must not produce a bench line; A/B runs of experiment builds say so explicitly and carry their flags
+	if os.environ.get("PUZZLE_MI355_ALLOW_VARIANT") != "1":
+		lib.requireShippedBuild()
 
 	np.random.seed(1234)                        # identical seeds -> identical initial parameters on every rank
 	# actInplace=True is the reference's own flag (Models/Nets/ResNet.py:63): ReLUs overwrite their input
@@ -475,7 +479,8 @@ def main():
 										"<= max(5e-5, 2x the fp32-summing oracle's own distance from the fp64-summing oracle); median <= 5e-5",
 		},
 		"build": {"library_build_id": lib.buildId(), "source_id": lib.sourceId(),
-				  "matches_sources": lib.sourceId() in (None, lib.buildId())},
+				  "matches_sources": lib.sourceId() in (None, lib.buildId()),
+				  "flags": lib.buildFlags(), "shipped_flags": lib.buildFlags() == lib.defaultFlags()},
 		"model_tflops_note": "direct-convolution FLOP of the network (conv1 dgrad not counted) / step time",
 		"model_tflops_per_gpu": per_gpu * FLOP_PER_IMAGE / 1e12,
 		"pct_of_f32_mfma_peak": per_gpu * FLOP_PER_IMAGE / 1e12 / PEAK_F32_MFMA_TFLOPS * 100.0,

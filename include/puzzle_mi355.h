@@ -37,7 +37,8 @@ typedef struct pz_comm *pz_comm_t;
 
 /* ---- library / device: replaces Driver.Device (Cuda/Source/Core/Device.c:160-173) -------------- */
 int pz_version(void);
-const char *pz_build_id(void);                            /* first 16 hex digits of sha256 over the sources this .so was built from */
+const char *pz_build_id(void);                            /* first 16 hex digits of sha256 over the sources AND compiler flags this .so was built from */
+const char *pz_build_flags(void);                         /* the compiler flags themselves (csrc/Makefile: FLAGS + EXTRA); anything but the default = a variant build */
 const char *pz_last_error(void);
 int pz_init(int device);                                  /* hipSetDevice + arch check (gfx950)  */
 int pz_device_count(int *count);

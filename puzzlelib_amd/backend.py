@@ -301,11 +301,31 @@ class Mi355Backend:
 
 
 	@staticmethod
-	def copyBand(dst, src):
-		"""dst <- src, same shape, either side a strided view: one launch of the strided-copy kernel (4-byte element types)"""
-		if dst.dtype.itemsize != 4:
-			raise NotImplementedError("concatenate / split of %s tensors (4-byte element types only)" % dst.dtype)
-		dst.stridedCopyFrom(src)
+	def copyBand(dst, src, axis):
+		"""dst <- src, same shape, either side a band along `axis` of a dense tensor. 4-byte element types: one launch of the
+		strided-copy kernel. Any other element size (float16, int8 / uint8 masks, int64, float64): one pitched copy, as the
+		reference does for every type (Cuda/GPUBackend.py:296,320) — rows = the axes in front of `axis`, row pitch = their stride"""
+		if dst.dtype.itemsize == 4:
+			dst.stridedCopyFrom(src)
+			return
+		inner = dst.dtype.itemsize
+		for d in range(axis + 1, dst.ndim):
+			inner *= dst.shape[d]
+		height = 1
+		for d in range(axis):
+			height *= dst.shape[d]
+		width = dst.shape[axis] * inner
+		if width == 0 or height == 0:
+			return
+		pitches = []
+		for ary in (dst, src):
+			st = ary.strides
+			dense = st[-1] == ary.dtype.itemsize and all(st[d] == st[d + 1] * ary.shape[d + 1] for d in range(axis, ary.ndim - 1))
+			rows = all(st[d] == st[d + 1] * ary.shape[d + 1] for d in range(axis - 1))
+			if not (dense and rows):
+				raise NotImplementedError("concatenate / split of a %s view with strides %s" % (ary.dtype, st))
+			pitches.append(st[axis - 1] if axis > 0 else width)
+		lib.pz_memcpy_2d(dst.wptr, pitches[0], src.rptr, pitches[1], width, height, None)
 
 
 	def concatenate(self, tup, axis, out=None, allocator=None):
@@ -328,7 +348,7 @@ class Mi355Backend:
 
 		at = 0
 		for a in tup:
-			self.copyBand(self.axisBand(out, axis, at, at + a.shape[axis]), a)
+			self.copyBand(self.axisBand(out, axis, at, at + a.shape[axis]), a, axis)
 			at += a.shape[axis]
 		return out
 
@@ -340,7 +360,7 @@ class Mi355Backend:
 		outs, at = [], 0
 		for size in sections:
 			piece = GPUArray.empty(ary.shape[:axis] + (size, ) + ary.shape[axis + 1:], dtype=ary.dtype, allocator=allocator)
-			self.copyBand(piece, self.axisBand(ary, axis, at, at + size))
+			self.copyBand(piece, self.axisBand(ary, axis, at, at + size), axis)
 			outs.append(piece)
 			at += size
 		return outs

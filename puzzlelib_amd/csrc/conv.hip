@@ -25,15 +25,8 @@
 #include <type_traits>
 #include <vector>
 
-// ablation switches for kernel experiments (tools/ablate.sh builds variant libraries); 0 = the shipped kernel
-#ifndef PZ_ABL
-#define PZ_ABL 0
-#endif
-#if PZ_ABL & 128        // ablation: fold every gather address into the first 64 KB of the tensor (cache-resident)
-#define PZ_ABL_NEAR(off) ((off) & 0xfffcu)
-#else
-#define PZ_ABL_NEAR(off) (off)
-#endif
+// structural knobs with measured-equal alternatives. The timing-only ablation rig (PZ_ABL & co.) is
+// not part of the shipped sources: tools/dev/measurement_rig.patch puts it back onto a scratch copy (tools/ablate.sh).
 #ifndef PZ_IG_LOAD_STEPS
 #define PZ_IG_LOAD_STEPS 8        // k2-steps of a k-tile over which the next tile's global loads are spread
 #endif
@@ -55,13 +48,6 @@
 #endif
 #ifndef PZ_LB
 #define PZ_LB 4
-#endif
-#ifndef PZ_IG_PRIO
-#define PZ_IG_PRIO 0             // experiment switch: 1 = the implicit GEMM's waves raise their priority as their k-loop advances
-                                 // (progress_prio), 2 = for the epilogue only, 3 = from their last k-tile on
-#endif
-#ifndef PZ_EPI_AUX
-#define PZ_EPI_AUX 0              // cache policy bits of the epilogue's 16-byte stores (2 = nt, 16 = sc1): experiment switch
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -425,11 +411,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 	const int opix = strip0 + c16 * 4;                            // this lane's 4 pixels
 	const int n_img = opix / PQ, pq = opix - n_img * PQ;
 	const int nvalid = min(4, a.npix - opix);                     // <= 0: beyond the tensor
-#ifdef PZ_EPI_FORCE_SCALAR
-	const bool whole = false;
-#else
 	const bool whole = nvalid == 4 && pq + 3 < PQ;
-#endif
 
 #pragma unroll
 	for (int i = 0; i < TM; ++i) {
@@ -473,20 +455,14 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 
 				const unsigned chan_off = (unsigned)(g * a.M + ch) * (unsigned)PQ;
 				if (whole) {
-#if PZ_ABL & 4096       // ablation: epilogue transposes through LDS but every store is dropped (timing only)
-					const unsigned off = kOOB + 0u * (unsigned)n_img * chan_off * pq;
-#elif PZ_ABL & 32768    // ablation: every store of the epilogue goes to the first 1 MB of y (L2-resident: no HBM write stream)
-					const unsigned off = row_ok ? ((((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u) & 0xffff0u : kOOB;
-#else
 					const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + chan_off + pq) * 4u : kOOB;
-#endif
 					if (a.gate) {                // (wave-uniform; out-of-range rows read zeros and are not stored)
 						const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gate, 0, a.y_bytes, 0x00020000);
 						const f32x4 gt = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, off, 0, 0));
 #pragma unroll
 						for (int e = 0; e < 4; ++e) v[e] = v[e] * (gt[e] > 0.f ? 1.f : 0.f);      // OpReluDer's form
 					}
-					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, PZ_EPI_AUX);
+					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yr, off, 0, 0);
 				} else {
 					auto store_one = [&](int e, float val) {
 						const int o = opix + e;
@@ -699,17 +675,11 @@ igemm_conv_kernel(IgemmArgs a) {
 				for (int q = 0; q < (BK / 2) / PZ_IG_LOAD_STEPS; ++q) load_part(kt_next, j * ((BK / 2) / PZ_IG_LOAD_STEPS) + q, Set0{});
 			}
 			__builtin_amdgcn_sched_barrier(0);        // keep this step's LDS reads / gather ahead of its MFMAs ...
-#if PZ_ABL & 4
-			__builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
 			for (int i = 0; i < TM; ++i)
 #pragma unroll
 				for (int jj = 0; jj < TN; ++jj)
 					acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j & 1][i], bv[j & 1][jj], acc[i][jj], 0, 0, 0);
-#if PZ_ABL & 4
-			__builtin_amdgcn_s_setprio(0);
-#endif
 			__builtin_amdgcn_sched_barrier(0);        // ... and the next step's behind them (they run in the MFMA shadow)
 		}
 	};
@@ -720,24 +690,6 @@ igemm_conv_kernel(IgemmArgs a) {
 		kt0 = (int)((long)nk_all * kslice / a.tail_splits);
 		kt1 = (int)((long)nk_all * (kslice + 1) / a.tail_splits);
 	}
-
-	// Progress priority. The waves that share a SIMD belong to different workgroups doing the same work at the same fair
-	// share of the matrix pipe, so the resident workgroups finish — and wait for their stores to land — all at the same
-	// time, and the pipe idles through every such drain (tools/probes/mfma_store.hip: MFMAs 0.687 ms, stores 0.131 ms,
-	// both 0.745 ms; with this 0.691 ms). A wave raises its own priority at each quarter of its k-loop: whoever is ahead is
-	// issued first and gets further ahead, the workgroups of a CU spread out over the phases and one's epilogue runs
-	// under the others' MFMAs.
-	const int nk_mine = kt1 - kt0;
-	const int prio_q1 = (nk_mine + 3) >> 2, prio_q2 = (nk_mine + 1) >> 1, prio_q3 = (3 * nk_mine + 3) >> 2;
-	auto progress_prio = [&](int t) {          // called before k-tile t (0-based) of this workgroup's nk_mine
-#if PZ_IG_PRIO == 1
-		if (t == prio_q1) __builtin_amdgcn_s_setprio(1);
-		if (t == prio_q2) __builtin_amdgcn_s_setprio(2);
-		if (t == prio_q3) __builtin_amdgcn_s_setprio(3);
-#elif PZ_IG_PRIO == 3
-		if (t == nk_mine - 1) __builtin_amdgcn_s_setprio(3);
-#endif
-	};
 
 	if constexpr (PF2) {
 		float av[2][TM], bv[2][TN];
@@ -793,15 +745,11 @@ igemm_conv_kernel(IgemmArgs a) {
 
 		int t = 0;                                       // tile t: loads of tile t+2 into set t & 1, parks set (t+1) & 1
 		for (; t + 2 < nk; t += 2) {
-			progress_prio(t);
 			tile_body(0, Set0{}, Set1{}, kt0 + t + 2, true, true);
-			progress_prio(t + 1);
 			tile_body(1, Set1{}, Set0{}, kt0 + t + 3, t + 3 < nk, true);
 		}
-		progress_prio(t);
 		if (nk - t == 2) {
 			tile_body(0, Set0{}, Set1{}, 0, false, true);
-			progress_prio(t + 1);
 			tile_body(1, Set1{}, Set0{}, 0, false, false);
 		} else {
 			tile_body(0, Set0{}, Set1{}, 0, false, false);
@@ -815,29 +763,14 @@ igemm_conv_kernel(IgemmArgs a) {
 
 	for (int kt = kt0; kt + 1 < kt1; ++kt) {
 		const int buf = (kt - kt0) & 1;
-		progress_prio(kt - kt0);
-#if PZ_ABL & 1          // ablation: no global loads / LDS stores in the loop (wrong results, timing only)
-		compute_tile(buf, kt + 1, false);
-#else
 		compute_tile(buf, kt + 1, true);
 		store_tile(buf ^ 1, Set0{});
-#endif
-#if !(PZ_ABL & 2)       // ablation: no barrier
 		__syncthreads();
-#endif
 	}
-	progress_prio(kt1 - 1 - kt0);
 	compute_tile((kt1 - 1 - kt0) & 1, 0, false);
 	}
 
-#if PZ_IG_PRIO == 2
-	__builtin_amdgcn_s_setprio(3);
-#endif
 	if (kslice < 0) {
-#if PZ_ABL & 256        // ablation: no epilogue stores except one element per lane (timing only)
-		a.y[(size_t)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15];
-		return;
-#endif
 		if (a.contig) {
 			__syncthreads();          // every wave is done reading the operand tiles
 			igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, smem);
@@ -997,17 +930,9 @@ igemm_split_kernel(IgemmArgs a) {
 				}
 			}
 			u32x4 hi, mid, lo;
-#if PZ_ABL & 8          // ablation: no split arithmetic (timing only)
-			for (int q = 0; q < 4; ++q) hi[q] = __builtin_bit_cast(unsigned, v[q]), mid[q] = __builtin_bit_cast(unsigned, v[4 + q]), lo[q] = hi[q] ^ mid[q];
-#else
 			split3_cells(v, hi, mid, lo);
-#endif
 			const int half = kb0 * CB + c;
-#if PZ_ABL & 16         // ablation: one LDS store instead of three (timing only)
-			Bs16[buf][half][jb] = hi ^ mid ^ lo;
-#else
 			Bs16[buf][half][jb] = hi, Bs16[buf][2 + half][jb] = mid, Bs16[buf][4 + half][jb] = lo;
-#endif
 		}
 	};
 	auto mma_tile = [&](int buf) {
@@ -1041,22 +966,12 @@ igemm_split_kernel(IgemmArgs a) {
 		constexpr int SET = decltype(set_tag)::value;
 		constexpr int FILL = AHEAD == 2 ? SET : 0, DRAIN = AHEAD == 2 ? SET ^ 1 : 0;
 		const int kt_a = min(kt + 1, kt_last), kt_b = min(kt + AHEAD, kt_last);
-#if !(PZ_ABL & 1)
-#if !(PZ_ABL & 32)      // ablation: no filter loads / stores
 		issue_a(kt_a);
-#endif
 		issue_b(kt_b, rb[FILL], rb2[FILL]);
-#endif
 		mma_tile(SET);
-#if !(PZ_ABL & 1)
 		split_b(kt_a, rb[DRAIN], rb2[DRAIN], SET ^ 1);
-#if !(PZ_ABL & 32)
 		store_a(SET ^ 1);
-#endif
-#endif
-#if !(PZ_ABL & 2)
 		__syncthreads();
-#endif
 	};
 
 	issue_a(kt0);
@@ -1075,10 +990,6 @@ igemm_split_kernel(IgemmArgs a) {
 
 	float *scratch = reinterpret_cast<float *>(smem16);
 	if (kslice < 0) {
-#if PZ_ABL & 256
-		a.y[(size_t)blockIdx.x * 256 + tid] = acc[0][0][0] + acc[TM - 1][TN - 1][15];
-		return;
-#endif
 		if (a.contig)         // (the last step's barrier: every wave is done reading the operand tiles)
 			igemm_store_tile_lds<BM, BN, WM, WN, TM, TN>(a, tm, tn, g, wm, wn, wave, lane, acc, scratch);
 		else
@@ -1302,10 +1213,10 @@ wgrad_conv_kernel(WgradArgs a) {
 			const int i = j;
 			const bool ok = dy_off != kOOB && (full_m || tm * BM + row0 + RP * i < a.Kg);
 			ra[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-			    dyr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
+			    dyr, ok ? dy_off : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
 			if constexpr (BNX)
 				ra2[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-				    bnr, ok ? PZ_ABL_NEAR(dy_off) : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
+				    bnr, ok ? dy_off : kOOB, (unsigned)(RP * i) * (unsigned)PQ * 4u, 0));
 		} else if (j < NA + NB) {
 			const int i = j - NA;
 			const int w0 = wb + tap_w[i];
@@ -1315,7 +1226,7 @@ wgrad_conv_kernel(WgradArgs a) {
 			if constexpr (POINTWISE) {
 				const unsigned m = (1u << nq) - 1u;          // nq = 0 for runs beyond the tensor
 				rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-				    xr, m != 0u ? PZ_ABL_NEAR((unsigned)first * 4u) : kOOB, 0, 0));
+				    xr, m != 0u ? (unsigned)first * 4u : kOOB, 0, 0));
 				mb[set][i] = m;
 			} else if constexpr (UNIT_W) {
 				// valid pixels of the run: q in [lo, hi)
@@ -1326,7 +1237,7 @@ wgrad_conv_kernel(WgradArgs a) {
 				// the 32-bit offset: such a lane loads nothing here and is flagged (bit 4) for store_step to gather it.
 				const bool far_left = first < 0 && m != 0u;
 				rb[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-				    xr, (m != 0u && first >= 0) ? PZ_ABL_NEAR((unsigned)first * 4u) : kOOB, 0, 0));
+				    xr, (m != 0u && first >= 0) ? (unsigned)first * 4u : kOOB, 0, 0));
 				mb[set][i] = far_left ? (m | 16u) : m;      // the mask is applied when the run is parked in LDS: no wait on the load here
 			} else {
 				f32x4 v;
@@ -1640,17 +1551,9 @@ wgrad_split_kernel(WgradArgs a) {
 				if constexpr (BNX) v[e] = __builtin_fmaf(bnc[i].x, v[e], __builtin_fmaf(bnc[i].y, (float)ra2[set][i][e >> 2][e & 3], bnc[i].z));
 			}
 			u32x4 hi, mid, lo;
-#if PZ_ABL & 2048       // ablation: no split arithmetic
-			for (int q = 0; q < 4; ++q) hi[q] = __builtin_bit_cast(unsigned, v[q]), mid[q] = __builtin_bit_cast(unsigned, v[4 + q]), lo[q] = hi[q] ^ mid[q];
-#else
 			split3_cells(v, hi, mid, lo);
-#endif
 			const int r = row0 + 128 * i;
-#if PZ_ABL & 1024       // ablation: one LDS store per cell
-			if (BM % 128 == 0 || r < BM) As16[buf][0][cell][r] = hi ^ mid ^ lo;
-#else
 			if (BM % 128 == 0 || r < BM) As16[buf][0][cell][r] = hi, As16[buf][1][cell][r] = mid, As16[buf][2][cell][r] = lo;
-#endif
 		}
 		// the last cell of an image plane is shorter than 8 pixels: its tail reads the next plane (or nothing) and is
 		// zeroed in operand B. Rare (one k-step in PQ/16), so the masking sits behind a wave-uniform test.
@@ -1690,20 +1593,7 @@ wgrad_split_kernel(WgradArgs a) {
 				for (int i = 0; i < TM; ++i)
 #pragma unroll
 					for (int jj = 0; jj < TN; ++jj)
-#if PZ_ABL & 512        // ablation: no MFMA (a VALU op keeps the fragments alive)
-						acc[i][jj][0] += (float)fa[i][ta][0] * (float)fb[jj][tb][0];
-#elif PZ_ABL & 8192     // ablation: fp32 MFMAs of the same count / twice the pipe time in place of the bf16 ones
-						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)fa[i][ta][0], (float)fb[jj][tb][0], acc[i][jj], 0, 0, 0);
-#elif PZ_ABL & 16384    // ablation: the small bf16 MFMA shape
-						{
-							typedef float f32x4_ __attribute__((ext_vector_type(4)));
-							f32x4_ t4 = {acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]};
-							t4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ta], fb[jj][tb], t4, 0, 0, 0);
-							acc[i][jj][0] = t4[0], acc[i][jj][1] = t4[1], acc[i][jj][2] = t4[2], acc[i][jj][3] = t4[3];
-						}
-#else
 						acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][ta], fb[jj][tb], acc[i][jj], 0, 0, 0);
-#endif
 			}
 	};
 

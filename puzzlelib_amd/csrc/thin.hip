@@ -127,11 +127,7 @@ PZ_UNROLL(PZ_THIN_UNROLL)
 		for (int dr = 0; dr < WROWS; ++dr)
 #pragma unroll
 			for (int ds = 0; ds < WS; ++ds)
-#ifdef PZ_THIN_ABL      // timing only: no window loads
-				v[dr][ds] = __builtin_bit_cast(float, woff[dr][ds] + soff);
-#else
 				v[dr][ds] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dyr, woff[dr][ds], soff, 0));
-#endif
 
 		const f32x2 *wk = reinterpret_cast<const f32x2 *>(wpk + (size_t)k * per_k);      // wave-uniform: scalar loads
 #pragma unroll

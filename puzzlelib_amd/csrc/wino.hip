@@ -21,10 +21,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef WN_ABL
-#define WN_ABL 0        // timing-only ablations (wrong results): 1 no global loads, 2 no LDS stores, 4 no MFMAs, 8 no epilogue,
-                        // 16 no barrier, 32 no fragment reads
-#endif
 
 #ifndef WN_WAVES
 #define WN_WAVES 8      // forward / backward-data workgroup: 8 waves (2 positions each, 4 waves per SIMD) or 4 (4 positions, 2 per SIMD)
@@ -334,16 +330,11 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 		auto body = [&](int ch, Frag &cur, Frag &nxt) {
 			const int s_nxt = s_cur == 2 ? 0 : s_cur + 1, s_wr = s_nxt == 2 ? 0 : s_nxt + 1;
 			Frag late;
-#if WN_ABL & 32
-			late = cur, nxt = cur;
-#else
 			read_frags(smem + s_cur * kStage, late, 2);
 			read_frags(smem + s_nxt * kStage, nxt, 0);       // past the last chunk: a stale stage, never used
-#endif
 			// past the last chunk the slices store stale registers into a stage nobody reads any more, and the loads fetch
 			// the last chunk again: no branches in the steady state
 			float *wr = smem + s_wr * kStage;
-#if !(WN_ABL & 4)
 #pragma unroll
 			for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -351,28 +342,19 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 					const Frag &f = p < 2 ? cur : late;
 					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][0], f.bv[p & 1][0], acc[p][m], 0, 0, 0);
 				}
-#endif
 			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int p = 0; p < 4; ++p)
 #pragma unroll
 				for (int m = 0; m < 2; ++m) {
 					const Frag &f = p < 2 ? cur : late;
-#if !(WN_ABL & 4)
 					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][1], f.bv[p & 1][1], acc[p][m], 0, 0, 0);
-#endif
-#if !(WN_ABL & 2)
 					store_slice(half, fixed, wr, p * 2 + m);
-#endif
 					__builtin_amdgcn_sched_barrier(0);
 				}
-#if !(WN_ABL & 1)
 			issue_loads(min(ch + 3, a.chunks - 1));
-#endif
 			__builtin_amdgcn_sched_barrier(0);
-#if !(WN_ABL & 16)
 			__syncthreads();
-#endif
 			s_cur = s_nxt;
 		};
 
@@ -394,15 +376,6 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel(WinoArgs a) {
 		run(std::integral_constant<int, 1>{}, std::false_type{});
 	}
 
-#if WN_ABL & 8
-	{
-		float sum = 0.f;
-#pragma unroll
-		for (int p = 0; p < 4; ++p) sum += acc[p][0][p] + acc[p][1][15 - p];
-		a.y[(size_t)blockIdx.x * 256 + tid] = sum;
-		return;
-	}
-#endif
 
 	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
 }
@@ -633,16 +606,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 				for (int p = 0; p < 2; ++p)
 #pragma unroll
 					for (int m = 0; m < 2; ++m) {
-#if !(WN_ABL & 4)
 						acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.av[p][m][s2], cur.bv[p][s2], acc[p][m], 0, 0, 0);
-#endif
-#if !(WN_ABL & 2)
 						store_slice(role, half, fixed, wr, s2 * 4 + p * 2 + m);
-#endif
-#if !(WN_ABL & 1)
 						// the patch rows are consumed by slice 5, the filter registers by the last slice
 						if (s2 * 4 + p * 2 + m == (decltype(role)::value == 0 ? 5 : 7)) issue_loads(role, min(ch + 3, a.chunks - 1));
-#endif
 						__builtin_amdgcn_sched_barrier(0);
 					}
 			__syncthreads();
@@ -822,19 +789,12 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
 #pragma unroll
 				for (int m = 0; m < 2; ++m) {
 					const Frag &f = p < 2 ? lo : hi;
-#if !(WN_ABL & 4)
 					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][0], f.bv[p & 1][0], acc[p][m], 0, 0, 0);
-#endif
-#if !(WN_ABL & 2)
 					store_slice(row, fixed, oth_stage, p * 2 + m);
-#endif
 					__builtin_amdgcn_sched_barrier(0);
 				}
-#if !(WN_ABL & 1)
 			issue_loads(min(ch + 2, a.chunks - 1));
-#endif
 			__builtin_amdgcn_sched_barrier(0);
-#if !(WN_ABL & 4)
 #pragma unroll
 			for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -842,7 +802,6 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
 					const Frag &f = p < 2 ? lo : hi;
 					acc[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.av[p & 1][m][1], f.bv[p & 1][1], acc[p][m], 0, 0, 0);
 				}
-#endif
 			__builtin_amdgcn_sched_barrier(0);
 		};
 
@@ -867,15 +826,6 @@ __global__ void __launch_bounds__(256, 2) wino_conv_kernel_sw(WinoArgs a) {
 	else
 		dispatch(std::false_type{});
 
-#if WN_ABL & 8
-	{
-		float sum = 0.f;
-#pragma unroll
-		for (int p = 0; p < 4; ++p) sum += acc[p][0][p] + acc[p][1][15 - p];
-		a.y[(size_t)blockIdx.x * 256 + tid] = sum;
-		return;
-	}
-#endif
 	__syncthreads();              // every wave is done with its ring before the epilogue reuses the memory
 	wino_epilogue(a, acc, smem, kb, tb, tid, wave, lane);
 }

@@ -34,10 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef W4_ABL
-#define W4_ABL 0        // timing-only ablations (wrong results): 1 no patch loads, 2 no transform / LDS stores, 4 no MFMAs, 8 no epilogue,
-                        // 16 patch rows from 16-byte aligned offsets, 32 no filter fragment loads in the loop, 64 patches of chunk 0 only
-#endif
 
 namespace {
 
@@ -348,11 +344,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 			const int row = 4 * ty - a.pad_h + 2 * r + lhi;
 			const bool ok = tv && (unsigned)row < (unsigned)a.H;
 			const long off = (((long)n * a.C + wave) * a.H + row) * a.W + col0;
-#if W4_ABL & 16
-			voff[r] = ok ? (unsigned)(off * 4) & ~15u : kOOB;
-#else
 			voff[r] = ok ? (unsigned)(off * 4) : kOOB;
-#endif
 			anyfix = anyfix || (ok && off < 0);
 		}
 #pragma unroll
@@ -394,12 +386,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	// and turns offsets below zero into out-of-range ones: they read as the padding they are.
 	auto issue_row = [&](auto fixed, auto rc, int chunk) {
 		constexpr int R = decltype(rc)::value;
-#if !(W4_ABL & 1)
-#if W4_ABL & 64
-		const unsigned soff = 0;
-#else
 		const unsigned soff = (unsigned)chunk * (BC * hw4);
-#endif
 		if constexpr (decltype(fixed)::value) {
 			float v[6];
 #pragma unroll
@@ -412,9 +399,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 			sa[R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[R], soff, 0));
 			sb[R] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, voff[R] + 16u, soff, 0));
 		}
-#else
-		(void)chunk;
-#endif
 	};
 
 	// slot S (0-17, one per MFMA of the chunk) of the transform of the staged rows into stage `stg`:
@@ -422,9 +406,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 	//   6 + 3 c .. 8 + 3 c: column c read back, B^T, stored as V
 	auto patch_slot = [&](auto fixed, auto slot, float *stg, int reload) {
 		constexpr int S = decltype(slot)::value;
-#if W4_ABL & 2
-		return;
-#endif
 		if constexpr (S < 6 && S % 2 == 0) {
 			constexpr int R = S / 2;
 			float d[6];
@@ -480,9 +461,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 	auto run = [&](auto fixed) {
 		const int last = a.chunks - 1;
-#ifdef W4_DUMMY_VALU
-		float dummy = 1.f;
-#endif
 
 		// ---- prologue: V(0), V(1) into the two stages, the fragments of chunk 0 into registers
 		static_for<5>([&](auto sc) { load_a(sc, 0); });
@@ -513,15 +491,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 				constexpr int G = decltype(gc)::value;
 				static_for<6>([&](auto jc) {
 					constexpr int J = decltype(jc)::value, I = 3 * G + J % 3, S2 = J / 3;
-#if !(W4_ABL & 4)
-#ifdef W4_PRIO
-					__builtin_amdgcn_s_setprio(1);
-#endif
 					acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(IC<I>{}, IC<S2>{}), bv[I][S2], acc[I], 0, 0, 0);
-#ifdef W4_PRIO
-					__builtin_amdgcn_s_setprio(0);
-#endif
-#endif
 					if constexpr (PRE) {
 						// V(ch + 2): requested behind the chunk's first MFMA, parked behind its last (a chunk of MFMAs covers the latency)
 						if constexpr (6 * G + J == 0) pre_load(min(ch + 2, last));
@@ -529,17 +499,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 					} else {
 						patch_slot(fixed, IC<6 * G + J>{}, wr, reload);
 					}
-#ifdef W4_DUMMY_VALU      // measurement aid: N extra vector instructions behind every MFMA (experiment 12: they cost their full issue time)
-#pragma unroll
-					for (int dv = 0; dv < W4_DUMMY_VALU; ++dv) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
-#endif
-#ifndef W4_NOSB
 					__builtin_amdgcn_sched_barrier(0);
-#endif
 				});
 				// the fragments are reloaded in place for chunk ch + 1 once their positions are through
 				static_for<3>([&](auto jc) { load_b(rd, IC<3 * G + decltype(jc)::value>{}); });
-#if !(W4_ABL & 32)
 				if constexpr (G == 0) {
 					load_a(IC<0>{}, nxt);
 				} else if constexpr (G == 1) {
@@ -549,20 +512,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 					load_a(IC<3>{}, nxt);
 					load_a(IC<4>{}, nxt);
 				}
-#endif
 			});
 			__syncthreads();
 		}
 
-#if W4_ABL & 8
-		{
-			float sum = 0.f;
-#pragma unroll
-			for (int i = 0; i < 9; ++i) sum += acc[i][i] + acc[i][15 - i];
-			a.y[(size_t)blockIdx.x * 256 + tid] = sum;
-			return;
-		}
-#endif
 		w4_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
 	};
 

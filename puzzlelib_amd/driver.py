@@ -268,7 +268,9 @@ class MemoryPool:
 		self.handle = handle.value
 		self.holding = True
 		self.front, self.frontBytes, self.frontBlocks = {}, 0, 0
-		self.lock = threading.Lock()
+		# re-entrant: Buffer.__del__ -> release() can run inside allocate() / release() / flushFront() on the SAME thread when a
+		# garbage collection starts on one of their allocations and finalises a Buffer of this pool that sat in a reference cycle
+		self.lock = threading.RLock()
 		MemoryPool.pools.add(self)
 
 

@@ -366,9 +366,40 @@ pz_version.restype = c_int
 _lib.pz_build_id.restype = c_char_p
 
 
+_lib.pz_build_flags.restype = c_char_p
+
+
 def buildId():
-	"""hash of the sources the loaded library was compiled from (csrc/Makefile: BUILD_ID)"""
+	"""hash of the sources and compiler flags the loaded library was compiled from (csrc/Makefile: BUILD_ID)"""
 	return _lib.pz_build_id().decode()
+
+
+def buildFlags():
+	"""compiler flags of the loaded library (csrc/Makefile: FLAGS + EXTRA)"""
+	return _lib.pz_build_flags().decode()
+
+
+def defaultFlags():
+	"""the flags of the shipped build as csrc/Makefile states them (ARCH = gfx950, EXTRA empty), or None without the sources"""
+	import re
+	path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "Makefile")
+	if not os.path.exists(path):
+		return None
+	text = open(path).read()
+	flags = re.search(r"^FLAGS\s*\?=\s*(.*)$", text, re.M).group(1)
+	arch = re.search(r"^ARCH\s*\?=\s*(.*)$", text, re.M).group(1).strip()
+	return " ".join(flags.replace("$(ARCH)", arch).split())
+
+
+def requireShippedBuild():
+	"""bench.py / smoke(): refuse a variant library (measurement rig, experiment switches) and a library older than the tree"""
+	flags, want = buildFlags(), defaultFlags()
+	if want is not None and flags != want:
+		raise RuntimeError("%s was built with flags %r, the shipped build uses %r: rebuild with `make -C puzzlelib_amd/csrc`" % (LIBPATH, flags, want))
+	if "-D" in flags:
+		raise RuntimeError("%s is a variant build (%s)" % (LIBPATH, flags))
+	if sourceId() not in (None, buildId()):
+		raise RuntimeError("%s (build %s) was not built from the sources in the tree (%s)" % (LIBPATH, buildId(), sourceId()))
 
 
 def sourceId():
@@ -382,6 +413,7 @@ def sourceId():
 	digest = hashlib.sha256()
 	for path in files + [header, os.path.join(here, "Makefile")]:
 		digest.update(open(path, "rb").read())
+	digest.update(defaultFlags().encode())
 	return digest.hexdigest()[:16]
 
 COMM_ID_BYTES = 128
@@ -403,4 +435,4 @@ BN_ACT_NONE, BN_ACT_RELU = 0, 1
 
 
 def declaredSymbols():
-	return sorted(list(_PROTOS.keys()) + ["pz_version", "pz_last_error", "pz_build_id"])
+	return sorted(list(_PROTOS.keys()) + ["pz_version", "pz_last_error", "pz_build_id", "pz_build_flags"])

@@ -94,6 +94,24 @@ def test_concatenate_split_tile_sharedarray(bnd):
 	assert (sh["y"].ptr - sh["x"].ptr) % 16 == 0
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.int8, np.float16, np.int64, np.float64])
+def test_concatenate_split_tile_of_non_word_element_types(bnd, dtype):
+	"""the reference copies bands with memcpy2D for ANY element size (Cuda/GPUBackend.py:275-325); masks (uint8),
+	half tensors and 8-byte indices must concatenate / split / tile like float32 ones"""
+	rng = np.random.RandomState(2)
+	mk = lambda *shape: (rng.randn(*shape) * 50).astype(dtype)
+	src, a, b = mk(3, 4, 5, 3), mk(3, 2, 5, 3), mk(3, 1, 5, 3)
+	out = bnd.concatenate((gpu(bnd, src), gpu(bnd, a), gpu(bnd, b)), axis=1)
+	assert out.dtype == np.dtype(dtype) and np.array_equal(out.get(), np.concatenate((src, a, b), axis=1))
+	for axis in range(4):
+		n = src.shape[axis]
+		outs = bnd.split(gpu(bnd, src), (1, n - 1), axis=axis)
+		assert all(np.array_equal(o.get(), e) for o, e in zip(outs, np.split(src, [1], axis=axis)))
+		assert np.array_equal(bnd.concatenate(outs, axis=axis).get(), src)
+	assert np.array_equal(bnd.tile(gpu(bnd, b), 3, axis=1).get(), np.tile(b, (1, 3, 1, 1)))
+	assert np.array_equal(bnd.tile(gpu(bnd, b), 2, axis=3).get(), np.tile(b, (1, 1, 1, 2)))
+
+
 # ------------------------------------------------------------------------------------------------ convolution
 @pytest.mark.parametrize("algo", ["auto", "direct"])
 @pytest.mark.parametrize("case", CONV_CASES)
@@ -321,6 +339,37 @@ def test_batchnorm_golden(bnd, ops):
 	assert_close(dx.get(), ops["bn_orc_dx"], what="dx")
 	assert_close(dscale.get(), ops["bn_orc_dscale"], atol=1e-4, what="dscale")
 	assert_close(dbias.get(), ops["bn_orc_dbias"], atol=1e-4, what="dbias")
+
+
+def running_variance_known_answer():
+	"""The convention no reference test pins, stated as a closed-form case instead of through the oracle: the
+	running variance takes the UNBIASED batch variance m/(m-1) * var_biased — what miopenBatchNormalizationForwardTraining
+	(the call the reference makes, Hip/Wrappers/MIOpen.py:656-660) and cuDNN (Cuda/Wrappers/CuDnnNorm.py) write — while
+	saveinvvar and the normalisation use the biased one. Channel c holds m = 8 values {c, c+1, ..., c+7} * (c+1):
+	mean = (c + 3.5)(c+1), biased variance = 5.25 (c+1)^2, unbiased = 6 (c+1)^2."""
+	c = 3
+	x = np.empty((2, c, 2, 2), np.float32)
+	for ch in range(c):
+		x[:, ch] = ((ch + np.arange(8, dtype=np.float32)) * (ch + 1)).reshape(2, 2, 2)
+	k = np.arange(1, c + 1, dtype=np.float64)
+	f, rm0, rv0 = 0.25, np.full(c, 2.0, np.float32), np.full(c, 10.0, np.float32)
+	exp = {
+		"mean": (np.arange(c) + 3.5) * k, "invvar": 1.0 / np.sqrt(5.25 * k * k + 1e-5),
+		"runmean": 0.75 * 2.0 + 0.25 * (np.arange(c) + 3.5) * k,
+		"runvar": 0.75 * 10.0 + 0.25 * 6.0 * k * k,                # NOT 0.25 * 5.25 k^2
+	}
+	return x, f, rm0, rv0, exp
+
+
+def test_batchnorm_running_variance_convention_known_answer(bnd):
+	x, f, rm0, rv0, exp = running_variance_known_answer()
+	ones, zeros = np.ones(3, np.float32), np.zeros(3, np.float32)
+	grm, grv = gpu(bnd, rm0), gpu(bnd, rv0)
+	_, sm, si = bnd.dnn.batchNormNd(gpu(bnd, x), grm, grv, gpu(bnd, ones), gpu(bnd, zeros), 1e-5, f, False)
+	assert_close(sm.get().ravel(), exp["mean"], atol=1e-5, what="save mean")
+	assert_close(si.get().ravel(), exp["invvar"], atol=1e-6, rtol=1e-5, what="save invvar (biased variance)")
+	assert_close(grm.get().ravel(), exp["runmean"], atol=1e-5, what="running mean")
+	assert_close(grv.get().ravel(), exp["runvar"], atol=1e-5, rtol=1e-6, what="running variance (unbiased batch variance)")
 
 
 @pytest.mark.parametrize("shape", [(4, 5, 2, 3), (16, 5, 4, 2), (3, 7, 55, 55), (5, 3, 7, 7), (2, 2, 56, 56), (8, 130, 14, 14)])

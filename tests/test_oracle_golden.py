@@ -292,3 +292,20 @@ def test_f3_oracle_reproduces_its_fixtures_and_independent_formulas(ops):
 	per = (dy * x * (x <= 0)).sum(axis=(0, 2, 3))
 	assert_close(ops["f3_prelu_orc_map_ds"], per, atol=1e-4)
 	assert_close(ops["f3_prelu_orc_shared_ds"], [per.sum()], atol=1e-4)
+
+
+def test_batchnorm_running_variance_convention_known_answer():
+	"""closed-form case for the convention no reference test pins: running variance <- UNBIASED batch variance (what the
+	reference's MIOpen / cuDNN calls write, Hip/Wrappers/MIOpen.py:656-660), saveinvvar from the biased one. Same case as the
+	device test (tests/test_gpu_0_ops.py::running_variance_known_answer)."""
+	c = 3
+	x = np.empty((2, c, 2, 2), np.float32)
+	for ch in range(c):
+		x[:, ch] = ((ch + np.arange(8, dtype=np.float32)) * (ch + 1)).reshape(2, 2, 2)
+	k = np.arange(1, c + 1, dtype=np.float64)
+	rm, rv = np.full(c, 2.0, np.float32), np.full(c, 10.0, np.float32)
+	_, sm, si = R.bn_fwd_train(x, np.ones(c, np.float32), np.zeros(c, np.float32), rm, rv, 1e-5, 0.25)
+	assert np.allclose(sm, (np.arange(c) + 3.5) * k, atol=1e-5)
+	assert np.allclose(si, 1.0 / np.sqrt(5.25 * k * k + 1e-5), rtol=1e-5)
+	assert np.allclose(rm, 0.75 * 2.0 + 0.25 * (np.arange(c) + 3.5) * k, atol=1e-5)
+	assert np.allclose(rv, 0.75 * 10.0 + 0.25 * 6.0 * k * k, rtol=1e-6), "running variance must use m/(m-1) * biased variance"

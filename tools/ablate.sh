@@ -4,11 +4,9 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p puzzlelib_amd/variants
-build() {   # name, extra flags
+build() {   # name, extra flags: a scratch copy of csrc/ with the measurement rig applied (tools/variant_build.sh)
 	local name=$1; shift
-	hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c puzzlelib_amd/csrc/conv.hip -o puzzlelib_amd/variants/conv_$name.o
-	hipcc --offload-arch=gfx950 -shared -fPIC -o puzzlelib_amd/variants/lib_$name.so puzzlelib_amd/variants/conv_$name.o \
-		$(ls puzzlelib_amd/csrc/build/*.o | grep -v conv.o) -ldl
+	tools/variant_build.sh $name --rig "$@"
 }
 PASS=${PASS:-fwd}
 if [ "$1" = "build" ]; then

@@ -4,11 +4,9 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p puzzlelib_amd/variants
-build() {   # name, extra flags
+build() {   # name, extra flags: a scratch copy of csrc/ with the measurement rig applied (tools/variant_build.sh)
 	local name=$1; shift
-	hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c puzzlelib_amd/csrc/wino.hip -o puzzlelib_amd/variants/wino_$name.o
-	hipcc --offload-arch=gfx950 -shared -fPIC -o puzzlelib_amd/variants/libw_$name.so puzzlelib_amd/variants/wino_$name.o \
-		$(ls puzzlelib_amd/csrc/build/*.o | grep -v wino.o) -ldl
+	tools/variant_build.sh w_$name --rig "$@"
 }
 if [ "$1" = "build" ]; then
 	shift
@@ -22,7 +20,7 @@ if [ "$1" = "build" ]; then
 else
 	for v in ${VARIANTS:-base noload nostore nomfma noepi mfmaonly}; do
 		for layer in ${LAYERS:-4 5 7}; do
-			echo "== $v layer $layer: $(PUZZLE_MI355_LIB=$PWD/puzzlelib_amd/variants/libw_$v.so python tools/wino_check.py --only $layer | sed 's/.*| fwd/fwd/')"
+			echo "== $v layer $layer: $(PUZZLE_MI355_LIB=$PWD/puzzlelib_amd/variants/lib_w_$v.so python tools/wino_check.py --only $layer | sed 's/.*| fwd/fwd/')"
 		done
 	done
 fi
