@@ -48,6 +48,10 @@ class PoolDesc(ctypes.Structure):
 # the C-ABI call sequences two callers produce. Never a compute path: results are not computed at all.
 DRYRUN = os.environ.get("PUZZLE_MI355_DRYRUN", "0") == "1"
 trace = []
+# Dry run only: a test harness may take over the device-facing entries (callHook(name, args) -> True when it executed the call).
+# The build container's tests use it to run the C ABI on host buffers (a numpy emulation that lives with the tests, not in
+# this package), so that the Python glue can be exercised with values where no GPU exists. Never set outside dry-run mode.
+callHook = None
 
 
 def _load():
@@ -282,7 +286,9 @@ def _dry(name, argtypes):
 	"""Stand-in for a device-facing entry point: records the call, fabricates handles / addresses where the caller
 	expects one back. Pointer arguments are recorded as 1 / 0 (given / null), everything else by value."""
 	def call(*args):
-		if name in ("pz_malloc", "pz_host_alloc_pinned"):
+		if callHook is not None and callHook(name, args):
+			pass
+		elif name in ("pz_malloc", "pz_host_alloc_pinned"):
 			_store(args[0], _fakeHandle(args[1]))
 		elif name == "pz_pool_alloc":
 			_store(args[2], _fakeHandle(args[1]))
