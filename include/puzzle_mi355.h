@@ -354,6 +354,12 @@ int pz_argmax_cols(const float *t, int z, int h, int w, int32_t *out, pz_stream_
 int pz_bias_add(float *out, const float *mat, const float *vec, int z, int n, int m, int veclen, int axis,
                 pz_stream_t stream);
 int pz_count_neq_i32(const int32_t *x, const int32_t *y, size_t count, float *out, pz_stream_t stream);
+/* the accuracy / divergence reductions of CostModule.getAccuracyKernel (Cuda/Kernels/Costs.py:184-203; callers Cost/BCE.py:32-33,
+ * Cost/L1Hinge.py:40-41, Cost/KLDivergence.py:33-34,55-56): kind 0 = calcBCEAccuracy (count of labels == 1 ? x <= 0 : x > 0),
+ * kind 1 = l1HingeAccuracy (count of (d <= 1) != label); pz_kl_divergence writes grad = (y - x) * gradnorm and
+ * *out = sum of y (log y - log x) over y > 0. Two-stage sums in a fixed order.                                              */
+int pz_cost_accuracy(int kind, const float *x, const int32_t *labels, size_t count, float *out, pz_stream_t stream);
+int pz_kl_divergence(const float *x, const float *y, float *grad, float gradnorm, size_t count, float *out, pz_stream_t stream);
 int pz_reduce_minmax_f32(const float *x, size_t count, int is_max, float *out, pz_stream_t stream);
 int pz_reduce_minmax_i32(const int32_t *x, size_t count, int is_max, int32_t *out, pz_stream_t stream);
 int pz_dot(const float *x, const float *y, size_t count, float *out, pz_stream_t stream);
@@ -505,6 +511,11 @@ int pz_comm_info(pz_comm_t comm, int *nranks, int *rank);
 int pz_comm_async_error(pz_comm_t comm);
 int pz_comm_wait_event(pz_comm_t comm, pz_event_t event, double timeout_s);
 int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, size_t count, pz_stream_t stream);
+/* in-place sum over several ranges of ONE tensor (element offsets / counts relative to base) as one RCCL group: a completion-set
+ * bucket of a flat gradient arena whose blocks are laid out in sorted-name order (Optimizers/Optimizer.py:66-68) is not
+ * contiguous — the blocks of the layers that finish together are scattered over the arena                                  */
+int pz_comm_allreduce_sum_f32_ranges(pz_comm_t comm, float *base, const size_t *offsets, const size_t *counts, int nranges,
+                                     pz_stream_t stream);
 int pz_comm_broadcast(pz_comm_t comm, void *buf, size_t nbytes, int root, pz_stream_t stream);
 
 #ifdef __cplusplus

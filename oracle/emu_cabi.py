@@ -321,6 +321,19 @@ def pz_count_neq_i32(x, y, count, o, stream):
 	V(o, 1, F)[0] = R.count_neq(V(x, count, np.int32), V(y, count, np.int32))
 
 
+def pz_cost_accuracy(kind, x, labels, count, o, stream):
+	xv, lab = V(x, count, F), V(labels, count, np.int32)
+	wrong = np.where(lab == 1, xv <= 0, xv > 0) if kind == 0 else ((xv <= 1).astype(np.int32) != lab)
+	V(o, 1, F)[0] = F(wrong.sum())
+
+
+def pz_kl_divergence(x, y, grad, gradnorm, count, o, stream):
+	xv, yv = V(x, count, F), V(y, count, F)
+	V(grad, count, F)[:] = (yv - xv) * F(gradnorm)
+	pos = yv > 0
+	V(o, 1, F)[0] = F((yv[pos].astype(np.float64) * (np.log(yv[pos].astype(np.float64)) - np.log(xv[pos].astype(np.float64)))).sum())
+
+
 def pz_reduce_minmax_f32(x, count, is_max, o, stream):
 	v = V(x, count, F)
 	V(o, 1, F)[0] = v.max() if is_max else v.min()
@@ -629,7 +642,9 @@ def elt_ops():
 		L.OP_RMSPROP_GRAVES: inplace(R.rmsprop_graves), L.OP_SMORMS3: inplace(R.smorms3),
 		L.OP_ADD3: store(lambda a, b: (a + b).astype(F)), L.OP_IADD: iadd, L.OP_IMUL: imul,
 		L.OP_ADD3_RELU: store(lambda a, b: R.relu((a + b).astype(F))), L.OP_ADD3_GATE: store(lambda a, b, y: R.relu_der((a + b).astype(F), y)),
-		L.OP_L1_PENALTY: store(lambda g, d, a: (g - F(a) * np.sign(d)).astype(F)),
+		L.OP_L1_PENALTY: store(lambda g, d, a: (g - F(a) * ((F(0) <= d).astype(F) - (d < F(0)).astype(F))).astype(F)),
+		L.OP_L1_GRAD: store(lambda pred, target, norm: np.where(pred - target > F(0), -F(norm), F(norm)).astype(F)),      # l1gradKer, Cuda/Kernels/ElementWise.py:1135-1140
+		L.OP_RBM: store(lambda x, uni: (uni < F(1) / (F(1) + np.exp(-x))).astype(F)),
 	}
 
 
@@ -671,6 +686,109 @@ def pz_rng_fill_uniform(rng, o, count, stream):
 
 def pz_rng_fill_normal(rng, o, count, mean, stddev, stream):
 	V(o, count, F)[:] = EMU.rngs[rng].normal(mean, stddev, size=count)
+
+
+
+# ---------------------------------------------------------------------------------------------------- beside the hot path (f3)
+def pz_maskpool2d_fwd(d, x, y, mask, stream):
+	d = desc(d)
+	xs, ys, kw = pool_geom(d)
+	res, m = R.maskpool2d_fwd(Fv(x, *xs), kw["size"], kw["stride"], kw["pad"])
+	Fv(y, *ys)[...] = res
+	V(mask, int(np.prod(ys)), np.int32).reshape(ys)[...] = m
+
+
+def pz_maskpool2d_bwd(d, dy, mask, dx, stream):
+	d = desc(d)
+	xs, ys, kw = pool_geom(d)
+	Fv(dx, *xs)[...] = R.maskpool2d_bwd(Fv(dy, *ys), V(mask, int(np.prod(ys)), np.int32).reshape(ys), xs)
+
+
+def pz_maxunpool2d_fwd(x, mask, y, planes, in_plane, out_plane, stream):
+	m = V(mask, planes * in_plane, np.int32).reshape(1, planes, in_plane)
+	Fv(y, planes * out_plane)[...] = R.maxunpool2d_fwd(Fv(x, 1, planes, in_plane), m, (1, planes, 1, out_plane)).ravel()
+
+
+def pz_maxunpool2d_bwd(dy, mask, dx, planes, in_plane, out_plane, stream):
+	m = V(mask, planes * in_plane, np.int32).reshape(1, planes, in_plane)
+	Fv(dx, planes * in_plane)[...] = R.maxunpool2d_bwd(Fv(dy, 1, planes, out_plane), m).ravel()
+
+
+def pz_lrn_fwd(x, y, scale, n, c, h, w, size, alpha, beta, k, cross, stream):
+	X = Fv(x, n, c, h, w)
+	Fv(y, n, c, h, w)[...] = R.lrn_fwd(X, size, alpha, beta, k, bool(cross))
+	if scale:
+		Fv(scale, n, c, h, w)[...] = R.lrn_norms(X, size, alpha, k, bool(cross))
+
+
+def pz_lrn_bwd(x, dy, scale, dx, n, c, h, w, size, alpha, beta, k, cross, stream):
+	Fv(dx, n, c, h, w)[...] = R.lrn_bwd(Fv(x, n, c, h, w), Fv(dy, n, c, h, w), size, alpha, beta, k, bool(cross))
+
+
+def pz_svm_cost(scores, labels, samples, cases, spatial, squared, grad, terms, stream):
+	S = Fv(scores, samples, cases, spatial)
+	lab = V(labels, samples * spatial, np.int32).reshape(samples, spatial)
+	err, g = R.svm_cost(S, lab, "l2" if squared else "l1")
+	Fv(grad, samples, cases, spatial)[...] = g
+	t = Fv(terms, samples * cases * spatial)
+	t[...] = 0
+	t[0] = err                                           # the caller sums the terms (pz_asum)
+
+
+def pz_cost_pointwise(kind, a, b, labels, error, grad, grad2, terms, total, numsamples, numcases, norm, fullnorm, stream):
+	A = V(a, total, F)
+	if kind == 0:
+		err, g = R.bce_cost(A, V(labels, total, np.int32), numsamples, numcases)
+	elif kind == 1:
+		err, g = R.hinge_cost(A, V(labels, total, np.int32), numsamples, numcases)
+	elif kind == 2:
+		err, g = R.smooth_l1_cost(A, V(b, total, F), norm, fullnorm)
+	else:
+		err, g, g2 = R.l1_hinge_cost(A.reshape(numsamples, numcases), V(b, total, F).reshape(numsamples, numcases),
+									 V(labels, numsamples, np.int32), numsamples, numcases)
+		V(grad2, total, F)[:] = g2.ravel()
+	V(grad, total, F)[:] = g.ravel()
+	V(error, 1, F)[0] += err
+
+
+def pz_prelu_fwd(x, slopes, y, n, maps, mapsize, shared, stream):
+	Fv(y, n, maps, mapsize)[...] = R.prelu_fwd(Fv(x, n, maps, mapsize), V(slopes, 1 if shared else maps, F), bool(shared))
+
+
+def pz_prelu_bwd_data(dy, slopes, x, dx, n, maps, mapsize, shared, stream):
+	Fv(dx, n, maps, mapsize)[...] = R.prelu_bwd_data(Fv(dy, n, maps, mapsize), V(slopes, 1 if shared else maps, F), Fv(x, n, maps, mapsize), bool(shared))
+
+
+def pz_prelu_bwd_params(x, dy, per_map, n, maps, mapsize, stream):
+	V(per_map, maps, F)[:] = R.prelu_bwd_params(Fv(x, n, maps, mapsize), Fv(dy, n, maps, mapsize), False)
+
+
+def pz_reflectpad2d_fwd(x, y, planes, inh, inw, upad, bpad, lpad, rpad, stream):
+	Fv(y, 1, planes, inh + upad + bpad, inw + lpad + rpad)[...] = R.reflectpad_fwd(Fv(x, 1, planes, inh, inw), (upad, bpad, lpad, rpad))
+
+
+def pz_reflectpad2d_bwd(dy, dx, planes, inh, inw, upad, bpad, lpad, rpad, stream):
+	Fv(dx, 1, planes, inh, inw)[...] = R.reflectpad_bwd(Fv(dy, 1, planes, inh + upad + bpad, inw + lpad + rpad), (upad, bpad, lpad, rpad))
+
+
+def pz_upsample_fwd(x, y, planes, ind, inh, inw, sd, sh, sw, linear, stream):
+	Fv(y, 1, planes, ind * sd, inh * sh, inw * sw)[...] = R.upsample_fwd(Fv(x, 1, planes, ind, inh, inw), (sd, sh, sw), "linear" if linear else "nearest")
+
+
+def pz_upsample_bwd(dy, dx, planes, ind, inh, inw, sd, sh, sw, linear, stream):
+	Fv(dx, 1, planes, ind, inh, inw)[...] = R.upsample_bwd(Fv(dy, 1, planes, ind * sd, inh * sh, inw * sw), (sd, sh, sw), "linear" if linear else "nearest")
+
+
+def pz_embed_fwd(words, vocab, o, tokens, embsize, stream):
+	w = V(words, tokens, np.int32)
+	rows = int(w.max()) + 1 if tokens else 0
+	Fv(o, tokens, embsize)[...] = R.embed_fwd(w, Fv(vocab, max(rows, 1), embsize))
+
+
+def pz_embed_bwd_params(words, grad, vocab, scale, tokens, embsize, stream):
+	w = V(words, tokens, np.int32)
+	rows = int(w.max()) + 1 if tokens else 0
+	R.embed_bwd_params(w, Fv(grad, tokens, embsize), Fv(vocab, max(rows, 1), embsize), scale)
 
 
 # ---------------------------------------------------------------------------------------------------- dispatch

@@ -64,6 +64,10 @@ class SharedArray:
 		for name, shape, offset in self.plan:
 			nbytes = prod(shape) * self.dtype.itemsize
 			self.blocks[name] = GPUArray(shape, self.dtype, gpudata=self.ary.gpudata[offset:offset + nbytes])
+		# the allocation knows it is an arena: the data-parallel exchange plans its buckets from the blocks (grid.ArenaWatcher)
+		lazy.stateOf(self.ary.gpudata.root).arena = [
+			(name, offset, prod(shape) * self.dtype.itemsize) for name, shape, offset in self.plan
+		]
 
 	def __getitem__(self, name):
 		return self.blocks[name]

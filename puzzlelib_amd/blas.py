@@ -82,8 +82,15 @@ class BlasContext:
 
 		ga, ra, ca, lda, offA = view(A, formatA)
 		gb, rb, cb, ldb, offB = view(B, formatB)
-		if ga != gb:
+		# an operand with ONE group serves every group of the other (batch stride 0, Cuda/Source/Libs/CuBlas.c:251-257,303-304:
+		# GroupLinear with wmode / inmode "one", Modules/Sum via a single ones-matrix)
+		if ga != gb and ga != 1 and gb != 1:
 			raise ValueError("gemmBatched: %d groups in A, %d in B" % (ga, gb))
+		if ga == 1 and gb > 1:
+			offA = lambda i: 0
+		if gb == 1 and ga > 1:
+			offB = lambda i: 0
+		ga = max(ga, gb)
 		m, k = (ca, ra) if transpA else (ra, ca)
 		kb, n = (cb, rb) if transpB else (rb, cb)
 		if k != kb:

@@ -28,6 +28,8 @@ struct Rccl {
 	ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 	ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 Rccl g_rccl;
@@ -59,6 +61,8 @@ int load_rccl() {
 	PZ_SYM(CommAbort, "ncclCommAbort")
 	PZ_SYM(CommCount, "ncclCommCount")
 	PZ_SYM(CommUserRank, "ncclCommUserRank")
+	PZ_SYM(GroupStart, "ncclGroupStart")
+	PZ_SYM(GroupEnd, "ncclGroupEnd")
 #undef PZ_SYM
 
 	g_rccl.lib = lib;
@@ -167,6 +171,27 @@ int pz_comm_allreduce_sum_f32(pz_comm_t comm, const float *send, float *recv, si
 	PZ_REQUIRE(comm != nullptr && comm->comm && send && recv, "pz_comm_allreduce_sum_f32: null argument or aborted communicator");
 	if (count == 0) return PZ_OK;
 	PZ_NCCL(g_rccl.AllReduce(send, recv, count, ncclFloat32, ncclSum, comm->comm, pz::as_stream(stream)));
+	return PZ_OK;
+}
+
+int pz_comm_allreduce_sum_f32_ranges(pz_comm_t comm, float *base, const size_t *offsets, const size_t *counts, int nranges,
+                                     pz_stream_t stream) {
+	PZ_REQUIRE(comm != nullptr && comm->comm && base && offsets && counts && nranges >= 0,
+	           "pz_comm_allreduce_sum_f32_ranges: null argument or aborted communicator");
+	if (nranges == 0) return PZ_OK;
+	// one group: RCCL batches the ranges' collectives into as few launches as it can, every rank lists the same ranges in the same order
+	PZ_NCCL(g_rccl.GroupStart());
+	for (int i = 0; i < nranges; ++i) {
+		if (counts[i] == 0) continue;
+		const ncclResult_t r = g_rccl.AllReduce(base + offsets[i], base + offsets[i], counts[i], ncclFloat32, ncclSum, comm->comm,
+		                                        pz::as_stream(stream));
+		if (r != 0) {
+			g_rccl.GroupEnd();
+			pz::set_error("ncclAllReduce (range %d of %d) failed: %s", i, nranges, g_rccl.GetErrorString(r));
+			return PZ_ERR_COMM;
+		}
+	}
+	PZ_NCCL(g_rccl.GroupEnd());
 	return PZ_OK;
 }
 

@@ -93,14 +93,30 @@ __global__ void __launch_bounds__(256) bias_add_kernel(float *out, const float *
 }
 
 // ---- generic two-stage scalar reductions -------------------------------------------------------
-enum { RED_NEQ = 0, RED_DOT, RED_ASUM, RED_MIN_F, RED_MAX_F, RED_MIN_I, RED_MAX_I };
+enum { RED_NEQ = 0, RED_DOT, RED_ASUM, RED_MIN_F, RED_MAX_F, RED_MIN_I, RED_MAX_I, RED_BCE_ACC, RED_L1HINGE_ACC };
 
 template <int KIND>
 __device__ __forceinline__ float red_map(const void *x, const void *y, size_t i) {
 	if (KIND == RED_NEQ) return ((const int32_t *)x)[i] != ((const int32_t *)y)[i] ? 1.f : 0.f;
 	if (KIND == RED_DOT) return ((const float *)x)[i] * ((const float *)y)[i];
 	if (KIND == RED_ASUM) return fabsf(((const float *)x)[i]);
+	// the reference's accuracy reductions (Cuda/Kernels/Costs.py:184-203): x = scores / distances, y = int32 labels
+	if (KIND == RED_BCE_ACC) return (((const int32_t *)y)[i] == 1 ? ((const float *)x)[i] <= 0.f : ((const float *)x)[i] > 0.f) ? 1.f : 0.f;
+	if (KIND == RED_L1HINGE_ACC) return ((int32_t)(((const float *)x)[i] <= 1.f) != ((const int32_t *)y)[i]) ? 1.f : 0.f;
 	return ((const float *)x)[i];
+}
+
+// klDivergence (Cuda/Kernels/Costs.py:190-197): grad[i] = (y[i] - x[i]) * gradnorm on the way, sum of y (log y - log x) where y > 0
+__global__ void __launch_bounds__(256) kl_stage1(const float *x, const float *y, float *grad, float gradnorm, size_t n, float *part) {
+	__shared__ float red[16];
+	float acc = 0.f;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+		const float xv = x[i], yv = y[i];
+		grad[i] = (yv - xv) * gradnorm;
+		acc += yv > 0.f ? yv * (logf(yv) - logf(xv)) : 0.f;
+	}
+	acc = block_sum(acc, red);
+	if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
 template <int KIND>
@@ -227,6 +243,30 @@ int pz_bias_add(float *out, const float *mat, const float *vec, int z, int n, in
 
 int pz_count_neq_i32(const int32_t *x, const int32_t *y, size_t count, float *out, pz_stream_t stream) {
 	return reduce_sum<RED_NEQ>(x, y, count, out, pz::as_stream(stream));
+}
+
+int pz_cost_accuracy(int kind, const float *x, const int32_t *labels, size_t count, float *out, pz_stream_t stream) {
+	PZ_REQUIRE(kind == 0 || kind == 1, "pz_cost_accuracy: kind %d", kind);
+	return kind == 0 ? reduce_sum<RED_BCE_ACC>(x, labels, count, out, pz::as_stream(stream))
+	                 : reduce_sum<RED_L1HINGE_ACC>(x, labels, count, out, pz::as_stream(stream));
+}
+
+int pz_kl_divergence(const float *x, const float *y, float *grad, float gradnorm, size_t count, float *out, pz_stream_t stream) {
+	PZ_REQUIRE(x && y && grad && out, "pz_kl_divergence: null tensor");
+	hipStream_t st = pz::as_stream(stream);
+	if (count == 0) {
+		PZ_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+		return PZ_OK;
+	}
+	float *part;
+	if (int rc = scratch(&part)) return rc;
+	int blocks = pz::stream_grid(count, 256 * 8);
+	if (blocks > kMaxParts) blocks = kMaxParts;
+	kl_stage1<<<blocks, 256, 0, st>>>(x, y, grad, gradnorm, count, part);
+	PZ_LAUNCH_CHECK();
+	red_sum_stage2<<<1, 256, 0, st>>>(part, blocks, out);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
 }
 
 int pz_dot(const float *x, const float *y, size_t count, float *out, pz_stream_t stream) {

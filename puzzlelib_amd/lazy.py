@@ -47,7 +47,7 @@ def on(pattern):
 class State:
 	"""thunk: pending contents; deps: weak references to allocations whose thunk / facts derive from this one's contents;
 	meta: facts about the contents; wev / rev: [(event, stream, lo, hi)] — byte ranges a foreign stream still writes / reads"""
-	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small", "version", "snap")
+	__slots__ = ("thunk", "deps", "meta", "wev", "rev", "base", "small", "version", "snap", "arena", "watch")
 
 	def __init__(self, base):
 		self.thunk, self.deps, self.meta, self.wev, self.rev, self.base = None, None, None, None, None, base
@@ -55,6 +55,9 @@ class State:
 		self.version = 0          # bumped by every write barrier: what was derived from the contents (prepared filter
 		                          # operands, DnnContext.prepared) is current while the number stands
 		self.snap = None          # (version, Buffer): a copy of the allocation as of that version (lazy.snapshot)
+		self.arena = None         # [(name, byte offset, nbytes)] when the allocation is a flat arena (backend.SharedArray.build)
+		self.watch = None         # watch(lo, hi): told of every write barrier's byte range before the write is issued — the
+		                          # data-parallel exchange follows the gradient arena's writes with it (grid.ArenaWatcher)
 
 
 def stateOf(root):
@@ -207,6 +210,9 @@ def settleDependents(root):
 def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
 	lz.version += 1
+	if lz.watch is not None:
+		lo = 0 if buf is None else buf.ptr - lz.base
+		lz.watch(lo, lo + (root.size if buf is None else buf.size))
 	if lz.small is not None:
 		touchSmall(lz, root if buf is None else buf, True)
 	# dependents first: one of them may need this buffer's own pending contents (B = copy of A while A is a pending zero

@@ -201,6 +201,8 @@ _PROTOS = {
 	"pz_argmax_cols": [P, c_int, c_int, c_int, P, P],
 	"pz_bias_add": [P, P, P, c_int, c_int, c_int, c_int, c_int, P],
 	"pz_count_neq_i32": [P, P, c_size_t, P, P],
+	"pz_cost_accuracy": [c_int, P, P, c_size_t, P, P],
+	"pz_kl_divergence": [P, P, P, c_float, c_size_t, P, P],
 	"pz_reduce_minmax_f32": [P, c_size_t, c_int, P, P],
 	"pz_reduce_minmax_i32": [P, c_size_t, c_int, P, P],
 	"pz_dot": [P, P, c_size_t, P, P],
@@ -225,6 +227,7 @@ _PROTOS = {
 	"pz_comm_async_error": [P],
 	"pz_comm_wait_event": [P, P, ctypes.c_double],
 	"pz_comm_allreduce_sum_f32": [P, P, P, c_size_t, P],
+	"pz_comm_allreduce_sum_f32_ranges": [P, P, POINTER(c_size_t), POINTER(c_size_t), c_int, P],
 	"pz_comm_broadcast": [P, P, c_size_t, c_int, P],
 }
 
@@ -288,7 +291,14 @@ def _dry(name, argtypes):
 	def call(*args):
 		if callHook is not None and callHook(name, args):
 			pass
-		elif name in ("pz_malloc", "pz_host_alloc_pinned"):
+		elif name == "pz_host_alloc_pinned":
+			# HOST memory: the caller writes into it (pipeline.HostStager), so the dry run hands out real memory
+			block = ctypes.create_string_buffer(max(int(args[1]), 1))
+			_fake.setdefault("pinned", {})[ctypes.addressof(block)] = block
+			_store(args[0], ctypes.addressof(block))
+		elif name == "pz_host_free_pinned":
+			_fake.get("pinned", {}).pop(args[0] if isinstance(args[0], int) else getattr(args[0], "value", None), None)
+		elif name == "pz_malloc":
 			_store(args[0], _fakeHandle(args[1]))
 		elif name == "pz_pool_alloc":
 			_store(args[2], _fakeHandle(args[1]))

@@ -134,16 +134,32 @@ class CostModule:
 		krl = self.accKernelCache.get(name, None)
 
 		if krl is None:
-			if name != "calcAccuracy":
-				raise NotImplementedError(name)
-
 			def calcAccuracy(x, y, allocator=None):
 				assert x.dtype == np.int32 and y.dtype == np.int32 and x.size == y.size
 				out = GPUArray.empty((), dtype=np.float32, allocator=allocator)
 				lib.pz_count_neq_i32(x.rptr, y.rptr, x.size, out.optr, None)
 				return out
 
-			krl = self.accKernelCache[name] = ReductionCallable(calcAccuracy)
+			def costAccuracy(kind):
+				def kernel(x, labels, allocator=None):
+					assert x.dtype == np.float32 and labels.dtype == np.int32 and x.size == labels.size
+					out = GPUArray.empty((), dtype=np.float32, allocator=allocator)
+					lib.pz_cost_accuracy(kind, x.rptr, labels.rptr, x.size, out.optr, None)
+					return out
+				return kernel
+
+			def klDivergence(x, y, grad, gradnorm, allocator=None):
+				requireF32(x, y, grad)
+				assert x.size == y.size == grad.size
+				out = GPUArray.empty((), dtype=np.float32, allocator=allocator)
+				lib.pz_kl_divergence(x.rptr, y.rptr, grad.optr, gradnorm, x.size, out.optr, None)
+				return out
+
+			kernels = {"calcAccuracy": calcAccuracy, "calcBCEAccuracy": costAccuracy(0), "l1HingeAccuracy": costAccuracy(1),
+					   "klDivergence": klDivergence}
+			if name not in kernels:
+				raise NotImplementedError(name)
+			krl = self.accKernelCache[name] = ReductionCallable(kernels[name])
 
 		return krl
 

@@ -16,6 +16,8 @@ data-parallel reducer's buckets (puzzlelib_amd/grid.py) complete progressively i
 import math
 from collections import OrderedDict
 
+import os
+
 import numpy as np
 
 from puzzlelib_amd.surface import bound as S
@@ -195,6 +197,8 @@ class Optimizer:
 				state[key].set(np.full(like.shape, value, dtype=np.float32))
 		return state
 
+	arenaLayout = os.environ.get("PUZZLE_MI355_ARENA", "execution")
+
 	@staticmethod
 	def arenaOrder(net):
 		"""parameter names in the order backward finishes them: last layer first; inside a residual block the main branch
@@ -220,7 +224,9 @@ class Optimizer:
 
 		SharedArray = S().gpuarray.SharedArray
 		self.params, self.grads = SharedArray(np.float32), SharedArray(np.float32)
-		order = self.arenaOrder(net)
+		# "execution": blocks in the order backward finishes them (contiguous completion-set buckets); "sorted": the reference's
+		# own layout, variables sorted by name (Optimizers/Optimizer.py:66-68) — what an unpatched PuzzleLib hands the backend
+		order = self.arenaOrder(net) if self.arenaLayout == "execution" else sorted(named)
 		assert sorted(order) == sorted(named)
 		for name in order:
 			self.params.register(named[name].data.shape, np.float32, name)
@@ -260,7 +266,9 @@ class Optimizer:
 		# with the overlapped reducer, all-reduces of this step's buckets are still in flight on the communication stream:
 		# the exchange is completed before any hook touches the gradients (for the reference's hooks — weight decay with
 		# identical parameters on every rank — mean-then-hook equals hook-then-mean)
-		early = exchange and bool(getattr(self.nodeinfo, "reducers", None))
+		# (only for a reducer registered by grid.enableOverlap; without one the reference's order stands — hooks, then
+		# sumTensor — and the arena's own watcher completes an overlapped exchange in front of a hook's write, grid.ArenaWatcher)
+		early = exchange and "grad" in (getattr(self.nodeinfo, "reducers", None) or {})
 
 		for idx, (target, state) in enumerate(self.targets):
 			stream = None if streams is None else streams[idx]

@@ -366,6 +366,159 @@ def dp_bucket_progress():
 		len(red.buckets), 100 * before_last, 100 * half
 	))
 
+# ------------------------------------------------------------------------------------------------ overlap for an unpatched caller
+def singleRankNode():
+	"""a one-rank grid in this process (dry run: the communicator is a stand-in, every pz_comm_* call is recorded)"""
+	import socket
+	with socket.socket() as sock:
+		sock.bind(("127.0.0.1", 0))
+		port = sock.getsockname()[1]
+	return grid.connectNode(0, 1, 0, "127.0.0.1", port)
+
+
+def dp_auto_overlap_sorted_arena():
+	"""the data-parallel exchange overlaps with backward for a caller that only ever calls
+	nodeinfo.sumTensor (the reference's unpatched Optimizer): ResNet-50 with the gradient arena in the REFERENCE's sorted-name
+	order (Optimizers/Optimizer.py:66-68), no executor hook (`net.gradsReady` unset, `grid.enableOverlap` not called). The
+	watcher on the arena learns the completion order from the first two steps; from the third on, scattered completion-set
+	buckets go out during backward — at least 80 % of the gradient bytes before the last layer's gradients are written."""
+	optim.Optimizer.arenaLayout = "sorted"
+	node = singleRankNode()
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="none")
+	opt = optim.Adam(nodeinfo=node)
+	opt.setupOn(net, useGlobalState=True)
+	names_ = [b[0] for b in grid.arenaBlocks(opt.grads)]
+	assert names_ == sorted(names_) and net.gradsReady is None and not node.reducers
+
+	g = bound().gpuarray
+	trainer = optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=2)
+	data, labels = g.to_gpu(np.zeros((2, 3, 224, 224), np.float32)), g.to_gpu(np.zeros((2, ), np.int32))
+	per_step = []
+	for step in range(5):
+		lib.trace.clear()
+		trainer.step([data, labels])
+		net.reset()
+		per_step.append(names())
+	watcher = node.watchers["grad"]
+	assert watcher.reducer is not None and watcher.steps == 5
+	red = watcher.reducer
+	assert len(red.buckets) >= 4 and any(len(b.ranges) > 1 for b in red.buckets), "sorted-name arena -> scattered buckets"
+	total = sum(b.nbytes for b in red.buckets)
+	assert total >= sum(b[2] for b in watcher.blocks)
+
+	# step 1 ends with the first sumTensor (the watcher is attached there), steps 2-3 are observed: one whole-arena collective at
+	# update time each; steps 4-5: grouped collectives inside backward
+	for calls in per_step[:3]:
+		assert calls.count("pz_comm_allreduce_sum_f32") == 1 and "pz_comm_allreduce_sum_f32_ranges" not in calls
+	for calls in per_step[3:]:
+		comm = [i for i, n in enumerate(calls) if n.startswith("pz_comm_allreduce")]
+		assert len(comm) == len(red.buckets)
+		last_wgrad = max(i for i, n in enumerate(calls) if n.startswith("pz_conv2d_bwd_filter"))
+		early = [i for i in comm if i < last_wgrad]
+		assert len(early) >= len(red.buckets) - 2, "buckets must leave during backward: %s of %s did" % (len(early), len(comm))
+		assert calls.index("pz_eltwise", comm[-1]) > comm[-1], "the update follows the last collective"
+
+	# byte progress over the write events of the last step: what was in flight before the LAST block (the stem) was written
+	prog = watcher_progress(node, trainer, data, labels, net)
+	before_last = prog[-2] / total
+	assert before_last >= 0.80, "only %.0f %% of the gradient bytes were in flight before the last layer's gradient" % (100 * before_last)
+	half = next(i for i, b in enumerate(prog) if b / total >= 0.5) / len(prog)
+	print("auto overlap, sorted-name arena: %d buckets (%d byte ranges), %.0f %% of bytes out before the last gradient write, half after %.0f %% of the writes" % (
+		len(red.buckets), sum(len(b.ranges) for b in red.buckets), 100 * before_last, 100 * half))
+	node.close()
+
+
+def watcher_progress(node, trainer, data, labels, net):
+	watcher = node.watchers["grad"]
+	log = watcher.launchedBytes = []
+	trainer.step([data, labels])
+	net.reset()
+	return list(log)
+
+
+def dp_auto_overlap_with_hook():
+	"""a hook that writes the whole arena before sumTensor (weight decay; the reference runs hooks first, Optimizer.py:160-167):
+	the exchange — early buckets and the rest — completes and the mean is applied as a pass BEFORE the hook's kernel; the
+	following sumTensor adds nothing. Config 3's network with the reference script's optimizer and hook."""
+	optim.Optimizer.arenaLayout = "sorted"
+	node = singleRankNode()
+	np.random.seed(1234)
+	net = nets.buildNiN()
+	opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9, nodeinfo=node)
+	opt.addHook(optim.WeightDecay(1e-4))
+	opt.setupOn(net, useGlobalState=True)
+	opt.targets[0][0].wc = 1.0            # (the flat variable's decay factor is 0 by default, in the reference too: the hook would do nothing)
+	g = bound().gpuarray
+	trainer = optim.Trainer(net, optim.CrossEntropy(maxlabels=10), opt, batchsize=8)
+	data, labels = g.to_gpu(np.zeros((8, 3, 32, 32), np.float32)), g.to_gpu(np.zeros((8, ), np.int32))
+	for step in range(5):
+		lib.trace.clear()
+		trainer.step([data, labels])
+		net.reset()
+	calls = [(n, a) for n, a in lib.trace if not n.startswith(SKIP)]
+	idx = {"comm": [i for i, (n, _) in enumerate(calls) if n.startswith("pz_comm_allreduce")],
+		   "decay": [i for i, (n, a) in enumerate(calls) if n == "pz_eltwise" and a[0] == lib.OP_WEIGHT_DECAY],
+		   "scale": [i for i, (n, a) in enumerate(calls) if n == "pz_eltwise" and a[0] == lib.OP_LINEAR]}
+	assert node.watchers["grad"].reducer is not None and idx["comm"] and len(idx["decay"]) == 1
+	assert max(idx["comm"]) < idx["decay"][0], "every collective is queued before the hook touches the gradients"
+	assert any(max(idx["comm"]) < i < idx["decay"][0] for i in idx["scale"]), "the mean is applied before the hook"
+	print("auto overlap with a whole-arena hook: %d collectives, mean pass, then the hook" % len(idx["comm"]))
+	node.close()
+
+
+# ------------------------------------------------------------------------------------------------ runGrid (Grid.py:4-35)
+def gridTrain(nodeinfo, verbose, epochs=2):
+	"""the body of TestLib/MultiGPUMnist.py:6-57 on synthetic data: identical seeds on every node, LeNet,
+	MomentumSGD(nodeinfo=nodeinfo) in global-state mode, a Trainer over this node's shard, nodeinfo.meanValue of the errors"""
+	np.random.seed(1234)
+	net = nets.loadLeNet(None)
+	optimizer = optim.MomentumSGD(learnRate=0.1, momRate=0.9, nodeinfo=nodeinfo)
+	optimizer.setupOn(net, useGlobalState=True)
+	cost = optim.CrossEntropy(maxlabels=10)
+	batch = 128 // nodeinfo.gridsize
+	trainer = optim.Trainer(net, cost, optimizer, batchsize=batch)
+
+	rng = np.random.RandomState(7)
+	data, labels = rng.randn(1024, 1, 28, 28).astype(np.float32), rng.randint(0, 10, size=(1024, )).astype(np.int32)
+	part = data.shape[0] // nodeinfo.gridsize
+	start, end = nodeinfo.index * part, (nodeinfo.index + 1) * part
+	for epoch in range(epochs):
+		trainer.trainFromHost(data[start:end], labels[start:end], macroBatchSize=part)
+		trerr = nodeinfo.meanValue(cost.getMeanError())
+		if nodeinfo.index == 0 and verbose:
+			print("Epoch %s global train error: %s" % (epoch + 1, trerr))
+		optimizer.learnRate *= 0.9
+	calls = names()
+	assert calls.count("pz_comm_init_rank") == 1 and calls.count("pz_comm_broadcast") == 1
+	steps = epochs * (part // batch)
+	assert sum(1 for n in calls if n.startswith("pz_comm_allreduce")) >= steps, "one exchange per step at least"
+	print("node %d of %d on device %d: %d steps, %d collectives" % (nodeinfo.index, nodeinfo.gridsize, nodeinfo.device, steps,
+																	sum(1 for n in calls if n.startswith("pz_comm_allreduce"))))
+
+
+def run_grid(size):
+	grid.runGrid(target=gridTrain, size=size, verbose=True, devices=[0] * size)       # (dry run: every node on the simulated device)
+	try:
+		grid.runGrid(target=gridFails, size=2, devices=[0, 0])
+	except RuntimeError as e:
+		assert "exited with status" in str(e)
+	else:
+		raise AssertionError("a dying node must make runGrid raise")
+	print("runGrid OK")
+
+
+def gridFails(nodeinfo):
+	if nodeinfo.index == 1:
+		raise SystemExit(3)
+
+
+def run_grid_2():
+	run_grid(2)
+
+
+def run_grid_8():
+	run_grid(8)
+
 
 if __name__ == "__main__":
 	globals()[sys.argv[1]]()

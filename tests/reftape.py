@@ -1,0 +1,297 @@
+"""
+Record / replay of a test program at the backend object's surface.
+
+The reference's own unit tests (Modules/Conv2D.py:80-353, Optimizers/Optimizer.py:249-325, Handlers/Trainer.py:38-108, ...) cannot
+travel to the GPU box, and in the build container there is no GPU. So each one is run ONCE in the build container on top of this
+repository's backend object with the C ABI emulated on host buffers (oracle/emu_cabi.py), where the reference's own asserts
+judge the values — and everything the test did to the backend object is written down as a TAPE: every attribute it fetched,
+every call it made (arguments by reference to earlier results, host arrays by value), every host value it read back, and the
+point at which it dropped each object. `replay` runs a tape against a live backend object — on the MI355X: the real library
+under the same Python glue, fusion policy included — and requires every value read back to equal the value the reference's
+asserts accepted, within the fp32 tolerance stated in the tape.
+
+A tape is data: a JSON list of operations plus the arrays it mentions (one .npz). It contains no reference source text.
+Written by oracle/make_reftests.py (recorder), read by tests/test_gpu_7_reftests.py (replayer).
+
+Values produced by the device's random generator differ between the emulation (numpy) and the device (Philox): after every
+call of a generator method the recorder notes the values the filled array got ("poke") and the replayer writes them over
+the device's own — the test then continues on identical numbers.
+"""
+import enum, json, weakref
+
+import numpy as np
+
+PLAIN = (bool, int, float, str, bytes, type(None), np.generic, np.dtype, slice, type(Ellipsis))
+RNG_METHODS = ("fillUniform", "fillNormal", "fillInteger")
+
+
+def isPlain(x):
+	if isinstance(x, enum.Enum):
+		return False
+	if isinstance(x, PLAIN) or isinstance(x, np.ndarray):
+		return True
+	if isinstance(x, type) and issubclass(x, np.generic):
+		return True
+	if isinstance(x, (tuple, list)):
+		return all(isPlain(v) for v in x)
+	return False
+
+
+# ---------------------------------------------------------------------------------------------------- recorder
+class Tape:
+	def __init__(self, name, atol=1e-5, rtol=1e-4):
+		self.name, self.ops, self.arrays = name, [], {}
+		self.atol, self.rtol = atol, rtol
+		self.nextId = 0
+		self.live = weakref.WeakValueDictionary()       # id(real object) -> proxy
+		self.closed = False
+
+	def newId(self):
+		self.nextId += 1
+		return self.nextId
+
+	def store(self, array):
+		key = "a%d" % len(self.arrays)
+		self.arrays[key] = np.array(array, copy=True)
+		return key
+
+	def emit(self, **op):
+		if not self.closed:
+			self.ops.append(op)
+
+	# ---- encoding of arguments / results
+	def enc(self, x):
+		if isinstance(x, Proxy):
+			return {"ref": object.__getattribute__(x, "_pid")}
+		if isinstance(x, np.ndarray):
+			return {"np": self.store(x)}
+		if isinstance(x, np.generic):
+			return {"s": x.item(), "dt": str(x.dtype)}
+		if isinstance(x, np.dtype):
+			return {"dtype": str(x)}
+		if isinstance(x, type) and issubclass(x, np.generic):
+			return {"nptype": np.dtype(x).name}
+		if isinstance(x, slice):
+			return {"slice": [self.enc(x.start), self.enc(x.stop), self.enc(x.step)]}
+		if x is Ellipsis:
+			return {"ellipsis": 1}
+		if isinstance(x, tuple):
+			return {"tuple": [self.enc(v) for v in x]}
+		if isinstance(x, list):
+			return {"list": [self.enc(v) for v in x]}
+		if isinstance(x, dict):
+			return {"dict": {str(k): self.enc(v) for k, v in x.items()}}
+		if isinstance(x, (bool, int, float, str, type(None))):
+			return x
+		raise TypeError("cannot put %r (%s) on a tape" % (x, type(x)))
+
+	def wrap(self, real):
+		"""result of an attribute fetch / call as the test sees it, and its encoding"""
+		if isPlain(real):
+			if isinstance(real, np.ndarray):
+				return real, {"np": self.store(real)}
+			if isinstance(real, (float, np.floating)):
+				return real, {"f": float(real)}
+			return real, {"plain": 1}
+		if isinstance(real, (tuple, list)):
+			pairs = [self.wrap(v) for v in real]
+			return type(real)(p[0] for p in pairs), {"tuple" if isinstance(real, tuple) else "list": [p[1] for p in pairs]}
+		if isinstance(real, dict):
+			pairs = {k: self.wrap(v) for k, v in real.items()}
+			return {k: p[0] for k, p in pairs.items()}, {"dict": {str(k): p[1] for k, p in pairs.items()}}
+		proxy = self.live.get(id(real))
+		if proxy is None or object.__getattribute__(proxy, "_real") is not real:
+			proxy = Proxy(self, real, self.newId())
+			try:
+				self.live[id(real)] = proxy
+			except TypeError:
+				pass
+		return proxy, {"ref": object.__getattribute__(proxy, "_pid")}
+
+	def save(self, path):
+		self.closed = True
+		header = {"name": self.name, "atol": self.atol, "rtol": self.rtol, "ops": self.ops}
+		np.savez_compressed(path, __tape__=np.frombuffer(json.dumps(header, separators=(",", ":")).encode(), dtype=np.uint8), **self.arrays)
+
+
+def unwrap(x):
+	if isinstance(x, Proxy):
+		return object.__getattribute__(x, "_real")
+	if isinstance(x, tuple):
+		return tuple(unwrap(v) for v in x)
+	if isinstance(x, list):
+		return [unwrap(v) for v in x]
+	if isinstance(x, dict):
+		return {k: unwrap(v) for k, v in x.items()}
+	return x
+
+
+class Proxy:
+	"""stands for one object of the backend (the backend itself, a class, a context, an array, a kernel, a bound method ...)"""
+	__slots__ = ("_tape", "_real", "_pid", "_name", "__weakref__")
+
+	def __init__(self, tape, real, pid, name=None):
+		object.__setattr__(self, "_tape", tape)
+		object.__setattr__(self, "_real", real)
+		object.__setattr__(self, "_pid", pid)
+		object.__setattr__(self, "_name", name)
+
+	def __del__(self):
+		try:
+			object.__getattribute__(self, "_tape").emit(k="del", id=object.__getattribute__(self, "_pid"))
+		except Exception:
+			pass
+
+	def __getattr__(self, name):
+		tape, real, pid = (object.__getattribute__(self, n) for n in ("_tape", "_real", "_pid"))
+		value = getattr(real, name)
+		if isPlain(value):
+			return value
+		seen, encoded = tape.wrap(value)
+		tape.emit(k="attr", t=pid, n=name, r=encoded)
+		if isinstance(seen, Proxy):
+			object.__setattr__(seen, "_name", name)
+		return seen
+
+	def __setattr__(self, name, value):
+		tape, real, pid = (object.__getattribute__(self, n) for n in ("_tape", "_real", "_pid"))
+		tape.emit(k="setattr", t=pid, n=name, v=tape.enc(value))
+		setattr(real, name, unwrap(value))
+
+	def __call__(self, *args, **kwargs):
+		tape, real, pid, name = (object.__getattribute__(self, n) for n in ("_tape", "_real", "_pid", "_name"))
+		a, kw = tape.enc(list(args)), tape.enc(dict(kwargs))
+		result = real(*unwrap(args), **unwrap(kwargs))
+		seen, encoded = tape.wrap(result)
+		tape.emit(k="call", t=pid, a=a, kw=kw, r=encoded)
+		if name in RNG_METHODS:
+			for arg in list(args) + list(kwargs.values()):
+				if isinstance(arg, Proxy) and hasattr(unwrap(arg), "get") and hasattr(unwrap(arg), "set"):
+					tape.emit(k="poke", t=object.__getattribute__(arg, "_pid"), v=tape.store(unwrap(arg).get()))
+		return seen
+
+	def __instancecheck__(self, obj):
+		return isinstance(unwrap(obj), object.__getattribute__(self, "_real"))
+
+	def __iter__(self):
+		tape, real = object.__getattribute__(self, "_tape"), object.__getattribute__(self, "_real")
+		if isinstance(real, type) and issubclass(real, enum.Enum):
+			return iter([getattr(self, member.name) for member in real])
+		raise TypeError("iteration over %r is not taped" % (real, ))
+
+	def __repr__(self):
+		return "<taped %r>" % (object.__getattribute__(self, "_real"), )
+
+	def __bool__(self):
+		return True
+
+
+def _dunder(name):
+	def method(self, *args):
+		return Proxy.__getattr__(self, name)(*args)
+	method.__name__ = name
+	return method
+
+
+for _n in ("__getitem__", "__setitem__", "__add__", "__radd__", "__iadd__", "__mul__", "__rmul__", "__imul__", "__sub__", "__len__",
+		   "__enter__", "__exit__", "__eq__", "__hash__"):
+	if _n in ("__eq__", "__hash__"):
+		continue
+	setattr(Proxy, _n, _dunder(_n))
+
+
+# ---------------------------------------------------------------------------------------------------- replayer
+def load(path):
+	data = np.load(path, allow_pickle=False)
+	header = json.loads(bytes(data["__tape__"]).decode())
+	return header, data
+
+
+def replay(path, getBackend, check=None):
+	"""runs the tape at `path` against the backend `getBackend(initmode)` returns; `check(got, want, what)` compares a value read
+	back with the recorded one (default: |got - want| <= atol + rtol |want| with the tape's tolerances). Returns the number of
+	values compared."""
+	header, data = load(path)
+	atol, rtol = header["atol"], header["rtol"]
+	refs, compared = {}, [0]
+
+	def default_check(got, want, what):
+		got, want = np.asarray(got), np.asarray(want)
+		assert got.shape == want.shape, "%s: shape %s, recorded %s" % (what, got.shape, want.shape)
+		if want.dtype.kind == "f":
+			err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+			bound = atol + rtol * np.abs(want.astype(np.float64))
+			bad = ~(err <= bound)
+			assert not bad.any(), "%s: %d of %d values off, worst |err| %.3e where the recorded value is %.3e (bound %.1e + %.1e |x|)" % (
+				what, int(bad.sum()), bad.size, float(err[bad].max()), float(np.abs(want)[bad][np.argmax(err[bad])]), atol, rtol)
+		else:
+			assert np.array_equal(got, want), "%s: integer values differ" % what
+	check = check or default_check
+
+	def dec(x):
+		if isinstance(x, dict):
+			if "ref" in x:
+				return refs[x["ref"]]
+			if "np" in x:
+				return data[x["np"]]
+			if "s" in x:
+				return np.dtype(x["dt"]).type(x["s"])
+			if "dtype" in x:
+				return np.dtype(x["dtype"])
+			if "nptype" in x:
+				return np.dtype(x["nptype"]).type
+			if "slice" in x:
+				return slice(*[dec(v) for v in x["slice"]])
+			if "ellipsis" in x:
+				return Ellipsis
+			if "tuple" in x:
+				return tuple(dec(v) for v in x["tuple"])
+			if "list" in x:
+				return [dec(v) for v in x["list"]]
+			if "dict" in x:
+				return {k: dec(v) for k, v in x["dict"].items()}
+			raise ValueError("unknown tape value %r" % (x, ))
+		return x
+
+	def bind(enc, value, what):
+		"""binds the references of a recorded result to the live result; compares recorded host values"""
+		if not isinstance(enc, dict):
+			return
+		if "ref" in enc:
+			refs[enc["ref"]] = value
+		elif "np" in enc:
+			compared[0] += 1
+			check(value, data[enc["np"]], what)
+		elif "f" in enc:
+			compared[0] += 1
+			check(np.float64(value), np.float64(enc["f"]), what)
+		elif "tuple" in enc or "list" in enc:
+			items = enc.get("tuple", enc.get("list"))
+			assert len(value) == len(items), "%s: %d results, recorded %d" % (what, len(value), len(items))
+			for i, (e, v) in enumerate(zip(items, value)):
+				bind(e, v, "%s[%d]" % (what, i))
+		elif "dict" in enc:
+			for k, e in enc["dict"].items():
+				bind(e, value[k], "%s[%s]" % (what, k))
+
+	names = {}
+	for i, op in enumerate(header["ops"]):
+		kind = op["k"]
+		if kind == "root":
+			refs[op["r"]] = getBackend(op["initmode"])
+		elif kind == "attr":
+			names[op["r"].get("ref", -1) if isinstance(op["r"], dict) else -1] = op["n"]
+			bind(op["r"], getattr(refs[op["t"]], op["n"]), "op %d: .%s" % (i, op["n"]))
+		elif kind == "setattr":
+			setattr(refs[op["t"]], op["n"], dec(op["v"]))
+		elif kind == "call":
+			what = "op %d: %s(...)" % (i, names.get(op["t"], "?"))
+			bind(op["r"], refs[op["t"]](*dec(op["a"]), **dec(op["kw"])), what)
+		elif kind == "poke":
+			refs[op["t"]].set(data[op["v"]])
+		elif kind == "del":
+			refs.pop(op["id"], None)
+			names.pop(op["id"], None)
+		else:
+			raise ValueError("unknown tape operation %r" % kind)
+	return compared[0]

@@ -51,6 +51,25 @@ def test_gradient_buckets_leave_progressively_for_resnet50():
 	run("dp_bucket_progress")
 
 
+def test_exchange_overlaps_for_a_caller_that_only_calls_sumTensor():
+	"""the reference's unpatched Optimizer (sorted-name arena, no hook into backward): completion order learned from the
+	arena's own write barriers, scattered completion-set buckets, >= 80 % of the bytes in flight before the last layer"""
+	assert "auto overlap" in run("dp_auto_overlap_sorted_arena", timeout=600)
+
+
+def test_exchange_completes_before_a_hook_that_writes_the_whole_arena():
+	assert "then the hook" in run("dp_auto_overlap_with_hook")
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("size", [2, 8])
+def test_runGrid_runs_a_MultiGPUMnist_shaped_target(size):
+	"""grid.runGrid(target, size, *args, devices=None, **kwargs) / nodeRunner with the reference's signatures (Grid.py:4-35):
+	the body of TestLib/MultiGPUMnist.py's train(nodeinfo, verbose) on synthetic data, one spawned process per node"""
+	out = run("run_grid_%d" % size, timeout=280)
+	assert "runGrid OK" in out and out.count(" of %d on device" % size) == size
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("ranks", [2, 8])
 def test_bench_starts_its_own_ranks_and_runs_the_data_parallel_path(ranks):

@@ -1,0 +1,57 @@
+"""
+The reference's own unit tests, replayed on the MI355X (SURVEY f3's finish line, Unittester.py:114-122).
+
+Each tests/golden/reftests/<Module>.npz is the tape of one `unittest()` of the reference (Modules/Conv2D.py:80-353,
+Modules/BatchNorm2D.py:34-82, Optimizers/Optimizer.py:249-325 trainSimpleTest / trainHardTest, Handlers/Trainer.py:38-108, ...),
+recorded in the build container by oracle/make_reftests.py while the unmodified reference ran on this repository's backend
+object with the C ABI emulated on host buffers: every call the test (through the reference's Modules / Containers / Optimizers)
+made on the backend object, every host array it uploaded, and every value it read back — values the reference's own asserts
+accepted there. Here the same program runs through the same Python glue on the real library; every value read back must equal
+the accepted one within the tape's fp32 tolerance (atol 1e-5, rtol 1e-4: SURVEY.md 8c). Both with the backend's lazy fusion
+layer on (its default) and off (one kernel per call).
+"""
+import glob, json, os
+
+import numpy as np
+import pytest
+
+import reftape
+from conftest import GOLDEN
+
+TAPES = sorted(glob.glob(os.path.join(GOLDEN, "reftests", "*.npz")))
+MANIFEST = json.load(open(os.path.join(GOLDEN, "reftests", "MANIFEST.json"))) if TAPES else {}
+
+
+def tape_id(path):
+	return os.path.basename(path)[:-4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", ["fused", "literal"])
+@pytest.mark.parametrize("tape", TAPES, ids=tape_id)
+def test_reference_unittest_replayed_on_the_device(bnd, tape, fusion):
+	from puzzlelib_amd import backend, lazy
+	before = (lazy.enabled, set(lazy.disabled))
+	lazy.enabled, lazy.disabled = fusion == "fused", set()
+	try:
+		compared = reftape.replay(tape, lambda initmode: backend.getBackend(0, initmode))
+	finally:
+		lazy.flushSmall()
+		lazy.enabled, lazy.disabled = before
+	assert compared == MANIFEST[tape_id(tape)]["values"], "the replay compared %d values, the recording read back %d" % (
+		compared, MANIFEST[tape_id(tape)]["values"])
+
+
+def test_tapes_are_data_and_listed():
+	"""-m "not gpu": every committed tape loads, is listed in the manifest with the number of values it checks, and mentions
+	nothing but backend attributes, calls, host arrays and scalars"""
+	assert len(TAPES) >= 12 and set(MANIFEST) == {tape_id(t) for t in TAPES}
+	for path in TAPES:
+		header, data = reftape.load(path)
+		assert header["name"] == tape_id(path) and header["atol"] <= 1e-5 and header["rtol"] <= 1e-4
+		kinds = {op["k"] for op in header["ops"]}
+		assert kinds <= {"root", "attr", "setattr", "call", "poke", "del"}, kinds
+		reads = sum(1 for op in header["ops"] if op["k"] in ("attr", "call") and json.dumps(op["r"]).count('"np"') + json.dumps(op["r"]).count('"f"'))
+		assert reads > 0, "%s reads nothing back" % path
+		for key in data.files:
+			assert data[key].dtype.kind in "fiub", (path, key, data[key].dtype)
