@@ -31,6 +31,10 @@ CASES = {
 	# config 3: TestLib/CnnCifar10NIN.py's own buildNet, optimizer and hook (:13-49, :68-70) — Conv2D(bias) -> Activation(relu)
 	# out of place, Dropout, both pooling modes
 	"nin_b8": (lambda: refNiN(), (8, 3, 32, 32), 10),
+	# the data-parallel path of TestLib/MultiGPUMnist.py:6-57: the reference's own MomentumSGD(nodeinfo=...) in global-state mode
+	# (Optimizers/Optimizer.py:107-109 broadcastBuffer, :166-167 sumTensor) on a one-rank grid of this backend — five steps, so
+	# that the arena's watcher goes from observing to overlapping (puzzlelib_amd/grid.py ArenaWatcher)
+	"lenet_dp_b16": (lambda: refLeNet(), (16, 1, 28, 28), 10),
 }
 SKIP = ("pz_pool_", "pz_event_", "pz_stream_", "pz_malloc", "pz_free", "pz_device_", "pz_init")
 
@@ -89,21 +93,32 @@ def record(case):
 	data = gpuarray.to_gpu(np.zeros(shape, np.float32))
 	labels = gpuarray.to_gpu(np.zeros(shape[:1], np.int32))
 
+	nsteps = 2
 	if case.startswith("nin"):
 		from PuzzleLib.Optimizers.MomentumSGD import MomentumSGD
 		from PuzzleLib.Optimizers import Hooks
 		optimizer = MomentumSGD(learnRate=0.1, momRate=0.9)
 		optimizer.addHook(Hooks.WeightDecay(0.0001))
+	elif "_dp_" in case:
+		import socket
+		from PuzzleLib.Optimizers.MomentumSGD import MomentumSGD
+		from puzzlelib_amd import grid
+		with socket.socket() as sock:
+			sock.bind(("127.0.0.1", 0))
+			port = sock.getsockname()[1]
+		optimizer = MomentumSGD(learnRate=0.1, momRate=0.9, nodeinfo=grid.connectNode(0, 1, 0, "127.0.0.1", port))
+		nsteps = 5
 	else:
 		optimizer = Adam(alpha=1e-3)
 	optimizer.setupOn(net, useGlobalState=True)
 	trainer = Trainer(net, CrossEntropy(maxlabels=classes) if case.startswith("nin") else CrossEntropy(), optimizer, batchsize=shape[0])
 
 	steps = []
-	for _ in range(2):
-		lib.trace.clear()
+	lib.trace.clear()
+	for _ in range(nsteps):
 		trainer.train(data, labels, random=False)
 		steps.append(compute(lib.trace))
+		lib.trace.clear()
 	return steps
 
 
@@ -115,10 +130,10 @@ def main():
 		path = os.path.join(ROOT, "tests", "golden", "trace_%s.json" % case)
 		if check:
 			assert json.load(open(path))["steps"] == json.loads(json.dumps(steps)), "trace of %s changed" % case
-			print("trace %s: unchanged (%d + %d calls)" % (case, len(steps[0]), len(steps[1])))
+			print("trace %s: unchanged (%s calls)" % (case, " + ".join(str(len(st)) for st in steps)))
 		else:
 			json.dump({"case": case, "steps": steps}, open(path, "w"), separators=(",", ":"))
-			print("wrote %s (%d + %d calls)" % (path, len(steps[0]), len(steps[1])))
+			print("wrote %s (%s calls)" % (path, " + ".join(str(len(st)) for st in steps)))
 
 
 if __name__ == "__main__":

@@ -1970,6 +1970,8 @@ static int ig_prefetch2_min_ktiles() {
 template <int BM, int BN, int WM, int WN>
 void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t st, double flops) {
 	constexpr int lds_pad = 0;
+	// the instantiation the two-tiles-ahead form exists for; every other tile falls through to the plain kernels
+	constexpr bool kHasPF2 = BM == 128 && BN == 128 && WM * WN == 4;
 	{
 		// profile bracket = the MFMA kernel alone (what rocprofv3 lists under its name); all of the launch's algorithmic
 		// FLOP are its work — the slab reduce of a k-sliced last round only adds
@@ -1989,8 +1991,8 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 		}
 		if (a.x2)
 			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
-		else if (a.tapmajor && BM == 128 && BN == 128 && a.kred_pad >= 16 * ig_prefetch2_min_ktiles()) {
-			if constexpr (BM == 128 && BN == 128 && WM * WN == 4)
+		else if (kHasPF2 && a.tapmajor && a.kred_pad >= 16 * ig_prefetch2_min_ktiles()) {
+			if constexpr (kHasPF2)
 				igemm_conv_kernel<BM, BN, WM, WN, true, false, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		} else if (a.tapmajor)
 			igemm_conv_kernel<BM, BN, WM, WN, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);

@@ -263,15 +263,19 @@ GemmPlan plan_gemm(int m, int n, int k, bool vec = true) {
 	return p;
 }
 
+// false: the plan names a tile this loader has no kernel for (256 x 256 exists for the 16-byte loader only; plan_gemm(vec = false)
+// never picks it) — the caller reports it instead of returning with C unwritten
 template <bool TA, bool TB, bool VEC>
-void launch(const GemmPlan &p, const GemmArgs &g, hipStream_t st) {
+bool launch(const GemmPlan &p, const GemmArgs &g, hipStream_t st) {
 	const dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
 	if (p.bm == 256) {
 		if constexpr (VEC) gemm_kernel<256, 256, 4, 4, TA, TB, true><<<grid, 1024, 0, st>>>(g);
+		else return false;
 	} else if (p.bm == 128 && p.bn == 128) gemm_kernel<128, 128, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
 	else if (p.bm == 128) gemm_kernel<128, 64, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
 	else if (p.bn == 128) gemm_kernel<64, 128, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
 	else gemm_kernel<64, 64, 2, 2, TA, TB, VEC><<<grid, 256, 0, st>>>(g);
+	return true;
 }
 
 }  // namespace
@@ -306,9 +310,11 @@ int pz_gemm_ws(int trans_a, int trans_b, int m, int n, int k, float alpha, const
 	           p.ksteps_per_split, vec ? (unsigned)a_ext : 0u, vec ? (unsigned)b_ext : 0u};
 	hipStream_t st = pz::as_stream(stream);
 
-	if (trans_a) vec ? launch<true, false, true>(p, g, st) : launch<true, false, false>(p, g, st);
-	else if (trans_b) vec ? launch<false, true, true>(p, g, st) : launch<false, true, false>(p, g, st);
-	else vec ? launch<false, false, true>(p, g, st) : launch<false, false, false>(p, g, st);
+	bool launched;
+	if (trans_a) launched = vec ? launch<true, false, true>(p, g, st) : launch<true, false, false>(p, g, st);
+	else if (trans_b) launched = vec ? launch<false, true, true>(p, g, st) : launch<false, true, false>(p, g, st);
+	else launched = vec ? launch<false, false, true>(p, g, st) : launch<false, false, false>(p, g, st);
+	PZ_REQUIRE(launched, "pz_gemm: no kernel for a %d x %d tile with the 4-byte loader", p.bm, p.bn);
 	PZ_LAUNCH_CHECK();
 
 	if (p.splits > 1) {

@@ -268,6 +268,10 @@ class DnnContext:
 		if bias is not None and not given and not want and lazy.on("convrelu") and lazy.whole(out) and \
 				self.epilogueSupported(desc, lib.CONV_FWD, algo):
 			lazy.attach(out, fusion.ConvFwd(self, desc, algo, data, W, bias))
+			if lazy.enabled:
+				# (a BatchNorm reading this tensor must still find out which filter made it: the adaptive policy registers the
+				# filter in statsWanted and the NEXT step's convolution leaves strip sums instead of waiting for a ReLU)
+				lazy.setFact(out, "fromconv", key)
 			return out
 
 		stats = None

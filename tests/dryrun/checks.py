@@ -39,7 +39,14 @@ def executor_trace(case):
 		net, shape = nets.buildNiN(), (8, 3, 32, 32)
 	else:
 		net, shape = nets.loadLeNet(None), (16, 1, 28, 28)
-	if case == "nin_b8":                                   # TestLib/CnnCifar10NIN.py:68-72
+	nsteps = 2
+	if case == "lenet_dp_b16":                             # the reference's MomentumSGD(nodeinfo=...) on a one-rank grid, its own arena order
+		optim.Optimizer.arenaLayout = "sorted"
+		opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9, nodeinfo=singleRankNode())
+		opt.setupOn(net, useGlobalState=True)
+		trainer = optim.Trainer(net, optim.CrossEntropy(), opt, batchsize=shape[0])
+		nsteps = 5
+	elif case == "nin_b8":                                   # TestLib/CnnCifar10NIN.py:68-72
 		opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9)
 		opt.addHook(optim.WeightDecay(0.0001))
 		opt.setupOn(net, useGlobalState=True)
@@ -48,7 +55,7 @@ def executor_trace(case):
 		trainer, _ = trainerFor(net, shape[0])
 	data, labels = g.to_gpu(np.zeros(shape, np.float32)), g.to_gpu(np.zeros(shape[:1], np.int32))
 	steps = []
-	for _ in range(2):
+	for _ in range(nsteps):
 		lib.trace.clear()
 		trainer.train(data, labels, random=False)
 		steps.append([[n, list(a)] for n, a in lib.trace if not n.startswith(SKIP)])
@@ -72,6 +79,10 @@ def trace_resnet50():
 
 def trace_lenet():
 	check_trace("lenet_b16")
+
+
+def trace_lenet_dp():
+	check_trace("lenet_dp_b16")
 
 
 def trace_nin():

@@ -108,10 +108,41 @@ class Tape:
 				pass
 		return proxy, {"ref": object.__getattribute__(proxy, "_pid")}
 
+	def scalarTolerance(self):
+		return scalarTolerance(self.ops, self.atol, self.rtol)
+
 	def save(self, path):
 		self.closed = True
-		header = {"name": self.name, "atol": self.atol, "rtol": self.rtol, "ops": self.ops}
+		header = {"name": self.name, "atol": self.atol, "rtol": self.rtol, "scalars": self.scalarTolerance(), "ops": self.ops}
 		np.savez_compressed(path, __tape__=np.frombuffer(json.dumps(header, separators=(",", ":")).encode(), dtype=np.uint8), **self.arrays)
+
+
+EARLY = 20
+
+
+def scalarTolerance(ops, atol, rtol):
+	"""Host scalars a test reads back (Blas.dot / cost errors: "f" results). A test that reads many of them follows a training
+	TRAJECTORY — Optimizers/Optimizer.py:249-325 trainSimpleTest / trainHardTest print the error of 200 consecutive updates and
+	assert nothing about it — and a trajectory amplifies rounding differences step by step: RMSProp's error starts at 5e-3 and
+	oscillates between 6e-5 and 1.2e-4 after 150 updates, where two fp32 summation orders differ by 12 %. The first EARLY such
+	monitors of a trajectory tape are held to atol + 1e-3 |x| (nothing has been amplified yet: a wrong kernel shows there), the
+	later ones to 2 % of the LARGEST value the tape reads. The arrays a test reads — what the reference's asserts compare — and
+	the scalars of tapes without a trajectory keep atol / rtol."""
+	scalars = []
+
+	def walk(enc):
+		if isinstance(enc, dict):
+			if "f" in enc:
+				scalars.append(abs(enc["f"]))
+			for key in ("tuple", "list"):
+				for item in enc.get(key, ()):
+					walk(item)
+	for op in ops:
+		if op["k"] in ("attr", "call"):
+			walk(op["r"])
+	if len(scalars) <= EARLY:
+		return {"atol": atol, "rtol": rtol, "trajectory": False}
+	return {"atol": atol, "rtol": 1e-3, "trajectory": True, "late_atol": max(atol, 2e-2 * max(scalars))}
 
 
 def unwrap(x):
@@ -215,18 +246,31 @@ def replay(path, getBackend, check=None):
 	atol, rtol = header["atol"], header["rtol"]
 	refs, compared = {}, [0]
 
-	def default_check(got, want, what):
+	scalars = scalarTolerance(header["ops"], atol, rtol)
+	nscalar = [0]
+
+	def default_check(got, want, what, scalar=False):
 		got, want = np.asarray(got), np.asarray(want)
 		assert got.shape == want.shape, "%s: shape %s, recorded %s" % (what, got.shape, want.shape)
 		if want.dtype.kind == "f":
 			err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-			bound = atol + rtol * np.abs(want.astype(np.float64))
+			a, r = atol, rtol
+			if scalar:
+				nscalar[0] += 1
+				late = scalars["trajectory"] and nscalar[0] > EARLY
+				a, r = (scalars["late_atol"] if late else scalars["atol"]), scalars["rtol"]
+			bound = a + r * np.abs(want.astype(np.float64))
 			bad = ~(err <= bound)
 			assert not bad.any(), "%s: %d of %d values off, worst |err| %.3e where the recorded value is %.3e (bound %.1e + %.1e |x|)" % (
-				what, int(bad.sum()), bad.size, float(err[bad].max()), float(np.abs(want)[bad][np.argmax(err[bad])]), atol, rtol)
+				what, int(bad.sum()), bad.size, float(err[bad].max()), float(np.abs(want)[bad][np.argmax(err[bad])]),
+				a, r)
 		else:
 			assert np.array_equal(got, want), "%s: integer values differ" % what
-	check = check or default_check
+	if check is None:
+		check = default_check
+	else:
+		user = check
+		check = lambda got, want, what, scalar=False: user(got, want, what)
 
 	def dec(x):
 		if isinstance(x, dict):
@@ -264,7 +308,7 @@ def replay(path, getBackend, check=None):
 			check(value, data[enc["np"]], what)
 		elif "f" in enc:
 			compared[0] += 1
-			check(np.float64(value), np.float64(enc["f"]), what)
+			check(np.float64(value), np.float64(enc["f"]), what, True)
 		elif "tuple" in enc or "list" in enc:
 			items = enc.get("tuple", enc.get("list"))
 			assert len(value) == len(items), "%s: %d results, recorded %d" % (what, len(value), len(items))

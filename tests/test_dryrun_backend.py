@@ -26,7 +26,7 @@ def run(name, timeout=300):
 	return res.stdout
 
 
-@pytest.mark.parametrize("check", ["trace_lenet", "trace_resnet50", "trace_nin"])
+@pytest.mark.parametrize("check", ["trace_lenet", "trace_resnet50", "trace_nin", "trace_lenet_dp"])
 def test_executor_sends_what_the_reference_modules_send(check):
 	assert "identical" in run(check)
 
