@@ -292,6 +292,19 @@ int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *b
 int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx,
                             const float *bncoef, float *dw, float alpha, float beta, int algo,
                             void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* The mirror image on the forward side: a BatchNorm (+ in-place ReLU) whose only readers are the pointwise
+ * convolution behind it — its forward and its filter gradient (conv -> bn -> relu -> conv 1x1 inside every bottleneck block of
+ * Models/Nets/ResNet.py:27-33) — is never written: both passes read the BatchNorm's INPUT x and evaluate
+ * relu?(xcoef[2c] * x + xcoef[2c + 1]) per input channel c while gathering ({a, b} pairs of pz_bn_fwd_train_coef; the expression
+ * of pz_bn_apply_add, so the results are bit-identical to convolving the written tensor). w or packed (pz_conv2d_prepack) as in
+ * pz_conv2d_fwd_relu; stats as in pz_conv2d_fwd_stats (NULL: none); bnx / bncoef of pz_conv2d_bwd_filter_xbn are the optional
+ * gradient-side fold of pz_conv2d_bwd_filter_bn (both NULL: dy is read as it is).                                          */
+int pz_conv2d_xbn_supported(const pz_conv_desc *d, int which, int algo, int *supported);
+int pz_conv2d_fwd_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *w, const void *packed,
+                      const float *bias, float *y, float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
+int pz_conv2d_bwd_filter_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *dy, const float *bnx,
+                             const float *bncoef, float *dw, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
+                             pz_stream_t stream);
 /* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
  * projection shortcut of Models/Nets/ResNet.py:36-58) the normalised tensor is never written. pz_bn_fwd_train_defer does
  * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;

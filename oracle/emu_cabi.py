@@ -198,6 +198,23 @@ def pz_conv2d_fwd_pre(d, x, packed, bias, y, stats, algo, ws, wsb, stream):
 	conv_fwd_impl(d, x, None, packed, bias, y, stats, strips_for(algo))
 
 
+def xbn_input(d, x, xcoef, xrelu):
+	"""relu?(a * x + b) per input channel: the tensor pz_bn_apply_add would have written"""
+	d = desc(d)
+	X = affine(Fv(x, d.n, d.c, d.h * d.w), xcoef, d.c)
+	return np.ascontiguousarray(R.relu(X) if xrelu else X).reshape(d.n, d.c, d.h, d.w)
+
+
+def pz_conv2d_fwd_xbn(d, x, xcoef, xrelu, w, packed, bias, y, stats, algo, ws, wsb, stream):
+	X = xbn_input(d, x, xcoef, xrelu)
+	conv_fwd_impl(d, X.ctypes.data, w, packed, bias, y, stats, strips_for(algo))
+
+
+def pz_conv2d_bwd_filter_xbn(d, x, xcoef, xrelu, dy, bnx, bncoef, dw, alpha, beta, algo, ws, wsb, stream):
+	X = xbn_input(d, x, xcoef, xrelu)
+	bwd_filter_impl(d, X.ctypes.data, dy, dw, None, alpha, beta, bn=(bnx, bncoef) if bnx else None)
+
+
 def pz_conv2d_prepack(jobs, njobs, stream):
 	for i in range(njobs):
 		job = jobs[i]

@@ -325,6 +325,10 @@ struct IgemmArgs {
 	// gate <= 0 (gate: a tensor of y's shape — the output of the ReLU whose backward follows this backward-data pass)
 	int relu;
 	const float *gate;
+	// XBN kernels: the gathered tensor is relu?(xbn[c].x * x + xbn[c].y) per channel c — a BatchNorm (+ in-place ReLU) whose
+	// normalised output was never written (Conv2D 1x1 behind BatchNorm2D + Activation(relu), Models/Nets/ResNet.py:27-33)
+	const float2 *xbn;
+	int xbn_relu;
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -499,10 +503,11 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 // quarter of a tile ago, and the k-tile boundary (park, barrier, first fragment read) is in the shadow of MFMAs. Costs 16
 // registers (3 waves per SIMD instead of 4); tools/probes/igemm_pipe.hip variant V3 measured it at +4..6 % from 3 to 24
 // tiles per CU (profiles/r04_igemm_pipe_probe.txt). Same products in the same order: bit-identical results.
-template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false, bool PF2 = false>
+template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false, bool PF2 = false, bool XBN = false>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((BNX && WM * WN == 4) || PF2 ? 3 : 4, 8)))
 igemm_conv_kernel(IgemmArgs a) {
 	static_assert(!BNX || TAPMAJOR, "the BatchNorm-backward gather rides on the tap-major order");
+	static_assert(!XBN || (TAPMAJOR && !BNX && !PF2), "the BatchNorm-forward gather: tap-major, plain loop");
 	static_assert(!PF2 || (TAPMAJOR && !BNX && WM * WN == 4), "two-tiles-ahead loads: tap-major, plain gathers, 4 waves");
 	constexpr int BK = 16, NT = 64 * WM * WN;
 	constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -582,6 +587,7 @@ igemm_conv_kernel(IgemmArgs a) {
 	float rb[NSETS][NB];
 	float rb2[BNX ? NB : 1];                  // BNX: the BatchNorm input elements that go with the gradient elements
 	float4 bnc[BNX ? NB : 1];                 // ... and the coefficients of their channels (scalar loads)
+	float2 xc[XBN ? NB : 1];                  // XBN: {a, b} of the gathered channels (scalar loads)
 	const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void *)(BNX ? a.x2 : a.x), 0, a.x_bytes, 0x00020000);
 
 	const int l31 = lane & 31, lhi = lane >> 5;
@@ -608,6 +614,11 @@ igemm_conv_kernel(IgemmArgs a) {
 				const int ch0 = g * a.Cg + (kt * BK) % a.Cg + kb0 * NB;
 #pragma unroll
 				for (int i = 0; i < NB; ++i) bnc[i] = a.xcoef[ch0 + i];
+			}
+			if constexpr (XBN) {
+				const int ch0 = g * a.Cg + (kt * BK) % a.Cg + kb0 * NB;
+#pragma unroll
+				for (int i = 0; i < NB; ++i) xc[i] = a.xbn[ch0 + i];
 			}
 		} else {
 #pragma unroll
@@ -649,6 +660,10 @@ igemm_conv_kernel(IgemmArgs a) {
 		for (int i = 0; i < NB; ++i) {
 			float v = rb[SET][i];
 			if constexpr (BNX) v = __builtin_fmaf(bnc[i].x, rb[SET][i], __builtin_fmaf(bnc[i].y, rb2[i], bnc[i].z));
+			if constexpr (XBN) {                  // bn_apply_add_kernel's own expression (csrc/bn.hip): same bits as the written tensor
+				v = __builtin_fmaf(rb[SET][i], xc[i].x, xc[i].y);
+				if (a.xbn_relu) v = v > 0.f ? v : 0.f;
+			}
 			Bs[buf][kb0 * NB + i][jb] = v;
 		}
 	};
@@ -1092,6 +1107,10 @@ struct WgradArgs {
 	// BIAS kernels: the bias gradient db[k] = sum over (image, pixel) of dy rides on the operand-A runs the workgroups of
 	// tile column 0 park anyway (no pass of its own over dy): db (direct) or per-split partials [split][K_total]
 	float *db_out;
+	// XBN kernels (pointwise gathers): operand B is relu?(xbn[c].x * x + xbn[c].y) per input channel c — the normalised, activated
+	// input of this convolution, never written (see IgemmArgs)
+	const float2 *xbn;
+	int xbn_relu;
 };
 
 // The reduction axis is enumerated in RUNS of 4 consecutive output pixels of one output row (rows padded to a multiple
@@ -1105,10 +1124,11 @@ struct WgradArgs {
 // WM x WN = 4 or 8 waves. With 8 (PZ_WG_WAVES=8, tiles of at least 8 MFMA tiles) a wave owns half as many accumulators
 // and gathers half as many runs, so two workgroups per CU (the LDS limit) put 4 waves on every SIMD instead of 2 — what
 // gave the Winograd kernels 6-11 % changes nothing here (every census layer within +-2 %), so 4 stays the default.
-template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false, bool BIAS = false>
+template <int BM, int BN, int WM, int WN, int GATHER, int RUNS, bool BNX = false, bool BIAS = false, bool XBN = false>
 __global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(RUNS == 8 || BM > 128 ? WM * WN / 2 : 4, 8)))
 wgrad_conv_kernel(WgradArgs a) {
 	static_assert(!(BNX && BIAS), "a convolution in front of a BatchNorm has no bias gradient of its own to fold");
+	static_assert(!XBN || (GATHER == 2 && !BIAS), "the BatchNorm-forward gather: pointwise layers without a bias");
 	constexpr bool UNIT_W = GATHER >= 1, POINTWISE = GATHER == 2;
 	constexpr int NT = 64 * WM * WN;
 	constexpr int RP = NT / RUNS;                // tile rows loaded per pass (one 16-byte run per thread)
@@ -1185,6 +1205,11 @@ wgrad_conv_kernel(WgradArgs a) {
 		for (int i = 0; i < NA; ++i) bnc[i] = a.bncoef[g * a.Kg + min(tm * BM + row0 + RP * i, a.Kg - 1)];
 	}
 	const bool full_m = tm * BM + BM <= a.Kg;
+	float2 xc[XBN ? NB : 1];                 // ... and its operand-B rows the same input channels (pointwise: column = channel)
+	if constexpr (XBN) {
+#pragma unroll
+		for (int i = 0; i < NB; ++i) xc[i] = a.xbn[g * a.Cg + min(tn * BN + row0 + RP * i, a.Cg - 1)];
+	}
 
 	// ---- per-step state of this thread's run: image / row / first column, number of real pixels in the run
 	unsigned dy_off = kOOB;        // byte offset of dy[n, g*Kg + tm*BM + row0, p, q0]
@@ -1284,8 +1309,14 @@ wgrad_conv_kernel(WgradArgs a) {
 			// bit q of m -> all-ones / zero word (v_bfe_i32), then one AND per element: 2 VALU instead of test + compare + select
 			f32x4 v;
 #pragma unroll
-			for (int q = 0; q < 4; ++q)
-				v[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)rb[set][i][q]) & __builtin_amdgcn_sbfe((int)m, q, 1));
+			for (int q = 0; q < 4; ++q) {
+				float t = (float)rb[set][i][q];
+				if constexpr (XBN) {              // bn_apply_add_kernel's expression, THEN the mask (relu(b) of a pixel beyond the row is not 0)
+					t = __builtin_fmaf(t, xc[i].x, xc[i].y);
+					if (a.xbn_relu) t = t > 0.f ? t : 0.f;
+				}
+				v[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, t) & __builtin_amdgcn_sbfe((int)m, q, 1));
+			}
 			Bs[buf][run >> 1][run & 1][row0 + RP * i] = v;
 		}
 	};
@@ -1989,7 +2020,10 @@ void launch_igemm(const FwdPlan &p, const IgemmArgs &a, int groups, hipStream_t 
 				goto launched;
 			}
 		}
-		if (a.x2)
+		if (a.xbn) {                             // (conv2d_fwd_impl admits it for this instantiation only: xbn_fwd_eligible)
+			if constexpr (kHasPF2)
+				igemm_conv_kernel<BM, BN, WM, WN, true, false, false, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
+		} else if (a.x2)
 			igemm_conv_kernel<BM, BN, WM, WN, true, true><<<dim3(p.blocks, 1, groups), 64 * WM * WN, lds_pad, st>>>(a);
 		else if (kHasPF2 && a.tapmajor && a.kred_pad >= 16 * ig_prefetch2_min_ktiles()) {
 			if constexpr (kHasPF2)
@@ -2298,7 +2332,40 @@ static FwdPlan fwd_pack_args(const pz_conv_desc *d, int P, int Q, const float *w
 }
 
 static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
-                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu = 0);
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu = 0,
+                           const float *xbn = nullptr, int xbn_relu = 0);
+
+// Convolutions whose gathers can apply a PRECEDING BatchNorm (+ ReLU) on the fly (pz_conv2d_fwd_xbn / pz_conv2d_bwd_filter_xbn):
+// pointwise, unit stride, unpadded (a padded tap would have to read 0, not relu(b)), ungrouped, reduction channels in whole
+// k-tiles, fp32 math. Forward: the 128 x 128 implicit GEMM below the two-tiles-ahead threshold (that form parks a tile's gathers
+// a tile after it read their coefficients). Backward-filter: the pointwise form of wgrad_conv_kernel.
+static bool xbn_eligible(const pz_conv_desc *d, int which, int P, int Q, int algo) {
+	if (!(d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1 && d->groups == 1 &&
+	      d->c % 16 == 0 && algo != PZ_CONV_ALGO_DIRECT && igemm_eligible(d, P, Q) && pz::g_conv_math == 0))
+		return false;
+	if (which == PZ_CONV_FWD) {
+		const FwdPlan p = plan_igemm(d->k, d->c, (long)d->n * P * Q, 1, d->c);
+		return p.bm == 128 && p.kred_pad < 16 * ig_prefetch2_min_ktiles();
+	}
+	return which == PZ_CONV_BWD_FILTER;
+}
+
+int pz_conv2d_xbn_supported(const pz_conv_desc *d, int which, int algo, int *supported) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(supported != nullptr, "pz_conv2d_xbn_supported: null output");
+	*supported = xbn_eligible(d, which, P, Q, algo) ? 1 : 0;
+	return PZ_OK;
+}
+
+int pz_conv2d_fwd_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *w, const void *packed,
+                      const float *bias, float *y, float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(xcoef != nullptr, "pz_conv2d_fwd_xbn: null coefficients");
+	PZ_REQUIRE(xbn_eligible(d, PZ_CONV_FWD, P, Q, algo), "pz_conv2d_fwd_xbn: this convolution cannot normalise its input on the fly (pz_conv2d_xbn_supported)");
+	return conv2d_fwd_impl(d, x, packed ? nullptr : w, packed, bias, y, stats, algo, workspace, ws_bytes, stream, 0, xcoef, xrelu);
+}
 
 // Which passes can apply an activation in their epilogue (pz_conv2d_fwd_relu / pz_conv2d_bwd_data_gate): implicit-GEMM
 // launches whose output pixels are contiguous per image — every forward pass on that path, backward-data at unit stride.
@@ -2335,7 +2402,8 @@ int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed,
 }
 
 static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y,
-                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu) {
+                           float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, int relu, const float *xbn,
+                           int xbn_relu) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && (w || packed) && y, "pz_conv2d_fwd: null tensor");
@@ -2398,6 +2466,7 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 	a.tapmajor = pa.tapmajor;
 	a.contig = 1, a.stats = reinterpret_cast<float4 *>(stats);
 	a.relu = relu;
+	a.xbn = reinterpret_cast<const float2 *>(xbn), a.xbn_relu = xbn_relu;
 	a.stat_strips = pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	static_assert(PZ_CONV_STATS_STRIP == 64, "strip = 32 * TN pixels of both tile configurations");
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);
@@ -2630,7 +2699,19 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 
 static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx, const float *bncoef,
                                   float *dw, float *db, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
-                                  pz_stream_t stream);
+                                  pz_stream_t stream, const float *xbn = nullptr, int xbn_relu = 0);
+
+int pz_conv2d_bwd_filter_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *dy, const float *bnx,
+                             const float *bncoef, float *dw, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
+                             pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(xcoef != nullptr, "pz_conv2d_bwd_filter_xbn: null coefficients");
+	PZ_REQUIRE((bnx == nullptr) == (bncoef == nullptr), "pz_conv2d_bwd_filter_xbn: the gradient-side fold needs both its operands");
+	PZ_REQUIRE(xbn_eligible(d, PZ_CONV_BWD_FILTER, P, Q, algo) && (bnx == nullptr || bn_fold_eligible(d, P, Q, algo)),
+	           "pz_conv2d_bwd_filter_xbn: this convolution cannot normalise its input on the fly (pz_conv2d_xbn_supported)");
+	return conv2d_bwd_filter_impl(d, x, dy, bnx, bncoef, dw, nullptr, alpha, beta, algo, workspace, ws_bytes, stream, xcoef, xrelu);
+}
 
 int pz_conv2d_bwd_filter(const pz_conv_desc *d, const float *x, const float *dy, float *dw, float *db, float alpha,
                          float beta, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream) {
@@ -2648,7 +2729,7 @@ int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *
 
 static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx, const float *bncoef,
                                   float *dw, float *db, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
-                                  pz_stream_t stream) {
+                                  pz_stream_t stream, const float *xbn, int xbn_relu) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(x && dy && dw, "pz_conv2d_bwd_filter: null tensor");
@@ -2736,6 +2817,7 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	a.out = a.direct ? dw : slabs;
 	a.slab = p.slab_elems;
 	a.bnx = bnx, a.bncoef = reinterpret_cast<const float4 *>(bncoef);
+	a.xbn = reinterpret_cast<const float2 *>(xbn), a.xbn_relu = xbn_relu;
 	float *bpart = fold_bias ? (float *)((char *)workspace + need_all - bias_part_bytes(d, p.splits)) : nullptr;
 	a.db_out = fold_bias ? (a.direct ? db : bpart) : nullptr;
 
@@ -2758,7 +2840,9 @@ static int conv2d_bwd_filter_impl(const pz_conv_desc *d, const float *x, const f
 	const bool unit_w = d->stride_w == 1;
 	const bool pointwise = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && unit_w;
 #define PZ_WGRAD_LAUNCH(BM_, BN_, WM_, WN_) \
-	(a.bnx     ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	(a.xbn     ? (a.bnx ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, true, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
+	                    : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, false, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a)) \
+	 : a.bnx   ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
 	                        : wgrad_conv_kernel<BM_, BN_, WM_, WN_, 0, PZ_WG_RUNS, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a)) \
 	 : a.db_out ? (pointwise ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 2, PZ_WG_RUNS, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \
 	               : unit_w  ? wgrad_conv_kernel<BM_, BN_, WM_, WN_, 1, PZ_WG_RUNS, false, true><<<grid, 64 * WM_ * WN_, 0, st>>>(a) \

@@ -277,7 +277,12 @@ class DnnContext:
 		stats = None
 		if want and nstrips > 0:
 			stats = GPUArray.empty((W.shape[0], nstrips, 4), dtype=np.float32, allocator=allocator)
-		self.launchForward(desc, algo, data, W, bias, out, False, stats=stats, allocator=allocator)
+		# the input is a BatchNorm (+ in-place ReLU) that was only described, and this layer can apply it while gathering: the
+		# normalised tensor stays unwritten (its other reader, this layer's filter gradient, does the same)
+		xbn = self.describedInput(data)
+		if xbn is not None and not self.xbnSupported(desc, lib.CONV_FWD, algo):
+			xbn = None
+		self.launchForward(desc, algo, data, W, bias, out, False, stats=stats, allocator=allocator, xbn=xbn)
 		if stats is not None:
 			lazy.setFact(out, "convstats", (stats, outshape))
 			lazy.count("conv_stats")
@@ -287,7 +292,7 @@ class DnnContext:
 		return out
 
 
-	def launchForward(self, desc, algo, data, W, bias, out, relu, stats=None, allocator=None, prepared=True, settling=False):
+	def launchForward(self, desc, algo, data, W, bias, out, relu, stats=None, allocator=None, prepared=True, settling=False, xbn=None):
 		"""the forward launch itself (out: the whole output, overwritten). prepared=False: W is not a live parameter (a snapshot):
 		its packed operand is made inside the call instead of being kept per parameter version. settling=True: called while
 		`out`'s own description runs (lazy.settle) — its address is taken without a write barrier (the barrier that led here
@@ -298,7 +303,14 @@ class DnnContext:
 		if packed is not None:
 			wsbytes = self.workspaceWithPrepared(desc, lib.CONV_FWD, algo)
 		ws = self.workspace(wsbytes, allocator)
-		if relu:
+		if xbn is not None:
+			assert not relu
+			lib.pz_conv2d_fwd_xbn(
+				byref(desc), xbn.x.rptr, fusion.raw(xbn.coef), int(xbn.relu), None if packed is not None else W.rptr, packed, rptrOf(bias),
+				optr, None if stats is None else stats.optr, algo, rptrOf(ws), wsbytes, None
+			)
+			lazy.count("conv_xbn")
+		elif relu:
 			assert stats is None
 			lib.pz_conv2d_fwd_relu(
 				byref(desc), data.rptr, None if packed is not None else W.rptr, packed, rptrOf(bias), optr, algo, rptrOf(ws),
@@ -350,6 +362,28 @@ class DnnContext:
 		used = c_int(0)
 		lib.pz_conv2d_algo_used(byref(desc), which, toAlgoId(algo), byref(used))
 		return used.value
+
+
+	def xbnSupported(self, desc, which, algo):
+		"""can this pass evaluate a preceding BatchNorm (+ ReLU) while it gathers its input (pz_conv2d_fwd_xbn / _bwd_filter_xbn)?"""
+		hit = desc.geo.get((which, algo, "xbn"))
+		if hit is None:
+			flag = c_int(0)
+			lib.pz_conv2d_xbn_supported(byref(desc), which, algo, byref(flag))
+			hit = desc.geo[(which, algo, "xbn")] = bool(flag.value)
+		return hit
+
+
+	@staticmethod
+	def describedInput(data):
+		"""`data` as a convolution may read it without making it exist: the description relu?(a * x + b) still pending on it
+		(fusion.BnApply over a tensor of data's own shape), or None"""
+		if not lazy.on("xbn") or not isinstance(data, GPUArray) or data.ndim != 4:
+			return None
+		waiting = lazy.pending(data, fusion.BnApply)
+		if waiting is None or waiting.x.shape != data.shape or not waiting.x.contiguous:
+			return None
+		return waiting
 
 
 	def bnFoldSupported(self, desc, algo):
@@ -549,11 +583,16 @@ class DnnContext:
 		fused = withbias and bcoef == wcoef and not deconv    # one library call reduces dw and db with the same (alpha, beta)
 		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
 		folded = bn is not None and not withbias and foldable
+		# the layer's input was never written (a described BatchNorm + ReLU, see convNd): this pass reads the BatchNorm's input too
+		xbn = self.describedInput(data) if not withbias and not deconv else None
+		if xbn is not None and not self.xbnSupported(desc, lib.CONV_BWD_FILTER, algo):
+			xbn = None
 
 		gflop = 2e-9 * prod(grad.shape) * prod(W.shape[1:])
 		side = self.filterGradStream(gflop) if (not withbias or fused) else None
 		st = side.handle if side is not None else None
-		reads = [data, bn.dy, bn.x] if folded else [data, grad]
+		src = data if xbn is None else xbn.x
+		reads = [src, bn.dy, bn.x] if folded else [src, grad]
 		writes = [wgrad] + ([bg] if fused else [])
 
 		def rp(ary):
@@ -566,7 +605,7 @@ class DnnContext:
 		# when nothing touched what it reads since, and what it writes was not produced by this call on the main stream.
 		early = self.earlyReady          # (kept until this call's own allocations are made: it holds backward-data's workspace)
 		mark = None
-		if side is not None and early is not None and not folded and not fresh and grad.gpudata.root is early[1] and \
+		if side is not None and early is not None and not folded and xbn is None and not fresh and grad.gpudata.root is early[1] and \
 				data.gpudata.root is early[2] and lazy.cleanSince(early[1], early[3]) and lazy.cleanSince(early[2], early[4]) and \
 				all(lazy.quiet(a) for a in writes):          # (a settle — a pending zero fill of the arena — would be behind the mark)
 			mark = early[0]
@@ -589,7 +628,15 @@ class DnnContext:
 		if poison:
 			lib.pz_memset_d32(ws.gpudata.ptr, 0x7fc00000, wsbytes // 4, st)
 
-		if folded:
+		if xbn is not None:
+			lib.pz_conv2d_bwd_filter_xbn(
+				byref(desc), rptrs[0], fusion.raw(xbn.coef), int(xbn.relu), rptrs[1], rptrs[2] if folded else None,
+				fusion.raw(bn.coef) if folded else None, wptrs[0], wcoef[0], wcoef[1], algo, rptrOf(ws), wsbytes, st
+			)
+			lazy.count("wgrad_xbn")
+			if folded:
+				lazy.count("wgrad_bn_fold")
+		elif folded:
 			lib.pz_conv2d_bwd_filter_bn(
 				byref(desc), rptrs[0], rptrs[1], rptrs[2], fusion.raw(bn.coef), wptrs[0], wcoef[0], wcoef[1], algo,
 				rptrOf(ws), wsbytes, st
@@ -603,7 +650,7 @@ class DnnContext:
 
 		self.earlyReady = early = None
 		if side is not None:
-			lazy.foreignEnd(side, ready, reads=reads, writes=writes, keep=(ws, bn.coef if folded else None))
+			lazy.foreignEnd(side, ready, reads=reads, writes=writes, keep=(ws, bn.coef if folded else None, xbn.coef if xbn is not None else None))
 
 		if withbias and not fused:
 			n, k = biasof.shape[:2]

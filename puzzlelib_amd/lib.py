@@ -124,6 +124,9 @@ _PROTOS = {
 	"pz_conv2d_prepack_bytes": [POINTER(ConvDesc), c_int, c_int, POINTER(c_size_t)],
 	"pz_conv2d_prepack": [POINTER(PrepackJob), c_int, P],
 	"pz_conv2d_fwd_pre": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_xbn_supported": [POINTER(ConvDesc), c_int, c_int, POINTER(c_int)],
+	"pz_conv2d_fwd_xbn": [POINTER(ConvDesc), P, P, c_int, P, P, P, P, P, c_int, P, c_size_t, P],
+	"pz_conv2d_bwd_filter_xbn": [POINTER(ConvDesc), P, P, c_int, P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_data_pre": [POINTER(ConvDesc), P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter": [POINTER(ConvDesc), P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
 
@@ -268,7 +271,7 @@ def _bind(name, argtypes):
 
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_workspace_bytes_pre", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_epilogue_supported", "pz_conv2d_algo_used",
-	"pz_conv2d_bn_fold_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
+	"pz_conv2d_bn_fold_supported", "pz_conv2d_xbn_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
 	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get",
 	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get"
 }

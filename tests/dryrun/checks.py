@@ -272,7 +272,9 @@ def fused_step_counts():
 
 	fusedCalls, fused = counts[True]
 	literalCalls, literal = counts[False]
-	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 6), ("bn_pool", 1), ("bn_bwd_gate", 7), ("wgrad_bn_fold", 4), ("dgrad_bn_fold", 4),
+	# (bn_apply_relu: the three relu(bn(.)) tensors in front of the 3x3 layers are written; the three in front of the pointwise
+	# layers are evaluated in those layers' forward and filter-gradient gathers — conv_xbn / wgrad_xbn)
+	for key, n in (("bn_apply_add", 3), ("bn_apply_relu", 3), ("conv_xbn", 3), ("wgrad_xbn", 3), ("bn_pool", 1), ("bn_bwd_gate", 7), ("wgrad_bn_fold", 4), ("dgrad_bn_fold", 4),
 				   ("gate_stats", 1), ("gate_stats_up2", 1), ("compact_dgrad", 2), ("conv_stats", 12), ("gate_by_mask", 2)):
 		assert fused.get(key, 0) == n, "%s taken %d times, expected %d (%s)" % (key, fused.get(key, 0), n, fused)
 	assert not any(k in literal for k in ("bn_apply_add", "bn_bwd_gate", "wgrad_bn_fold", "gate_stats", "compact_dgrad"))

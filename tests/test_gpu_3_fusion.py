@@ -788,3 +788,61 @@ def test_training_steps_with_prepared_operands_equal_per_call_packing(surf, mini
 	assert none == 0 and launches >= 3
 	for key in with_:
 		assert np.array_equal(with_[key], without[key]), key
+
+
+@pytest.mark.parametrize("cfg", [dict(n=8, c=64, hw=(55, 55), k=256), dict(n=6, c=128, hw=(28, 28), k=512), dict(n=5, c=256, hw=(14, 14), k=1024),
+								 dict(n=3, c=48, hw=(9, 11), k=136), dict(n=4, c=512, hw=(7, 7), k=2048), dict(n=3, c=24, hw=(6, 6), k=32)])
+def test_pointwise_convolution_reads_a_batchnorm_relu_that_was_never_written(surf, cfg):
+	"""conv -> BatchNorm2D -> Activation(relu, inplace) -> Conv2D 1x1 -> BatchNorm2D and back, as the reference's bottleneck
+	blocks issue it (Models/Nets/ResNet.py:27-33): the pointwise layer's forward and its filter gradient evaluate
+	relu(a * x + b) while they gather (pz_conv2d_fwd_xbn / pz_conv2d_bwd_filter_xbn, the latter together with the fold of
+	the FOLLOWING BatchNorm's backward) and the normalised tensor is never written — it still reads correctly afterwards.
+	Bit-identical to the same calls with the fold off (the gathers use bn_apply's own expression). Layers the kernels do not
+	take (512 channels: the two-tiles-ahead implicit GEMM; 24 channels: not whole k-tiles) write the tensor and agree too."""
+	from puzzlelib_amd import lazy
+	g, Dnn, El = surf.gpuarray, surf.Dnn, surf.ElementWise
+	n, c, (h, w), k = cfg["n"], cfg["c"], cfg["hw"], cfg["k"]
+	rng = np.random.RandomState(5)
+	x = (0.3 + rng.randn(n, c, h, w)).astype(np.float32)
+	W = (rng.randn(k, c, 1, 1) / np.sqrt(c)).astype(np.float32)
+	dz = rng.randn(n, k, h, w).astype(np.float32)
+	(_, _, _, _), fresh = bnParams(surf, rng, c)
+	(_, _, _, _), fresh2 = bnParams(surf, rng, k)
+
+	def run():
+		gs, gb, grm, grv = fresh()
+		gs2, gb2, grm2, grv2 = fresh2()
+		gx, gW, gdz = g.to_gpu(x), g.to_gpu(W), g.to_gpu(dz)
+		y, sm, si = Dnn.batchNormNd(gx, gs, gb, grm, grv, 1e-5, 0.3, False)
+		El.reluKer(np.float32)(y, y)
+		algo = surf.backend.ConvFwdAlgo.auto
+		z = Dnn.convNd(y, gW, None, 1, 0, 1, 1, algo)
+		u, sm2, si2 = Dnn.batchNormNd(z, gs2, gb2, grm2, grv2, 1e-5, 0.3, False)
+		# backward: the following BatchNorm's input gradient (described), then this layer's two backward passes
+		dzbn, ds2, db2 = Dnn.batchNormNdBackward(z, gdz, gs2, sm2, si2, 1e-5)
+		dy = Dnn.convNdBackwardData(dzbn, gW, y, 1, 0, 1, 1, surf.backend.ConvBwdDataAlgo.auto)
+		wgrad = g.zeros(W.shape, dtype=np.float32)
+		Dnn.convNdBackwardParams(y, dzbn, gW, None, 1, 0, 1, 1, wgrad, None, 1.0, 0.0, surf.backend.ConvBwdFilterAlgo.auto)
+		unwritten = lazy.pending(y) is not None
+		return [a.get() for a in (z, u, dy, wgrad, y)], unwritten
+
+	lazy.counters.clear()
+	folded, unwritten = run()
+	taken = dict(lazy.counters)
+	lazy.disabled = {"xbn"}
+	lazy.counters.clear()
+	plain, _ = run()
+	lazy.disabled = set()
+
+	dnn = surf.backend.dnn
+	desc = dnn.convDesc((n, c, h, w), W.shape, 1, 0, 1, 1)
+	from puzzlelib_amd import lib
+	takes = dnn.xbnSupported(desc, lib.CONV_FWD, lib.CONV_ALGO_AUTO)
+	assert takes == (cfg["k"] in (256, 512, 1024)), "the three bottleneck shapes fold; 64-row tiles, the two-tiles-ahead form and 24 channels do not"
+	assert (taken.get("conv_xbn", 0), taken.get("wgrad_xbn", 0)) == ((1, 1) if takes else (0, 0)), taken
+	assert unwritten == takes, "the normalised tensor must stay a description through both passes"
+	for a, b, what in zip(folded, plain, ("z", "bn(z)", "dy", "dW", "relu(bn(x)) read afterwards")):
+		assert np.array_equal(a, b), what
+
+	z_ref = R.conv2d_fwd(folded[4], W, None, acc=np.float64)
+	assert_close(folded[0], z_ref, atol=1e-4 * np.abs(z_ref).max(), rtol=1e-4, what="z vs oracle on the device's own relu(bn(x))")
