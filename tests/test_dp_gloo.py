@@ -143,3 +143,104 @@ def test_host_group_over_tcp_three_ranks(tmp_path):
 		assert bytes(out["blob"]) == b"id-from-rank-0" * 9
 		assert list(out["red"]) == [6.0, 1.0, 3.0]
 		assert np.array_equal(out["array"], np.full(1000, 6.0, np.float32))
+
+
+def _watcher_worker(rank, world, port, outdir):
+	"""the exchange of a caller that only calls sumTensor (grid.ArenaWatcher) over gloo: an arena in sorted-name order whose blocks
+	are finished in another order, the write barriers simulated by calling the watcher as lazy.writeBarrier does"""
+	sys.path.insert(0, ROOT)
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+	import torch, torch.distributed as dist
+	from puzzlelib_amd import grid
+
+	dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+	sizes = {"bn1.bias": 16, "bn1.scale": 16, "conv1.W": 1200, "conv2.W": 4000, "fc.W": 2600, "fc.b": 10, "bn2.bias": 64, "bn2.scale": 64}
+	finish = ["fc.W", "fc.b", "bn2.scale", "bn2.bias", "conv2.W", "bn1.scale", "bn1.bias", "conv1.W"]       # backward's order
+	blocks, offset = [], 0
+	for name in sorted(sizes):
+		blocks.append((name, offset, sizes[name] * 4))
+		offset += (sizes[name] * 4 + 15) // 16 * 16
+	where = {b[0]: (b[1], b[2]) for b in blocks}
+	arena = np.zeros(offset // 4, dtype=np.float32)
+	log = []
+
+	class HostOps:
+		def markReady(self):
+			return len(log)
+
+		def allreduce(self, start, stop, token):
+			dist.all_reduce(torch.from_numpy(arena[start // 4:stop // 4]))
+			log.append(("one", start, stop))
+
+		def allreduceRanges(self, ranges, token):
+			for lo, hi in ranges:
+				dist.all_reduce(torch.from_numpy(arena[lo // 4:hi // 4]))
+			log.append(("group", len(ranges)))
+
+		def finish(self, scale):
+			arena[...] *= np.float32(scale)
+
+	class Node:
+		gridsize, bucketBytes, reducers = world, 6000, {}
+
+		def reduceOps(self, tensor):
+			return HostOps()
+
+		def plainSum(self, tensor):
+			dist.all_reduce(torch.from_numpy(arena))
+			arena[...] *= np.float32(1.0 / world)
+			log.append(("plain", ))
+
+	watcher = grid.ArenaWatcher(Node(), "grad", None, blocks)
+	rng = np.random.RandomState(10 + rank)
+	result = {}
+	for step in range(5):
+		del log[:]
+		watcher.onWrite(0, arena.nbytes)                     # zeroGradParams
+		arena[...] = 0
+		local = {}
+		for name in finish:
+			off, nbytes = where[name]
+			watcher.onWrite(off, off + nbytes)               # the barrier comes BEFORE the write is issued
+			local[name] = rng.randn(nbytes // 4).astype(np.float32)
+			arena[off // 4:(off + nbytes) // 4] = local[name]
+		early = len(log)
+		if step == 4:                                        # a hook that writes the whole arena before sumTensor (weight decay)
+			watcher.onWrite(0, arena.nbytes)
+			arena += np.float32(0.5)
+		watcher.sumTensor()
+		result["arena%d" % step] = arena.copy()
+		result["early%d" % step] = np.array([early, sum(1 for e in log if e[0] == "group"), sum(1 for e in log if e[0] == "plain")])
+		for name, g in local.items():
+			result["g%d_%s" % (step, name)] = g
+	np.savez(os.path.join(outdir, "w%d.npz" % rank), **result)
+	dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_watcher_overlaps_a_sorted_name_arena_over_gloo(tmp_path):
+	"""two ranks, an arena laid out by sorted names (Optimizers/Optimizer.py:66-68) and finished in backward's order: after two
+	observed steps the watcher's completion-set buckets — several byte ranges each — leave during "backward"; every step, every
+	rank ends with the mean of the ranks' gradients (Grid.py:123-135); a whole-arena write before sumTensor (a hook) finds the
+	exchange complete and the mean applied"""
+	import torch.multiprocessing as mp
+	import cpu_ref as R
+
+	world, port = 2, _free_port()
+	mp.spawn(_watcher_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+	ranks = [np.load(os.path.join(str(tmp_path), "w%d.npz" % r)) for r in range(world)]
+
+	sizes = {"bn1.bias": 16, "bn1.scale": 16, "conv1.W": 1200, "conv2.W": 4000, "fc.W": 2600, "fc.b": 10, "bn2.bias": 64, "bn2.scale": 64}
+	for step in range(5):
+		assert np.array_equal(ranks[0]["arena%d" % step], ranks[1]["arena%d" % step])
+		offset = 0
+		for name in sorted(sizes):
+			expected = R.grad_mean_allreduce([r["g%d_%s" % (step, name)] for r in ranks]) + (np.float32(0.5) if step == 4 else 0)
+			got = ranks[0]["arena%d" % step][offset // 4:offset // 4 + sizes[name]]
+			assert np.allclose(got, expected, atol=1e-6), (step, name)
+			offset += (sizes[name] * 4 + 15) // 16 * 16
+		early, groups, plain = ranks[0]["early%d" % step]
+		if step < 2:
+			assert (early, plain) == (0, 1), "steps 1-2 are observed: one collective over the arena at sumTensor"
+		else:
+			assert plain == 0 and early >= 2 and groups >= 1, "step %d: %d buckets left during backward, %d as groups of ranges" % (step + 1, early, groups)

@@ -227,10 +227,11 @@ def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
 	]
 	assert [p.wait(timeout=900) for p in procs] == [0, 0]
 
+	META = ("transport", "auto_buckets", "auto_ranges")
 	a, b = np.load(single), np.load(dual)
 	assert str(b["transport"]) in ("rccl", "host-staged")
 	for name in a.files:
-		if name != "transport":
+		if name not in META:
 			assert np.array_equal(a[name], b[name]), "parameter %s differs between 1 and 2 ranks" % name
 
 	# ... and one rank with a real RCCL communicator (PUZZLE_MI355_FORCE_COMM=1): the same hooks, buckets and event joins, the
@@ -240,8 +241,22 @@ def test_data_parallel_rehearsal_matches_single_process(bnd, tmp_path):
 	c = np.load(solo)
 	assert str(c["transport"]) == "rccl"
 	for name in a.files:
-		if name != "transport":
+		if name not in META:
 			assert np.array_equal(a[name], c[name]), "parameter %s differs with a one-rank RCCL communicator" % name
+
+	# ... and the exchange of an UNPATCHED caller (sorted-name arena, nothing but sumTensor): the arena's watcher learns the
+	# completion order in steps 2-3 and from step 4 on sends scattered completion-set buckets as RCCL groups during backward
+	# (pz_comm_allreduce_sum_f32_ranges) — six steps must leave exactly the parameters of six single-process steps
+	six = dict(env, PUZZLE_MI355_REHEARSE_STEPS="6", PUZZLE_MI355_REHEARSE_AUTO="1", PUZZLE_MI355_REHEARSE_BUCKET="8192")
+	plain6, auto6 = str(tmp_path / "plain6.npz"), str(tmp_path / "auto6.npz")
+	subprocess.run([sys.executable, script, plain6], check=True, env=six, timeout=600)
+	subprocess.run([sys.executable, script, auto6], check=True, env=dict(six, PUZZLE_MI355_FORCE_COMM="1"), timeout=600)
+	d, e = np.load(plain6), np.load(auto6)
+	assert str(e["transport"]) == "rccl" and int(e["auto_buckets"]) >= 3 and int(e["auto_ranges"]) > int(e["auto_buckets"]), (
+		"the watcher must have planned scattered buckets: %s buckets, %s ranges" % (e["auto_buckets"], e["auto_ranges"]))
+	for name in d.files:
+		if name not in META:
+			assert np.array_equal(d[name], e[name]), "parameter %s differs under the watcher's overlapped exchange" % name
 
 
 @pytest.mark.gpu

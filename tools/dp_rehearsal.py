@@ -17,7 +17,7 @@ from puzzlelib_amd import grid
 
 out = sys.argv[1]
 Config.deviceIdx = int(os.environ.get("PUZZLE_MI355_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-nodeinfo = grid.nodeFromEnv(bucketBytes=64 << 10)          # small buckets: several exchanges overlap with backward
+nodeinfo = grid.nodeFromEnv(bucketBytes=int(os.environ.get("PUZZLE_MI355_REHEARSE_BUCKET", 64 << 10)))          # small buckets: several exchanges overlap with backward
 
 from puzzlelib_amd import nets, optim
 from puzzlelib_amd.surface import bound
@@ -34,17 +34,25 @@ if rank == 0:
 	for name, var in net.namedParams().items():
 		var.data.set(golden["init_" + name])
 
+# PUZZLE_MI355_REHEARSE_AUTO=1: what an unpatched PuzzleLib does — the arena in sorted-name order (Optimizers/Optimizer.py:66-68),
+# no hook into backward, only nodeinfo.sumTensor at update time: the overlap then comes from the arena's watcher (grid.ArenaWatcher)
+auto = os.environ.get("PUZZLE_MI355_REHEARSE_AUTO", "0") == "1"
+if auto:
+	optim.Optimizer.arenaLayout = "sorted"
 optimizer = optim.Adam(alpha=1e-3, nodeinfo=nodeinfo)
 optimizer.setupOn(net, useGlobalState=True)
-if nodeinfo is not None:
+if nodeinfo is not None and not auto:
 	grid.enableOverlap(optimizer, nodeinfo)
 
 trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=4)
 data, labels = gpuarray.to_gpu(golden["data"]), gpuarray.to_gpu(golden["labels"])
-for _ in range(3):
+for _ in range(int(os.environ.get("PUZZLE_MI355_REHEARSE_STEPS", "3"))):
 	trainer.train(data, labels, random=False)
 
 if rank == 0:
+	watcher = getattr(nodeinfo, "watchers", {}).get("grad")
 	np.savez(out, transport=np.array(getattr(nodeinfo, "transport", "single")),
+			 auto_buckets=np.array(len(watcher.reducer.buckets) if watcher is not None and watcher.reducer is not None else 0),
+			 auto_ranges=np.array(sum(len(b.ranges) for b in watcher.reducer.buckets) if watcher is not None and watcher.reducer is not None else 0),
 			 **{name: var.data.get() for name, var in net.namedParams().items()})
 grid.barrier()
