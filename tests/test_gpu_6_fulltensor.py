@@ -133,6 +133,87 @@ def test_conv_whole_tensors_vs_fp64_oracle(bnd, case):
 		assert ratio <= 1.0, "%s: an element is %.2f x its bound (families %s)" % (name, ratio, family)
 
 
+# The launches of the training step that read a DESCRIBED operand (the lazy layer's folds) — at the same sizes, straight through the
+# C ABI, element by element against the fp64 oracle applied to the host-evaluated operand (until round 5
+# these were tied to the oracle at batch 256 only through fused == literal bit identity):
+#   pz_conv2d_fwd_xbn            y  = conv(relu(a x + b), w)                      bottleneck blocks' last 1x1 layer, forward
+#   pz_conv2d_bwd_filter_xbn     dw = relu(a x + b) (x) (A dy + B z + C)          ... its filter gradient, both operands described
+#   pz_conv2d_bwd_data_bn        dx = conv^T(A dy + B z + C, w)                   ... and every 1x1 layer's backward-data behind a BatchNorm
+#   pz_conv2d_bwd_filter_bn      dw = x (x) (A dy + B z + C)
+# + the compact stride-2 backward-data (a stride-1 problem on the output grid).
+FOLDED = [
+	(256, (64, 55, 55), 256), (256, (128, 28, 28), 512), (256, (256, 14, 14), 1024),      # xbn + gradient-side fold (128x128 tiles)
+	(256, (256, 55, 55), 64), (256, (1024, 14, 14), 256), (256, (2048, 7, 7), 512),       # 64x256 tiles / two-tiles-ahead reductions: no xbn
+	(256, (256, 28, 28), 128),                                                            # = the compact grid of (256,55,55) -> 128 /2
+]
+
+
+@pytest.mark.parametrize("case", FOLDED, ids=lambda c: "b%d_%dx%dx%d_to_%d" % ((c[0], ) + c[1] + (c[2], )))
+def test_folded_launches_whole_tensors_vs_fp64_oracle(bnd, case):
+	import ctypes
+	from puzzlelib_amd import lib
+	G = bnd.GPUArray
+	n, (c, h, w), k = case
+	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, 1, 1), 1, 0, 1, 1)
+	algo = lib.CONV_ALGO_AUTO
+	rng = np.random.RandomState(41)
+
+	x, z, dy = dev_randn(bnd, (n, c, h, w), 42), dev_randn(bnd, (n, k, h, w), 43), dev_randn(bnd, (n, k, h, w), 44)
+	wh = (rng.randn(k, c, 1, 1) / np.sqrt(c)).astype(np.float32)
+	xco = np.stack([0.5 + rng.rand(c), 0.3 * rng.randn(c)], axis=1).astype(np.float32)                    # {a, b} per input channel
+	gco = np.concatenate([np.stack([0.5 + rng.rand(k), 0.2 * rng.randn(k), 0.1 * rng.randn(k)], axis=1), np.zeros((k, 1))], axis=1).astype(np.float32)
+	wt, gxco, ggco = gpu(bnd, wh), gpu(bnd, xco), gpu(bnd, gco)
+
+	def ws(which):
+		nbytes = bnd.dnn.convGeometry(desc, which, algo)[2]
+		return (G.empty((max(nbytes, 4), ), dtype=np.uint8), nbytes)
+
+	y = G.empty((n, k, h, w), dtype=np.float32)
+	dx = G.empty((n, c, h, w), dtype=np.float32)
+	dw_bn, dw_xbn = G.zeros(wh.shape, dtype=np.float32), G.zeros(wh.shape, dtype=np.float32)
+	takes_xbn = bnd.dnn.xbnSupported(desc, lib.CONV_FWD, algo)
+	assert takes_xbn == (k >= 128 and c <= 256), "128-row tiles below the two-tiles-ahead threshold take the forward gather"
+
+	wsf, nf = ws(lib.CONV_FWD)
+	if takes_xbn:
+		lib.pz_conv2d_fwd_xbn(ctypes.byref(desc), x.rptr, gxco.rptr, 1, wt.rptr, None, None, y.optr, None, algo, wsf.optr, nf, None)
+	wsd, nd = ws(lib.CONV_BWD_DATA)
+	lib.pz_conv2d_bwd_data_bn(ctypes.byref(desc), dy.rptr, z.rptr, ggco.rptr, wt.rptr, dx.optr, algo, wsd.optr, nd, None)
+	wsw, nw = ws(lib.CONV_BWD_FILTER)
+	lib.pz_conv2d_bwd_filter_bn(ctypes.byref(desc), x.rptr, dy.rptr, z.rptr, ggco.rptr, dw_bn.optr, 1.0, 0.0, algo, wsw.optr, nw, None)
+	if bnd.dnn.xbnSupported(desc, lib.CONV_BWD_FILTER, algo):
+		lib.pz_conv2d_bwd_filter_xbn(ctypes.byref(desc), x.rptr, gxco.rptr, 1, dy.rptr, z.rptr, ggco.rptr, dw_xbn.optr, 1.0, 0.0, algo,
+									 wsw.optr, nw, None)
+
+	xh, zh, dyh = x.get(), z.get(), dy.get()
+	yh, dxh, dwbh, dwxh = y.get(), dx.get(), dw_bn.get(), dw_xbn.get()
+	del x, z, dy, y, dx
+
+	okw = dict(stride=(1, 1), pad=(0, 0), dilation=(1, 1), groups=1)
+	npix = n * h * w
+	ratios = {}
+	dw_bn_ref, dw_xbn_ref = np.zeros(wh.shape, np.float64), np.zeros(wh.shape, np.float64)
+	for c0 in range(0, n, CHUNK):
+		sel = slice(c0, min(n, c0 + CHUNK))
+		# the described operands, evaluated on the host in fp64 from the device's own inputs
+		act = np.maximum(xco[None, :, 0, None, None].astype(np.float64) * xh[sel] + xco[None, :, 1, None, None], 0.0)
+		g = gco[None, :, 0, None, None].astype(np.float64) * dyh[sel] + gco[None, :, 1, None, None] * zh[sel] + gco[None, :, 2, None, None]
+		if takes_xbn:
+			ref = R.conv2d_fwd(act, wh, None, acc=np.float64, **okw)
+			ratios["forward (xbn)"] = max(ratios.get("forward (xbn)", 0.0), worst(yh[sel], ref, 1e-5 * max(1.0, rms(ref)), 1e-4))
+		ref = R.conv2d_bwd_data(g, wh, (sel.stop - sel.start, c, h, w), acc=np.float64, **okw)
+		ratios["backward-data (bn)"] = max(ratios.get("backward-data (bn)", 0.0), worst(dxh[sel], ref, 1e-5 * max(1.0, rms(ref)), 1e-4))
+		dw_bn_ref += R.conv2d_bwd_filter(xh[sel].astype(np.float64), g, wh.shape, withbias=False, acc=np.float64, **okw)
+		dw_xbn_ref += R.conv2d_bwd_filter(act, g, wh.shape, withbias=False, acc=np.float64, **okw)
+	ratios["backward-filter (bn)"] = worst(dwbh, dw_bn_ref, 1e-5 * np.sqrt(npix), 1e-4)
+	if dwxh.any():
+		ratios["backward-filter (xbn + bn)"] = worst(dwxh, dw_xbn_ref, 1e-5 * np.sqrt(npix), 1e-4)
+	print("whole-tensor error / bound:", {k_: round(v, 3) for k_, v in ratios.items()})
+	assert len(ratios) == (4 if takes_xbn else 3)
+	for name, ratio in ratios.items():
+		assert ratio <= 1.0, "%s: an element is %.2f x its bound" % (name, ratio)
+
+
 def adoptDeviceGatesNested(cnet, layers, spec, prefix=""):
 	"""test_gpu_5_nets.adoptDeviceGates for nested specs: the oracle's backward gates with the ReLU outputs / max-pool
 	operands the DEVICE produced (cache keys as oracle/cpu_net.py builds them: "<index>", "<index>.b.<index>", ...). Returns
@@ -163,10 +244,10 @@ def test_resnet50_full_depth_training_step_vs_oracle(bnd, batch):
 	logits, loss, cross-entropy gradient and ALL 161 parameter gradients against oracle/cpu_net.py on the same inputs and
 	initial values. The oracle's backward gates with the device's ReLU / max-pool decisions (a pre-activation within rounding
 	of zero may round to either side; see adoptDeviceGates in test_gpu_5_nets.py). Bound, per parameter gradient: relative L2
-	error against the oracle with fp64 sums inside every operator <= max(5e-5, 2 x the distance of the fp32-summing oracle from
+	error against the oracle with fp64 sums inside every operator <= max(5e-5, 1.3 x the distance of the fp32-summing oracle from
 	that same yardstick) — 53 layers deep the order of fp32 sums alone moves the last block's gradients by ~1e-4 (two numpy
 	runs differing only in accumulation type), so a fixed 5e-5 would test numpy's summation order, not the kernels; median over
-	the 161 gradients <= 5e-5; every element within 1e-3 of its gradient's top."""
+	the 161 gradients <= 5e-5; no gradient above 1.6e-4 in absolute terms; every element within 1e-3 of its gradient's top."""
 	from puzzlelib_amd import nets, optim, lazy
 	from puzzlelib_amd.surface import bound
 	gpuarray = bound().gpuarray
@@ -243,9 +324,14 @@ def test_resnet50_full_depth_training_step_vs_oracle(bnd, batch):
 		assert np.isfinite(got).all(), name
 		dev, own = rel(got, ref), rel(c32.grads[name], ref)
 		rels.append((dev, own, name))
-		assert dev <= max(floor, 2.0 * own), "grad %s: relative L2 error %.3e (the fp32 oracle's own: %.3e)" % (name, dev, own)
+		# (round 5: the factor was 2 — a kernel twice as far from the yardstick as numpy's fp32 sums would have passed. Measured: 14 of
+		# the 161 gradients lie above the floor, the device is at most 1.04 x the fp32-summing oracle's distance on them, worst 1.14e-4.)
+		assert dev <= max(floor, 1.3 * own), "grad %s: relative L2 error %.3e (the fp32 oracle's own: %.3e)" % (name, dev, own)
+		assert dev <= (1.6e-4 if bnd.dnn.convMath == "f32" else 2.5e-4), "grad %s: relative L2 error %.3e above the absolute cap" % (name, dev)
 		assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-9, "element of grad %s" % name
 	rels.sort(reverse=True)
+	above = [(d / o, d, o, nm) for d, o, nm in rels if d > floor]
+	print("gradients above the floor: %d; worst device / fp32-oracle ratio %s" % (len(above), max(above)[:3] if above else None))
 	median = rels[len(rels) // 2][0]
 	print("ResNet-50 b%d training step vs fp64-summing oracle: worst relative L2 gradient error %.3e (%s; fp32-summing oracle %.3e), "
 		  "median %.3e, %d flipped gates adopted, worst forward mismatch %.2e" % (batch, rels[0][0], rels[0][2], rels[0][1], median, flips, mism))
