@@ -210,6 +210,7 @@ def settleDependents(root):
 def writeBarrier(root, buf=None, whole=False, stream=None):
 	lz = root.lz
 	lz.version += 1
+	lz.snap = None                            # (a copy of the previous version: whoever still reads it holds it)
 	if lz.watch is not None:
 		lo = 0 if buf is None else buf.ptr - lz.base
 		lz.watch(lo, lo + (root.size if buf is None else buf.size))
@@ -400,6 +401,9 @@ def whole(ary):
 	return ary.contiguous and buf.ptr == root.ptr and ary.nbytes == root.size
 
 
+snapshotWhole = 32 << 20          # allocations up to this size are snapshot whole (one copy shared by every description of the step)
+
+
 def snapshot(ary):
 	"""A view like `ary` over a COPY of its allocation as it stands now. One copy per allocation and write-version: with the
 	parameters in one flat arena, every description of a step that has to outlive the optimizer's update (fusion.ConvFwd /
@@ -410,6 +414,14 @@ def snapshot(ary):
 	root = buf.root
 	lz = stateOf(root)
 	readBarrier(root)
+	if root.size > snapshotWhole and buf.size < root.size:
+		# a large arena (a VGG-sized model: 0.5 GB): copying all of it for one filter would move and hold a second copy of every
+		# parameter each step — the caller gets a private copy of the bytes it reads
+		alloc = GPUArray.defaultAllocator.allocate if GPUArray.defaultAllocator is not None else driver.Buffer.allocate
+		piece = alloc(buf.size)
+		lib.pz_memcpy_d2d(piece.ptr, buf.ptr, buf.size, None)
+		count("param_snapshot_piece")
+		return GPUArray(ary.shape, ary.dtype, gpudata=piece)
 	if lz.snap is None or lz.snap[0] != lz.version:
 		copy = GPUArray.defaultAllocator.allocate(root.size) if GPUArray.defaultAllocator is not None else driver.Buffer.allocate(root.size)
 		lib.pz_memcpy_d2d(copy.ptr, root.ptr, root.size, None)

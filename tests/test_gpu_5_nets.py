@@ -515,3 +515,50 @@ def test_checkpoint_round_trip_continues_bit_for_bit(bnd, mini_golden, tmp_path)
 
 	with pytest.raises(ValueError):
 		checkpoint.load(net2, path, optimizer=optim.MomentumSGD())
+
+
+def test_descriptions_that_outlive_an_update_copy_only_what_they_read_of_a_large_arena(bnd):
+	"""a described pre-activation convolution (Conv2D(bias) -> Activation(relu) out of place) that has to survive the
+	optimizer's write to the arena used to snapshot the WHOLE arena. Above lazy.snapshotWhole it now copies only its own filter
+	and bias bytes. Three NiN steps with the threshold at 0 (every description takes private pieces) must leave exactly the
+	parameters of three steps with one shared whole-arena copy per step — and read the same stale pre-activation values."""
+	from puzzlelib_amd import nets, optim, lazy, backend
+	from puzzlelib_amd.surface import bound
+	gpuarray = bound().gpuarray
+	rng = np.random.RandomState(6)
+	data = gpuarray.to_gpu(rng.randn(8, 3, 32, 32).astype(np.float32))
+	labels = gpuarray.to_gpu(rng.randint(0, 10, size=(8, )).astype(np.int32))
+
+	def run(threshold):
+		before, lazy.snapshotWhole = lazy.snapshotWhole, threshold
+		try:
+			np.random.seed(1234)
+			net = nets.buildNiN()
+			devrng = backend.RandomNumberGenerator(seed=20260930)      # (the two runs must draw identical dropout words)
+			for layer in net.walk():
+				if layer.kind == "dropout":
+					layer.cfg["rng"] = devrng
+			optimizer = optim.MomentumSGD(learnRate=0.05, momRate=0.9)
+			optimizer.setupOn(net, useGlobalState=True)
+			trainer = optim.Trainer(net, optim.CrossEntropy(), optimizer, batchsize=8)
+			net.trainMode()
+			lazy.counters.clear()
+			kept = None
+			for step in range(3):
+				trainer.step([data, labels])
+				if step == 1:
+					first = next(l for l in net.walk() if l.kind == "conv")
+					kept = first.y                            # the convolution's own (pre-activation) output: only described so far
+				net.reset()
+			stale = None if kept is None else kept.get()      # read AFTER two more updates of the parameters it was computed from
+			return {k: p.data.get() for k, p in net.namedParams().items()}, stale, dict(lazy.counters)
+		finally:
+			lazy.snapshotWhole = before
+
+	whole, stale_w, cw = run(1 << 40)
+	pieces, stale_p, cp = run(0)
+	assert cw.get("param_snapshot", 0) > 0 and cw.get("param_snapshot_piece", 0) == 0, cw
+	assert cp.get("param_snapshot_piece", 0) > 0 and cp.get("param_snapshot", 0) == 0, cp
+	for name in whole:
+		assert np.isfinite(whole[name]).all() and np.array_equal(whole[name], pieces[name]), name
+	assert stale_w is not None and np.isfinite(stale_w).all() and np.array_equal(stale_w, stale_p)
