@@ -2467,6 +2467,10 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 	a.contig = 1, a.stats = reinterpret_cast<float4 *>(stats);
 	a.relu = relu;
 	a.xbn = reinterpret_cast<const float2 *>(xbn), a.xbn_relu = xbn_relu;
+	// launch_igemm has the described-operand gather in ONE instantiation (128x128, four waves, plain math): any other plan
+	// would launch nothing and leave y unwritten — refuse here, whatever xbn_fwd_eligible and plan_igemm say today
+	PZ_REQUIRE(xbn == nullptr || (p.bm == 128 && !p.split),
+			   "pz_conv2d_fwd_xbn: the plan of this layer (tile %d, split %d) has no form that reads a described operand", p.bm, p.split);
 	a.stat_strips = pz::ceil_div((long)d->n * P * Q, PZ_CONV_STATS_STRIP);
 	static_assert(PZ_CONV_STATS_STRIP == 64, "strip = 32 * TN pixels of both tile configurations");
 	run_igemm(p, a, slabs, d->groups, st, 2.0 * d->n * P * Q * (double)d->k * Cg * d->r * d->s);

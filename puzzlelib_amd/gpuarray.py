@@ -506,15 +506,19 @@ def eltwise(op, count, arrays, scalars=(), slc=None, stream=None, readonly=None,
 	if readonly is None:
 		readonly = range(1, nptrs)
 
-	if stream is None:
-		ptrs = (PTRS.get(nptrs) or ctypes.c_void_p * nptrs)(*[
-			a.gpudata.ptr if i == rawIdx else a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)
-		])
-	else:
-		# a borrowed stream (Optimizer.update(useStreams=True)): it follows the main stream up to here, and what it writes
-		# carries its completion event, so the main stream waits exactly when it touches those buffers again
-		ptrs = (ctypes.c_void_p * nptrs)(*[a.ptrOn(stream, i not in readonly) for i, a in enumerate(arrays)])
-		ready = lazy.foreignBegin(stream)
+	lazy.writeOp = op
+	try:
+		if stream is None:
+			ptrs = (PTRS.get(nptrs) or ctypes.c_void_p * nptrs)(*[
+				a.gpudata.ptr if i == rawIdx else a.rptr if i in readonly else a.wptr for i, a in enumerate(arrays)
+			])
+		else:
+			# a borrowed stream (Optimizer.update(useStreams=True)): it follows the main stream up to here, and what it writes
+			# carries its completion event, so the main stream waits exactly when it touches those buffers again
+			ptrs = (ctypes.c_void_p * nptrs)(*[a.ptrOn(stream, i not in readonly) for i, a in enumerate(arrays)])
+			ready = lazy.foreignBegin(stream)
+	finally:
+		lazy.writeOp = None
 
 	# scalars travel as raw float32 words (bit patterns such as the dropout threshold must survive untouched)
 	if isinstance(scalars, np.ndarray):

@@ -53,7 +53,8 @@ class HostGroup:
 	followed by a scatter of the result: bytes broadcast, float64 reductions, float32 array sums (the fallback gradient
 	transport), barrier. Messages are length-prefixed; every call is made by all ranks in the same order."""
 
-	def __init__(self, rank, world, addr, port, timeout=120.0):
+	def __init__(self, rank, world, addr, port, timeout=120.0, publish=None):
+		"""`port` 0 on rank 0: the system picks a free one; `publish(port)` is told which, once the socket listens"""
 		self.rank, self.world = rank, world
 		self.peers = []
 		if world == 1:
@@ -64,6 +65,8 @@ class HostGroup:
 			server.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
 			server.bind((addr, port))
 			server.listen(world)
+			if publish is not None:
+				publish(server.getsockname()[1])
 			server.settimeout(timeout)
 			slots = [None] * world
 			for _ in range(world - 1):
@@ -278,6 +281,16 @@ class GradReducer:
 				self.ops.allreduce(lo, hi, token)
 		bucket.launched = True
 
+	def unlaunch(self, bucket):
+		"""A bucket that is already with the transport is about to be written again (a second backward pass before the update:
+		gradient accumulation). What is in flight becomes the SUM over the ranks; the compute stream waits for it, turns it into
+		the MEAN (the same on every rank), the caller's write then adds this rank's new contribution, and the bucket goes out
+		again at finishStep: sum_r (mean + d_r) = sum_r g_r + sum_r d_r — what one exchange at the end would have produced, up
+		to rounding. The bucket no longer leaves early in this step."""
+		assert bucket.launched
+		self.ops.unlaunch(bucket.ranges, 1.0 / self.gridsize)
+		bucket.launched, bucket.pending = False, {None}          # (nothing reports None: only finishStep launches it)
+
 	def finishStep(self):
 		for bucket in self.buckets:
 			if not bucket.launched:
@@ -374,6 +387,11 @@ class RcclNodeInfo(NodeInfo):
 			lib.pz_comm_destroy(self.comm)
 			self.comm = None
 
+	def watcherOf(self, name):
+		"""the live ArenaWatcher that follows the arena exchanged under `name` (None: not overlapped by a watcher)"""
+		found = [w for (n, _), w in self.watchers.items() if n == name and w is not None and w.root() is not None]
+		return found[-1] if found else None
+
 	def commSummary(self):
 		"""per-step exposed exchange time and per-bucket bus rates of the overlapped reducer (None: nothing measured)"""
 		reducer = self.reducers.get("grad", None)
@@ -412,6 +430,10 @@ class RcclNodeInfo(NodeInfo):
 		"""no bucket plan: one collective over the whole tensor on the compute stream, then the mean"""
 		from puzzlelib_amd import lib
 		from puzzlelib_amd.gpuarray import eltwise
+		if tensor.dtype != np.float32 or not tensor.contiguous:
+			# (the reference exchanges one arena per dtype, Optimizers/Optimizer.py:163-167; this backend computes in float32 only)
+			raise NotImplementedError("sumTensor: contiguous float32 tensors only (got %s%s)" % (
+				tensor.dtype, "" if tensor.contiguous else ", strided"))
 		self.ensureComm()
 		if self.transport == "rccl":
 			ptr = tensor.wptr
@@ -427,9 +449,17 @@ class RcclNodeInfo(NodeInfo):
 			# Nobody registered a bucket plan (the reference's own Optimizer only ever calls broadcastBuffer / sumTensor,
 			# Optimizers/Optimizer.py:107-109,166-167): when the tensor is a flat arena (backend.SharedArray), a watcher on
 			# its allocation learns in which order backward finishes its blocks and overlaps the exchange from then on
-			watcher = self.watchers.get(name, None)
-			if watcher is None or watcher.tensor.gpudata.root is not tensor.gpudata.root:
-				watcher = self.watchers[name] = ArenaWatcher.attach(self, name, tensor)
+			# (keyed by name AND allocation: the reference calls sumTensor("grad", ...) once per dtype arena under one name)
+			root = tensor.gpudata.root
+			key = (name, id(root))
+			watcher = self.watchers.get(key, None)
+			if watcher is not None and watcher.root() is not root:          # (the id was recycled by a new allocation)
+				watcher.detach()
+				watcher = None
+			if watcher is None and key not in self.watchers:
+				for other in [k for k, w in self.watchers.items() if w is not None and w.root() is None]:
+					self.watchers.pop(other).detach()                       # arenas that no longer exist
+				watcher = self.watchers[key] = ArenaWatcher.attach(self, name, tensor)
 			if watcher is not None and watcher.sumTensor():
 				return
 
@@ -553,6 +583,21 @@ class HipReduceOps:
 		done.record(node.commStream)
 		self.events.append((token, done, ranges[0][0], sum(hi - lo for lo, hi in ranges), begin))
 
+	def unlaunch(self, ranges, scale):
+		"""GradReducer.unlaunch: the compute stream waits for the collectives over `ranges`, scales them to the mean, and the
+		host waits for that — the write that follows may be queued on another stream behind an EARLIER mark of this one."""
+		from puzzlelib_amd import lib
+		lo, hi = ranges[0][0], ranges[-1][1]
+		for _, done, start, _, _ in self.events:
+			if lo <= start < hi:
+				lib.pz_stream_wait_event(None, done.handle)
+		P, F = ctypes_ptrs(2), np.array([scale, 0.0], dtype=np.float32)
+		base = self.tensor.gpudata.ptr
+		for rlo, rhi in ranges:
+			ptrs = P(base + rlo, base + rlo)
+			lib.pz_eltwise(lib.OP_LINEAR, (rhi - rlo) // 4, ptrs, 2, F.ctypes.data_as(lib.POINTER(lib.c_float)), 2, 0, (rhi - rlo) // 4, 1, None)
+		lib.pz_stream_sync(None)
+
 	def finish(self, scale):
 		from puzzlelib_amd import lib, lazy, fusion, driver
 		from puzzlelib_amd.gpuarray import eltwise
@@ -600,10 +645,24 @@ class HostStagedReduceOps:
 		lib.pz_memcpy_h2d(ptr, host.ctypes.data, stop - start, None)
 		lib.pz_stream_sync(None)
 
+	def unlaunch(self, ranges, scale):
+		from puzzlelib_amd import lib
+		P, F = ctypes_ptrs(2), np.array([scale, 0.0], dtype=np.float32)
+		base = self.tensor.gpudata.ptr
+		for rlo, rhi in ranges:
+			lib.pz_eltwise(lib.OP_LINEAR, (rhi - rlo) // 4, P(base + rlo, base + rlo), 2, F.ctypes.data_as(lib.POINTER(lib.c_float)), 2,
+						   0, (rhi - rlo) // 4, 1, None)
+		lib.pz_stream_sync(None)
+
 	def finish(self, scale):
 		from puzzlelib_amd import lib
 		from puzzlelib_amd.gpuarray import eltwise
 		eltwise(lib.OP_LINEAR, self.tensor.size, (self.tensor, self.tensor), np.array([scale, 0.0], dtype=np.float32))
+
+
+def ctypes_ptrs(n):
+	import ctypes
+	return ctypes.c_void_p * n
 
 
 def arenaBlocks(sharedArray):
@@ -636,32 +695,47 @@ class ArenaWatcher:
 	What the backend sees of a data-parallel training step is: writes into views of one flat allocation (the gradient arena
 	of backend.SharedArray — every write goes through a lazy-buffer write barrier, puzzlelib_amd/lazy.py), and one
 	`nodeinfo.sumTensor("grad", arena)` per step. The watcher sits on the arena's allocation (`State.watch`) and is told of
-	every write barrier BEFORE the write is issued:
-	  * the first sumTensor attaches the watcher; the next two steps are only observed: the sequence of blocks written
-	    between two sumTensor calls. When two consecutive
-	    steps wrote the same sequence, the position of each block's LAST write gives the order in which backward finishes
-	    the blocks, whatever order the arena is laid out in (the reference: sorted names, Optimizers/Optimizer.py:66-68) —
-	    completion-set buckets of scattered byte ranges (planScatteredBuckets) are planned from it;
-	  * from then on a block whose last expected write has been ISSUED (= the next barrier on the arena is reached, or
-	    sumTensor) is reported to the GradReducer, and a bucket whose blocks are all final is all-reduced at once on the
-	    communication stream, behind events of the compute and the filter-gradient stream.
-	Safety: a step that writes anything else than the learned sequence stops launching early (the rest goes out at
-	sumTensor, as without overlap); a write into a bucket that is already in flight cannot be repaired and raises. A write of
-	the WHOLE arena after block writes (a hook: weight decay runs before sumTensor in the reference, Optimizer.py:160-167)
-	completes the exchange first — the mean is applied as a pass, the hook then works on mean gradients, which for a hook that
-	is linear in the gradient and reads rank-identical parameters equals the reference's hook-then-mean — and the
-	following sumTensor finds nothing left to do."""
+	every write barrier BEFORE the write is issued, and (lib.issueWatchers) of every library call AFTER it was queued:
+	  * the first sumTensor attaches the watcher; the following steps are only observed: the sequence of blocks written (and
+	    of whole-arena writes behind them: hooks) between two sumTensor calls. When two consecutive steps wrote the same
+	    sequence, the position of each block's LAST write gives the order in which backward finishes the blocks, whatever
+	    order the arena is laid out in (the reference: sorted names, Optimizers/Optimizer.py:66-68) — completion-set buckets
+	    of scattered byte ranges (planScatteredBuckets) are planned from it;
+	  * from then on a block whose last expected write has been ISSUED is reported to the GradReducer, and a bucket whose
+	    blocks are all final is all-reduced at once on the communication stream, behind events of the compute and the
+	    filter-gradient stream. "Issued" = a library call carrying an address inside the byte range of that write's barrier
+	    was made after the barrier: one launch may take several write addresses first (a filter gradient and its bias
+	    gradient: two barriers, then pz_conv2d_bwd_filter), so the next barrier on the arena proves nothing by itself.
+	Steps that do not follow the learned pattern are served exactly, without overlap, and the pattern is learned again:
+	  * any other write sequence: nothing more goes out early, the rest leaves at sumTensor;
+	  * a write into a bucket that is already in flight (a second backward pass before the update): the bucket is taken back
+	    (GradReducer.unlaunch) and leaves again at sumTensor;
+	  * a write of the WHOLE arena behind block writes is a hook (the reference runs hooks before sumTensor,
+	    Optimizer.py:160-167). Only the weight-decay kernel (Optimizers/Hooks.py:16-19: linear in the gradient, reads parameters
+	    that are identical on every rank) may trade places with the mean: the exchange completes first, the mean is applied as a
+	    pass, the hook then works on mean gradients and the following sumTensor finds nothing left to do. A network whose
+	    observed steps contain any OTHER whole-arena write is never overlapped (hook, then one collective at sumTensor: the
+	    reference's order). If such a write first appears in an overlapped step, what is already in flight cannot be taken
+	    back for a non-linear hook: that one step runs mean-then-hook, says so on stderr, and overlap stays off from then on."""
+
+	HOOK_LINEAR, HOOK_OTHER = -1, -2                 # log entries for whole-arena writes behind block writes
 
 	def __init__(self, node, name, tensor, blocks):
+		import weakref
 		self.node, self.name, self.tensor = node, name, tensor
+		# (tensor None: a host-side rehearsal drives onWrite / onIssue itself, tests/test_dp_gloo.py)
+		self.root = weakref.ref(tensor.gpudata.root) if tensor is not None else (lambda: None)
+		self.base = tensor.gpudata.ptr if tensor is not None else 0
 		self.blocks = sorted(blocks, key=lambda b: b[1])
 		self.starts = [b[1] for b in self.blocks]
 		self.end = self.blocks[-1][1] + self.blocks[-1][2]
 		self.log, self.previous = [], None           # block indices written this step / the step before
 		self.sequence = self.last = self.reducer = None
 		self.pos, self.armed, self.exact, self.done, self.busy = 0, [], True, False, False
+		self.relearn = False                         # this step left the learned pattern in a way that needs a new plan
 		self.launchedBytes = []                      # (tests, telemetry) bytes in flight after each write event of the step
 		self.steps = 0
+		self.listening = False
 
 	@classmethod
 	def attach(cls, node, name, tensor):
@@ -677,6 +751,14 @@ class ArenaWatcher:
 		watcher = cls(node, name, tensor, blocks)
 		lz.watch = watcher.onWrite
 		return watcher
+
+	def detach(self):
+		"""the arena was replaced (or is gone): its allocation no longer reports to this watcher"""
+		self.listen(False)
+		root = self.root()
+		if root is not None and root.lz is not None and root.lz.watch == self.onWrite:
+			root.lz.watch = None
+		self.tensor = None
 
 	# ---- called by lazy.writeBarrier with the byte range about to be written
 	def onWrite(self, lo, hi):
@@ -694,33 +776,108 @@ class ArenaWatcher:
 			if offset >= hi:
 				break
 			if offset + nbytes > lo:
-				self.blockWritten(idx)
+				self.blockWritten(idx, lo, hi)
 
-	def blockWritten(self, idx):
+	def blockWritten(self, idx, lo, hi):
 		self.log.append(idx)
 		if self.reducer is None:
 			return
-		self.report()                                 # what was armed by earlier writes has been issued by now
+		self.report()                                 # what was armed by earlier barriers AND has been issued since
 		name = self.blocks[idx][0]
-		if self.reducer.owner[name].launched:
-			raise RuntimeError(
-				"data-parallel overlap: gradient block %s was written after its bucket went to the all-reduce (the step does not "
-				"follow the write pattern learned from the first steps); set PUZZLE_MI355_DP_OVERLAP=0" % name)
+		bucket = self.reducer.owner[name]
+		if bucket.launched:
+			# not the learned step (e.g. a second backward pass before the update): take the bucket back, serve the step without
+			# further overlap, learn again
+			self.busy = True
+			try:
+				self.reducer.unlaunch(bucket)
+			finally:
+				self.busy = False
+			self.exact, self.armed, self.relearn = False, [], True
 		if self.exact and self.pos < len(self.sequence) and self.sequence[self.pos] == idx:
 			if self.last[idx] == self.pos:
-				self.armed.append(name)
+				self.armed.append([name, lo, hi, False])
+				self.listen(True)
 			self.pos += 1
 		else:
 			self.exact, self.armed = False, []       # a different step: nothing more goes out early
+			self.listen(False)
 		self.launchedBytes.append(sum(b.nbytes for b in self.reducer.buckets if b.launched))
 
-	def report(self):
-		armed, self.armed = self.armed, []
-		for name in armed:
-			self.reducer.variableReady(name)
+	# ---- called by the library binding after every queued call while blocks are armed (lib.issueWatchers)
+	def listen(self, on):
+		from puzzlelib_amd import lib
+		if on and not self.listening:
+			lib.issueWatchers.append(self.onIssue)
+		elif not on and self.listening:
+			lib.issueWatchers.remove(self.onIssue)
+		self.listening = on
+
+	def onIssue(self, name, args):
+		if self.busy:
+			return
+		import ctypes
+		base, end = self.base, self.base + self.end
+		for arg in args:
+			if type(arg) is int:
+				if base <= arg < end:
+					self.issued(arg - base)
+			elif isinstance(arg, ctypes.Array):
+				if getattr(arg, "_type_", None) is ctypes.c_void_p:
+					for ptr in arg:
+						if ptr is not None and base <= ptr < end:
+							self.issued(ptr - base)
+			elif isinstance(arg, ctypes.c_void_p):
+				if arg.value is not None and base <= arg.value < end:
+					self.issued(arg.value - base)
+
+	def issued(self, offset):
+		waiting = False
+		for entry in self.armed:
+			if entry[1] <= offset < entry[2]:
+				entry[3] = True
+			waiting = waiting or not entry[3]
+		if not waiting:
+			self.listen(False)
+
+	def report(self, everything=False):
+		"""hands the armed blocks whose write has been issued (at sumTensor: all of them) to the reducer"""
+		if everything:
+			from puzzlelib_amd import lazy
+			lazy.flushSmall()                         # queued small accumulates are issued now
+		ready = [entry for entry in self.armed if entry[3] or everything]
+		self.armed = [entry for entry in self.armed if not (entry[3] or everything)]
+		if not self.armed:
+			self.listen(False)
+		for entry in ready:
+			self.reducer.variableReady(entry[0])
 
 	def hook(self):
-		"""a whole-arena write behind block writes, before sumTensor: finish the exchange now (see the class comment)"""
+		"""a whole-arena write behind block writes, before sumTensor (see the class comment)"""
+		from puzzlelib_amd import lazy, lib
+		linear = lazy.writeOp == lib.OP_WEIGHT_DECAY
+		self.log.append(self.HOOK_LINEAR if linear else self.HOOK_OTHER)
+		if self.reducer is None:
+			return                                    # observed steps: hook, then one collective at sumTensor (the reference's order)
+		expected = self.exact and self.pos < len(self.sequence) and self.sequence[self.pos] == self.log[-1]
+		if linear and expected:
+			self.pos += 1
+			self.finish(asPass=True)
+			self.done = True
+			return
+		self.exact, self.relearn = False, True
+		self.armed = []
+		self.listen(False)
+		if linear or not any(b.launched for b in self.reducer.buckets):
+			# weight decay where none was learned: it may still trade places with the mean (it does in every learned step);
+			# nothing in flight: hook first, everything leaves at sumTensor
+			if linear:
+				self.finish(asPass=True)
+				self.done = True
+			return
+		print("[puzzlelib_amd.grid] rank %d: an unknown kernel wrote the whole gradient arena %r before sumTensor while buckets of "
+			  "this step were already being all-reduced: THIS step applies it to the mean gradients (exact only for a hook that "
+			  "is linear in the gradient); overlap is off from the next step on" % (self.node.index, self.name), file=sys.stderr, flush=True)
 		self.finish(asPass=True)
 		self.done = True
 
@@ -732,7 +889,7 @@ class ArenaWatcher:
 				self.node.plainSum(self.tensor)
 				return
 			if self.exact:
-				self.report()
+				self.report(everything=True)
 			if asPass:
 				lazy.disabled.add("gradscale")
 				try:
@@ -749,19 +906,27 @@ class ArenaWatcher:
 		if not self.done:
 			self.finish()
 		self.steps += 1
-		# learn: two consecutive steps with the same write sequence fix the plan
-		if self.reducer is None and self.log and self.log == self.previous:
+		self.armed = []
+		self.listen(False)
+		if self.reducer is not None and (self.relearn or not self.exact or (not self.done and self.pos != len(self.sequence))):
+			# the step was not the learned one (served without overlap from the point it differed): learn again
+			self.node.reducers.pop("auto:" + self.name, None)
+			self.sequence = self.last = self.reducer = None
+		# learn: two consecutive steps with the same write sequence fix the plan — unless they contain a whole-arena write of an
+		# unknown kernel (only hook-then-mean is exact for those: never overlapped)
+		if self.reducer is None and self.log and self.log == self.previous and self.HOOK_OTHER not in self.log:
 			self.sequence = list(self.log)
 			self.last = {}
 			for pos, idx in enumerate(self.sequence):
-				self.last[idx] = pos
+				if idx >= 0:
+					self.last[idx] = pos
 			order = [self.blocks[idx][0] for idx in sorted(self.last, key=self.last.get)]
 			order += [b[0] for i, b in enumerate(self.blocks) if i not in self.last]        # never written: with the last bucket
 			ops = self.node.reduceOps(self.tensor)
 			self.reducer = GradReducer(self.blocks, ops, self.node.gridsize, self.node.bucketBytes, order=order)
 			self.node.reducers["auto:" + self.name] = self.reducer          # (commSummary finds its telemetry)
 		self.previous, self.log = self.log, []
-		self.pos, self.armed, self.exact, self.done = 0, [], True, False
+		self.pos, self.exact, self.done, self.relearn = 0, True, False, False
 		if self.reducer is not None:
 			self.reducer.beginStep()
 		return True
@@ -770,23 +935,28 @@ class ArenaWatcher:
 # ---------------------------------------------------------------------------------------------- runGrid (Grid.py:4-35)
 class GridNode:
 	"""What runGrid hands each child process: its place in the grid and where the ranks meet (picklable; the live
-	RcclNodeInfo is made inside the child by `connect`)."""
+	RcclNodeInfo is made inside the child by `connect`). `portCell` (a shared integer made by runGrid): node 0 binds a port
+	the system picks and writes it there, the others read it — no port is chosen before somebody holds it."""
 
-	def __init__(self, index, gridsize, device, addr, port, bucketBytes=25 << 20):
+	def __init__(self, index, gridsize, device, addr, port, bucketBytes=25 << 20, portCell=None):
 		self.index, self.gridsize, self.device, self.addr, self.port, self.bucketBytes = index, gridsize, device, addr, port, bucketBytes
+		self.portCell = portCell
 
 	def connect(self):
-		return connectNode(self.index, self.gridsize, self.device, self.addr, self.port, self.bucketBytes)
+		return connectNode(self.index, self.gridsize, self.device, self.addr, self.port, self.bucketBytes, portCell=self.portCell)
 
 
-def generateGridInfo(size, devices=None):
+def generateGridInfo(size, devices=None, portCell=None):
 	"""Grid.py:15-22: one node description per process, device i for node i unless `devices` says otherwise"""
 	devices = list(range(size)) if devices is None else list(devices)
 	assert len(devices) >= size, "runGrid(size=%d) with %d devices" % (size, len(devices))
-	with socket.socket() as s:
-		s.bind(("127.0.0.1", 0))
-		port = s.getsockname()[1]
-	return [GridNode(index, size, devices[index], "127.0.0.1", port) for index in range(size)]
+	port = 0
+	if portCell is None:
+		# (a caller without a shared cell: a free port found now — another process may take it before node 0 binds it)
+		with socket.socket() as s:
+			s.bind(("127.0.0.1", 0))
+			port = s.getsockname()[1]
+	return [GridNode(index, size, devices[index], "127.0.0.1", port, portCell=portCell) for index in range(size)]
 
 
 def nodeRunner(target, nodeinfo, *args, **kwargs):
@@ -816,18 +986,29 @@ def runGrid(target, size, *args, devices=None, **kwargs):
 	`runGrid(target=train, size=2, verbose=True)`): one process per device, each running `target(nodeinfo, *args, **kwargs)`
 	with a nodeinfo that offers index / gridsize / device / meanValue / broadcastBuffer / sumTensor / close — here over RCCL.
 	Children are SPAWNED (the parent may hold a HIP context; a forked copy of it is not usable), so `target` must be
-	importable: a module-level function, as in the reference's scripts. A child that dies makes runGrid raise."""
+	importable: a module-level function, as in the reference's scripts. A child that dies makes runGrid raise: the others —
+	which would wait for it in the host group or inside a collective forever — are terminated (the reference's queue-based
+	launcher hangs there, Grid.py:105,119,129)."""
 	import multiprocessing
 	ctx = multiprocessing.get_context("spawn")
-	gridinfo = generateGridInfo(size, devices)
+	gridinfo = generateGridInfo(size, devices, portCell=ctx.Value("i", 0))
 	nodes = [ctx.Process(target=nodeRunner, args=(target, nodeinfo) + args, kwargs=kwargs) for nodeinfo in gridinfo]
 	for node in nodes:
 		node.start()
+	failed = []
+	while not failed and any(node.exitcode is None for node in nodes):
+		for node in nodes:
+			node.join(0.05)
+		failed = [(i, node.exitcode) for i, node in enumerate(nodes) if node.exitcode not in (None, 0)]
+	if failed:
+		for node in nodes:
+			if node.exitcode is None:
+				node.terminate()
 	for node in nodes:
 		node.join()
-	failed = [(i, node.exitcode) for i, node in enumerate(nodes) if node.exitcode != 0]
 	if failed:
-		raise RuntimeError("runGrid: node(s) %s exited with status %s" % ([i for i, _ in failed], [c for _, c in failed]))
+		raise RuntimeError("runGrid: node(s) %s exited with status %s (the other nodes were stopped)" % (
+			[i for i, _ in failed], [c for _, c in failed]))
 
 
 # ---------------------------------------------------------------------------------------------- process bootstrap
@@ -851,10 +1032,23 @@ def nodeFromEnv(bucketBytes=25 << 20):
 	return connectNode(rank, world, local, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, bucketBytes)
 
 
-def connectNode(rank, world, device, addr, port, bucketBytes=25 << 20):
+def connectNode(rank, world, device, addr, port, bucketBytes=25 << 20, portCell=None):
 	"""joins the host group of the grid and returns this rank's RcclNodeInfo (the RCCL id travels over the host group)"""
 	global hostGroup
-	hostGroup = HostGroup(rank, world, addr, port)
+	if portCell is not None and world > 1:
+		if rank == 0:
+			def publish(actual):
+				portCell.value = actual
+			hostGroup = HostGroup(rank, world, addr, 0, publish=publish)
+		else:
+			deadline = time.time() + 120.0
+			while portCell.value == 0:
+				if time.time() > deadline:
+					raise TimeoutError("node 0 of the grid never published its port")
+				time.sleep(0.01)
+			hostGroup = HostGroup(rank, world, addr, portCell.value)
+	else:
+		hostGroup = HostGroup(rank, world, addr, port)
 
 	from puzzlelib_amd.settings import Config
 	Config.deviceIdx = device

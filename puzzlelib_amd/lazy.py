@@ -34,6 +34,8 @@ from puzzlelib_amd import lib
 enabled = os.environ.get("PUZZLE_MI355_LAZY", "1") == "1"
 disabled = set(filter(None, os.environ.get("PUZZLE_MI355_LAZY_OFF", "").split(",")))      # individual patterns, for tests
 counters = {}                      # pattern name -> times taken (tests and tools read it)
+writeOp = None                     # element-wise op id whose operands are being fetched (gpuarray.eltwise): a watcher on a written
+                                   # allocation (State.watch) can tell a known kernel — the weight-decay hook — from an unknown write
 
 
 def count(name):

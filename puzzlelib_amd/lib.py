@@ -52,6 +52,10 @@ trace = []
 # The build container's tests use it to run the C ABI on host buffers (a numpy emulation that lives with the tests, not in
 # this package), so that the Python glue can be exercised with values where no GPU exists. Never set outside dry-run mode.
 callHook = None
+# Observers of ISSUED calls: each is called with (name, args) right after a device-facing entry returned. The data-parallel
+# arena watcher (grid.ArenaWatcher) uses it to learn that the launch writing a gradient block has actually been queued — a
+# write barrier alone only says that somebody asked for the address. Empty (one truth test per call) outside such a run.
+issueWatchers = []
 
 
 def _load():
@@ -264,6 +268,9 @@ def _bind(name, argtypes):
 		status = fn(*args)
 		if status != 0:
 			_raise(status, name)
+		if issueWatchers:
+			for watcher in tuple(issueWatchers):
+				watcher(name, args)
 
 	call.__name__ = name
 	return call
@@ -348,6 +355,9 @@ def _dry(name, argtypes):
 			else:
 				rec.append("obj")
 		trace.append((name, tuple(rec)))
+		if issueWatchers:
+			for watcher in tuple(issueWatchers):
+				watcher(name, args)
 
 	call.__name__ = name
 	return call

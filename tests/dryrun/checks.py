@@ -412,7 +412,7 @@ def dp_auto_overlap_sorted_arena():
 		trainer.step([data, labels])
 		net.reset()
 		per_step.append(names())
-	watcher = node.watchers["grad"]
+	watcher = node.watcherOf("grad")
 	assert watcher.reducer is not None and watcher.steps == 5
 	red = watcher.reducer
 	assert len(red.buckets) >= 4 and any(len(b.ranges) > 1 for b in red.buckets), "sorted-name arena -> scattered buckets"
@@ -442,7 +442,7 @@ def dp_auto_overlap_sorted_arena():
 
 
 def watcher_progress(node, trainer, data, labels, net):
-	watcher = node.watchers["grad"]
+	watcher = node.watcherOf("grad")
 	log = watcher.launchedBytes = []
 	trainer.step([data, labels])
 	net.reset()
@@ -472,10 +472,74 @@ def dp_auto_overlap_with_hook():
 	idx = {"comm": [i for i, (n, _) in enumerate(calls) if n.startswith("pz_comm_allreduce")],
 		   "decay": [i for i, (n, a) in enumerate(calls) if n == "pz_eltwise" and a[0] == lib.OP_WEIGHT_DECAY],
 		   "scale": [i for i, (n, a) in enumerate(calls) if n == "pz_eltwise" and a[0] == lib.OP_LINEAR]}
-	assert node.watchers["grad"].reducer is not None and idx["comm"] and len(idx["decay"]) == 1
+	assert node.watcherOf("grad").reducer is not None and idx["comm"] and len(idx["decay"]) == 1
 	assert max(idx["comm"]) < idx["decay"][0], "every collective is queued before the hook touches the gradients"
 	assert any(max(idx["comm"]) < i < idx["decay"][0] for i in idx["scale"]), "the mean is applied before the hook"
 	print("auto overlap with a whole-arena hook: %d collectives, mean pass, then the hook" % len(idx["comm"]))
+	node.close()
+
+
+def dp_auto_overlap_conv_bias():
+	"""one launch may take several arena write addresses before it is queued — convNdBackwardParams with the
+	fused bias path takes wgrad's and the bias gradient's (two barriers, then pz_conv2d_bwd_filter). A block is final only when
+	the launch that writes it was ISSUED: with buckets so small that every filter closes one by itself, no bucket's collective
+	may be queued before the last library call that carries an address inside that bucket. LeNet (convolutions with biases)
+	under the reference script's optimizer, sorted-name arena, no executor hook."""
+	import ctypes
+	optim.Optimizer.arenaLayout = "sorted"
+	node = singleRankNode()
+	node.bucketBytes = 256
+	np.random.seed(1234)
+	net = nets.loadLeNet(None)
+	opt = optim.MomentumSGD(learnRate=0.1, momRate=0.9, nodeinfo=node)
+	opt.setupOn(net, useGlobalState=True)
+	g = bound().gpuarray
+	trainer = optim.Trainer(net, optim.CrossEntropy(maxlabels=10), opt, batchsize=8)
+	data, labels = g.to_gpu(np.zeros((8, 1, 28, 28), np.float32)), g.to_gpu(np.zeros((8, ), np.int32))
+
+	arena = opt.grads.ary
+	base, end = arena.gpudata.ptr, arena.gpudata.ptr + arena.nbytes
+	seen = []                                  # (entry point, [arena byte offsets among its arguments]) of every call, in order
+
+	def observe(name, args):
+		offsets = []
+		for arg in args:
+			if type(arg) is int and base <= arg < end:
+				offsets.append(arg - base)
+			elif isinstance(arg, ctypes.Array) and getattr(arg, "_type_", None) is ctypes.c_void_p:
+				offsets += [ptr - base for ptr in arg if ptr is not None and base <= ptr < end]
+		seen.append((name, offsets, args))
+
+	lib.issueWatchers.append(observe)
+	for step in range(5):
+		del seen[:]
+		trainer.step([data, labels])
+		net.reset()
+	lib.issueWatchers.remove(observe)
+
+	watcher = node.watcherOf("grad")
+	red = watcher.reducer
+	assert red is not None and len(red.buckets) >= 6
+	fused = [i for i, (n, offs, _) in enumerate(seen) if n == "pz_conv2d_bwd_filter" and len(offs) == 2]
+	assert fused, "LeNet's filter-gradient launches carry the bias gradient's address too"
+
+	comm = [(i, n, args) for i, (n, _, args) in enumerate(seen) if n.startswith("pz_comm_allreduce")]
+	assert len(comm) == len(red.buckets)
+	early = 0
+	last_write = max(i for i, (n, offs, _) in enumerate(seen) if offs and not n.startswith(("pz_comm_", "pz_eltwise")))
+	for i, n, args in comm:
+		if n == "pz_comm_allreduce_sum_f32":
+			ranges = [(args[1] - base, args[1] - base + 4 * args[3])]
+		else:
+			ranges = [(4 * o, 4 * (o + c)) for o, c in zip(list(args[2]), list(args[3]))]
+		writers = [j for j, (m, offs, _) in enumerate(seen) if j <= last_write and not m.startswith("pz_comm_") and
+				   any(lo <= off < hi for off in offs for lo, hi in ranges)]
+		assert writers and max(writers) < i, "bucket %s was handed to the all-reduce at call %d, its last writer is call %d (%s)" % (
+			ranges, i, max(writers), seen[max(writers)][0])
+		early += i < last_write
+	assert early >= len(comm) // 2, "buckets still leave during backward: %d of %d" % (early, len(comm))
+	print("auto overlap, two barriers before one launch: %d buckets, %d left during backward, none before its writer was issued" % (
+		len(comm), early))
 	node.close()
 
 

@@ -61,6 +61,11 @@ def test_exchange_completes_before_a_hook_that_writes_the_whole_arena():
 	assert "then the hook" in run("dp_auto_overlap_with_hook")
 
 
+def test_a_bucket_never_leaves_before_the_launch_that_writes_it_was_issued():
+	"""two write barriers, then one launch (filter gradient + fused bias gradient): the filter's bucket waits for the launch"""
+	assert "none before its writer" in run("dp_auto_overlap_conv_bias")
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("size", [2, 8])
 def test_runGrid_runs_a_MultiGPUMnist_shaped_target(size):

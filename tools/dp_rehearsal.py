@@ -50,7 +50,7 @@ for _ in range(int(os.environ.get("PUZZLE_MI355_REHEARSE_STEPS", "3"))):
 	trainer.train(data, labels, random=False)
 
 if rank == 0:
-	watcher = getattr(nodeinfo, "watchers", {}).get("grad")
+	watcher = nodeinfo.watcherOf("grad") if hasattr(nodeinfo, "watcherOf") else None
 	np.savez(out, transport=np.array(getattr(nodeinfo, "transport", "single")),
 			 auto_buckets=np.array(len(watcher.reducer.buckets) if watcher is not None and watcher.reducer is not None else 0),
 			 auto_ranges=np.array(sum(len(b.ranges) for b in watcher.reducer.buckets) if watcher is not None and watcher.reducer is not None else 0),
