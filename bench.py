@@ -18,7 +18,10 @@ Prints ONE JSON line on rank 0 with the driver's contract plus
   cpu_baseline  the numpy oracle (a restatement of the reference's CPU algorithm, extended with backward) timed on this
                 host's cores on a bounded sample (rank 0, N == 1 only)
   dropin        the same step with the backend's lazy fusion switched off (one kernel per call, what a literal backend
-                does with this call sequence) and with the harness allowed to skip conv1's input gradient
+                does with this call sequence), with the harness allowed to skip conv1's input gradient, and with the 3x3 layers
+                forced onto the implicit GEMM (`winograd_off`: the number under SURVEY 8c's strict per-element bound)
+  single_gpu_same_run   (N > 1 only) rank 0 alone, the N = 1 configuration, timed in the same process right before the
+                data-parallel run — the N = 1 point of a scaling curve measured on the same box in the same minute
   configs       config 2 (Conv2D 3x3 64->128 56x56 b128, three passes, both kernel families) and config 3 (NiN b128 step)
 """
 import argparse, json, os, subprocess, sys, time
@@ -123,6 +126,18 @@ def spawnRanks(args):
 		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
 	codes = [p.wait() for p in procs]
 	sys.exit(max(codes))
+
+
+def convLayers(net):
+	"""every convolution layer of an engine.Net, residual branches included"""
+	def visit(layers):
+		for layer in layers:
+			if layer.kind == "resid":
+				for branch in layer.branches:
+					yield from visit(branch)
+			elif layer.kind == "conv":
+				yield layer
+	return list(visit(net.layers))
 
 
 def oomEvents(lib):
@@ -268,6 +283,36 @@ def main():
 	data = gpuarray.to_gpu(rng.randn(args.batch, 3, 224, 224).astype(np.float32))
 	labels = gpuarray.to_gpu(rng.randint(0, 1000, size=(args.batch, )).astype(np.int32))
 
+	# N > 1: the N = 1 point of the scaling curve from this very run — rank 0 trains a second, private copy of the network
+	# without a node (exactly the N = 1 configuration) while the other ranks wait at the host barrier
+	single = None
+	if world > 1:
+		if rank == 0 and os.environ.get("PUZZLE_MI355_BENCH_N1", "1") == "1":
+			np.random.seed(1234)
+			solo = nets.loadResNet(None, "50", actInplace=True, initscheme="he")
+			soloOpt = optim.Adam(alpha=1e-3)
+			soloOpt.setupOn(solo, useGlobalState=True)
+			soloTrainer = optim.Trainer(solo, optim.CrossEntropy(), soloOpt, batchsize=args.batch)
+			solo.trainMode()
+
+			def soloStep():
+				soloTrainer.step([data, labels])
+				solo.reset()
+			for _ in range(args.warmup):
+				soloStep()
+			lib.pz_device_sync()
+			t0 = time.perf_counter()
+			for _ in range(args.steps):
+				soloStep()
+			lib.pz_device_sync()
+			dt = time.perf_counter() - t0
+			single = {"value": args.batch * args.steps / dt, "unit": "images/sec", "ms_per_step": dt / args.steps * 1e3,
+					  "steps": args.steps, "warmup": args.warmup,
+					  "what": "rank 0 alone, no node, no exchange: bench.py --gpus 1 inside this process, before the %d-rank run" % world}
+			del soloTrainer, soloOpt, solo
+			bnd.memoryPool.freeHeld()
+		grid.barrier()
+
 	optimizer = optim.Adam(alpha=1e-3, nodeinfo=nodeinfo)
 	optimizer.setupOn(net, useGlobalState=True)
 	if nodeinfo is not None:
@@ -352,6 +397,17 @@ def main():
 		t_literal = timeSteps(step, n, lib, grid) / n
 		lazy.enabled = True
 		step()
+		# the sixteen 3x3 layers on the implicit GEMM in all three passes (what `auto` gives them is Winograd F(4x4) / F(2x2),
+		# held to |err| <= 6e-5 max|ref| instead of the per-element bound the implicit GEMM meets: `tolerance`)
+		igemm = (surf.Dnn.ConvFwdAlgo.implicitGemm, surf.Dnn.ConvBwdDataAlgo.implicitGemm, surf.Dnn.ConvBwdFilterAlgo.implicitGemm)
+		threes = [(layer, layer.cfg["algos"]) for layer in convLayers(net) if tuple(layer.params["W"].data.shape[2:]) == (3, 3)]
+		for layer, _ in threes:
+			layer.cfg["algos"] = igemm
+		step(); step()
+		t_igemm = timeSteps(step, n, lib, grid) / n
+		for layer, algos in threes:
+			layer.cfg["algos"] = algos
+		step()
 		dropin = {
 			"caller": "reference-literal call sequence through wrappers with the reference's signatures only "
 					  "(tests/golden/trace_resnet50_b8.json, recorded from the reference's own Python on this backend)",
@@ -359,6 +415,9 @@ def main():
 			"note": "this IS `value`: there is no patched caller any more; fusion is decided inside the backend",
 			"lazy_fusion_off": {"images_per_sec": world * args.batch / t_literal, "ms_per_step": t_literal * 1e3,
 								"what": "PUZZLE_MI355_LAZY=0: one kernel (or two) per reference call, nothing deferred"},
+			"winograd_off": {"images_per_sec": world * args.batch / t_igemm, "ms_per_step": t_igemm * 1e3, "layers": len(threes),
+							 "what": "the 3x3 stride-1 layers pinned to the implicit GEMM (forward, backward-data, backward-filter): every "
+									 "convolution of the step then meets |err| <= 1e-5*s + 1e-4*|ref| per element (tolerance.implicit_gemm_and_stem)"},
 			"harness_skips_conv1_input_grad": {"images_per_sec": world * args.batch / t_skip, "ms_per_step": t_skip * 1e3,
 											   "what": "engine.Net.skipInputGrad=True: updGrad=False honoured (the reference "
 													   "means to, Containers/Sequential.py:215-218 is unreachable)"},
@@ -410,6 +469,12 @@ def main():
 				"kernel": FAMILY[i], "launches": int(launches[i]), "avg_launch_ms": ms[i] / launches[i],
 				"total_ms_per_step": ms[i] / roof_steps, "achieved_tflops": flops[i] / (ms[i] * 1e-3) / 1e12
 			})
+			# fraction of the fp32-MFMA peak by FLOP the matrix pipe executes: all of them for the implicit GEMM families; for the
+			# Winograd family 1/4 of the forward + backward-data share (two of its three passes) and 1/2.25 of the backward-filter share
+			share = (2.0 / 3.0 / 4.0 + 1.0 / 3.0 / 2.25) if i == 3 else 1.0
+			fams[-1]["frac"] = fams[-1]["achieved_tflops"] * share / PEAK_F32_MFMA_TFLOPS
+			fams[-1]["frac_is"] = "executed FLOP / time / %.1f TFLOP/s" % PEAK_F32_MFMA_TFLOPS + (
+				" (direct-equivalent rate x %.4f)" % share if i == 3 else "")
 			if concurrent and timed[i][2] > 0:          # the same family inside the timed region, launches sharing the device
 				fams[-1]["timed_region_concurrent"] = {
 					"launches": int(timed[i][2]), "avg_launch_ms": timed[i][0] / timed[i][2],
@@ -514,6 +579,8 @@ def main():
 		},
 		"conv_kernel_families": fams,
 	}
+	if single is not None:
+		result["single_gpu_same_run"] = single
 	if dropin is not None:
 		result["dropin"] = dropin
 	if mathModes is not None:

@@ -12,6 +12,15 @@
  *   - no torch / Python types appear in any signature.
  *
  * Each group cites the reference interface it replaces (paths relative to puzzlelib/PuzzleLib).
+ *
+ * Stability. Entries declared plainly are the STABLE boundary: one per reference interface (SURVEY.md section 8b's list — device /
+ * memory / streams / events, pz_conv2d_{fwd,bwd_data,bwd_filter} + workspace and shape queries, pz_gemm, pz_bn_{fwd_train,fwd_infer,
+ * bwd}, pz_pool2d_*, pz_softmax_*, pz_cross_entropy, the reductions, pz_eltwise, casts, pz_rng_*, pz_comm_*, and the operators beside
+ * the hot path). Entries marked PZ_FUSED are PRIVATE to this build's own Python shim (puzzlelib_amd/dnn.py, fusion.py, kernels.py):
+ * fused or partial forms of the stable entries — an epilogue, a described operand, a statistics hand-over between two launches —
+ * whose buffers have layouts private to the library and whose signatures may change from build to build together with the shim.
+ * A third-party binding needs the stable entries only; every PZ_FUSED entry computes what a sequence of
+ * stable entries computes (tests/test_gpu_3_fusion.py holds them to that sequence, bit for bit where the summation order is kept).
  */
 #ifndef PUZZLE_MI355_H
 #define PUZZLE_MI355_H
@@ -22,6 +31,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define PZ_FUSED             /* marks entries private to the build's own shim (see "Stability" above) */
 
 typedef void *pz_stream_t;   /* hipStream_t */
 typedef void *pz_event_t;    /* hipEvent_t  */
@@ -109,17 +120,17 @@ int pz_conv2d_algo_used(const pz_conv_desc *d, int which, int algo, int *used);
 int pz_conv2d_workspace_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
 /* ... the same for a pass that is handed a prepared filter operand (pz_conv2d_fwd_pre / pz_conv2d_bwd_data_pre): only what
  * the launch itself needs (slabs of k-sliced tiles), not a second copy of the packed filters. */
-int pz_conv2d_workspace_bytes_pre(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
+PZ_FUSED int pz_conv2d_workspace_bytes_pre(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
 /* y = conv(x, w) (+ bias[k] when bias != NULL) */
 /* Activation epilogues (backend-internal fusion behind Conv2D -> Activation(relu), Modules/Activation.py:52-70): is the pass
  * served by a kernel that can apply them (implicit GEMM, output pixels contiguous per image)? */
-int pz_conv2d_epilogue_supported(const pz_conv_desc *d, int which, int algo, int *supported);
+PZ_FUSED int pz_conv2d_epilogue_supported(const pz_conv_desc *d, int which, int algo, int *supported);
 /* y = max(conv(x, w) + bias, 0); w, or packed = a prepared operand (pz_conv2d_prepack) with w ignored */
-int pz_conv2d_fwd_relu(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y, int algo,
+PZ_FUSED int pz_conv2d_fwd_relu(const pz_conv_desc *d, const float *x, const float *w, const void *packed, const float *bias, float *y, int algo,
                        void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* dx = bwd_data(dy, w) where gate > 0, else 0 (gate: dx's shape — the output of the ReLU in front of this convolution, whose
  * reluDer follows; Modules/Activation.py:58-60) */
-int pz_conv2d_bwd_data_gate(const pz_conv_desc *d, const float *dy, const float *w, const float *gate, float *dx, int algo,
+PZ_FUSED int pz_conv2d_bwd_data_gate(const pz_conv_desc *d, const float *dy, const float *w, const float *gate, float *dx, int algo,
                             void *workspace, size_t ws_bytes, pz_stream_t stream);
 int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                   int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
@@ -129,8 +140,8 @@ int pz_conv2d_fwd(const pz_conv_desc *d, const float *x, const float *w, const f
  * shift = the strip's first value of channel k. pz_conv2d_fwd_stats_strips reports the number of strips (0: this
  * configuration runs on a path that cannot produce them — call pz_conv2d_fwd and let the BN compute its own).  */
 #define PZ_CONV_STATS_STRIP 64
-int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips);
-int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+PZ_FUSED int pz_conv2d_fwd_stats_strips(const pz_conv_desc *d, int algo, int *strips);
+PZ_FUSED int pz_conv2d_fwd_stats(const pz_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                         float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* dx = conv^T(dy, w); dx has the (n,c,h,w) of the descriptor */
 int pz_conv2d_bwd_data(const pz_conv_desc *d, const float *dy, const float *w, float *dx,
@@ -146,11 +157,11 @@ typedef struct {
 	const float *w;
 	void *packed;
 } pz_prepack_job;
-int pz_conv2d_prepack_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
-int pz_conv2d_prepack(const pz_prepack_job *jobs, int njobs, pz_stream_t stream);
-int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed, const float *bias, float *y, float *stats,
+PZ_FUSED int pz_conv2d_prepack_bytes(const pz_conv_desc *d, int which, int algo, size_t *nbytes);
+PZ_FUSED int pz_conv2d_prepack(const pz_prepack_job *jobs, int njobs, pz_stream_t stream);
+PZ_FUSED int pz_conv2d_fwd_pre(const pz_conv_desc *d, const float *x, const void *packed, const float *bias, float *y, float *stats,
                       int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
-int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
+PZ_FUSED int pz_conv2d_bwd_data_pre(const pz_conv_desc *d, const float *dy, const void *packed, float *dx, int algo, void *workspace,
                            size_t ws_bytes, pz_stream_t stream);
 /* dw <- beta*dw + alpha*sum(x (x) dy); db (optional) <- beta*db + alpha*sum(dy): the accumulate contract of
  * MIOpen.py:414-433,441-455 (scale = alpha, momentum = beta) fused into the reduction epilogue. With the workspace of
@@ -184,8 +195,8 @@ int pz_conv_winograd_tile_get(int *tile);
  * (forward, backward-data and backward-filter of 3x3 stride-1 layers; F(4x4,3x3) / F(2x2,3x3) tiles, see pz_conv_winograd_tile_set). `total_flops` is the algorithmic (direct-convolution) count in every family; the Winograd
  * kernel executes 1/2.25 of it on the matrix pipe (times the padding of odd maps to whole 2x2 tiles).            */
 #define PZ_CONV_PROFILE_FAMILIES 4
-int pz_conv_profile_enable(int on);
-int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double total_flops[PZ_CONV_PROFILE_FAMILIES],
+PZ_FUSED int pz_conv_profile_enable(int on);
+PZ_FUSED int pz_conv_profile_collect(double total_ms[PZ_CONV_PROFILE_FAMILIES], double total_flops[PZ_CONV_PROFILE_FAMILIES],
                             long long launches[PZ_CONV_PROFILE_FAMILIES]);
 
 /* ---- GEMM: replaces BlasContext.gemm (Cuda/Source/Libs/CuBlas.c:327-402); row-major,
@@ -196,8 +207,8 @@ int pz_gemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const fl
  * would otherwise run on a handful of the 256 CUs); partial tiles are added in a fixed order, no atomics.
  * Batched GEMM (BlasContext.gemmBatched, CuBlas.c:308-312, both group formats) is a loop of these calls over the
  * groups: lda / ldb / ldc express the "bgp" layout directly.                                                      */
-int pz_gemm_workspace_bytes(int m, int n, int k, size_t *nbytes);
-int pz_gemm_ws(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda, const float *b, int ldb,
+PZ_FUSED int pz_gemm_workspace_bytes(int m, int n, int k, size_t *nbytes);
+PZ_FUSED int pz_gemm_ws(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a, int lda, const float *b, int ldb,
                float beta, float *c, int ldc, void *workspace, size_t ws_bytes, pz_stream_t stream);
 
 /* ---- batch normalisation (spatial): replaces DnnContext.batchNormNd / batchNormNdBackward
@@ -218,19 +229,19 @@ int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, 
  * (bn(x) > 0), re-created from x, scale, bias and the saved statistics — reluDer's rule (Cuda/Kernels/ElementWise.py
  * :119-172) without the two extra tensor passes. act = PZ_BN_ACT_NONE is pz_bn_fwd_train / pz_bn_bwd.            */
 enum pz_bn_act { PZ_BN_ACT_NONE = 0, PZ_BN_ACT_RELU = 1 };
-int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+PZ_FUSED int pz_bn_fwd_train_act(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
                         float *run_mean, float *run_var, float *save_mean, float *save_invvar,
                         float epsilon, float factor, int act, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* pz_bn_fwd_train_act with the statistics pass replaced by the producer's strip sums (pz_conv2d_fwd_stats): the
  * strips are merged per channel in fp64 with the pairwise (count, mean, M2) update, in a fixed order.            */
-int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
+PZ_FUSED int pz_bn_fwd_train_pre(const float *x, float *y, int n, int c, int hw, const float *scale, const float *bias,
                         float *run_mean, float *run_var, float *save_mean, float *save_invvar,
                         float epsilon, float factor, int act, const float *stats, int strips,
                         void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* pz_bn_bwd_act that also accumulates the parameter gradients where the optimiser reads them:
  * dscale_acc <- alpha*dscale + beta*dscale_acc (same for dbias_acc; either may be NULL) — BatchNormND.accGradParams
  * (Modules/BatchNormND.py:74-83, Blas.addVectorToVector with alpha = scale, beta = momentum) without its two launches. */
-int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+PZ_FUSED int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, float *dscale_acc, float *dbias_acc, float alpha, float beta,
                   void *workspace, size_t ws_bytes, pz_stream_t stream);
@@ -242,7 +253,7 @@ int pz_bn_bwd_acc(const float *x, const float *dy, float *dx, int n, int c, int 
  * pass.                                                                                                          */
 /* `mask` (optional, from pz_bn_apply_add_mask over the tensor y): the gate is read from one bit per element and y is not
  * touched (may be NULL) — 1/16 of the bytes; the same predicate, so the same results. */
-int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, const unsigned char *mask, float *gout, int n, int c,
+PZ_FUSED int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, const unsigned char *mask, float *gout, int n, int c,
                      int hw, const float *xa, const float *mean_a, float *part_a,
                      const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
 /* pz_bn_gate_stats whose two incoming gradients come from stride-2 pointwise convolutions (the first convolutions of a
@@ -250,10 +261,10 @@ int pz_bn_gate_stats(const float *g0, const float *g1, const float *y, const uns
  * ceil(w/2)) = the values at pixels (2i, 2j), every other pixel of the (n, c, h, w) gradients being zero. Same results,
  * bit for bit, as zero-filling them first; their backward-data passes write a quarter of the tensor (as a stride-1
  * problem on the compact grid) and nothing is memset. */
-int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, const unsigned char *mask, float *gout, int n,
+PZ_FUSED int pz_bn_gate_stats_up2(const float *g0c, const float *g1c, const float *y, const unsigned char *mask, float *gout, int n,
                          int c, int h, int w, const float *xa, const float *mean_a, float *part_a,
                          const float *xb, const float *mean_b, float *part_b, pz_stream_t stream);
-int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+PZ_FUSED int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                             const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                             float *dscale_acc, float *dbias_acc, float alpha, float beta, const float *partials,
                             pz_stream_t stream);
@@ -261,18 +272,18 @@ int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, i
  * Hip/Wrappers/MIOpen.py:634-664, minus writing y): statistics from the producing convolution's strip sums (`stats`,
  * pz_conv2d_fwd_stats) or, with stats == NULL, from a pass over x; saved / running statistics; coef[2k..2k+1] = {a, b} of
  * y = a*x + b for whoever reads the normalised tensor (pz_bn_apply_add). Workspace: pz_bn_workspace_bytes.            */
-int pz_bn_fwd_train_coef(const float *x, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
+PZ_FUSED int pz_bn_fwd_train_coef(const float *x, int n, int c, int hw, const float *scale, const float *bias, float *run_mean,
                          float *run_var, float *save_mean, float *save_invvar, float epsilon, float factor,
                          const float *stats, int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* pz_bn_bwd whose incoming gradient is first gated with (y > 0), y = a*x + b re-created from x with the forward's own
  * pairs `gate_coef` (pz_bn_fwd_train_coef): BatchNormND.backward + Activation(relu, inplace).backward of the reference
  * (Modules/BatchNormND.py:75-88, Modules/Activation.py:62-70) in one pair of passes.                                */
-int pz_bn_bwd_gate(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+PZ_FUSED int pz_bn_bwd_gate(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                    const float *save_mean, const float *save_invvar, float *dscale, float *dbias, const float *gate_coef,
                    void *workspace, size_t ws_bytes, pz_stream_t stream);
 /* the statistics pass of pz_bn_bwd alone: `partials` (pz_bn_workspace_bytes) in the layout pz_bn_bwd_coef /
  * pz_bn_bwd_from_partials consume                                                                                  */
-int pz_bn_bwd_stats(const float *x, const float *dy, int n, int c, int hw, const float *save_mean, float *partials,
+PZ_FUSED int pz_bn_bwd_stats(const float *x, const float *dy, int n, int c, int hw, const float *save_mean, float *partials,
                     pz_stream_t stream);
 /* BatchNorm backward folded into the gathers of the convolution in front of it (Conv2D -> BatchNorm2D, both backward):
  * pz_bn_bwd_coef turns the partial sums (pz_bn_gate_stats) into the parameter gradients and coef[4k..4k+2] = {A, B, C}
@@ -280,18 +291,35 @@ int pz_bn_bwd_stats(const float *x, const float *dy, int n, int c, int hw, const
  * pz_conv2d_bwd_filter whose `dy` operand is that expression evaluated on the fly from dy (the BN's incoming gradient)
  * and bnx (the BN's input = this convolution's forward output). The BN's 12 B/elem apply pass and its output tensor
  * disappear. Only for convolutions pz_conv2d_bn_fold_supported accepts (1x1, no padding, ungrouped, MFMA path).   */
-int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_mean, const float *save_invvar,
+PZ_FUSED int pz_bn_bwd_coef(int n, int c, int hw, const float *scale, const float *save_mean, const float *save_invvar,
                    float *dscale, float *dbias, float *dscale_acc, float *dbias_acc, float alpha, float beta,
                    const float *partials, float *coef, pz_stream_t stream);
 /* the same expression written out, dx = A*dy + (B*x + C), for a consumer that cannot fold it */
-int pz_bn_bwd_apply_coef(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *coef,
+PZ_FUSED int pz_bn_bwd_apply_coef(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *coef,
                          pz_stream_t stream);
-int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported);
-int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef,
+PZ_FUSED int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported);
+PZ_FUSED int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef,
                           const float *w, float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
-int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx,
+PZ_FUSED int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *dy, const float *bnx,
                             const float *bncoef, float *dw, float alpha, float beta, int algo,
                             void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* The backward twin of pz_conv2d_fwd_stats (round 6): the layer's input was y = relu(gab[c].x * gx + gab[c].y) — the ReLU output of
+ * the BatchNorm in front of it (conv -> bn -> relu -> THIS conv, Models/Nets/ResNet.py:27-33), so the gradient dx this launch
+ * produces goes through that ReLU's derivative and into that BatchNorm's backward next (Modules/Activation.py:62-70,
+ * Modules/BatchNormND.py:65-72; formulas Cuda/Wrappers/CuDnnNorm.py:55-63). The epilogue, holding the dx tile, reads the same tile
+ * of gx and leaves {sum q, sum q * (gx - gmean[c])}, q = dx * (y > 0), per channel in `partials` (pz_conv2d_bwd_data_bnstats_bytes
+ * bytes; the merged pair per channel where pz_bn_bwd_gate_from_partials / pz_bn_bwd_coef read it): the statistics pass of that
+ * BatchNorm's backward — two reads of tensors of dx's size — does not run. dx itself is stored ungated, as pz_conv2d_bwd_data
+ * stores it. bnx / bncoef: optional fold of the BatchNorm BEHIND the layer on the gathered side (pz_conv2d_bwd_data_bn), or NULL.
+ * Only for configurations with the contiguous-output epilogue (pz_conv2d_epilogue_supported; _bytes returns 0 otherwise). */
+PZ_FUSED int pz_conv2d_bwd_data_bnstats_bytes(const pz_conv_desc *d, int algo, size_t *nbytes);
+PZ_FUSED int pz_conv2d_bwd_data_bnstats(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
+                               float *dx, const float *gx, const float *gab, const float *gmean, float *partials, int algo,
+                               void *workspace, size_t ws_bytes, pz_stream_t stream);
+/* pz_bn_bwd_gate with the statistics pass already done (partials from pz_conv2d_bwd_data_bnstats): the apply pass alone */
+PZ_FUSED int pz_bn_bwd_gate_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                                 const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                                 const float *gate_coef, const float *partials, pz_stream_t stream);
 /* The mirror image on the forward side: a BatchNorm (+ in-place ReLU) whose only readers are the pointwise
  * convolution behind it — its forward and its filter gradient (conv -> bn -> relu -> conv 1x1 inside every bottleneck block of
  * Models/Nets/ResNet.py:27-33) — is never written: both passes read the BatchNorm's INPUT x and evaluate
@@ -299,10 +327,10 @@ int pz_conv2d_bwd_filter_bn(const pz_conv_desc *d, const float *x, const float *
  * of pz_bn_apply_add, so the results are bit-identical to convolving the written tensor). w or packed (pz_conv2d_prepack) as in
  * pz_conv2d_fwd_relu; stats as in pz_conv2d_fwd_stats (NULL: none); bnx / bncoef of pz_conv2d_bwd_filter_xbn are the optional
  * gradient-side fold of pz_conv2d_bwd_filter_bn (both NULL: dy is read as it is).                                          */
-int pz_conv2d_xbn_supported(const pz_conv_desc *d, int which, int algo, int *supported);
-int pz_conv2d_fwd_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *w, const void *packed,
+PZ_FUSED int pz_conv2d_xbn_supported(const pz_conv_desc *d, int which, int algo, int *supported);
+PZ_FUSED int pz_conv2d_fwd_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *w, const void *packed,
                       const float *bias, float *y, float *stats, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream);
-int pz_conv2d_bwd_filter_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *dy, const float *bnx,
+PZ_FUSED int pz_conv2d_bwd_filter_xbn(const pz_conv_desc *d, const float *x, const float *xcoef, int xrelu, const float *dy, const float *bnx,
                              const float *bncoef, float *dw, float alpha, float beta, int algo, void *workspace, size_t ws_bytes,
                              pz_stream_t stream);
 /* Deferred apply: for a BatchNorm whose only consumer is a residual Add (bn*_branch2c and the
@@ -310,17 +338,17 @@ int pz_conv2d_bwd_filter_xbn(const pz_conv_desc *d, const float *x, const float 
  * everything pz_bn_fwd_train_pre does except the pass over x and returns coef[2k..2k+1] = {a, b} of y = a*x + b;
  * pz_bn_apply_add computes out = act((a1*x1 + b1) + (coef2 ? a2*x2 + b2 : x2)) — or out = a1*x1 + b1 when x2 == NULL —
  * with the same fma and summation order as the unfused kernels (bit-identical), saving 8 B/elem per deferred BN. */
-int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float *bias, float *run_mean, float *run_var,
+PZ_FUSED int pz_bn_fwd_train_defer(int n, int c, int hw, const float *scale, const float *bias, float *run_mean, float *run_var,
                           float *save_mean, float *save_invvar, float epsilon, float factor, const float *stats,
                           int strips, float *coef, void *workspace, size_t ws_bytes, pz_stream_t stream);
-int pz_bn_apply_add(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
+PZ_FUSED int pz_bn_apply_add(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
                     int n, int c, int hw, int relu, pz_stream_t stream);
 /* ... also leaving the sign mask of the fused ReLU's output (pz_relu_mask_bytes bytes: one bit per element, a byte per 4
  * consecutive elements of a (n, channel) plane) for pz_bn_gate_stats, which then does not read `out` back. */
-int pz_relu_mask_bytes(int n, int c, int hw, size_t *nbytes);
-int pz_bn_apply_add_mask(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
+PZ_FUSED int pz_relu_mask_bytes(int n, int c, int hw, size_t *nbytes);
+PZ_FUSED int pz_bn_apply_add_mask(const float *x1, const float *coef1, const float *x2, const float *coef2, float *out,
                          unsigned char *mask, int n, int c, int hw, int relu, pz_stream_t stream);
-int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+PZ_FUSED int pz_bn_bwd_act(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
                   const float *bias, const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
                   int act, void *workspace, size_t ws_bytes, pz_stream_t stream);
 
@@ -340,8 +368,8 @@ int pz_pool2d_fwd(const pz_pool_desc *d, const float *x, float *y, uint8_t *inde
  * ReLU, while it stages the rows — the normalised tensor between Modules/BatchNorm2D.py, Modules/Activation.py (in place)
  * and Modules/MaxPool2D.py (the ResNet stem, Models/Nets/ResNet.py:88-96) is never written. Bit-identical to pz_bn_apply_add
  * followed by pz_pool2d_fwd. Only for the geometries pz_pool2d_fwd_bn_supported reports (max pooling, band kernel). */
-int pz_pool2d_fwd_bn_supported(const pz_pool_desc *d, int *supported);
-int pz_pool2d_fwd_bn(const pz_pool_desc *d, const float *x, const float *coef, int relu, float *y, uint8_t *index_ws,
+PZ_FUSED int pz_pool2d_fwd_bn_supported(const pz_pool_desc *d, int *supported);
+PZ_FUSED int pz_pool2d_fwd_bn(const pz_pool_desc *d, const float *x, const float *coef, int relu, float *y, uint8_t *index_ws,
                      pz_stream_t stream);
 /* x/y are only read for max pooling when index_ws == NULL (arg-max recomputed, first maximum wins) */
 int pz_pool2d_bwd(const pz_pool_desc *d, const float *dy, const float *x, const float *y, const uint8_t *index_ws,
@@ -426,10 +454,14 @@ int pz_eltwise(int op, size_t count, void *const *ptrs, int nptrs, const float *
 /* up to PZ_MULTI_ADD_MAX independent small `out = alpha*x + beta*y` (addKer, Cuda/Kernels/ElementWise.py:1017-1045) in one
  * launch, one workgroup per job: the per-layer parameter-gradient accumulates of BatchNormND.accGradParams              */
 #define PZ_MULTI_ADD_MAX 96
-int pz_multi_add(int njobs, float *const *out, const float *const *x, const float *const *y, const float *alpha,
+PZ_FUSED int pz_multi_add(int njobs, float *const *out, const float *const *x, const float *const *y, const float *alpha,
                  const float *beta, const unsigned *n, pz_stream_t stream);
 int pz_cast_i32_f32(float *out, const int32_t *in, size_t count, pz_stream_t stream);
 int pz_cast_f32_i32(int32_t *out, const float *in, size_t count, pz_stream_t stream);
+/* fp16 as a STORAGE type only (GPUArray.astype, Cuda/GPUArray.py:188-199; castFP32toFP16 / castFP16toFP32,
+ * Cuda/Kernels/ElementWise.py:1143-1156): IEEE half bit patterns, round to nearest even. No operator computes in fp16. */
+int pz_cast_f32_f16(uint16_t *out, const float *in, size_t count, pz_stream_t stream);
+int pz_cast_f16_f32(float *out, const uint16_t *in, size_t count, pz_stream_t stream);
 
 /* ---- RNG: replaces RandomNumberGenerator.fillInteger/fillUniform/fillNormal (Cuda/Source/Libs/CuRand.c:231-234).
  *      Counter-based Philox4x32-10; statistical parity only (the reference's XORWOW stream is not reproduced). */

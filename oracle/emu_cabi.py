@@ -30,6 +30,8 @@ class Emu:
 		self.blocks = {}          # address -> numpy uint8 buffer (kept alive; a released block stays readable, as on the device)
 		self.rngs = {}
 		self.calls = {}
+		import reftape
+		self.newState = reftape.LoggedState          # (a recording tape puts its own factory here: Tape.deviceState)
 
 	# ------------------------------------------------------------------ memory
 	def alloc(self, nbytes):
@@ -114,6 +116,14 @@ def pz_cast_i32_f32(o, i, count, stream):
 
 def pz_cast_f32_i32(o, i, count, stream):
 	V(o, count, np.int32)[:] = V(i, count, F).astype(np.int32)
+
+
+def pz_cast_f32_f16(o, i, count, stream):
+	V(o, count, np.float16)[:] = V(i, count, F).astype(np.float16)
+
+
+def pz_cast_f16_f32(o, i, count, stream):
+	V(o, count, F)[:] = V(i, count, np.float16).astype(F)
 
 
 # ---------------------------------------------------------------------------------------------------- convolution
@@ -251,6 +261,17 @@ def pz_conv2d_bwd_data_gate(d, dy, w, gate, dx, algo, ws, wsb, stream):
 
 def pz_conv2d_bwd_data_bn(d, dy, bnx, bncoef, w, dx, algo, ws, wsb, stream):
 	bwd_data_impl(d, dy, w, None, dx, bn=(bnx, bncoef))
+
+
+def pz_conv2d_bwd_data_bnstats(d, dy, bnx, bncoef, w, dx, gx, gab, gmean, partials, algo, ws, wsb, stream):
+	"""dx as pz_conv2d_bwd_data[_bn] stores it, and in `partials` the sums of the gated gradient q = dx * (gab.x * gx + gab.y > 0)
+	for the BatchNorm whose input gx is (the emulation's own partials layout: write_partials)"""
+	bwd_data_impl(d, dy, w, None, dx, bn=(bnx, bncoef) if bnx else None)
+	dd = desc(d)
+	n, c, hw = dd.n, dd.c, dd.h * dd.w
+	X = Fv(gx, n, c, hw)
+	q = (Fv(dx, n, c, hw) * (affine(X, gab, c) > 0)).astype(F)
+	write_partials(partials, q, X, gmean, c)
 
 
 def bwd_filter_impl(d, x, dy, dw, db, alpha, beta, bn=None):
@@ -543,6 +564,13 @@ def pz_bn_bwd_gate(x, dy, dx, n, c, hw, scale, save_mean, save_invvar, dscale, d
 	bn_bwd_impl(x, g, dx, n, c, hw, scale, save_mean, save_invvar, dscale, dbias)
 
 
+def pz_bn_bwd_gate_from_partials(x, dy, dx, n, c, hw, scale, save_mean, save_invvar, dscale, dbias, gate_coef, partials, stream):
+	X = Fv(x, n, c, hw)
+	g = (Fv(dy, n, c, hw) * (affine(X, gate_coef, c) > 0)).astype(F)
+	A, B, C = param_grads(c, n * hw, scale, save_mean, save_invvar, dscale, dbias, None, None, 1.0, 0.0, partials)
+	Fv(dx, n, c, hw)[...] = (A[None, :, None] * g + (B[None, :, None] * X + C[None, :, None])).astype(F)
+
+
 def pz_bn_bwd_acc(x, dy, dx, n, c, hw, scale, bias, save_mean, save_invvar, dscale, dbias, act, dscale_acc, dbias_acc, alpha, beta,
 				  ws, wsb, stream):
 	g = Fv(dy, n, c, hw)
@@ -689,21 +717,21 @@ def pz_multi_add(njobs, outs, xs, ys, alphas, betas, sizes, stream):
 # ---------------------------------------------------------------------------------------------------- RNG (statistical parity only)
 def pz_rng_create(seed, ref):
 	handle = EMU.alloc(8)
-	EMU.rngs[handle] = np.random.RandomState(int(seed) & 0xffffffff)
+	EMU.rngs[handle] = EMU.newState(seed)
 	out(ref, handle)
 
 
+# what a fill draws is written down in tests/reftape.py (DEVICE_DRAWS): the tapes regenerate these values on the GPU box
 def pz_rng_fill_u32(rng, o, count, stream):
-	V(o, count, np.uint32)[:] = EMU.rngs[rng].randint(0, 2 ** 32, size=count, dtype=np.uint64).astype(np.uint32)
+	V(o, count, np.uint32)[:] = EMU.rngs[rng].draw("u32", count)
 
 
 def pz_rng_fill_uniform(rng, o, count, stream):
-	V(o, count, F)[:] = 1.0 - EMU.rngs[rng].random_sample(count)
+	V(o, count, F)[:] = EMU.rngs[rng].draw("uniform", count)
 
 
 def pz_rng_fill_normal(rng, o, count, mean, stddev, stream):
-	V(o, count, F)[:] = EMU.rngs[rng].normal(mean, stddev, size=count)
-
+	V(o, count, F)[:] = EMU.rngs[rng].draw("normal", count, float(mean), float(stddev))
 
 
 # ---------------------------------------------------------------------------------------------------- beside the hot path (f3)
@@ -806,6 +834,25 @@ def pz_embed_bwd_params(words, grad, vocab, scale, tokens, embsize, stream):
 	w = V(words, tokens, np.int32)
 	rows = int(w.max()) + 1 if tokens else 0
 	R.embed_bwd_params(w, Fv(grad, tokens, embsize), Fv(vocab, max(rows, 1), embsize), scale)
+
+
+def pz_ctc_loss(probs, datalen, labels, offsets, order, seg_start, seg_label, seg_off, T, batch, vocab, blank, max_positions,
+				alphas, nll, grad, error, stream):
+	"""contract of the header: probs are softmax OUTPUTS; writes the forward variables, nll per sample, the gradient inside
+	datalen (the caller zero-filled the rest) and ADDS the summed nll to *error. The sort tables are the kernel's business."""
+	off = V(offsets, batch + 1, np.int32)
+	lengths = np.diff(off)
+	lab = V(labels, int(off[-1]), np.int32)
+	dl = V(datalen, batch, np.int32)
+	total, g, al = R.ctc_loss(Fv(probs, T, batch, vocab), dl, lab, lengths, blank, normalized=True)
+	Fv(alphas, al.size)[...] = al
+	# per-sample nll: the oracle returns their sum; each sample alone gives its own
+	per = Fv(nll, batch)
+	for b in range(batch):
+		one, _, _ = R.ctc_loss(Fv(probs, T, batch, vocab)[:, b:b + 1], dl[b:b + 1], lab[off[b]:off[b + 1]], lengths[b:b + 1], blank, normalized=True)
+		per[b] = one
+	Fv(grad, T, batch, vocab)[...] = g
+	Fv(error, 1)[0] += F(total)
 
 
 # ---------------------------------------------------------------------------------------------------- dispatch

@@ -44,10 +44,79 @@ TESTS = [
 	"Optimizers.RMSProp", "Optimizers.RMSPropGraves", "Optimizers.SMORMS3",
 	"Handlers.Trainer", "Handlers.Validator", "Handlers.Calculator",
 	"Models.Nets.LeNet", "Models.Nets.ResNet",
+	# the rest of the list Unittester.py:114-122 walks on HIP (round 6)
+	"Modules.Embedder", "Cost.CTC", "Models.Nets.NiN", "Models.Nets.VGG", "Models.Nets.Inception", "Models.Nets.UNet",
+	"Models.Nets.MiniYolo", "Models.Nets.WaveToLetter", "Passes.ConvertToGraph",
+	# the backend-boundary tests (parameterised by a backend object `bnd`, shared by the reference's CUDA and HIP
+	# backends) with bnd = this backend: Hip/Wrappers/MIOpenNorm.py and RocBlas.py import as they are; the others are the
+	# BOUNDARY table below
+	"Hip.Wrappers.MIOpenNorm", "Hip.Wrappers.RocBlas",
+	"Boundary.MIOpen", "Boundary.MatVec", "Boundary.Pool", "Boundary.Costs", "Boundary.Memory", "Boundary.PRelu", "Boundary.Pad",
+	"Boundary.Upsample", "Boundary.Embedder", "Boundary.CTC", "Boundary.GPUArray", "Boundary.Utils",
 ]
-# run and judged here, not replayed on the GPU: ResNet-50/101/152 with host-initialised parameters (0.9 GB of uploads); the
-# handlers' and Sequential's tests, which push 40-500 MB of random data through the net (their tapes would be that large)
-NO_TAPE = {"Models.Nets.ResNet", "Handlers.Trainer", "Handlers.Validator", "Handlers.Calculator", "Containers.Sequential"}
+NO_TAPE = set()
+# tests that assert nothing about values (forward / training smokes): their tapes carry audits — samples of the device arrays
+# the test drops (tests/reftape.py) — so that the replay on the MI355X has values to compare
+AUDIT = {"Models.Nets.ResNet", "Handlers.Trainer", "Handlers.Validator", "Handlers.Calculator", "Containers.Sequential",
+		 "Models.Nets.NiN", "Models.Nets.VGG", "Models.Nets.Inception", "Models.Nets.UNet", "Models.Nets.MiniYolo",
+		 "Models.Nets.WaveToLetter", "Models.Nets.LeNet", "Passes.ConvertToGraph"}
+# not runnable anywhere without files the reference does not ship (TestData/.gitignore): Models/Misc/RBM.py's unittest() loads
+# MNIST from ../../TestData; RNN / SpatialTf / Cast (fp16) are SURVEY section 2's out-of-scope modules
+
+# What Unittester.py runs under Hip/ are thin files that call the bnd-parameterised tests of Cuda/ with the HIP backend —
+# but their backendTest() first builds the REFERENCE's own kernel module from CUDA source strings (MatModule(backend) ->
+# backend.SourceModule(...), Cuda/Kernels/MatVec.py:382-384), which is the thing this backend replaces: here the test functions
+# get the backend's own module objects instead. (module, function, arguments: b = bnd, d = dtype, a = atol, c = calctype
+# float32, m:<attr> = that module object of bnd). "src": the function is taken out of a file that cannot be imported without
+# the reference's compiled Hip.Driver extension — only that function's definition is executed (nothing is copied anywhere).
+BOUNDARY = {   # (initmode 2 everywhere: the module objects exist from initKernels on, Cuda/GPUBackend.py:159-215)
+	# Hip/Wrappers/MIOpen.py:754-770
+	"Boundary.MIOpen": (1, [("Cuda.Wrappers.CuDnn", f, "bda") for f in (
+		"conv2dTest", "conv3dTest", "convGroupTest", "deconv2dTest", "deconv3dTest", "deconvGroupTest")] + [
+		("src:Hip/Wrappers/MIOpen.py", "maxpool2dTest", "bda"), ("Cuda.Wrappers.CuDnn", "softmax2dTest", "bda")]),
+	# Hip/Kernels/MatVec.py -> Cuda/Kernels/MatVec.py:382-425 (speed tests print timings only)
+	"Boundary.MatVec": (0, [("Cuda.Kernels.MatVec", "calcTest", "m:matmod da"), ("Cuda.Kernels.MatVec", "batchCalcTest", "m:matmod da")]),
+	"Boundary.Pool": (0, [("Cuda.Kernels.Pool", "poolTest", "m:poolmod"), ("Cuda.Kernels.Pool", "unpoolTest", "m:poolmod")]),
+	"Boundary.Costs": (1, [("Cuda.Kernels.Costs", "crossEntropyTest", "m:costmod"), ("Cuda.Kernels.Costs", "svmTest", "m:costmod")]),
+	"Boundary.Memory": (0, [("Cuda.Kernels.Memory", f, "b m:memmod d") for f in ("transposeTest", "moveAxisTest", "swapAxesTest", "depthConcatTest")]),
+	"Boundary.PRelu": (0, [("Cuda.Kernels.PRelu", "preluTest", "m:prelumod")]),
+	"Boundary.Pad": (0, [("Cuda.Kernels.Pad", "reflectpad1dTest", "m:padmod d"), ("Cuda.Kernels.Pad", "reflectpad2dTest", "m:padmod da")]),
+	"Boundary.Upsample": (0, [("Cuda.Kernels.Upsample", f, "m:upsamplemod") for f in (
+		"upsample2dNearestTest", "upsample2dLinearTest", "upsample3dNearestTest", "upsample3dLinearTest")]),
+	"Boundary.Embedder": (0, [("Cuda.Kernels.Embedder", "embedTest", "m:embedmod da")]),
+	"Boundary.CTC": (1, [("Cuda.Kernels.CTC", "ctcLossTest", "m:ctcmod")]),
+	# Hip/GPUArray.py:12-50, Hip/Utils.py:11-58
+	"Boundary.GPUArray": (0, [("Cuda.GPUArray", "arithmTest", "bd"), ("src:Hip/GPUArray.py", "memoryTest", "bd")]),
+	"Boundary.Utils": (2, [("Cuda.Utils", "shareMemTest", "bd"), ("src:Hip/Utils.py", "memCopyTest", "bd"), ("Cuda.Utils", "randomTest", "b")]),
+}
+
+
+def functionFromSource(relpath, fname, namespace):
+	"""the definition of ONE function of a reference file that cannot be imported here, executed in `namespace`"""
+	import ast
+	path = os.path.join("/root/reference", relpath)
+	tree = ast.parse(open(path).read(), filename=path)
+	node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == fname)
+	module = ast.Module(body=[node], type_ignores=[])
+	exec(compile(module, path, "exec"), namespace)
+	return namespace[fname]
+
+
+def runBoundary(name, getBackend):
+	import importlib, itertools
+	import numpy as np
+	_, steps = BOUNDARY[name]
+	bnd = getBackend(0, 2)
+	for dtype, atol in bnd.dtypesSupported():
+		for source, fname, pattern in steps:
+			if source.startswith("src:"):
+				fn = functionFromSource(source[4:], fname, {"np": np, "itertools": itertools, "GPUArray": bnd.GPUArray, "PoolMode": bnd.PoolMode})
+			else:
+				fn = getattr(importlib.import_module("PuzzleLib." + source), fname)
+			args = []
+			for token in pattern.replace("bda", "b d a").replace("bd", "b d").replace(" da", " d a").split():
+				args.append({"b": bnd, "d": dtype, "a": atol, "c": np.float32}[token] if not token.startswith("m:") else getattr(bnd, token[2:]))
+			fn(*args)
 
 
 def runOne(name, lazyOn, tapePath):
@@ -69,7 +138,9 @@ def runOne(name, lazyOn, tapePath):
 	import puzzlelib_amd.backend as ours
 	emu_cabi.install()
 
-	tape = reftape.Tape(name)
+	tape = reftape.Tape(name, audit=name in AUDIT)
+	if tapePath:
+		emu_cabi.EMU.newState = tape.deviceState
 
 	def getBackend(deviceIdx, initmode=0, logger=None):
 		real = ours.getBackend(deviceIdx, initmode, logger)
@@ -94,18 +165,35 @@ def runOne(name, lazyOn, tapePath):
 		return strict(a, b, rtol=max(rtol, 1e-4), atol=max(atol, 1e-5), **kw)
 	np.allclose = allclose
 
+	# the tests write scratch files relative to the working directory ("../TestData/embedder.hdf", Modules/Embedder.py:238)
+	import tempfile
+	scratch = tempfile.mkdtemp(prefix="reftest_cwd_")
+	os.makedirs(os.path.join(scratch, "run"))
+	os.chdir(os.path.join(scratch, "run"))
+
+	undo = tape.watchGenerator() if tapePath else (lambda: None)
 	np.random.seed(int(hashlib.sha1(name.encode()).hexdigest()[:8], 16))
-	mod = importlib.import_module("PuzzleLib." + name)
 	t0 = time.time()
-	mod.unittest()
+	if name in BOUNDARY:
+		mod = None
+		runBoundary(name, shim.getBackend)
+	else:
+		mod = importlib.import_module("PuzzleLib." + name)
+		mod.unittest()
 	dt = time.time() - t0
 	np.allclose = strict
+	undo()
+	os.chdir(ROOT)
+	import shutil
+	shutil.rmtree(scratch, ignore_errors=True)
 
 	from puzzlelib_amd import lazy
 	info = {"name": name, "seconds": round(dt, 1), "allclose_calls": relaxed[1], "allclose_relaxed": relaxed[0],
 			"cabi_calls": sum(emu_cabi.EMU.calls.values()), "cabi_entries": len(emu_cabi.EMU.calls), "fusions": dict(lazy.counters)}
 	if tapePath:
 		del mod
+		import gc
+		gc.collect()
 		tape.save(tapePath)
 		info["tape_ops"], info["tape_bytes"] = len(tape.ops), os.path.getsize(tapePath)
 	print("REFTEST " + json.dumps(info))
@@ -190,7 +278,7 @@ def main():
 			if "tape_ops" in f:
 				rep = row.get("replay")
 				line += " %6d KB  %s" % (f["tape_bytes"] // 1024, ("%d values equal" % rep["compared"]) if rep else "FAIL: %s" % row.get("replay_err"))
-				if rep and rep["compared"] > 0 and f["tape_bytes"] <= (1 << 20):
+				if rep and rep["compared"] > 0 and f["tape_bytes"] <= (3 << 20):
 					src = os.path.join(scratch, row["name"] + ".npz")
 					manifest[row["name"]] = {"sha1": hashlib.sha1(open(src, "rb").read()).hexdigest(), "ops": f["tape_ops"], "values": rep["compared"],
 										 "asserts": f["allclose_calls"], "relaxed": f["allclose_relaxed"], "fusions": f["fusions"]}
@@ -220,8 +308,10 @@ def main():
 		print("reftests: %d reference unit tests pass on the emulated C ABI (fused and literal), %d tapes reproduce and match the committed ones" % (
 			len(rows), len(manifest)))
 	else:
+		if args.only and os.path.exists(path):          # a partial run updates its own entries only
+			manifest = dict(json.load(open(path)), **manifest)
 		json.dump(manifest, open(path, "w"), indent=1, sort_keys=True)
-		print("wrote %d tapes to %s" % (len(manifest), OUT))
+		print("wrote %d tapes to %s" % (len(rows), OUT))
 	sys.exit(0 if ok else 1)
 
 

@@ -257,10 +257,19 @@ class Mi355Backend:
 		self.l1penaltyKer = EltwiseKernel(lib.OP_L1_PENALTY, 3, 1, "l1penaltyKer")
 		self.l1gradKer = EltwiseKernel(lib.OP_L1_GRAD, 3, 1, "l1gradKer")
 
-		def unsupported(*args, **kwargs):
-			raise NotImplementedError("this kernel is outside the implemented operator path (fp32-only backend)")
-
-		self.castFP16toFP32 = self.castFP32toFP16 = unsupported
+		# castFP16toFP32(outdata, indata) / castFP32toFP16(outdata, indata) — Cuda/Kernels/ElementWise.py:1143-1156, read by
+		# Modules/Cast.py:69-70. fp16 is a storage type here: the casts exist, no operator computes in it
+		def castKernel(name, entry, src, dst):
+			def cast(outdata, indata, slice=None, stream=None):
+				if slice is not None or outdata.dtype != dst or indata.dtype != src or outdata.size != indata.size or \
+						not (outdata.contiguous and indata.contiguous):
+					raise ValueError("%s(outdata %s, indata %s): contiguous %s -> %s arrays of one size, no slice" % (
+						name, outdata.dtype, indata.dtype, np.dtype(src).name, np.dtype(dst).name))
+				entry(outdata.optr, indata.rptr, indata.size, None if stream is None else stream.handle)
+			cast.__name__ = name
+			return cast
+		self.castFP16toFP32 = castKernel("castFP16toFP32", lib.pz_cast_f16_f32, np.float16, np.float32)
+		self.castFP32toFP16 = castKernel("castFP32toFP16", lib.pz_cast_f32_f16, np.float32, np.float16)
 		# point-wise cost kernels with the reference's positional arguments (Cuda/Kernels/Costs.py:8-72)
 		self.bceKer = PointwiseCost(lib.COST_BCE, "bceKer")
 		self.hingeKer = PointwiseCost(lib.COST_HINGE, "hingeKer")

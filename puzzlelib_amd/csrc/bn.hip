@@ -1019,6 +1019,21 @@ int pz_bn_bwd_from_partials(const float *x, const float *dy, float *dx, int n, i
 	return PZ_OK;
 }
 
+// pz_bn_bwd_gate when the statistics pass is already done: `partials` carry {sum q, sum q*(x - mean)} of the GATED gradient
+// q = dy * (relu(a x + b) > 0) — left by the backward-data launch that produced dy (pz_conv2d_bwd_data_bnstats). One pass.
+int pz_bn_bwd_gate_from_partials(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale,
+                                 const float *save_mean, const float *save_invvar, float *dscale, float *dbias,
+                                 const float *gate_coef, const float *partials, pz_stream_t stream) {
+	if (int rc = bn_check(n, c, hw)) return rc;
+	PZ_REQUIRE(x && dy && dx && scale && save_mean && save_invvar && dscale && dbias && gate_coef && partials,
+	           "pz_bn_bwd_gate_from_partials: null tensor");
+	const BnGeom g = bn_geom(n, c, hw);
+	bn_bwd_apply_kernel<true><<<dim3(c, g.splits), 256, 0, pz::as_stream(stream)>>>(
+	    x, dy, dx, g, partials, scale, nullptr, save_mean, save_invvar, dscale, dbias, nullptr, nullptr, 1.f, 0.f, gate_coef);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
 int pz_bn_bwd(const float *x, const float *dy, float *dx, int n, int c, int hw, const float *scale, const float *save_mean,
               const float *save_invvar, float *dscale, float *dbias, void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	return pz_bn_bwd_act(x, dy, dx, n, c, hw, scale, nullptr, save_mean, save_invvar, dscale, dbias, PZ_BN_ACT_NONE, workspace,

@@ -329,6 +329,15 @@ struct IgemmArgs {
 	// normalised output was never written (Conv2D 1x1 behind BatchNorm2D + Activation(relu), Models/Nets/ResNet.py:27-33)
 	const float2 *xbn;
 	int xbn_relu;
+	// backward-data launches whose output is the gradient w.r.t. y = relu(gab[c].x * gx + gab[c].y) — the ReLU output of the
+	// BatchNorm in FRONT of this layer, never written (pz_conv2d_bwd_data_bnstats): the epilogue, which holds the gradient
+	// tile, reads the same tile of gx and leaves per channel row and 64-pixel strip {sum q, sum q * (gx - gmean[c])} with
+	// q = dx * (y > 0) in gst[channel * stat_strips + strip] — the statistics pass of that BatchNorm's backward
+	// (bn_bwd_stats_kernel<true>: two more reads of tensors of this size) disappears
+	const float *gx;
+	const float2 *gab;
+	const float *gmean;
+	float2 *gst;
 };
 
 // D[row][col] of one workgroup tile -> output tensor. col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -445,6 +454,38 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 					for (int e = 0; e < 4; ++e) v[e] = v[e] * (v[e] > 0.f ? 1.f : 0.f);
 				}
 
+				if (a.gst) {                     // (wave-uniform) q = v * (relu(bn(gx)) > 0): sums for that BatchNorm's backward
+					const int cg = g * a.M + min(ch, a.M - 1);
+					const float2 ab = a.gab[cg];
+					const float mu = a.gmean[cg];
+					const __amdgpu_buffer_rsrc_t gxr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gx, 0, a.y_bytes, 0x00020000);
+					const unsigned gchan = (unsigned)(g * a.M + ch) * (unsigned)PQ;
+					float s1 = 0.f, s2 = 0.f;
+					if (whole) {
+						const unsigned off = row_ok ? (((unsigned)n_img * a.OC_total) * (unsigned)PQ + gchan + pq) * 4u : kOOB;
+						const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gxr, off, 0, 0));
+#pragma unroll
+						for (int e = 0; e < 4; ++e) {
+							const float q = __builtin_fmaf(xv[e], ab.x, ab.y) > 0.f ? v[e] : 0.f;      // bn_gate<true>'s form
+							s1 += q;
+							s2 = __builtin_fmaf(q, xv[e] - mu, s2);
+						}
+					} else {
+#pragma unroll
+						for (int e = 0; e < 4; ++e) {
+							const int o = opix + e;
+							const int n2 = o / PQ, pq2 = o - n2 * PQ;
+							const bool ok = row_ok && e < nvalid;
+							const float xe = buf_load_f32(gxr, ok ? (((unsigned)n2 * a.OC_total) * (unsigned)PQ + gchan + pq2) * 4u : kOOB, 0);
+							const float q = (ok && __builtin_fmaf(xe, ab.x, ab.y) > 0.f) ? v[e] : 0.f;
+							s1 += q;
+							s2 = __builtin_fmaf(q, xe - mu, s2);
+						}
+					}
+					s1 = row16_sum(s1), s2 = row16_sum(s2);             // (every lane of the row holds them; its first lane stores)
+					if (c16 == 0 && row_ok && strip0 < a.npix) a.gst[(size_t)(g * a.M + ch) * a.stat_strips + strip0 / 64] = make_float2(s1, s2);
+				}
+
 				if (a.stats) {                   // (wave-uniform)
 					const float shift = __shfl(v[0], lane & ~15);      // first pixel of the strip, same for the row's 16 lanes
 					float s1 = 0.f, s2 = 0.f;
@@ -504,7 +545,7 @@ __device__ __forceinline__ void igemm_store_tile_lds(const IgemmArgs &a, int tm,
 // registers (3 waves per SIMD instead of 4); tools/probes/igemm_pipe.hip variant V3 measured it at +4..6 % from 3 to 24
 // tiles per CU (profiles/r04_igemm_pipe_probe.txt). Same products in the same order: bit-identical results.
 template <int BM, int BN, int WM, int WN, bool TAPMAJOR, bool BNX = false, bool PF2 = false, bool XBN = false>
-__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((BNX && WM * WN == 4) || PF2 ? 3 : 4, 8)))
+__global__ void __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu((BNX && WM * WN == 4 && BM != 64) || PF2 ? 3 : 4, 8)))
 igemm_conv_kernel(IgemmArgs a) {
 	static_assert(!BNX || TAPMAJOR, "the BatchNorm-backward gather rides on the tap-major order");
 	static_assert(!XBN || (TAPMAJOR && !BNX && !PF2), "the BatchNorm-forward gather: tap-major, plain loop");
@@ -2563,9 +2604,61 @@ int pz_conv2d_bn_fold_supported(const pz_conv_desc *d, int algo, int *supported)
 	return PZ_OK;
 }
 
+struct DgradBnStats {       // pz_conv2d_bwd_data_bnstats: the BatchNorm in front of the layer (IgemmArgs::gx ...) and where its sums go
+	const float *gx, *gab, *gmean;
+	float *partials;
+};
+
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
                                 float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed = nullptr,
-                                const float *gate = nullptr);
+                                const float *gate = nullptr, const DgradBnStats *bst = nullptr);
+
+// strip sums of a backward-data epilogue -> the merged pair per channel, in fp64 and a fixed order, where the BatchNorm
+// backward kernels read them (bn.hip: bn_merge — 2 c doubles at the head of the partials buffer)
+__global__ void __launch_bounds__(256) dgrad_bnstats_merge_kernel(const float2 *__restrict__ gst, int strips, double *__restrict__ merged) {
+	__shared__ double ra[256], rb[256];
+	const int ch = blockIdx.x, tid = threadIdx.x;
+	double sa = 0.0, sb = 0.0;
+	for (int i = tid; i < strips; i += 256) {
+		const float2 v = gst[(size_t)ch * strips + i];
+		sa += (double)v.x, sb += (double)v.y;
+	}
+	ra[tid] = sa, rb[tid] = sb;
+	__syncthreads();
+	for (int h = 128; h > 0; h >>= 1) {
+		if (tid < h) ra[tid] += ra[tid + h], rb[tid] += rb[tid + h];
+		__syncthreads();
+	}
+	if (tid == 0) merged[2 * ch] = ra[0], merged[2 * ch + 1] = rb[0];
+}
+
+static size_t dgrad_bnstats_head_bytes(int c) { return align256((size_t)c * 2 * sizeof(double)); }
+
+int pz_conv2d_bwd_data_bnstats_bytes(const pz_conv_desc *d, int algo, size_t *nbytes) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_bwd_data_bnstats_bytes: null output");
+	int ok = 0;
+	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_BWD_DATA, algo, &ok)) return rc;
+	// 0: this configuration has no such epilogue (Winograd / strided / direct forms)
+	*nbytes = ok ? dgrad_bnstats_head_bytes(d->c) + (size_t)d->c * pz::ceil_div((long)d->n * d->h * d->w, PZ_CONV_STATS_STRIP) * sizeof(float2) : 0;
+	return PZ_OK;
+}
+
+int pz_conv2d_bwd_data_bnstats(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
+                               float *dx, const float *gx, const float *gab, const float *gmean, float *partials, int algo,
+                               void *workspace, size_t ws_bytes, pz_stream_t stream) {
+	int P, Q;
+	if (int rc = check_desc(d, &P, &Q)) return rc;
+	int ok = 0;
+	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_BWD_DATA, algo, &ok)) return rc;
+	PZ_REQUIRE(ok, "pz_conv2d_bwd_data_bnstats: this configuration has no statistics epilogue (pz_conv2d_bwd_data_bnstats_bytes)");
+	PZ_REQUIRE(gx && gab && gmean && partials, "pz_conv2d_bwd_data_bnstats: null BatchNorm operand");
+	PZ_REQUIRE((bnx == nullptr) == (bncoef == nullptr), "pz_conv2d_bwd_data_bnstats: the gradient-side fold needs both its operands");
+	PZ_REQUIRE(bnx == nullptr || bn_fold_eligible(d, P, Q, algo), "pz_conv2d_bwd_data_bnstats: this convolution cannot fold a BatchNorm backward");
+	const DgradBnStats bst{gx, gab, gmean, partials};
+	return conv2d_bwd_data_impl(d, dy, bnx, bncoef, w, dx, algo, workspace, ws_bytes, stream, nullptr, nullptr, &bst);
+}
 
 int pz_conv2d_bwd_data_gate(const pz_conv_desc *d, const float *dy, const float *w, const float *gate, float *dx, int algo,
                             void *workspace, size_t ws_bytes, pz_stream_t stream) {
@@ -2597,7 +2690,7 @@ int pz_conv2d_bwd_data_bn(const pz_conv_desc *d, const float *dy, const float *b
 
 static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const float *bnx, const float *bncoef, const float *w,
                                 float *dx, int algo, void *workspace, size_t ws_bytes, pz_stream_t stream, const void *packed,
-                                const float *gate) {
+                                const float *gate, const DgradBnStats *bst) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(dy && (w || packed) && dx, "pz_conv2d_bwd_data: null tensor");
@@ -2695,9 +2788,20 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		a.gate = gate;
 		PZ_REQUIRE(gate == nullptr || a.contig, "pz_conv2d_bwd_data_gate: output pixels are not contiguous");
 		a.x2 = bnx, a.xcoef = reinterpret_cast<const float4 *>(bncoef);
+		if (bst) {
+			PZ_REQUIRE(a.contig && nc == 1, "pz_conv2d_bwd_data_bnstats: output pixels are not contiguous");
+			a.gx = bst->gx, a.gab = reinterpret_cast<const float2 *>(bst->gab), a.gmean = bst->gmean;
+			a.gst = reinterpret_cast<float2 *>((char *)bst->partials + dgrad_bnstats_head_bytes(d->c));
+			a.stat_strips = pz::ceil_div((long)a.npix, PZ_CONV_STATS_STRIP);
+		}
 		run_igemm(p, a, slabs, d->groups, st, flops_total * ((double)c.Pv * c.Qv * c.Rc * c.Sc) / gemm_total);
 		PZ_LAUNCH_CHECK();
+		if (bst) {
+			dgrad_bnstats_merge_kernel<<<d->c, 256, 0, st>>>(a.gst, a.stat_strips, reinterpret_cast<double *>(bst->partials));
+			PZ_LAUNCH_CHECK();
+		}
 	}
+	PZ_REQUIRE(bst == nullptr || nc == 1, "pz_conv2d_bwd_data_bnstats: no implicit-GEMM launch took the statistics");
 	return PZ_OK;
 }
 

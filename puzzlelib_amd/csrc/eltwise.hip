@@ -185,6 +185,16 @@ __global__ void __launch_bounds__(256) cast_f32_i32_kernel(int32_t *out, const f
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (int32_t)in[i];
 }
 
+// storage casts between fp32 and fp16 (GPUArray.astype, castFP32toFP16 / castFP16toFP32 of Cuda/Kernels/ElementWise.py:1143-1156):
+// round-to-nearest-even like numpy; arithmetic stays fp32 everywhere
+__global__ void __launch_bounds__(256) cast_f32_f16_kernel(_Float16 *out, const float *in, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (_Float16)in[i];
+}
+
+__global__ void __launch_bounds__(256) cast_f16_f32_kernel(float *out, const _Float16 *in, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+
 template <typename OP>
 int launch(const EltArgs &a, int nptrs, int nscalars, int need_scalars, bool dense, hipStream_t st) {
 	PZ_REQUIRE(nptrs == OP::NP, "pz_eltwise: op expects %d operands, got %d", OP::NP, nptrs);
@@ -334,6 +344,20 @@ int pz_cast_i32_f32(float *out, const int32_t *in, size_t count, pz_stream_t str
 int pz_cast_f32_i32(int32_t *out, const float *in, size_t count, pz_stream_t stream) {
 	if (count == 0) return PZ_OK;
 	cast_f32_i32_kernel<<<pz::stream_grid(count, 256), 256, 0, pz::as_stream(stream)>>>(out, in, count);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_cast_f32_f16(uint16_t *out, const float *in, size_t count, pz_stream_t stream) {
+	if (count == 0) return PZ_OK;
+	cast_f32_f16_kernel<<<pz::stream_grid(count, 256), 256, 0, pz::as_stream(stream)>>>((_Float16 *)out, in, count);
+	PZ_LAUNCH_CHECK();
+	return PZ_OK;
+}
+
+int pz_cast_f16_f32(float *out, const uint16_t *in, size_t count, pz_stream_t stream) {
+	if (count == 0) return PZ_OK;
+	cast_f16_f32_kernel<<<pz::stream_grid(count, 256), 256, 0, pz::as_stream(stream)>>>(out, (const _Float16 *)in, count);
 	PZ_LAUNCH_CHECK();
 	return PZ_OK;
 }

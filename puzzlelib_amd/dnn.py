@@ -347,6 +347,29 @@ class DnnContext:
 		return ws          # (the caller may have to keep it from being handed out again: markBeforeBackwardData)
 
 
+	def backwardStatsTarget(self, desc, algo, data):
+		"""(x, coef, mean, bytes of the partials) when `data` — the input of the layer whose backward-data is about to run — is
+		y = relu(a x + b), the described (or written) output of a BatchNorm over x with known coefficients and saved mean, and
+		the launch has the statistics epilogue (pz_conv2d_bwd_data_bnstats); else None"""
+		if not isinstance(data, GPUArray) or data.ndim != 4:
+			return None
+		info = lazy.fact(data, "bnapply")
+		if info is None:
+			waiting = lazy.pending(data, fusion.BnApply)
+			info = None if waiting is None else (waiting.x, waiting.coef, waiting.relu)
+		if info is None or not info[2] or tuple(info[0].shape) != tuple(data.shape):
+			return None
+		mean = lazy.fact(info[0], "bnsaved")
+		if mean is None:
+			return None
+		nbytes = desc.geo.get((lib.CONV_BWD_DATA, algo, "bst"))
+		if nbytes is None:
+			size = c_size_t(0)
+			lib.pz_conv2d_bwd_data_bnstats_bytes(byref(desc), algo, byref(size))
+			nbytes = desc.geo[(lib.CONV_BWD_DATA, algo, "bst")] = size.value
+		return (info[0], info[1], mean, nbytes) if nbytes > 0 else None
+
+
 	def epilogueSupported(self, desc, which, algo):
 		"""can this pass take an activation into its epilogue (pz_conv2d_fwd_relu / pz_conv2d_bwd_data_gate)?"""
 		hit = desc.geo.get((which, algo, "epi"))
@@ -449,7 +472,27 @@ class DnnContext:
 
 		# the gradient is the un-written input gradient of a BatchNorm (fusion.BnBwdApply): evaluate it while gathering
 		bn = lazy.pending(grad, fusion.BnBwdApply) if lazy.on("bnbwdfold") else None
-		if bn is not None and foldable:
+		bst = self.backwardStatsTarget(desc, algo, data) if (lazy.on("dgradstats") and not given and bias is None) else None
+		if bst is not None:
+			# this layer read y = relu(bn(x)), never written: its input gradient goes through that ReLU's derivative and into that
+			# BatchNorm's backward next — the epilogue that holds the gradient tile sums the gated gradient's statistics
+			x2, coef2, mean2, nbytes = bst
+			fold = bn is not None and foldable
+			if not fold:
+				self.markBeforeBackwardData(grad, W, data)
+			parts = GPUArray.empty((nbytes, ), dtype=np.uint8, allocator=allocator)
+			ws = self.workspace(wsbytes, allocator)
+			lib.pz_conv2d_bwd_data_bnstats(
+				byref(desc), bn.dy.rptr if fold else grad.rptr, bn.x.rptr if fold else None, fusion.raw(bn.coef) if fold else None,
+				W.rptr, out.optr, x2.rptr, fusion.raw(coef2), mean2.rptr, parts.optr, algo, rptrOf(ws), wsbytes, None
+			)
+			lazy.setFact(out, "gatedparts", (data, x2, coef2, mean2, parts), sources=(x2, mean2))
+			lazy.count("dgrad_bnstats")
+			if fold:
+				lazy.count("dgrad_bn_fold")
+			elif self.earlyReady is not None:
+				self.earlyReady += (ws, )
+		elif bn is not None and foldable:
 			ws = self.workspace(wsbytes, allocator)
 			lib.pz_conv2d_bwd_data_bn(
 				byref(desc), bn.dy.rptr, bn.x.rptr, fusion.raw(bn.coef), W.rptr, out.optr, algo, rptrOf(ws), wsbytes, None
@@ -894,6 +937,16 @@ class DnnContext:
 			if desc is None:
 				waiting = lazy.pending(gate.y, fusion.BnApply)
 				desc = None if waiting is None else (waiting.x, waiting.coef, waiting.relu)
+			parts = gate.parts if desc is not None and lazy.on("dgradstats") else None
+			if parts is not None and desc[2] and lazy.sameBuffer(desc[0], data) and lazy.sameBuffer(parts[1], data) and \
+					parts[2] is desc[1] and lazy.sameBuffer(parts[3], savemean):
+				# the backward-data launch that wrote this gradient summed the gated gradient's statistics in its epilogue
+				lib.pz_bn_bwd_gate_from_partials(
+					data.rptr, lazy.rawRead(grad), out.optr, n, c, hw, scale.rptr, savemean.rptr, saveinvvar.rptr,
+					scalegrad.optr, bgrad.optr, fusion.raw(desc[1]), fusion.raw(parts[4]), None
+				)
+				lazy.count("bn_bwd_gate_from_partials")
+				return out, scalegrad, bgrad
 			if desc is not None and desc[2] and lazy.sameBuffer(desc[0], data):
 				ws, nbytes = self.bnWorkspace(n, c, hw, allocator)
 				lib.pz_bn_bwd_gate(

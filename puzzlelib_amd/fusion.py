@@ -101,13 +101,15 @@ class BnBwdApply(Thunk):
 
 
 class Gate(Thunk):
-	"""In place: the buffer holds g, its value is g * (y > 0)."""
+	"""In place: the buffer holds g, its value is g * (y > 0). `parts`: (y, x, coef, mean, partials) when the backward-data launch
+	that wrote g already summed {q, q (x - mean)} of the gated gradient for the BatchNorm y = relu(coef.a x + coef.b) came out of
+	(dnn.convNdBackwardData, pz_conv2d_bwd_data_bnstats) — that BatchNorm's backward then needs no statistics pass."""
 
-	def __init__(self, y):
-		self.y = y
+	def __init__(self, y, parts=None):
+		self.y, self.parts = y, parts
 
 	def inputs(self):
-		return (self.y, )
+		return (self.y, ) if self.parts is None else (self.y, self.parts[1], self.parts[3])
 
 	def run(self, out):
 		ptrs = (ctypes.c_void_p * 3)(out.gpudata.ptr, out.gpudata.ptr, self.y.rptr)

@@ -413,6 +413,10 @@ class GPUArray:
 			lib.pz_cast_i32_f32(out.optr, self.rptr, self.size, None)
 		elif self.dtype == np.float32 and dtype == np.int32:
 			lib.pz_cast_f32_i32(out.optr, self.rptr, self.size, None)
+		elif self.dtype == np.float32 and dtype == np.float16:           # (storage only: no operator computes in fp16)
+			lib.pz_cast_f32_f16(out.optr, self.rptr, self.size, None)
+		elif self.dtype == np.float16 and dtype == np.float32:
+			lib.pz_cast_f16_f32(out.optr, self.rptr, self.size, None)
 		else:
 			raise NotImplementedError("astype %s -> %s" % (self.dtype, dtype))
 

@@ -89,8 +89,13 @@ def absorbReluDer(arrays, scalars):
 		return True
 
 	if lazy.on("gate"):
+		# sums the producing backward-data launch left for the BatchNorm behind this ReLU (a fact of the stored gradient: read
+		# before the write barrier drops it) stay with the gate as long as it is THIS output the gate is made of
+		parts = lazy.fact(ingrad, "gatedparts") if lazy.on("dgradstats") else None
+		if parts is not None and not lazy.sameBuffer(parts[0], outdata):
+			parts = None
 		ingrad.wptr                                          # whatever is pending gets written; dependents are settled
-		lazy.attach(ingrad, fusion.Gate(outdata))
+		lazy.attach(ingrad, fusion.Gate(outdata, parts))
 		return True
 	return False
 

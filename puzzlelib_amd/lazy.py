@@ -33,6 +33,11 @@ from puzzlelib_amd import lib
 
 enabled = os.environ.get("PUZZLE_MI355_LAZY", "1") == "1"
 disabled = set(filter(None, os.environ.get("PUZZLE_MI355_LAZY_OFF", "").split(",")))      # individual patterns, for tests
+# Patterns that are OFF unless asked for (`requested`; tests assign `disabled` freely, so this is a set of its own):
+# "dgradstats" (round 6: BatchNorm-backward statistics from the producing backward-data epilogue, pz_conv2d_bwd_data_bnstats)
+# changes the summation order of those statistics — opt-in until measured on the device (PUZZLE_MI355_DGRAD_STATS=1)
+OPT_IN = frozenset(("dgradstats", ))
+requested = set(p for p, env in (("dgradstats", "PUZZLE_MI355_DGRAD_STATS"), ) if os.environ.get(env, "0") == "1")
 counters = {}                      # pattern name -> times taken (tests and tools read it)
 writeOp = None                     # element-wise op id whose operands are being fetched (gpuarray.eltwise): a watcher on a written
                                    # allocation (State.watch) can tell a known kernel — the weight-decay hook — from an unknown write
@@ -43,7 +48,7 @@ def count(name):
 
 
 def on(pattern):
-	return enabled and pattern not in disabled
+	return enabled and pattern not in disabled and (pattern not in OPT_IN or pattern in requested)
 
 
 class State:

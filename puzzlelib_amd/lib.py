@@ -162,6 +162,9 @@ _PROTOS = {
 	"pz_conv2d_bn_fold_supported": [POINTER(ConvDesc), c_int, POINTER(c_int)],
 	"pz_conv2d_bwd_data_bn": [POINTER(ConvDesc), P, P, P, P, P, c_int, P, c_size_t, P],
 	"pz_conv2d_bwd_filter_bn": [POINTER(ConvDesc), P, P, P, P, P, c_float, c_float, c_int, P, c_size_t, P],
+	"pz_conv2d_bwd_data_bnstats_bytes": [POINTER(ConvDesc), c_int, POINTER(c_size_t)],
+	"pz_conv2d_bwd_data_bnstats": [POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, c_int, P, c_size_t, P],
+	"pz_bn_bwd_gate_from_partials": [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P, P],
 	"pz_bn_gate_stats": [P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, P],
 	"pz_bn_gate_stats_up2": [P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P],
 	"pz_relu_mask_bytes": [c_int, c_int, c_int, POINTER(c_size_t)],
@@ -219,6 +222,8 @@ _PROTOS = {
 	"pz_multi_add": [c_int, PP, PP, PP, POINTER(c_float), POINTER(c_float), POINTER(c_uint32), P],
 	"pz_cast_i32_f32": [P, P, c_size_t, P],
 	"pz_cast_f32_i32": [P, P, c_size_t, P],
+	"pz_cast_f32_f16": [P, P, c_size_t, P],
+	"pz_cast_f16_f32": [P, P, c_size_t, P],
 
 	"pz_rng_create": [c_uint64, PP],
 	"pz_rng_destroy": [P],
@@ -278,7 +283,7 @@ def _bind(name, argtypes):
 
 _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_workspace_bytes_pre", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_epilogue_supported", "pz_conv2d_algo_used",
-	"pz_conv2d_bn_fold_supported", "pz_conv2d_xbn_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
+	"pz_conv2d_bn_fold_supported", "pz_conv2d_bwd_data_bnstats_bytes", "pz_conv2d_xbn_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
 	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get",
 	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get"
 }

@@ -204,7 +204,7 @@ class MemModule:
 	between a tensor and a strided VIEW of the other side, so the index arithmetic lives in the view's strides."""
 
 	def __init__(self, backend):
-		self.backend = backend
+		self.backend, self.GPUArray = backend, backend.GPUArray       # (module.GPUArray: Cuda/Kernels/Memory.py:84, Pool.py:120)
 
 
 	@staticmethod
@@ -291,7 +291,7 @@ class PoolModule:
 	(MaxPool2D(useMask=True), MaxUnpool2D)."""
 
 	def __init__(self, backend):
-		self.backend = backend
+		self.backend, self.GPUArray = backend, backend.GPUArray       # (module.GPUArray: Cuda/Kernels/Memory.py:84, Pool.py:120)
 
 
 	@staticmethod

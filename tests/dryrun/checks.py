@@ -282,6 +282,91 @@ def fused_step_counts():
 	print("fused step: %d launches against %d with the lazy layer off" % (fusedCalls, literalCalls))
 
 
+def dgrad_stats_counts():
+	"""round 6, opt-in (PUZZLE_MI355_DGRAD_STATS=1 sets the pattern "dgradstats"): the backward-data launch of a pointwise layer whose
+	input was relu(bn(x)), never written, sums that BatchNorm's backward statistics in its epilogue (pz_conv2d_bwd_data_bnstats);
+	the BatchNorm's backward then is ONE pass (pz_bn_bwd_gate_from_partials) — in the mini-ResNet: the three bottleneck tails.
+	With the pattern off (the default) nothing of it runs."""
+	g = bound().gpuarray
+	spec = nets.resnet_spec(stages=((32, 1), (64, 2)), classes=10, stem=16, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	data, labels = g.to_gpu(np.zeros((4, 3, 64, 64), np.float32)), g.to_gpu(np.zeros((4, ), np.int32))
+	seen = {}
+	for on in (False, True):
+		(lazy.requested.add if on else lazy.requested.discard)("dgradstats")
+		np.random.seed(1)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		trainer, _ = trainerFor(net, 4)
+		trainer.train(data, labels, random=False)
+		lib.trace.clear()
+		lazy.counters.clear()
+		trainer.train(data, labels, random=False)
+		seen[on] = (names(), dict(lazy.counters))
+	lazy.requested.discard("dgradstats")
+	off, on = seen[False], seen[True]
+	assert "pz_conv2d_bwd_data_bnstats" not in off[0] and "dgrad_bnstats" not in off[1]
+	assert on[0].count("pz_conv2d_bwd_data_bnstats") == 3 and on[0].count("pz_bn_bwd_gate_from_partials") == 3, on[1]
+	assert on[1]["dgrad_bnstats"] == 3 and on[1]["bn_bwd_gate_from_partials"] == 3
+	assert on[1].get("bn_bwd_gate", 0) == off[1]["bn_bwd_gate"] - 3 and on[1]["dgrad_bn_fold"] == off[1]["dgrad_bn_fold"]
+	dgrad = lambda calls: sum(calls.count(k) for k in ("pz_conv2d_bwd_data", "pz_conv2d_bwd_data_bn", "pz_conv2d_bwd_data_bnstats"))
+	assert dgrad(on[0]) == dgrad(off[0]) and on[0].count("pz_bn_bwd_gate") == off[0].count("pz_bn_bwd_gate") - 3
+	assert len(on[0]) == len(off[0]), "one launch replaced by one launch, three times: %d vs %d calls" % (len(on[0]), len(off[0]))
+	print("dgrad statistics: 3 backward-data launches carry the BatchNorm sums, 3 BatchNorm backwards run as one pass")
+
+
+def dgrad_stats_values_on_emulation():
+	"""the same step WITH VALUES, the C ABI emulated on host buffers (oracle/emu_cabi.py: the header's contract executed with the
+	numpy oracle): every parameter gradient of a mini-ResNet step with the statistics taken from the backward-data epilogue
+	equals the gradient of the default path to fp32 rounding (the sums are formed in another order), and both match the CPU
+	oracle's step. Judges the Python glue — which tensor, which coefficients, which saved mean travel with the gate — not the
+	kernel (tests/test_gpu_6_fulltensor.py does that on the device)."""
+	sys.path.insert(0, os.path.join(ROOT, "oracle"))
+	sys.path.insert(0, os.path.join(ROOT, "tests"))
+	import emu_cabi, cpu_net as N, cpu_ref as R
+	emu_cabi.install()
+	g = bound().gpuarray
+	spec = nets.resnet_spec(stages=((8, 1), (16, 2)), classes=10, stem=8, softmax=False)
+	spec = [l if l[0] != "avgpool" else ("avgpool", l[1], 8, 1, 0) for l in spec]
+	rng = np.random.RandomState(3)
+	data, labels = rng.randn(4, 3, 64, 64).astype(np.float32), rng.randint(0, 10, size=(4, )).astype(np.int32)
+	grads = {}
+	for on in (False, True):
+		(lazy.requested.add if on else lazy.requested.discard)("dgradstats")
+		np.random.seed(11)
+		net = nets.build(spec, name="mini", initscheme="he", actInplace=True)
+		params = {name: p.data.get() for name, p in net.namedParams().items()}
+		opt = optim.Adam(alpha=1e-3)
+		opt.setupOn(net, useGlobalState=True)
+		cost = optim.CrossEntropy()
+		net.trainMode()
+		lazy.counters.clear()
+		grad = cost(net(g.to_gpu(data)), g.to_gpu(labels), queryError=False)
+		opt.zeroGradParams()
+		net.backward(grad, updGrad=False)
+		grads[on] = {name: p.grad.get() for name, p in net.namedParams().items()}
+		assert (lazy.counters.get("dgrad_bnstats", 0) > 0) == on, lazy.counters
+		net.reset()
+	lazy.requested.discard("dgradstats")
+
+	_, ashapes = nets.spec_param_shapes(spec)
+	attrs = {k: (np.zeros(sh, np.float32) if k.endswith(".mean") else np.ones(sh, np.float32)) for k, sh in ashapes.items()}
+	cnet = N.CpuNet(spec, params, attrs)
+	cnet.train = True
+	_, cgrad = R.cross_entropy(cnet.forward(data), labels)
+	cnet.zero_grads()
+	cnet.backward(cgrad)
+
+	worst = [0.0, 0.0]
+	for name, ref in cnet.grads.items():
+		scale = float(np.abs(ref).max()) + 1e-12
+		a, b = grads[False][name], grads[True][name]
+		worst[0] = max(worst[0], float(np.abs(a - b).max()) / scale)
+		worst[1] = max(worst[1], float(np.abs(b - ref).max()) / scale)
+	assert worst[0] < 2e-5, "epilogue statistics change a gradient by %.2e of its scale" % worst[0]
+	assert worst[1] < 2e-3, "gradients with epilogue statistics differ from the oracle by %.2e of their scale" % worst[1]
+	print("dgrad statistics on the emulated C ABI: gradients within %.1e of the default path, %.1e of the oracle" % tuple(worst))
+
+
 def reference_checkpoint_names():
 	"""checkpoint.load resolves the entries of a file the REFERENCE wrote (tests/golden/refckpt_mini_*.npz: Module.save output of
 	a small network built from the reference's own residBlock, both naming forms), refuses ambiguous and missing entries."""

@@ -39,6 +39,14 @@ def test_fused_paths_taken_and_switchable():
 	run("fused_step_counts")
 
 
+def test_backward_data_epilogue_carries_the_batchnorm_backward_sums_when_asked():
+	assert "one pass" in run("dgrad_stats_counts")
+
+
+def test_epilogue_statistics_give_the_same_gradients_on_the_emulated_cabi():
+	assert "within" in run("dgrad_stats_values_on_emulation")
+
+
 def test_checkpoints_written_by_the_reference_resolve():
 	run("reference_checkpoint_names")
 

@@ -69,9 +69,30 @@ def test_positional_signatures_match_the_wrappers(bnd):
 def test_out_of_scope_entries_fail_loudly(bnd):
 	x = bnd.GPUArray.zeros((2, 3, 4, 4), dtype=np.float32)
 	for call in (lambda: bnd.createRnn(4, 4, np.float32), lambda: bnd.acquireRnnParams(None, x),
-				 lambda: bnd.castFP32toFP16(x), lambda: bnd.castFP16toFP32(x), lambda: bnd.upsamplemod.upsample2d(x, 2, mode="cubic")):
+				 lambda: bnd.upsamplemod.upsample2d(x, 2, mode="cubic"), lambda: bnd.reluKer(np.float16)):
 		with pytest.raises(NotImplementedError):
 			call()
+
+
+def test_fp16_is_a_storage_type(bnd):
+	"""GPUArray.astype and the cast kernels (Cuda/GPUArray.py:279-296 arithmTest; Cuda/Kernels/ElementWise.py:1143-1156): fp32 <-> fp16
+	conversions round like numpy; no operator computes in fp16 (the kernel factories refuse the dtype)"""
+	rng = np.random.RandomState(5)
+	host = (rng.randn(1000, 37) * 50).astype(np.float32)
+	host[0, :4] = [65504.0, 1e-8, -70000.0, 6.1e-5]                # largest half, underflow, overflow to -inf, near the subnormal range
+	x = bnd.GPUArray.toGpu(host)
+	half = x.astype(np.float16)
+	with np.errstate(over="ignore"):
+		want = host.astype(np.float16)
+	assert half.dtype == np.float16 and np.array_equal(half.get().view(np.uint16), want.view(np.uint16))
+	back = half.astype(np.float32)
+	assert np.array_equal(back.get(), want.astype(np.float32))
+	out16, out32 = bnd.GPUArray.empty(host.shape, np.float16), bnd.GPUArray.empty(host.shape, np.float32)
+	bnd.castFP32toFP16(out16, x)
+	bnd.castFP16toFP32(out32, out16)
+	assert np.array_equal(out16.get().view(np.uint16), want.view(np.uint16)) and np.array_equal(out32.get(), want.astype(np.float32))
+	with pytest.raises(ValueError):
+		bnd.castFP32toFP16(out32, x)
 
 
 def test_rccl_single_rank_roundtrip(bnd):

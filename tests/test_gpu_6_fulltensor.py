@@ -214,6 +214,99 @@ def test_folded_launches_whole_tensors_vs_fp64_oracle(bnd, case):
 		assert ratio <= 1.0, "%s: an element is %.2f x its bound" % (name, ratio)
 
 
+# Round 6: the backward-data launch of a pointwise layer whose input was y = relu(a z + b) (the BatchNorm in FRONT of it, never
+# written) also sums, in its epilogue, the statistics of that BatchNorm's backward over the GATED gradient q = dx * (y > 0):
+# {sum q, sum q (z - mean)} per channel (pz_conv2d_bwd_data_bnstats; the reference's formulas: Cuda/Wrappers/CuDnnNorm.py:55-63,
+# the ReLU's derivative by the output sign: Cuda/Kernels/ElementWise.py:119-172). (n, (k, h, w), c): dy (n, k, h, w) -> dx (n, c, h, w).
+BNSTATS = [
+	(3, (40, 13, 9), 24),            # ragged everything: 24 < one tile row band, 351 pixels = strips that straddle images, last strip short
+	(5, (16, 7, 7), 130),            # two row tiles, the second nearly empty
+	(256, (256, 55, 55), 64),        # the 64-row tile (HBM-bound launches of stage 2's tails)
+	(256, (512, 28, 28), 128), (256, (1024, 14, 14), 256), (256, (2048, 7, 7), 512),       # 128-row tiles, k-sliced tail rounds
+]
+
+
+@pytest.mark.parametrize("fold", [False, True], ids=["plain", "bn_fold"])
+@pytest.mark.parametrize("case", BNSTATS, ids=lambda c: "b%d_%dx%dx%d_to_%d" % ((c[0], ) + c[1] + (c[2], )))
+def test_backward_data_epilogue_statistics_vs_fp64_oracle(bnd, case, fold):
+	"""dx bit-identical to the launch without the epilogue sums; the merged sums against fp64 sums over the device's own dx
+	(|err| <= 2e-6 * sum |terms|: fp32 strip sums of <= 64 terms each, merged in fp64); pz_bn_bwd_gate_from_partials against
+	pz_bn_bwd_gate (the two-pass form) on the same operands: the input gradient to 2e-5 of its top, the parameter gradients to
+	1e-5 of the sums of magnitudes behind them."""
+	import ctypes
+	from puzzlelib_amd import lib
+	G = bnd.GPUArray
+	n, (k, h, w), c = case
+	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, 1, 1), 1, 0, 1, 1)
+	algo = lib.CONV_ALGO_AUTO
+	rng = np.random.RandomState(51)
+	hw = h * w
+
+	dy, bz, z = dev_randn(bnd, (n, k, h, w), 52), dev_randn(bnd, (n, k, h, w), 53), dev_randn(bnd, (n, c, h, w), 54)
+	wh = (rng.randn(k, c, 1, 1) / np.sqrt(k)).astype(np.float32)
+	ab = np.stack([0.5 + rng.rand(c), 0.4 * rng.randn(c)], axis=1).astype(np.float32)       # the forward's {a, b} of the BatchNorm in front
+	mean = (0.3 * rng.randn(c)).astype(np.float32)
+	rstd = (0.5 + rng.rand(c)).astype(np.float32)
+	scale = (ab[:, 0] / rstd).astype(np.float32)
+	gco = np.concatenate([np.stack([0.5 + rng.rand(k), 0.2 * rng.randn(k), 0.1 * rng.randn(k)], axis=1), np.zeros((k, 1))], axis=1).astype(np.float32)
+	wt, gab, gmean, grstd, gscale, ggco = (gpu(bnd, a) for a in (wh, ab, mean, rstd, scale, gco))
+
+	size = ctypes.c_size_t(0)
+	lib.pz_conv2d_bwd_data_bnstats_bytes(ctypes.byref(desc), algo, ctypes.byref(size))
+	assert size.value >= 16 * c, "every pointwise stride-1 layer has the statistics epilogue"
+	parts = G.empty((size.value, ), dtype=np.uint8)
+	nbytes, foldable = bnd.dnn.convGeometry(desc, lib.CONV_BWD_DATA, algo)[2], bnd.dnn.convGeometry(desc, lib.CONV_BWD_DATA, algo)[4]
+	if fold and not foldable:
+		pytest.skip("this layer's gather cannot fold a BatchNorm backward (pz_conv2d_bn_fold_supported)")
+	ws = G.empty((max(nbytes, 4), ), dtype=np.uint8)
+
+	dx0, dx1 = G.empty((n, c, h, w), dtype=np.float32), G.empty((n, c, h, w), dtype=np.float32)
+	if fold:
+		lib.pz_conv2d_bwd_data_bn(ctypes.byref(desc), dy.rptr, bz.rptr, ggco.rptr, wt.rptr, dx0.optr, algo, ws.optr, nbytes, None)
+	else:
+		lib.pz_conv2d_bwd_data(ctypes.byref(desc), dy.rptr, wt.rptr, dx0.optr, algo, ws.optr, nbytes, None)
+	lib.pz_conv2d_bwd_data_bnstats(
+		ctypes.byref(desc), dy.rptr, bz.rptr if fold else None, ggco.rptr if fold else None, wt.rptr, dx1.optr, z.rptr, gab.rptr,
+		gmean.rptr, parts.optr, algo, ws.optr, nbytes, None
+	)
+	dxh, zh = dx1.get(), z.get()
+	assert np.array_equal(dx0.get(), dxh), "the epilogue sums must not change what is stored"
+
+	# the merged sums: 2 c doubles at the head of the partials
+	merged = parts.get()[:16 * c].view(np.float64).reshape(c, 2)
+	gate = (ab[None, :, 0, None, None] * zh + ab[None, :, 1, None, None]) > 0                # fp32 fma on the device; ties are measure-zero here
+	q = np.where(gate, dxh, 0).astype(np.float64)
+	d = zh.astype(np.float64) - mean[None, :, None, None]
+	s1, s2 = q.sum(axis=(0, 2, 3)), (q * d).sum(axis=(0, 2, 3))
+	m1, m2 = np.abs(q).sum(axis=(0, 2, 3)), np.abs(q * d).sum(axis=(0, 2, 3))
+	flips = int((np.abs(ab[None, :, 0, None, None].astype(np.float64) * zh + ab[None, :, 1, None, None]) < 1e-6).sum())
+	tol = lambda m: 2e-6 * m + 1e-6 + (1e-2 * flips)
+	assert (np.abs(merged[:, 0] - s1) <= tol(m1)).all(), "sum q: worst %.3e of %.3e" % (np.abs(merged[:, 0] - s1).max(), m1.max())
+	assert (np.abs(merged[:, 1] - s2) <= tol(m2)).all(), "sum q (z - mean): worst %.3e of %.3e" % (np.abs(merged[:, 1] - s2).max(), m2.max())
+
+	# the BatchNorm backward from these partials against the two-pass form
+	size = ctypes.c_size_t(0)
+	lib.pz_bn_workspace_bytes(n, c, hw, ctypes.byref(size))
+	bws = G.empty((size.value, ), dtype=np.uint8)
+	outs = []
+	for one_pass in (False, True):
+		gin, ds, db = G.empty((n, c, h, w), dtype=np.float32), G.empty((c, ), dtype=np.float32), G.empty((c, ), dtype=np.float32)
+		if one_pass:
+			lib.pz_bn_bwd_gate_from_partials(z.rptr, dx1.rptr, gin.optr, n, c, hw, gscale.rptr, gmean.rptr, grstd.rptr, ds.optr, db.optr,
+											 gab.rptr, parts.rptr, None)
+		else:
+			lib.pz_bn_bwd_gate(z.rptr, dx1.rptr, gin.optr, n, c, hw, gscale.rptr, gmean.rptr, grstd.rptr, ds.optr, db.optr, gab.rptr,
+							   bws.optr, size.value, None)
+		outs.append((gin.get(), ds.get(), db.get()))
+	(g2, ds2, db2), (g1, ds1, db1) = outs
+	top = float(np.abs(g2).max())
+	assert float(np.abs(g1 - g2).max()) <= 2e-5 * top, "input gradient differs by %.3e of its top" % (float(np.abs(g1 - g2).max()) / top)
+	assert (np.abs(db1 - db2) <= 1e-5 * m1 + 1e-6).all() and (np.abs(ds1 - ds2) <= (1e-5 * m2 + 1e-6) * rstd).all()
+	print("epilogue statistics: worst |sum err| / sum|terms| = %.2e / %.2e, one-pass BatchNorm backward within %.1e of the two-pass form" % (
+		float((np.abs(merged[:, 0] - s1) / (m1 + 1e-30)).max()), float((np.abs(merged[:, 1] - s2) / (m2 + 1e-30)).max()),
+		float(np.abs(g1 - g2).max()) / top))
+
+
 def adoptDeviceGatesNested(cnet, layers, spec, prefix=""):
 	"""test_gpu_5_nets.adoptDeviceGates for nested specs: the oracle's backward gates with the ReLU outputs / max-pool
 	operands the DEVICE produced (cache keys as oracle/cpu_net.py builds them: "<index>", "<index>.b.<index>", ...). Returns

@@ -50,8 +50,13 @@ def test_tapes_are_data_and_listed():
 		header, data = reftape.load(path)
 		assert header["name"] == tape_id(path) and header["atol"] <= 1e-5 and header["rtol"] <= 1e-4
 		kinds = {op["k"] for op in header["ops"]}
-		assert kinds <= {"root", "attr", "setattr", "call", "poke", "del"}, kinds
+		assert kinds <= {"root", "attr", "setattr", "call", "poke", "del", "audit"}, kinds
 		reads = sum(1 for op in header["ops"] if op["k"] in ("attr", "call") and json.dumps(op["r"]).count('"np"') + json.dumps(op["r"]).count('"f"'))
+		reads += sum(1 for op in header["ops"] if op["k"] == "audit")       # samples of dropped device arrays (tests that assert nothing)
 		assert reads > 0, "%s reads nothing back" % path
+		assert reads >= MANIFEST[tape_id(path)]["values"] or "audit" in kinds
+		# host inputs drawn from numpy's generator travel as (seed, call list): the calls must be plain data
+		for stream in header.get("rng", {}).values():
+			assert all(isinstance(call["n"], str) and not call["n"].startswith("_") for call in stream["calls"])
 		for key in data.files:
 			assert data[key].dtype.kind in "fiub", (path, key, data[key].dtype)

@@ -235,6 +235,31 @@ def test_header_and_ctypes_binding_agree():
 		assert getattr(lib, name[3:]) == index, "%s is %d in the header, %s in lib.py" % (name, index, getattr(lib, name[3:]))
 
 
+def test_header_marks_the_stable_boundary_and_the_private_fusion_entries():
+	"""include/puzzle_mi355.h: entries declared plainly are the stable boundary — SURVEY.md section 8b's list must be among them —
+	and every PZ_FUSED entry is private to the build's own shim: called from the backend's glue, never from the user-facing
+	dispatch wrappers (surface.py) or the harness (engine.py / optim.py / nets.py)."""
+	header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "puzzle_mi355.h")).read(), flags=re.S)
+	fused = set(re.findall(r"^PZ_FUSED\s+int\s+(pz_[a-z0-9_]+)\s*\(", header, flags=re.M))
+	stable = set(re.findall(r"^int\s+(pz_[a-z0-9_]+)\s*\(", header, flags=re.M))
+	assert len(fused) >= 40 and not (fused & stable)
+	for name in ("pz_init", "pz_device_count", "pz_malloc", "pz_free", "pz_pool_create", "pz_pool_alloc", "pz_pool_release", "pz_pool_free_held",
+				 "pz_pool_stats", "pz_memcpy_h2d", "pz_memcpy_d2h", "pz_memcpy_d2d", "pz_memcpy_2d", "pz_memset_d32", "pz_stream_create",
+				 "pz_stream_destroy", "pz_stream_sync", "pz_event_create", "pz_event_record", "pz_event_sync", "pz_event_elapsed_ms",
+				 "pz_conv2d_fwd", "pz_conv2d_bwd_data", "pz_conv2d_bwd_filter", "pz_conv2d_workspace_bytes", "pz_gemm", "pz_bn_fwd_train",
+				 "pz_bn_fwd_infer", "pz_bn_bwd", "pz_pool2d_fwd", "pz_pool2d_bwd", "pz_softmax_fwd", "pz_softmax_bwd", "pz_cross_entropy",
+				 "pz_reduce_sum_rows", "pz_reduce_sum_cols", "pz_argmax_rows", "pz_count_neq_i32", "pz_reduce_minmax_f32", "pz_dot", "pz_asum",
+				 "pz_bias_add", "pz_eltwise", "pz_rng_create", "pz_rng_fill_u32", "pz_rng_fill_uniform", "pz_rng_fill_normal",
+				 "pz_comm_unique_id", "pz_comm_init_rank", "pz_comm_allreduce_sum_f32", "pz_comm_broadcast", "pz_comm_destroy"):
+		assert name in stable, "%s (SURVEY 8b) must be a stable entry" % name
+	pkg = os.path.join(ROOT, "puzzlelib_amd")
+	text = {f: open(os.path.join(pkg, f)).read() for f in os.listdir(pkg) if f.endswith(".py")}
+	for name in fused:
+		users = [f for f, t in text.items() if re.search(r"\b%s\b" % name, t) and f != "lib.py"]
+		# (pz_bn_fwd_train_defer has no caller left in the shim; it stays for the sake of the bindings built against earlier headers)
+		assert not set(users) & {"surface.py", "engine.py", "optim.py", "nets.py"}, "%s (private) is called from %s" % (name, users)
+
+
 def test_convolution_family_resolution_without_device():
 	"""pz_conv2d_algo_used / workspace sizes are host logic: which kernel family serves a layer under each requested algo
 	(Hip/Wrappers/MIOpen.py:23-49 ids: direct 1, winograd 3, implicitGemm 5, auto -1)."""
