@@ -39,6 +39,7 @@ typedef void *pz_event_t;    /* hipEvent_t  */
 typedef struct pz_pool *pz_pool_t;
 typedef struct pz_rng *pz_rng_t;
 typedef struct pz_comm *pz_comm_t;
+typedef struct pz_module *pz_module_t;
 
 #define PZ_OK 0
 #define PZ_ERR_INVALID 1      /* bad argument / unsupported configuration (ValueError on the Python side) */
@@ -539,6 +540,21 @@ int pz_ctc_loss(const float *probs, const int32_t *datalen, const int32_t *label
 int pz_embed_fwd(const int32_t *words, const float *vocab, float *out, size_t tokens, int embsize, pz_stream_t stream);
 int pz_embed_bwd_params(const int32_t *words, const float *grad, float *vocab, float scale, size_t tokens, int embsize,
                         pz_stream_t stream);
+
+/* ---- run-time compiled kernels: replaces Driver.compile (Cuda/Source/Core/Driver.c:501-515; NVRTC there, `hipcc --genco` on the
+ *      reference's HIP backend, Hip/SourceModule.py:61-99) and Driver.Module / Function (Cuda/Source/Core/Module.c:258-290). For
+ *      USER kernels — backend.SourceModule / ElementwiseKernel / ReductionKernel (Cuda/SourceModule.py:31-393) — every operator
+ *      of the library itself is precompiled. pz_rtc_compile needs no device (hiprtc, target gfx950): *code is a malloc'ed code
+ *      object (pz_rtc_free_code), `log` gets the compiler's output; a compilation error is PZ_ERR_INVALID. pz_function_launch
+ *      takes the kernel arguments packed as the kernel's parameter list lays them out (natural alignment).               */
+int pz_rtc_compile(const char *source, const char *name, const char *const *options, int noptions, void **code, size_t *code_bytes,
+                   char *log, size_t log_bytes);
+int pz_rtc_free_code(void *code);
+int pz_module_load(const void *code, pz_module_t *module);
+int pz_module_unload(pz_module_t module);
+int pz_module_function(pz_module_t module, const char *name, void **function);
+int pz_function_launch(void *function, const unsigned *grid, const unsigned *block, unsigned shared_bytes, const void *args,
+                       size_t args_bytes, pz_stream_t stream);
 
 /* ---- data-parallel exchange: replaces NodeInfo.{sumTensor,broadcastBuffer} (Grid.py:54-63,103-157: IPC star)
  *      with RCCL collectives over xGMI. One communicator per process (one process per GPU).             */

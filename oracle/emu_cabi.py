@@ -855,6 +855,112 @@ def pz_ctc_loss(probs, datalen, labels, offsets, order, seg_start, seg_label, se
 	Fv(error, 1)[0] += F(total)
 
 
+# ---------------------------------------------------------------------------------------------------- run-time compiled kernels
+# pz_rtc_compile itself is NOT emulated: the real library compiles the generated HIP source with hiprtc (no device needed), so a
+# template that does not compile fails here as it would on the device. What cannot run here is the code object: for kernels
+# generated by puzzlelib_amd/rtc.py's templates, the recipe they carry in their first line ("// pz-rtc: {...}") is turned into
+# the same loops in plain C, compiled with gcc and called on the host buffers. A hand-written SourceModule has no recipe:
+# NotImplementedError.
+class HostKernels:
+	def __init__(self):
+		self.sources, self.modules, self.functions = {}, {}, {}
+
+	def remember(self, real):
+		"""wraps lib.pz_rtc_compile: compile for real, note which source the code object came from"""
+		def compile_(source, name, options, noptions, code, size, log, logbytes):
+			real(source, name, options, noptions, code, size, log, logbytes)
+			self.sources[code._obj.value] = source.decode()
+		return compile_
+
+	def load(self, code):
+		import json, os, subprocess, tempfile
+		source = self.sources.get(code if isinstance(code, int) else code.value)
+		assert source is not None, "pz_module_load: a code object pz_rtc_compile did not produce"
+		first = source.split("\n", 1)[0]
+		if not first.startswith("// pz-rtc: "):
+			raise NotImplementedError("the C-ABI emulation cannot run a hand-written SourceModule (no generation recipe)")
+		r = json.loads(first[len("// pz-rtc: "):])
+		params = ", ".join("%s %s" % (c, n) for c, n in r["args"])
+		if r["kind"] == "eltwise":
+			text = ("#include <math.h>\n#include <stdint.h>\n"
+					"void %(name)s(%(params)s, long long size) { for (long long i = 0; i < size; ++i) { %(op)s; } }\n"
+					"void %(name)s_strided(%(params)s, long long start, long long stop, long long step) "
+					"{ for (long long i = start; i < stop; i += step) { %(op)s; } }\n") % dict(name=r["name"], params=params, op=r["operation"])
+			entries = {r["name"]: [c for c, _ in r["args"]] + ["long long"], r["name"] + "_strided": [c for c, _ in r["args"]] + ["long long"] * 3}
+		else:
+			# (the device's own order: every thread of a workgroup strides over the elements, then a halving tree — bit-equal sums)
+			text = ("#include <math.h>\n#include <stdint.h>\ntypedef %(T)s pz_acc_t;\n"
+					"static pz_acc_t red(pz_acc_t a, pz_acc_t b) { return (%(reduceExpr)s); }\n"
+					"static pz_acc_t tree_(pz_acc_t *t) { for (int h = %(block)d / 2; h > 0; h >>= 1) for (int k = 0; k < h; ++k) t[k] = red(t[k], t[k + h]); return t[0]; }\n"
+					"void %(name)s_stage1(%(params)s, pz_acc_t *partials, long long size, int blocks) {\n"
+					"	for (int blk = 0; blk < blocks; ++blk) { pz_acc_t t[%(block)d];\n"
+					"		for (int th = 0; th < %(block)d; ++th) { pz_acc_t acc = %(neutral)s;\n"
+					"			for (long long i = (long long)blk * %(block)d + th; i < size; i += (long long)blocks * %(block)d) acc = red(acc, (pz_acc_t)(%(mapExpr)s));\n"
+					"			t[th] = acc; }\n"
+					"		partials[blk] = tree_(t); } }\n"
+					"void %(name)s_stage2(const pz_acc_t *partials, pz_acc_t *out, int count) {\n"
+					"	pz_acc_t t[%(block)d];\n"
+					"	for (int th = 0; th < %(block)d; ++th) { pz_acc_t acc = %(neutral)s; for (int i = th; i < count; i += %(block)d) acc = red(acc, partials[i]); t[th] = acc; }\n"
+					"	out[0] = tree_(t); }\n") % dict(r, params=params)
+			entries = {r["name"] + "_stage1": [c for c, _ in r["args"]] + ["pz_acc_t *", "long long", "+blocks"],
+					   r["name"] + "_stage2": ["pz_acc_t *", "pz_acc_t *", "int"]}
+		scratch = tempfile.mkdtemp(prefix="emu_rtc_")
+		path = os.path.join(scratch, "k.c")
+		open(path, "w").write(text)
+		subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-std=gnu99", "-o", path[:-2] + ".so", path, "-lm"], check=True, capture_output=True)
+		handle = EMU.alloc(8)
+		self.modules[handle] = (ctypes.CDLL(path[:-2] + ".so"), entries)
+		return handle
+
+	def function(self, module, name):
+		dll, entries = self.modules[module if isinstance(module, int) else module.value]
+		name = name.decode()
+		assert name in entries, "the module has no kernel %s" % name
+		handle = EMU.alloc(8)
+		self.functions[handle] = (getattr(dll, name), entries[name])
+		return handle
+
+	CT = {"float": ctypes.c_float, "double": ctypes.c_double, "int": ctypes.c_int, "unsigned int": ctypes.c_uint, "long long": ctypes.c_longlong,
+		  "unsigned long long": ctypes.c_ulonglong, "short": ctypes.c_short, "unsigned short": ctypes.c_ushort, "signed char": ctypes.c_byte,
+		  "unsigned char": ctypes.c_ubyte}
+
+	def launch(self, function, grid, args, nbytes):
+		fn, types = self.functions[function if isinstance(function, int) else function.value]
+		raw = bytes(args[:nbytes]) if isinstance(args, (bytes, bytearray)) else ctypes.string_at(args, nbytes)
+		values, offset = [], 0
+		for cname in types:
+			if cname == "+blocks":
+				values.append(ctypes.c_int(int(grid[0])))
+				continue
+			base = " ".join(w for w in cname.split() if w not in ("const", "volatile", "__restrict__", "restrict"))
+			ct = ctypes.c_void_p if base.endswith("*") else self.CT[base]
+			size = ctypes.sizeof(ct)
+			offset += -offset % size
+			values.append(ct.from_buffer_copy(raw[offset:offset + size]))
+			offset += size
+		fn.restype = None
+		fn(*values)
+
+
+HOST = HostKernels()
+
+
+def pz_module_load(code, ref):
+	out(ref, HOST.load(code))
+
+
+def pz_module_unload(module):
+	pass
+
+
+def pz_module_function(module, name, ref):
+	out(ref, HOST.function(module, name))
+
+
+def pz_function_launch(function, grid, block, shared, args, nbytes, stream):
+	HOST.launch(function, grid, args, nbytes)
+
+
 # ---------------------------------------------------------------------------------------------------- dispatch
 NOOPS = {
 	"pz_init", "pz_device_sync", "pz_free", "pz_pool_destroy", "pz_pool_release", "pz_pool_free_held", "pz_host_free_pinned",
@@ -887,4 +993,5 @@ def install():
 	from puzzlelib_amd import lib
 	assert lib.DRYRUN, "import puzzlelib_amd with PUZZLE_MI355_DRYRUN=1 before installing the emulation"
 	lib.callHook = dispatch
+	lib.pz_rtc_compile = HOST.remember(lib.pz_rtc_compile)
 	return EMU

@@ -14,7 +14,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from puzzlelib_amd import lib, driver, lazy, fusion
+from puzzlelib_amd import lib, driver, lazy, fusion, rtc
 from puzzlelib_amd.lib import HipError, ConvDesc, PoolDesc
 from puzzlelib_amd.driver import streamHandle
 from puzzlelib_amd.gpuarray import GPUArray, prod, eltwise, contiguousStrides
@@ -145,6 +145,9 @@ class Mi355Backend:
 	# the reference backend's `Rand` module attribute (Cuda/GPUBackend.py:33,62-63; Hip/Backend.py:29): generator class + type id
 	Rand = SimpleNamespace(__name__="puzzlelib_amd.rng", RandomNumberGenerator=RandomNumberGenerator, RAND_RNG_PSEUDO_PHILOX4_32_10=0)
 	RandomNumberGenerator = RandomNumberGenerator
+
+	# kernels a caller defines at run time (Cuda/GPUBackend.py:27-30; Cuda/SourceModule.py): hiprtc for gfx950, puzzlelib_amd/rtc.py
+	SourceModule, ElementwiseKernel, ElementHalf2Kernel, ReductionKernel = rtc.SourceModule, rtc.ElementwiseKernel, rtc.ElementHalf2Kernel, rtc.ReductionKernel
 
 	GroupFormat = GroupFormat
 	ConvPerf = ConvPerf

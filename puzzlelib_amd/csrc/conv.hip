@@ -2019,7 +2019,9 @@ int check_desc(const pz_conv_desc *d, int *P, int *Q) {
 	PZ_REQUIRE(eh >= 0 && ew >= 0, "conv: filter larger than padded input");
 	*P = eh / d->stride_h + 1;
 	*Q = ew / d->stride_w + 1;
-	PZ_REQUIRE((long)d->r * d->dil_h < kPadTap && (long)d->s * d->dil_w < kPadTap, "conv: filter extent too large");
+	// (filters of more than 63 taps or more than 31 rows / columns — a sentence-wide 3 x 128 filter, Models/Nets/SentiNet.py:23 — are
+	// served by the one-thread-per-output kernels: igemm_eligible keeps them off the tap tables, whose sentinel is kPadTap)
+	PZ_REQUIRE((long)d->r * d->dil_h < (1 << 16) && (long)d->s * d->dil_w < (1 << 16), "conv: filter extent too large");
 	PZ_REQUIRE((size_t)d->c * d->h * d->w < ((size_t)1 << 31) && (size_t)d->k * *P * *Q < ((size_t)1 << 31),
 	           "conv: one image exceeds 2^31 elements");
 	PZ_REQUIRE((size_t)d->n * *P * *Q < ((size_t)1 << 31) && (size_t)d->n * d->h * d->w < ((size_t)1 << 31),

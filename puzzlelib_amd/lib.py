@@ -231,6 +231,13 @@ _PROTOS = {
 	"pz_rng_fill_uniform": [P, P, c_size_t, P],
 	"pz_rng_fill_normal": [P, P, c_size_t, c_float, c_float, P],
 
+	"pz_rtc_compile": [c_char_p, c_char_p, POINTER(c_char_p), c_int, PP, POINTER(c_size_t), c_char_p, c_size_t],
+	"pz_rtc_free_code": [P],
+	"pz_module_load": [P, PP],
+	"pz_module_unload": [P],
+	"pz_module_function": [P, c_char_p, PP],
+	"pz_function_launch": [P, POINTER(c_uint32), POINTER(c_uint32), c_uint32, P, c_size_t, P],
+
 	"pz_comm_unique_id": [c_char_p],
 	"pz_comm_init_rank": [PP, c_int, c_char_p, c_int],
 	"pz_comm_destroy": [P],
@@ -285,7 +292,8 @@ _HOST_ONLY = {
 	"pz_conv2d_out_shape", "pz_conv2d_workspace_bytes", "pz_conv2d_workspace_bytes_pre", "pz_conv2d_prepack_bytes", "pz_conv2d_fwd_stats_strips", "pz_conv2d_epilogue_supported", "pz_conv2d_algo_used",
 	"pz_conv2d_bn_fold_supported", "pz_conv2d_bwd_data_bnstats_bytes", "pz_conv2d_xbn_supported", "pz_conv2d_fwd_bn_supported", "pz_bn_workspace_bytes", "pz_relu_mask_bytes",
 	"pz_pool2d_out_shape", "pz_pool2d_fwd_bn_supported", "pz_pool_oom_events", "pz_pool_driver_allocs", "pz_gemm_workspace_bytes", "pz_conv_math_set", "pz_conv_math_get",
-	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get"
+	"pz_conv_winograd_tile_set", "pz_conv_winograd_tile_get",
+	"pz_rtc_compile", "pz_rtc_free_code"                  # (hiprtc compiles for gfx950 without a device)
 }
 _fake = {"next": 0x7000_0000_0000}
 

@@ -242,6 +242,8 @@ class Tape:
 			return {"dict": {str(k): self.enc(v) for k, v in x.items()}}
 		if isinstance(x, (bool, int, float, str, type(None))):
 			return x
+		if hasattr(x, "typegen"):          # a C type object of the reference's code generator (Compiler/Codegen/Types.py): its spelling
+			return {"ctype": str(x)}
 		raise TypeError("cannot put %r (%s) on a tape" % (x, type(x)))
 
 	def wrap(self, real):
@@ -514,6 +516,8 @@ def replay(path, getBackend, check=None):
 				return np.dtype(x["dtype"])
 			if "nptype" in x:
 				return np.dtype(x["nptype"]).type
+			if "ctype" in x:
+				return x["ctype"]
 			if "slice" in x:
 				return slice(*[dec(v) for v in x["slice"]])
 			if "ellipsis" in x:

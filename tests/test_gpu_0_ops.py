@@ -178,6 +178,10 @@ FRESH = [
 	dict(n=2, c=40, h=9, w=10, k=130, r=3, s=3, stride=1, pad=1, dil=1, groups=1),
 	# the stem's filter gradient (64 x 147) on the 64 x 192 tile, here with fewer than 64 output maps and an odd map
 	dict(n=3, c=3, h=45, w=39, k=48, r=7, s=7, stride=2, pad=3, dil=1, groups=1),
+	# filters the tap tables do not take (more than 63 taps / more than 31 columns): the sentence-wide filters of
+	# Models/Nets/SentiNet.py:23 (Conv2D(1, 100, size=(fHeight, embsize))) — one-thread-per-output kernels, all three passes
+	dict(n=2, c=1, h=20, w=70, k=12, r=3, s=70, stride=1, pad=0, dil=1, groups=1),
+	dict(n=2, c=2, h=40, w=9, k=5, r=33, s=2, stride=1, pad=(1, 0), dil=1, groups=1),
 ]
 
 

@@ -74,6 +74,56 @@ def test_out_of_scope_entries_fail_loudly(bnd):
 			call()
 
 
+def test_runtime_compiled_kernels(bnd):
+	"""bnd.ElementwiseKernel / ReductionKernel / SourceModule (Cuda/SourceModule.py:31-393; tests :432-470): kernels the caller defines
+	at run time, compiled by hiprtc for gfx950, launched through pz_function_launch"""
+	from puzzlelib_amd import rtc
+	rng = np.random.RandomState(9)
+	G = bnd.GPUArray
+
+	hostIn = rng.randint(0, 1000, size=(1 << 18, )).astype(np.int32)
+	indata, outdata = G.toGpu(hostIn), G.empty(hostIn.shape, dtype=np.int32)
+	square = bnd.ElementwiseKernel([("int *", "outdata"), ("const int *", "indata")], "outdata[i] = indata[i] * indata[i]", "square")
+	square(outdata, indata)
+	want = hostIn ** 2
+	assert np.array_equal(outdata.get(), want)
+	square(outdata, outdata, slice=slice(None, None, 10))
+	want[::10] = want[::10] ** 2
+	assert np.array_equal(outdata.get(), want)
+	square(outdata, outdata, slice=slice(5, 1000, 7))
+	want[5:1000:7] = want[5:1000:7] ** 2
+	assert np.array_equal(outdata.get(), want)
+
+	x, y = rng.randn(100003).astype(np.float32), rng.randn(100003).astype(np.float32)
+	gx, gy = G.toGpu(x), G.toGpu(y)
+	saxpy = bnd.ElementwiseKernel([("float *", "y"), ("const float *", "x"), ("float", "a"), ("int", "k")], "y[i] = a * x[i] + y[i] + k", "saxpyk")
+	saxpy(gy, gx, 2.5, 3)
+	assert np.allclose(gy.get(), np.float32(2.5) * x + y + 3, atol=1e-6)
+
+	total = bnd.ReductionKernel(np.float32, neutral="0.0f", reduceExpr="a + b", mapExpr="data[i]", arguments=[("const float *", "data")], name="sum")
+	for host in (rng.randn((1 << 18) + 1).astype(np.float32), np.ones((1 << 20) + 1, dtype=np.float32), rng.randn(5).astype(np.float32)):
+		acc = total(G.toGpu(host))
+		assert acc.shape == () and np.isclose(float(acc.get()), float(np.sum(host.astype(np.float64))), rtol=1e-5, atol=1e-3)
+	absmax = bnd.ReductionKernel(np.float32, neutral="0.0f", reduceExpr="fmaxf(a, b)", mapExpr="fabsf(x[i]) * s", arguments=[("const float *", "x"), ("float", "s")], name="absmax")
+	assert float(absmax(gx, 2.0).get()) == float(np.abs(x).max() * 2)
+
+	mod = bnd.SourceModule("""
+extern "C" __global__ void rowscale(float *m, const float *v, int rows, int cols)
+{
+	int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+	if (c < cols && r < rows) m[r * cols + c] *= v[r];
+}
+""", name="rowscale")
+	m, v = rng.randn(37, 300).astype(np.float32), rng.randn(37).astype(np.float32)
+	gm, gv = G.toGpu(m), G.toGpu(v)
+	mod.rowscale(gm, gv, np.int32(37), np.int32(300), block=(128, 1, 1), grid=(3, 37, 1))
+	assert np.array_equal(gm.get(), m * v[:, None])
+	with pytest.raises(rtc.RtcError):
+		bnd.SourceModule("extern \"C\" __global__ void broken(float *x) { x[0] = nosuchthing; }", verbose=False).getFunction("broken")
+	with pytest.raises(NotImplementedError):
+		bnd.ElementHalf2Kernel([], "", "", "")
+
+
 def test_fp16_is_a_storage_type(bnd):
 	"""GPUArray.astype and the cast kernels (Cuda/GPUArray.py:279-296 arithmTest; Cuda/Kernels/ElementWise.py:1143-1156): fp32 <-> fp16
 	conversions round like numpy; no operator computes in fp16 (the kernel factories refuse the dtype)"""

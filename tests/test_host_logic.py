@@ -260,6 +260,35 @@ def test_header_marks_the_stable_boundary_and_the_private_fusion_entries():
 		assert not set(users) & {"surface.py", "engine.py", "optim.py", "nets.py"}, "%s (private) is called from %s" % (name, users)
 
 
+def test_runtime_kernels_compile_for_gfx950_without_a_device():
+	"""pz_rtc_compile (hiprtc, target gfx950) needs no device: the sources puzzlelib_amd/rtc.py generates for an element-wise and a
+	reduction kernel compile to code objects here; a source with an error is a ValueError carrying the compiler's message
+	(Driver.compile returning (None, log) -> RtcError, Cuda/SourceModule.py:66-76)"""
+	import ctypes
+	from puzzlelib_amd import lib, rtc
+
+	def compile_(source, name):
+		code, size, log = ctypes.c_void_p(), ctypes.c_size_t(0), ctypes.create_string_buffer(1 << 14)
+		opts = (ctypes.c_char_p * 1)()
+		lib.pz_rtc_compile(source.encode(), name, opts, 0, ctypes.byref(code), ctypes.byref(size), log, len(log))
+		blob = ctypes.string_at(code, size.value)
+		lib.pz_rtc_free_code(code)
+		return blob, log.value.decode()
+
+	elt = rtc.ElementwiseKernel([("float *", "y"), ("const float *", "x"), ("float", "a")], "y[i] = a * x[i] + y[i]", "axpy_like")
+	blob, _ = compile_(elt.generateSource(), b"axpy_like.hip")
+	assert blob[:4] == b"\x7fELF" and b"axpy_like_strided" in blob and elt.formats == ["P", "P", "f"] and elt.writes == (0, )
+	red = rtc.ReductionKernel(np.float32, neutral="-3.4e38f", reduceExpr="fmaxf(a, b)", mapExpr="fabsf(x[i])", arguments=[("const float *", "x")], name="absmax")
+	blob, _ = compile_(red.generateSource(), b"absmax.hip")
+	assert b"absmax_stage1" in blob and b"absmax_stage2" in blob
+	with pytest.raises(ValueError, match="undeclared|error"):
+		compile_("extern \"C\" __global__ void broken(float *x) { x[0] = nosuchthing; }", b"broken.hip")
+	# the argument buffer: every value at its natural alignment
+	assert rtc.pack(["P", "i", "q", "f", "d"], [0x1000, 7, 9, 1.5, 2.5]) == (
+		(0x1000).to_bytes(8, "little") + (7).to_bytes(4, "little") + bytes(4) + (9).to_bytes(8, "little") +
+		np.float32(1.5).tobytes() + bytes(4) + np.float64(2.5).tobytes())
+
+
 def test_convolution_family_resolution_without_device():
 	"""pz_conv2d_algo_used / workspace sizes are host logic: which kernel family serves a layer under each requested algo
 	(Hip/Wrappers/MIOpen.py:23-49 ids: direct 1, winograd 3, implicitGemm 5, auto -1)."""

@@ -6,7 +6,7 @@
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python -c "from puzzlelib_amd import lib; print('build', lib.buildId())" > gpurun_out/gpu_tests.txt 2>&1
-timeout 900 python -m pytest tests -m gpu -q >> gpurun_out/gpu_tests.txt 2>&1; echo "pytest exit $?" >> gpurun_out/gpu_tests.txt
+timeout 1800 python -m pytest tests -m gpu -q >> gpurun_out/gpu_tests.txt 2>&1; echo "pytest exit $?" >> gpurun_out/gpu_tests.txt
 bash tools/prof_bench.sh one_stream > gpurun_out/summary_one_stream.txt 2>&1
 bash tools/pmc_bench.sh > gpurun_out/pmc_bench.txt 2>&1
 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
