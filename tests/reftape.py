@@ -552,7 +552,7 @@ def replay(path, getBackend, check=None):
 			for k, e in enc["dict"].items():
 				bind(e, value[k], "%s[%s]" % (what, k))
 
-	names = {}
+	names, audited = {}, [0]
 	for i, op in enumerate(header["ops"]):
 		kind = op["k"]
 		if kind == "root":
@@ -576,9 +576,13 @@ def replay(path, getBackend, check=None):
 				want = data[op["v"]]
 				assert sample.shape == want.shape, "op %d: audit of a %s array, recorded %s" % (i, sample.shape, want.shape)
 				if want.dtype.kind == "f":
+					# (the dense early audits sit in front of any amplification; the sparse late ones of a training loop follow a
+					# trajectory hundreds of updates long — held like the late scalar monitors, to 2 % of the sample's top)
+					audited[0] += 1
+					rel = 1e-3 if audited[0] <= AUDIT_DENSE else 2e-2
 					scale = float(np.abs(want).max())
 					err = float(np.abs(sample.astype(np.float64) - want.astype(np.float64)).max()) if want.size else 0.0
-					assert err <= 1e-5 + 1e-3 * scale, "op %d: audit of %s differs by %.3e (largest recorded magnitude %.3e)" % (i, names.get(op["id"], "?"), err, scale)
+					assert err <= 1e-5 + rel * scale, "op %d: audit of %s differs by %.3e (largest recorded magnitude %.3e)" % (i, names.get(op["id"], "?"), err, scale)
 				else:
 					assert np.array_equal(sample, want), "op %d: audit of an integer array differs" % i
 				compared[0] += 1
