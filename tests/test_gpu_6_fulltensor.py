@@ -17,6 +17,8 @@ Tolerances (per element, stated where they are applied):
   Winograd F(4x4) fwd / bwd-data |err| <= 6e-5 max|ref|      (test_winograd_convolution's stated bound)
   Winograd F(2x2) bwd-filter     |err| <= 2e-5 max|ref| + 1e-5 sqrt(N P Q)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -226,6 +228,11 @@ BNSTATS = [
 ]
 
 
+# The epilogue behind this test was written in round 6, when no device was available to the build: it is
+# compiled, its glue and this test's own arithmetic were run on the emulated C ABI, but the kernel code has never executed. It is
+# opt-in in the product (PUZZLE_MI355_DGRAD_STATS=1) and so is its device test: tools/r06_validate.sh runs it first thing.
+@pytest.mark.skipif(os.environ.get("PUZZLE_MI355_DGRAD_STATS", "0") != "1" and os.environ.get("PUZZLE_MI355_UNVERIFIED", "0") != "1",
+					reason="opt-in feature (PUZZLE_MI355_DGRAD_STATS=1), device code not yet run on an MI355X: tools/r06_validate.sh")
 @pytest.mark.parametrize("fold", [False, True], ids=["plain", "bn_fold"])
 @pytest.mark.parametrize("case", BNSTATS, ids=lambda c: "b%d_%dx%dx%d_to_%d" % ((c[0], ) + c[1] + (c[2], )))
 def test_backward_data_epilogue_statistics_vs_fp64_oracle(bnd, case, fold):

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python -c "from puzzlelib_amd import lib; print('build', lib.buildId())" > gpurun_out/r06_new_tests.txt 2>&1
 # 1. the kernels and entries nobody has run on a device yet
-timeout 1200 python -m pytest tests/test_gpu_6_fulltensor.py tests/test_gpu_2_boundary.py tests/test_gpu_8_multigpu.py tests/test_gpu_0_ops.py \
+PUZZLE_MI355_UNVERIFIED=1 timeout 1200 python -m pytest tests/test_gpu_6_fulltensor.py tests/test_gpu_2_boundary.py tests/test_gpu_8_multigpu.py tests/test_gpu_0_ops.py \
 	-q -k "statistics or fp16 or out_of_scope or rehearsal or runGrid or (fresh and (r3ds1 or r33))" >> gpurun_out/r06_new_tests.txt 2>&1
 echo "new tests exit $?" >> gpurun_out/r06_new_tests.txt
 # 2. the new tapes (boundary tests, handlers, nets)
