@@ -30,11 +30,21 @@ inline int stream_grid(size_t work_items, int per_block) {
 	return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
+// pz_conv2d_bwd_data_bnstats: the BatchNorm in FRONT of the layer whose backward-data launch is asked to sum that BatchNorm's backward
+// statistics over the gated gradient in its epilogue — y = relu(gab[c].x * gx + gab[c].y) was the layer's input; per produced channel
+// and strip (64 pixels in the implicit GEMM, 32 tiles in the Winograd kernel) {sum q, sum q (gx - gmean[c])}, q = dx * (y > 0), to gst
+struct BnStatsOut {
+	const float *gx, *gab, *gmean;
+	float *gst;          // float2 [channel][strips]
+};
+
 // Winograd F(2x2, 3x3) forward / backward-data (wino.hip); `which` is PZ_CONV_FWD or PZ_CONV_BWD_DATA
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q);
 size_t wino_workspace_bytes(const pz_conv_desc *d, int which, int P, int Q);
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats = nullptr, bool filters_ready = false, void *vscratch = nullptr);
+              void *workspace, hipStream_t st, float *stats = nullptr, bool filters_ready = false, void *vscratch = nullptr,
+              const BnStatsOut *bst = nullptr);
+int wino_bnstats_strips(const pz_conv_desc *d, int P, int Q);     // strips per channel a backward-data launch leaves for `bst` (0: it cannot)
 // scratch for the transformed input of a forward / backward-data launch (0: the launch transforms its patches itself); passed
 // as `vscratch`
 size_t wino_input_bytes(const pz_conv_desc *d, int which, int P, int Q);
@@ -53,7 +63,7 @@ size_t wino4_workspace_bytes(const pz_conv_desc *d, int which);
 int wino4_stats_strips(const pz_conv_desc *d, int P, int Q);
 int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const float *const *w, float *const *u, int n, hipStream_t st);
 int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch);
+               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch, const BnStatsOut *bst = nullptr);
 size_t wino4_input_bytes(const pz_conv_desc *d, int which, int P, int Q);
 
 // direct backward-data for stride-2 convolutions with <= 4 input maps (thin.hip): the stem layer

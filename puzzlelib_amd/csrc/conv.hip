@@ -2636,14 +2636,22 @@ __global__ void __launch_bounds__(256) dgrad_bnstats_merge_kernel(const float2 *
 
 static size_t dgrad_bnstats_head_bytes(int c) { return align256((size_t)c * 2 * sizeof(double)); }
 
+// strips per channel the backward-data launch of this layer leaves: 64-pixel strips of the implicit GEMM's contiguous-output
+// epilogue, blocks of 32 output tiles of the F(4x4) Winograd kernel; 0 = the launch cannot sum them
+static long dgrad_bnstats_strips(const pz_conv_desc *d, int P, int Q, int algo) {
+	const ConvPath path = conv_path(d, PZ_CONV_BWD_DATA, P, Q, algo);
+	if (path == PATH_WINOGRAD) return pz::wino_bnstats_strips(d, P, Q);
+	if (path == PATH_IGEMM && d->stride_h == 1 && d->stride_w == 1) return pz::ceil_div((long)d->n * d->h * d->w, PZ_CONV_STATS_STRIP);
+	return 0;
+}
+
 int pz_conv2d_bwd_data_bnstats_bytes(const pz_conv_desc *d, int algo, size_t *nbytes) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
 	PZ_REQUIRE(nbytes != nullptr, "pz_conv2d_bwd_data_bnstats_bytes: null output");
-	int ok = 0;
-	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_BWD_DATA, algo, &ok)) return rc;
-	// 0: this configuration has no such epilogue (Winograd / strided / direct forms)
-	*nbytes = ok ? dgrad_bnstats_head_bytes(d->c) + (size_t)d->c * pz::ceil_div((long)d->n * d->h * d->w, PZ_CONV_STATS_STRIP) * sizeof(float2) : 0;
+	const long strips = dgrad_bnstats_strips(d, P, Q, algo);
+	// 0: this configuration has no such epilogue (F(2x2) Winograd / strided / direct forms)
+	*nbytes = strips > 0 ? dgrad_bnstats_head_bytes(d->c) + (size_t)d->c * strips * sizeof(float2) : 0;
 	return PZ_OK;
 }
 
@@ -2652,9 +2660,8 @@ int pz_conv2d_bwd_data_bnstats(const pz_conv_desc *d, const float *dy, const flo
                                void *workspace, size_t ws_bytes, pz_stream_t stream) {
 	int P, Q;
 	if (int rc = check_desc(d, &P, &Q)) return rc;
-	int ok = 0;
-	if (int rc = pz_conv2d_epilogue_supported(d, PZ_CONV_BWD_DATA, algo, &ok)) return rc;
-	PZ_REQUIRE(ok, "pz_conv2d_bwd_data_bnstats: this configuration has no statistics epilogue (pz_conv2d_bwd_data_bnstats_bytes)");
+	PZ_REQUIRE(dgrad_bnstats_strips(d, P, Q, algo) > 0,
+	           "pz_conv2d_bwd_data_bnstats: this configuration has no statistics epilogue (pz_conv2d_bwd_data_bnstats_bytes)");
 	PZ_REQUIRE(gx && gab && gmean && partials, "pz_conv2d_bwd_data_bnstats: null BatchNorm operand");
 	PZ_REQUIRE((bnx == nullptr) == (bncoef == nullptr), "pz_conv2d_bwd_data_bnstats: the gradient-side fold needs both its operands");
 	PZ_REQUIRE(bnx == nullptr || bn_fold_eligible(d, P, Q, algo), "pz_conv2d_bwd_data_bnstats: this convolution cannot fold a BatchNorm backward");
@@ -2704,6 +2711,20 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 		PZ_REQUIRE(need == 0 || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_bwd_data: workspace %zu < required %zu bytes", ws_bytes, need);
 		const size_t fbytes = packed ? 0 : align256(pz::wino_workspace_bytes(d, PZ_CONV_BWD_DATA, P, Q));
 		void *vscratch = pz::wino_input_bytes(d, PZ_CONV_BWD_DATA, P, Q) > 0 ? (char *)workspace + fbytes : nullptr;
+		if (bst) {
+			const int strips = pz::wino_bnstats_strips(d, P, Q);
+			PZ_REQUIRE(strips > 0, "pz_conv2d_bwd_data_bnstats: this Winograd form has no statistics epilogue");
+			const pz::BnStatsOut out{bst->gx, bst->gab, bst->gmean, (float *)((char *)bst->partials + dgrad_bnstats_head_bytes(d->c))};
+			{
+				ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
+				if (int rc = pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st,
+				                           nullptr, packed != nullptr, vscratch, &out))
+					return rc;
+			}
+			dgrad_bnstats_merge_kernel<<<d->c, 256, 0, st>>>(reinterpret_cast<const float2 *>(out.gst), strips, reinterpret_cast<double *>(bst->partials));
+			PZ_LAUNCH_CHECK();
+			return PZ_OK;
+		}
 		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
 		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st, nullptr,
 		                     packed != nullptr, vscratch);

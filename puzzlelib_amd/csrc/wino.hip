@@ -1510,9 +1510,16 @@ int wino_filter_batch(const pz_conv_desc *const *descs, const int *which, const 
 
 size_t wino_input_bytes(const pz_conv_desc *d, int which, int P, int Q) { return wino4_input_bytes(d, which, P, Q); }
 
+int wino_bnstats_strips(const pz_conv_desc *d, int P, int Q) {
+	// only the F(4x4) kernel's backward-data epilogue sums them: one strip per block of 32 output tiles of the INPUT map
+	if (!wino_eligible(d, PZ_CONV_BWD_DATA, P, Q) || !wino4_pick(d, PZ_CONV_BWD_DATA, P, Q)) return 0;
+	return ceil_div((long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4), 32);
+}
+
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-              void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch) {
-	if (wino4_pick(d, which, P, Q)) return wino4_conv(d, which, P, Q, in, w, bias, out, workspace, st, stats, filters_ready, vscratch);
+              void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch, const BnStatsOut *bst) {
+	if (wino4_pick(d, which, P, Q)) return wino4_conv(d, which, P, Q, in, w, bias, out, workspace, st, stats, filters_ready, vscratch, bst);
+	PZ_REQUIRE(bst == nullptr, "wino_conv: the F(2x2) kernel has no statistics epilogue for a BatchNorm in front of the layer");
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 

@@ -137,6 +137,12 @@ struct W4Args {
 	int chunks, tblocks, kblocks;
 	unsigned x_bytes, y_bytes;
 	float4 *stats;           // optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count}
+	// backward-data launches (pz_conv2d_bwd_data_bnstats, see BnStatsOut in common.h): y is the gradient w.r.t. relu(gab.x * gx + gab.y);
+	// per produced channel and tile block {sum q, sum q (gx - gmean)} with q = y * (relu(..) > 0) to gst[k * tblocks + tb]
+	const float *gx;
+	const float2 *gab;
+	const float *gmean;
+	float2 *gst;
 	const float *v;          // PRE: transformed patches [tblocks][chunks][kV] in the order of an LDS stage (wino4_input_kernel)
 };
 
@@ -271,6 +277,11 @@ __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], f
 			const unsigned o = obase + (unsigned)k * pq4;
 
 			float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+			float g1 = 0.f, g2 = 0.f, ga = 0.f, gb = 0.f, gmu = 0.f;
+			if (a.gst) {                               // (wave-uniform)
+				const float2 ab = a.gab[min(k, a.K - 1)];
+				ga = ab.x, gb = ab.y, gmu = a.gmean[min(k, a.K - 1)];
+			}
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
 				float y[4];
@@ -280,6 +291,27 @@ __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], f
 
 				const bool rv = kv && rowok[i];
 				const unsigned orow = o + (unsigned)i * q4;
+				if (a.gst) {
+					// the BatchNorm input at the very addresses this row is stored to (same shape as y): gate with the forward's own
+					// fma (bn_gate<true>'s form), sum the gated gradient and its product with the centred input
+					const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gx, 0, a.y_bytes, 0x00020000);
+					float xv[4];
+					if (wide) {
+						const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, rv && colok[3] ? orow : kOOB, 0, 0));
+						xv[0] = t4[0], xv[1] = t4[1], xv[2] = t4[2], xv[3] = t4[3];
+					} else {
+#pragma unroll
+						for (int j = 0; j < 4; ++j)
+							xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, rv && colok[j] ? orow + 4u * j : kOOB, 0, 0));
+					}
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						const bool ok = rv && colok[j];
+						const float q = (ok && __builtin_fmaf(xv[j], ga, gb) > 0.f) ? y[j] : 0.f;
+						g1 += q;
+						g2 = __builtin_fmaf(q, xv[j] - gmu, g2);
+					}
+				}
 				// whole tile rows as 16 bytes; the tile at the right edge of a map whose width is no multiple of 4 word by word
 				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{y[0], y[1], y[2], y[3]}), yr, rv && colok[3] ? orow : kOOB, 0, 0);
 				if (!wide) {
@@ -305,6 +337,11 @@ __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], f
 #pragma unroll
 				for (int msk = 16; msk > 0; msk >>= 1) s1 += __shfl_xor(s1, msk), s2 += __shfl_xor(s2, msk), cnt += __shfl_xor(cnt, msk);
 				if (l31 == 0 && k < a.K) a.stats[(size_t)k * a.tblocks + tb] = make_float4(shift, s1, s2, cnt);
+			}
+			if (a.gst) {                               // the same fixed tree over the half-wave's 32 tiles
+#pragma unroll
+				for (int msk = 16; msk > 0; msk >>= 1) g1 += __shfl_xor(g1, msk), g2 += __shfl_xor(g2, msk);
+				if (l31 == 0 && k < a.K) a.gst[(size_t)k * a.tblocks + tb] = make_float2(g1, g2);
 			}
 		}
 		if (qq < 3) __syncthreads();
@@ -608,7 +645,8 @@ int wino4_filter_batch(const pz_conv_desc *const *descs, const int *which, const
 }
 
 int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,
-               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch) {
+               void *workspace, hipStream_t st, float *stats, bool filters_ready, void *vscratch, const BnStatsOut *bst) {
+	PZ_REQUIRE(bst == nullptr || which == PZ_CONV_BWD_DATA, "wino4_conv: the gated statistics belong to a backward-data launch");
 	W4FilterArgs fa = w4_filter_args(d, which, w, (float *)workspace);
 	if (!filters_ready) {
 		const long ftotal = (long)fa.kblocks * fa.chunks * KB * BC;
@@ -629,6 +667,7 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
 	a.stats = reinterpret_cast<float4 *>(stats);
+	if (bst) a.gx = bst->gx, a.gab = reinterpret_cast<const float2 *>(bst->gab), a.gmean = bst->gmean, a.gst = reinterpret_cast<float2 *>(bst->gst);
 	if (vscratch != nullptr && wino4_input_bytes(d, which, P, Q) > 0) {
 		a.v = (const float *)vscratch;
 		wino4_input_kernel<<<a.tblocks * ((a.chunks + 1) / 2), 256, 0, st>>>(a, (float *)vscratch);

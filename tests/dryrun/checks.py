@@ -314,6 +314,28 @@ def dgrad_stats_counts():
 	print("dgrad statistics: 3 backward-data launches carry the BatchNorm sums, 3 BatchNorm backwards run as one pass")
 
 
+def dgrad_stats_resnet50():
+	"""the bench's own step (ResNet-50, batch 256) with the pattern on: all 32 BatchNorms in front of a bottleneck's 3x3 and last 1x1
+	layer get their backward sums from the backward-data launch behind them (16 implicit-GEMM epilogues, 16 F(4x4) Winograd
+	epilogues); of the 33 two-pass BatchNorm backwards only the stem's is left"""
+	lazy.requested.add("dgradstats")
+	g = bound().gpuarray
+	net = nets.loadResNet(None, "50", actInplace=True, initscheme="none")
+	trainer, _ = trainerFor(net, 256)
+	data, labels = g.empty((256, 3, 224, 224), np.float32), g.empty((256, ), np.int32)
+	net.trainMode()
+	for _ in range(3):
+		lib.trace.clear()
+		lazy.counters.clear()
+		trainer.step([data, labels])
+		net.reset()
+	lazy.requested.discard("dgradstats")
+	calls, counts = names(), dict(lazy.counters)
+	assert counts.get("dgrad_bnstats") == 32 and counts.get("bn_bwd_gate_from_partials") == 32 and counts.get("bn_bwd_gate") == 1, counts
+	assert calls.count("pz_conv2d_bwd_data_bnstats") == 32 and calls.count("pz_bn_bwd_gate") == 1
+	print("ResNet-50 b256: 32 backward-data launches carry BatchNorm sums, %d two-pass BatchNorm backward left" % calls.count("pz_bn_bwd_gate"))
+
+
 def dgrad_stats_values_on_emulation():
 	"""the same step WITH VALUES, the C ABI emulated on host buffers (oracle/emu_cabi.py: the header's contract executed with the
 	numpy oracle): every parameter gradient of a mini-ResNet step with the statistics taken from the backward-data epilogue

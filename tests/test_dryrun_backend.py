@@ -43,6 +43,10 @@ def test_backward_data_epilogue_carries_the_batchnorm_backward_sums_when_asked()
 	assert "one pass" in run("dgrad_stats_counts")
 
 
+def test_all_bottleneck_batchnorms_of_resnet50_get_their_backward_sums_from_an_epilogue_when_asked():
+	assert "32 backward-data launches" in run("dgrad_stats_resnet50", timeout=600)
+
+
 def test_epilogue_statistics_give_the_same_gradients_on_the_emulated_cabi():
 	assert "within" in run("dgrad_stats_values_on_emulation")
 

@@ -225,6 +225,9 @@ BNSTATS = [
 	(5, (16, 7, 7), 130),            # two row tiles, the second nearly empty
 	(256, (256, 55, 55), 64),        # the 64-row tile (HBM-bound launches of stage 2's tails)
 	(256, (512, 28, 28), 128), (256, (1024, 14, 14), 256), (256, (2048, 7, 7), 512),       # 128-row tiles, k-sliced tail rounds
+	# 3x3 layers (a fourth entry = the filter size): the F(4x4) Winograd kernel's backward-data epilogue — the BatchNorms in front of
+	# the bottlenecks' 3x3 layers; 55 and 7 are no multiples of 4 (edge tiles, word-by-word rows), 13 x 9 leaves a ragged last tile block
+	(256, (64, 55, 55), 64, 3), (256, (128, 28, 28), 128, 3), (256, (256, 14, 14), 256, 3), (256, (512, 7, 7), 512, 3), (40, (32, 13, 9), 64, 3),
 ]
 
 
@@ -234,7 +237,7 @@ BNSTATS = [
 @pytest.mark.skipif(os.environ.get("PUZZLE_MI355_DGRAD_STATS", "0") != "1" and os.environ.get("PUZZLE_MI355_UNVERIFIED", "0") != "1",
 					reason="opt-in feature (PUZZLE_MI355_DGRAD_STATS=1), device code not yet run on an MI355X: tools/r06_validate.sh")
 @pytest.mark.parametrize("fold", [False, True], ids=["plain", "bn_fold"])
-@pytest.mark.parametrize("case", BNSTATS, ids=lambda c: "b%d_%dx%dx%d_to_%d" % ((c[0], ) + c[1] + (c[2], )))
+@pytest.mark.parametrize("case", BNSTATS, ids=lambda c: "b%d_%dx%dx%d_to_%d%s" % ((c[0], ) + c[1] + (c[2], "_3x3" if len(c) > 3 else "")))
 def test_backward_data_epilogue_statistics_vs_fp64_oracle(bnd, case, fold):
 	"""dx bit-identical to the launch without the epilogue sums; the merged sums against fp64 sums over the device's own dx
 	(|err| <= 2e-6 * sum |terms|: fp32 strip sums of <= 64 terms each, merged in fp64); pz_bn_bwd_gate_from_partials against
@@ -243,14 +246,15 @@ def test_backward_data_epilogue_statistics_vs_fp64_oracle(bnd, case, fold):
 	import ctypes
 	from puzzlelib_amd import lib
 	G = bnd.GPUArray
-	n, (k, h, w), c = case
-	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, 1, 1), 1, 0, 1, 1)
+	n, (k, h, w), c = case[:3]
+	r = case[3] if len(case) > 3 else 1
+	desc = bnd.dnn.convDesc((n, c, h, w), (k, c, r, r), 1, r // 2, 1, 1)
 	algo = lib.CONV_ALGO_AUTO
 	rng = np.random.RandomState(51)
 	hw = h * w
 
 	dy, bz, z = dev_randn(bnd, (n, k, h, w), 52), dev_randn(bnd, (n, k, h, w), 53), dev_randn(bnd, (n, c, h, w), 54)
-	wh = (rng.randn(k, c, 1, 1) / np.sqrt(k)).astype(np.float32)
+	wh = (rng.randn(k, c, r, r) / np.sqrt(k * r * r)).astype(np.float32)
 	ab = np.stack([0.5 + rng.rand(c), 0.4 * rng.randn(c)], axis=1).astype(np.float32)       # the forward's {a, b} of the BatchNorm in front
 	mean = (0.3 * rng.randn(c)).astype(np.float32)
 	rstd = (0.5 + rng.rand(c)).astype(np.float32)
@@ -260,6 +264,8 @@ def test_backward_data_epilogue_statistics_vs_fp64_oracle(bnd, case, fold):
 
 	size = ctypes.c_size_t(0)
 	lib.pz_conv2d_bwd_data_bnstats_bytes(ctypes.byref(desc), algo, ctypes.byref(size))
+	if r == 3 and size.value == 0:
+		pytest.skip("this 3x3 layer runs on the F(2x2) Winograd kernel, which has no statistics epilogue")
 	assert size.value >= 16 * c, "every pointwise stride-1 layer has the statistics epilogue"
 	parts = G.empty((size.value, ), dtype=np.uint8)
 	nbytes, foldable = bnd.dnn.convGeometry(desc, lib.CONV_BWD_DATA, algo)[2], bnd.dnn.convGeometry(desc, lib.CONV_BWD_DATA, algo)[4]
