@@ -42,6 +42,30 @@ def test_reference_unittest_replayed_on_the_device(bnd, tape, fusion):
 		compared, MANIFEST[tape_id(tape)]["values"])
 
 
+# -m "not gpu": the same replay against the C ABI EMULATED on host buffers (oracle/emu_cabi.py: the header's contract executed with
+# the numpy oracle) — the Python glue between the backend object and the C ABI runs with values in the CPU suite too. A sample of the
+# tapes (hot-path modules, boundary tests, an optimizer trajectory, a network with audits and generator-drawn inputs, run-time
+# compiled kernels); oracle/make_reftests.py --check replays all of them.
+CPU_SAMPLE = ["Modules.Conv2D", "Modules.BatchNorm2D", "Modules.Linear", "Modules.MaxPool2D", "Cost.CrossEntropy", "Optimizers.Adam",
+			  "Boundary.MIOpen", "Boundary.MatVec", "Boundary.GPUArray", "Boundary.SourceModule", "Hip.Wrappers.MIOpenNorm", "Models.Nets.NiN"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", CPU_SAMPLE)
+def test_tape_replays_on_the_emulated_cabi(name):
+	import subprocess, sys
+	from conftest import ROOT
+	path = os.path.join(GOLDEN, "reftests", name + ".npz")
+	assert os.path.exists(path), "no committed tape %s" % name
+	env = dict(os.environ, PUZZLE_MI355_DRYRUN="1", PYTHONDONTWRITEBYTECODE="1")
+	env.pop("PUZZLE_MI355_DEBUG_ALLOC", None)
+	res = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_reftests.py"), "--replay", path], env=env,
+						 capture_output=True, text=True, timeout=580)
+	assert res.returncode == 0, res.stderr[-3000:]
+	line = next(l for l in res.stdout.splitlines() if l.startswith("REPLAY "))
+	assert json.loads(line.split(" ", 1)[1])["compared"] == MANIFEST[name]["values"]
+
+
 def test_tapes_are_data_and_listed():
 	"""-m "not gpu": every committed tape loads, is listed in the manifest with the number of values it checks, and mentions
 	nothing but backend attributes, calls, host arrays and scalars"""
