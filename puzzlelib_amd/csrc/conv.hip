@@ -2459,7 +2459,7 @@ static int conv2d_fwd_impl(const pz_conv_desc *d, const float *x, const float *w
 		PZ_REQUIRE(need == 0 || (workspace != nullptr && ws_bytes >= need), "pz_conv2d_fwd: workspace %zu < required %zu bytes", ws_bytes, need);
 		const size_t fbytes = packed ? 0 : align256(pz::wino_workspace_bytes(d, PZ_CONV_FWD, P, Q));
 		void *vscratch = pz::wino_input_bytes(d, PZ_CONV_FWD, P, Q) > 0 ? (char *)workspace + fbytes : nullptr;
-		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
+		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * d->r * d->s);
 		return pz::wino_conv(d, PZ_CONV_FWD, P, Q, x, w, bias, y, packed ? const_cast<void *>(packed) : workspace, st, stats, packed != nullptr,
 		                     vscratch);
 	}
@@ -2716,7 +2716,7 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 			PZ_REQUIRE(strips > 0, "pz_conv2d_bwd_data_bnstats: this Winograd form has no statistics epilogue");
 			const pz::BnStatsOut out{bst->gx, bst->gab, bst->gmean, (float *)((char *)bst->partials + dgrad_bnstats_head_bytes(d->c))};
 			{
-				ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
+				ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * d->r * d->s);
 				if (int rc = pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st,
 				                           nullptr, packed != nullptr, vscratch, &out))
 					return rc;
@@ -2725,7 +2725,7 @@ static int conv2d_bwd_data_impl(const pz_conv_desc *d, const float *dy, const fl
 			PZ_LAUNCH_CHECK();
 			return PZ_OK;
 		}
-		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * 9);
+		ProfScope prof(st, 3, 2.0 * d->n * P * Q * (double)d->k * d->c * d->r * d->s);
 		return pz::wino_conv(d, PZ_CONV_BWD_DATA, P, Q, dy, w, nullptr, dx, packed ? const_cast<void *>(packed) : workspace, st, nullptr,
 		                     packed != nullptr, vscratch);
 	}

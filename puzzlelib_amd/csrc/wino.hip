@@ -1443,8 +1443,17 @@ static void wino_dims(const pz_conv_desc *d, int which, int P, int Q, int *prod,
 
 bool wino_eligible(const pz_conv_desc *d, int which, int P, int Q) {
 	if (which != PZ_CONV_FWD && which != PZ_CONV_BWD_DATA) return false;
-	if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
-	if (d->pad_h != d->pad_w || d->pad_h > 1) return false;
+	// 5x5 filters with pad 2 (NiN's 96 -> 192 layer, TestLib/CnnCifar10NIN.py:13-49): F(2x2, 5x5) on the F(4x4, 3x3) kernel of wino4.hip —
+	// the same 6x6 patches and 36 positions, tile step 2, its own filter and output transforms. Written in round 6 without a
+	// device to run it on: opt-in (PUZZLE_MI355_WINO5=1) until it has been verified and timed.
+	const bool five = d->r == 5 && d->s == 5;
+	if (five) {
+		static const bool on = [] { const char *e = getenv("PUZZLE_MI355_WINO5"); return e && atoi(e) != 0; }();
+		if (!on || d->pad_h != 2 || d->pad_w != 2) return false;
+	} else if (d->r != 3 || d->s != 3 || d->pad_h != d->pad_w || d->pad_h > 1) {
+		return false;
+	}
+	if (d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1 || d->groups != 1) return false;
 	int prod, red;
 	wino_dims(d, which, P, Q, &prod, &red);
 	if (red % BC != 0) return false;
@@ -1513,7 +1522,8 @@ size_t wino_input_bytes(const pz_conv_desc *d, int which, int P, int Q) { return
 int wino_bnstats_strips(const pz_conv_desc *d, int P, int Q) {
 	// only the F(4x4) kernel's backward-data epilogue sums them: one strip per block of 32 output tiles of the INPUT map
 	if (!wino_eligible(d, PZ_CONV_BWD_DATA, P, Q) || !wino4_pick(d, PZ_CONV_BWD_DATA, P, Q)) return 0;
-	return ceil_div((long)d->n * ((d->h + 3) / 4) * ((d->w + 3) / 4), 32);
+	const int m = d->r == 5 ? 2 : 4;
+	return ceil_div((long)d->n * ((d->h + m - 1) / m) * ((d->w + m - 1) / m), 32);
 }
 
 int wino_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, const float *w, const float *bias, float *out,

@@ -33,6 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 
 namespace {
@@ -47,10 +48,10 @@ constexpr int kV = NP * TB * BC;     // floats of transformed patches per chunk 
 constexpr int kU = NP * KB * BC;     // floats of transformed filters per (channel block, chunk) (18 KB)
 
 struct W4FilterArgs {
-	const float *w;          // (K, C, 3, 3)
+	const float *w;          // (K, C, R, R), R = 3 (F(4x4, 3x3)) or 5 (F(2x2, 5x5): the same six interpolation points)
 	float *u;                // [kblocks][chunks][4 waves]{[4 position pairs][2][KB][2 positions][2], [2][KB][2]}: w4_u_index
 	int mode;                // 0: forward (produced = K, reduction = C); 1: backward-data (produced = C, reduction = K, taps flipped)
-	int K, C;                // dims of w
+	int K, C, R;             // dims of w
 	int prod, red;
 	int kblocks, chunks;
 };
@@ -76,7 +77,27 @@ __device__ __forceinline__ void w4_g_row(float g0, float g1, float g2, float (&o
 	o[5] = g2;
 }
 
+// one row of G5 . (g0 .. g4): the 6 x 5 matrix of F(2, 5) on the points 0, +-1, +-2, inf — row i = c_i (1, p_i, p_i^2, p_i^3, p_i^4)
+// with the c_i of w4_g_row (they depend on the points alone), last row (0, 0, 0, 0, 1)
+__device__ __forceinline__ void w5_g_row(float g0, float g1, float g2, float g3, float g4, float (&o)[6]) {
+	const float ev = g0 + g2 + g4, od = g1 + g3;
+	o[0] = 0.25f * g0;
+	o[1] = (-1.f / 6.f) * (ev + od);
+	o[2] = (-1.f / 6.f) * (ev - od);
+	const float e = (1.f / 24.f) * g0 + (1.f / 6.f) * g2 + (2.f / 3.f) * g4, f = (1.f / 12.f) * g1 + (1.f / 3.f) * g3;
+	o[3] = e + f;
+	o[4] = e - f;
+	o[5] = g4;
+}
+
+template <int R>
+__device__ __forceinline__ void w4_filter_body_r(const W4FilterArgs &a, long first, long step);
+
 __device__ __forceinline__ void w4_filter_body(const W4FilterArgs &a, long first, long step) {
+	if (a.R == 5) {
+		w4_filter_body_r<5>(a, first, step);
+		return;
+	}
 	const long total = (long)a.kblocks * a.chunks * KB * BC;
 	for (long i = first; i < total; i += step) {
 		const int ci = (int)(i % 2), kk = (int)((i / 2) % KB), h = (int)((i / (2 * KB)) % 2);
@@ -109,6 +130,41 @@ __device__ __forceinline__ void w4_filter_body(const W4FilterArgs &a, long first
 	}
 }
 
+template <int R>
+__device__ __forceinline__ void w4_filter_body_r(const W4FilterArgs &a, long first, long step) {
+	static_assert(R == 5, "the 3-tap form is w4_filter_body itself");
+	const long total = (long)a.kblocks * a.chunks * KB * BC;
+	for (long i = first; i < total; i += step) {
+		const int ci = (int)(i % 2), kk = (int)((i / 2) % KB), h = (int)((i / (2 * KB)) % 2);
+		const long blk = i / (2 * KB * 2);
+		const int chunk = (int)(blk % a.chunks), kb = (int)(blk / a.chunks);
+		const int k = kb * KB + kk, c = chunk * BC + h * 2 + ci;
+
+		float g[R][R];
+#pragma unroll
+		for (int r = 0; r < R; ++r)
+#pragma unroll
+			for (int t = 0; t < R; ++t) {
+				float v = 0.f;
+				if (k < a.prod && c < a.red)
+					v = a.mode == 0 ? a.w[((long)k * a.C + c) * (R * R) + r * R + t] : a.w[((long)c * a.C + k) * (R * R) + (R - 1 - r) * R + (R - 1 - t)];
+				g[r][t] = v;
+			}
+
+		float t6[R][6];          // t6[s][r] = (G g)[r][s]
+#pragma unroll
+		for (int t = 0; t < R; ++t) w5_g_row(g[0][t], g[1][t], g[2][t], g[3][t], g[4][t], t6[t]);
+		float *dst = a.u + blk * kU;
+#pragma unroll
+		for (int r = 0; r < 6; ++r) {
+			float u[6];
+			w5_g_row(t6[0][r], t6[1][r], t6[2][r], t6[3][r], t6[4][r], u);
+#pragma unroll
+			for (int t = 0; t < 6; ++t) dst[w4_u_index(r * 6 + t, h, kk, ci)] = u[t];
+		}
+	}
+}
+
 __global__ void __launch_bounds__(256) wino4_filter_kernel(W4FilterArgs a) {
 	w4_filter_body(a, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
@@ -133,7 +189,8 @@ struct W4Args {
 	float *y;                // (N, K, P, Q)
 	int N, C, H, W, K, P, Q;
 	int pad_h, pad_w;
-	int TY, TX, tiles;       // 4x4 tiles per image column / row, N*TY*TX
+	int TY, TX, tiles;       // output tiles per image column / row, N*TY*TX
+	int ts;                  // outputs per tile side = tile step: 4 (3x3 filters) or 2 (5x5 filters); the patch is 6x6 either way
 	int chunks, tblocks, kblocks;
 	unsigned x_bytes, y_bytes;
 	float4 *stats;           // optional [K][tblocks] {shift, sum(v - shift), sum((v - shift)^2), count}
@@ -197,7 +254,7 @@ __global__ void __launch_bounds__(256) wino4_input_kernel(W4Args a, float *__res
 	const bool tv = t < a.tiles;
 	const int n = t / (a.TY * a.TX), r0 = t - n * (a.TY * a.TX);
 	const int ty = r0 / a.TX, tx = r0 - ty * a.TX;
-	const int row0 = 4 * ty - a.pad_h, col0 = 4 * tx - a.pad_w;
+	const int row0 = a.ts * ty - a.pad_h, col0 = a.ts * tx - a.pad_w;
 	const bool inner = col0 >= 0 && col0 + 5 < a.W;
 	const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.x_bytes, 0x00020000);
 
@@ -348,7 +405,120 @@ __device__ __forceinline__ void w4_epilogue(const W4Args &a, f32x16 (&acc)[9], f
 	}
 }
 
-template <bool PRE>
+// A^T of F(2, 5) applied to six values: two results (rows (1 1 1 1 1 0) and (0 1 -1 2 -2 1) — the first two rows of w4_at's matrix,
+// the point at infinity moved to the last row there is)
+__device__ __forceinline__ void w5_at(const float (&m)[6], float (&o)[2]) {
+	const float p12 = m[1] + m[2], d12 = m[1] - m[2], p34 = m[3] + m[4], d34 = m[3] - m[4];
+	o[0] = m[0] + p12 + p34;
+	o[1] = __builtin_fmaf(2.f, d34, d12) + m[5];
+}
+
+// The epilogue of the 2x2-output form (5x5 filters): w4_epilogue with two output rows of two columns per tile — 8-byte stores, the
+// tile at the right edge of an odd map word by word; statistics blocks as there.
+__device__ __forceinline__ void w5_epilogue(const W4Args &a, f32x16 (&acc)[9], float *Ms, int kb, int tb, int tid, int pbase, int lane) {
+	const int l31 = lane & 31, lhi = lane >> 5;
+	const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)a.y, 0, a.y_bytes, 0x00020000);
+
+	const int t = tb * TB + l31;
+	const bool tv = t < a.tiles;
+	const int n = t / (a.TY * a.TX), rr = t - n * (a.TY * a.TX);
+	const int ty = rr / a.TX, tx = rr - ty * a.TX;
+	bool rowok[2], colok[2];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) rowok[i] = 2 * ty + i < a.P, colok[i] = 2 * tx + i < a.Q;
+	const bool wide = __builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(tv && !colok[1]) == 0ull)) != 0;
+	const unsigned pq4 = (unsigned)(a.P * a.Q) * 4u, q4 = (unsigned)a.Q * 4u;
+	const unsigned obase = (unsigned)((((long)n * a.K) * a.P + 2 * ty) * a.Q + 2 * tx) * 4u;
+	const int kk = tid >> 5;                           // 256 threads = 32 tiles x 8 channels
+
+#pragma unroll
+	for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+		for (int i = 0; i < 9; ++i)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) Ms[((pbase + i) * 8 + 4 * lhi + r) * 32 + l31] = acc[i][4 * qq + r];
+		__syncthreads();
+
+		{
+			const int k = kb * KB + qq * 8 + kk;
+			float s[2][6];                             // A^T m, one column of m at a time
+#pragma unroll
+			for (int c = 0; c < 6; ++c) {
+				float m[6], o[2];
+#pragma unroll
+				for (int r = 0; r < 6; ++r) m[r] = Ms[((r * 6 + c) * 8 + kk) * 32 + l31];
+				w5_at(m, o);
+				s[0][c] = o[0], s[1][c] = o[1];
+			}
+			const float b = (a.bias != nullptr && k < a.K) ? a.bias[k] : 0.f;
+			const bool kv = tv && k < a.K;
+			const unsigned o = obase + (unsigned)k * pq4;
+
+			float shift = 0.f, s1 = 0.f, s2 = 0.f, cnt = 0.f;
+			float g1 = 0.f, g2 = 0.f, ga = 0.f, gb = 0.f, gmu = 0.f;
+			if (a.gst) {                               // (wave-uniform)
+				const float2 ab = a.gab[min(k, a.K - 1)];
+				ga = ab.x, gb = ab.y, gmu = a.gmean[min(k, a.K - 1)];
+			}
+#pragma unroll
+			for (int i = 0; i < 2; ++i) {
+				float y[2];
+				w5_at(s[i], y);
+				y[0] += b, y[1] += b;
+
+				const bool rv = kv && rowok[i];
+				const unsigned orow = o + (unsigned)i * q4;
+				if (a.gst) {
+					const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void *)a.gx, 0, a.y_bytes, 0x00020000);
+					float xv[2];
+					if (wide) {
+						const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(gr, rv && colok[1] ? orow : kOOB, 0, 0));
+						xv[0] = t2[0], xv[1] = t2[1];
+					} else {
+#pragma unroll
+						for (int j = 0; j < 2; ++j)
+							xv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, rv && colok[j] ? orow + 4u * j : kOOB, 0, 0));
+					}
+#pragma unroll
+					for (int j = 0; j < 2; ++j) {
+						const bool ok = rv && colok[j];
+						const float q = (ok && __builtin_fmaf(xv[j], ga, gb) > 0.f) ? y[j] : 0.f;
+						g1 += q;
+						g2 = __builtin_fmaf(q, xv[j] - gmu, g2);
+					}
+				}
+				__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{y[0], y[1]}), yr, rv && colok[1] ? orow : kOOB, 0, 0);
+				if (!wide)
+					__builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[0]), yr, rv && !colok[1] && colok[0] ? orow : kOOB, 0, 0);
+
+				if (a.stats) {
+					if (i == 0) shift = __shfl(y[0], lane & 32);
+#pragma unroll
+					for (int j = 0; j < 2; ++j) {
+						const bool ok = rv && colok[j];
+						const float dlt = ok ? y[j] - shift : 0.f;
+						s1 += dlt, s2 = __builtin_fmaf(dlt, dlt, s2), cnt += ok ? 1.f : 0.f;
+					}
+				}
+			}
+			if (a.stats) {
+#pragma unroll
+				for (int msk = 16; msk > 0; msk >>= 1) s1 += __shfl_xor(s1, msk), s2 += __shfl_xor(s2, msk), cnt += __shfl_xor(cnt, msk);
+				if (l31 == 0 && k < a.K) a.stats[(size_t)k * a.tblocks + tb] = make_float4(shift, s1, s2, cnt);
+			}
+			if (a.gst) {
+#pragma unroll
+				for (int msk = 16; msk > 0; msk >>= 1) g1 += __shfl_xor(g1, msk), g2 += __shfl_xor(g2, msk);
+				if (l31 == 0 && k < a.K) a.gst[(size_t)k * a.tblocks + tb] = make_float2(g1, g2);
+			}
+		}
+		if (qq < 3) __syncthreads();
+	}
+}
+
+// M = outputs per tile side: 4 (3x3 filters, w4_epilogue) or 2 (5x5 filters, w5_epilogue); everything in front of the epilogue —
+// gathers, the B^T d B transform of the 6x6 patches, the 36 position products — is the same code (the tile step is W4Args::ts)
+template <bool PRE, int M = 4>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) wino4_conv_kernel(W4Args a) {
 	// two stages of V, then the waves' private blocks of row-transformed patches; the epilogue's block reuses all of it
 	__shared__ __attribute__((aligned(16))) float smem[3 * kV];                  // 54 KB
@@ -375,10 +545,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 		const bool tv = t < a.tiles;
 		const int n = t / (a.TY * a.TX), r0 = t - n * (a.TY * a.TX);
 		const int ty = r0 / a.TX, tx = r0 - ty * a.TX;
-		const int col0 = 4 * tx - a.pad_w;
+		const int col0 = a.ts * tx - a.pad_w;
 #pragma unroll
 		for (int r = 0; r < 3; ++r) {
-			const int row = 4 * ty - a.pad_h + 2 * r + lhi;
+			const int row = a.ts * ty - a.pad_h + 2 * r + lhi;
 			const bool ok = tv && (unsigned)row < (unsigned)a.H;
 			const long off = (((long)n * a.C + wave) * a.H + row) * a.W + col0;
 			voff[r] = ok ? (unsigned)(off * 4) : kOOB;
@@ -553,7 +723,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 			__syncthreads();
 		}
 
-		w4_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
+		if constexpr (M == 4)
+			w4_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
+		else
+			w5_epilogue(a, acc, smem, kb, tb, tid, pbase, lane);
 	};
 
 	if constexpr (PRE) {
@@ -580,7 +753,12 @@ static void w4_dims(const pz_conv_desc *d, int which, int *prod, int *red) {
 // (36 per 16 outputs against 16 per 4), on the same layers wino_eligible admits
 int g_wino_tile = 0;      // pz_conv_winograd_tile_set
 
+// outputs per tile side of this file's kernel for a layer: 4 under 3x3 filters, 2 under 5x5 filters (same 6x6 patches, same 36
+// positions: F(2x2, 5x5) multiplies 36 times per 4 outputs where the direct sum needs 100)
+static int w4_tile(const pz_conv_desc *d) { return d->r == 5 ? 2 : 4; }
+
 bool wino4_pick(const pz_conv_desc *d, int which, int P, int Q) {
+	if (d->r == 5) return true;          // (5x5 layers have no other Winograd form: wino_eligible decides whether they come here at all)
 	const int mode = g_wino_tile;
 	if (mode == 2) return false;
 	const int OP = which == PZ_CONV_FWD ? P : d->h, OQ = which == PZ_CONV_FWD ? Q : d->w;      // produced map
@@ -603,7 +781,7 @@ bool wino4_pick(const pz_conv_desc *d, int which, int P, int Q) {
 // a second launch cost more than the vector work they take out of the main loop — the fused kernel stays.
 size_t wino4_input_bytes(const pz_conv_desc *d, int which, int P, int Q) {
 	static const long limit_mb = [] { const char *e = getenv("PUZZLE_MI355_WINO_PRE_MB"); return e ? atol(e) : 0L; }();
-	if (!wino4_pick(d, which, P, Q)) return 0;
+	if (!wino4_pick(d, which, P, Q) || d->r != 3) return 0;
 	int prod, red;
 	w4_dims(d, which, &prod, &red);
 	const int OP = which == PZ_CONV_FWD ? P : d->h, OQ = which == PZ_CONV_FWD ? Q : d->w;
@@ -618,14 +796,17 @@ size_t wino4_workspace_bytes(const pz_conv_desc *d, int which) {
 	return (size_t)ceil_div(prod, KB) * (red / BC) * kU * sizeof(float);
 }
 
-int wino4_stats_strips(const pz_conv_desc *d, int P, int Q) { return ceil_div((long)d->n * ((P + 3) / 4) * ((Q + 3) / 4), TB); }
+int wino4_stats_strips(const pz_conv_desc *d, int P, int Q) {
+	const int m = w4_tile(d);
+	return ceil_div((long)d->n * ((P + m - 1) / m) * ((Q + m - 1) / m), TB);
+}
 
 static W4FilterArgs w4_filter_args(const pz_conv_desc *d, int which, const float *w, float *u) {
 	int prod, red;
 	w4_dims(d, which, &prod, &red);
 	W4FilterArgs fa{};
 	fa.w = w, fa.u = u, fa.mode = which == PZ_CONV_FWD ? 0 : 1;
-	fa.K = d->k, fa.C = d->c, fa.prod = prod, fa.red = red;
+	fa.K = d->k, fa.C = d->c, fa.R = d->r, fa.prod = prod, fa.red = red;
 	fa.kblocks = ceil_div(prod, KB), fa.chunks = red / BC;
 	return fa;
 }
@@ -660,9 +841,10 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 	if (which == PZ_CONV_FWD) {
 		a.H = d->h, a.W = d->w, a.P = P, a.Q = Q, a.pad_h = d->pad_h, a.pad_w = d->pad_w;
 	} else {
-		a.H = P, a.W = Q, a.P = d->h, a.Q = d->w, a.pad_h = 2 - d->pad_h, a.pad_w = 2 - d->pad_w;
+		a.H = P, a.W = Q, a.P = d->h, a.Q = d->w, a.pad_h = (d->r - 1) - d->pad_h, a.pad_w = (d->s - 1) - d->pad_w;
 	}
-	a.TY = (a.P + 3) / 4, a.TX = (a.Q + 3) / 4, a.tiles = a.N * a.TY * a.TX;
+	a.ts = w4_tile(d);
+	a.TY = (a.P + a.ts - 1) / a.ts, a.TX = (a.Q + a.ts - 1) / a.ts, a.tiles = a.N * a.TY * a.TX;
 	a.chunks = fa.chunks, a.tblocks = ceil_div(a.tiles, TB), a.kblocks = fa.kblocks;
 	a.x_bytes = (unsigned)((size_t)a.N * a.C * a.H * a.W * 4);
 	a.y_bytes = (unsigned)((size_t)a.N * a.K * a.P * a.Q * 4);
@@ -673,6 +855,8 @@ int wino4_conv(const pz_conv_desc *d, int which, int P, int Q, const float *in, 
 		wino4_input_kernel<<<a.tblocks * ((a.chunks + 1) / 2), 256, 0, st>>>(a, (float *)vscratch);
 		PZ_LAUNCH_CHECK();
 		wino4_conv_kernel<true><<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
+	} else if (a.ts == 2) {
+		wino4_conv_kernel<false, 2><<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
 	} else {
 		wino4_conv_kernel<false><<<ceil_div(a.tblocks, 8) * 8 * fa.kblocks, 256, 0, st>>>(a);
 	}

@@ -360,6 +360,36 @@ def test_convolution_family_resolution_without_device():
 		assert used(stemlike, lib.CONV_BWD_DATA, lib.CONV_ALGO_IMPLICIT_GEMM) == lib.CONV_ALGO_IMPLICIT_GEMM and size.value != thin_bytes
 
 
+def test_five_by_five_filters_take_the_winograd_kernel_only_when_asked():
+	"""round 6, opt-in (PUZZLE_MI355_WINO5=1; the kernel form has not run on a device yet): NiN's 96 -> 192 5x5 layer with pad 2
+	(TestLib/CnnCifar10NIN.py:13-49) resolves to the Winograd family for forward and backward-data — F(2x2, 5x5) on the F(4x4, 3x3)
+	kernel — and stays on the implicit GEMM for the filter gradient; without the switch everything is the implicit GEMM, as before;
+	the 3 -> 192 first layer (too few input maps) and an unpadded 5x5 layer never qualify."""
+	import subprocess, sys
+	code = ("import ctypes, sys; sys.path.insert(0, %r)\n"
+			"from puzzlelib_amd import lib\n"
+			"def used(n, c, h, w, k, r, pad):\n"
+			"	d = lib.ConvDesc(n, c, h, w, k, r, r, 1, 1, pad, pad, 1, 1, 1)\n"
+			"	out = []\n"
+			"	for which in (lib.CONV_FWD, lib.CONV_BWD_DATA, lib.CONV_BWD_FILTER):\n"
+			"		a, b = ctypes.c_int(0), ctypes.c_size_t(0)\n"
+			"		lib.pz_conv2d_algo_used(ctypes.byref(d), which, lib.CONV_ALGO_AUTO, ctypes.byref(a))\n"
+			"		lib.pz_conv2d_workspace_bytes(ctypes.byref(d), which, lib.CONV_ALGO_AUTO, ctypes.byref(b))\n"
+			"		out.append((a.value, b.value > 0))\n"
+			"	return out\n"
+			"print((used(128, 96, 32, 32, 192, 5, 2), used(128, 3, 32, 32, 192, 5, 2), used(128, 96, 32, 32, 192, 5, 0), used(128, 192, 8, 8, 192, 3, 1)))\n" % ROOT)
+	outs = {}
+	for flag in ("0", "1"):
+		res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PUZZLE_MI355_WINO5=flag), capture_output=True, text=True, timeout=120)
+		assert res.returncode == 0, res.stderr[-2000:]
+		outs[flag] = eval(res.stdout.strip().splitlines()[-1])
+	W, G = 3, 5                       # Hip/Wrappers/MIOpen.py:23-49 ids: winograd, implicitGemm
+	off, on = outs["0"], outs["1"]
+	assert [a for a, _ in off[0]] == [G, G, G] and [a for a, _ in on[0]] == [W, W, G] and all(ws for _, ws in on[0])
+	assert off[1] == on[1] and off[2] == on[2] and off[3] == on[3], "only the padded 5x5 layer with >= 32 maps on both sides changes"
+	assert [a for a, _ in on[3]][:2] == [W, W]
+
+
 def test_gemm_workspace_planning_without_device():
 	"""pz_gemm_workspace_bytes is host logic: only outputs of fewer tiles than CUs are split along K (slabs of m x n floats,
 	at least 8 k-tiles per slab, one balanced round); a problem big enough for 256 x 256 tiles — which the library takes only

@@ -18,6 +18,14 @@ for i in 1 2; do
 	python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2> /dev/null | tail -1 > gpurun_out/r06_ab_default_$i.json
 	PUZZLE_MI355_DGRAD_STATS=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2> /dev/null | tail -1 > gpurun_out/r06_ab_dgradstats_$i.json
 done
+# 4. F(2x2, 5x5) on the Winograd kernel (opt-in): parity, then config 3 with and without it
+PUZZLE_MI355_WINO5=1 timeout 600 python -m pytest tests/test_gpu_0_ops.py tests/test_gpu_5_nets.py -q -k "5x5 or nin" > gpurun_out/r06_wino5_tests.txt 2>&1
+echo "wino5 tests exit $?" >> gpurun_out/r06_wino5_tests.txt
+for i in 1 2; do
+	python tools/nin_step.py 300 2> /dev/null | tail -1 > gpurun_out/r06_nin_default_$i.txt
+	PUZZLE_MI355_WINO5=1 python tools/nin_step.py 300 2> /dev/null | tail -1 > gpurun_out/r06_nin_wino5_$i.txt
+done
+tail -2 gpurun_out/r06_wino5_tests.txt; tail -n 1 gpurun_out/r06_nin_default_*.txt gpurun_out/r06_nin_wino5_*.txt
 python - <<'PY' > gpurun_out/r06_dgradstats_step_ab.txt 2>&1
 import json
 for tag in ("default", "dgradstats"):
