@@ -109,3 +109,6 @@ def test_bench_starts_its_own_ranks_and_runs_the_data_parallel_path(ranks):
 	assert out["n_gpus"] == ranks and out["config"]["global_batch"] == 2 * ranks and out["scaling"] == "weak"
 	assert out["config"]["rccl_nranks"] == ranks and "comm" in out["config"] and "tolerance" in out
 	assert out["config"]["grad_allreduce"].startswith("RCCL")
+	# the N = 1 point of the same run: rank 0 alone, before the N-rank loop
+	assert out["single_gpu_same_run"]["steps"] == 2 and out["single_gpu_same_run"]["unit"] == "images/sec"
+	assert all("frac" in fam for fam in out["conv_kernel_families"])
