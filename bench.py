@@ -110,22 +110,37 @@ def cpu_baseline(sample_batch=32):
 
 def spawnRanks(args):
 	"""`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) and relay rank 0's line."""
-	import socket
-	# two free ports, both reserved at the same time: MASTER_PORT (kept for whoever reads it) and the host group's own
-	# (grid.nodeFromEnv would otherwise assume MASTER_PORT + 1 is free)
-	with socket.socket() as s, socket.socket() as t:
+	import socket, tempfile
+	# MASTER_PORT is kept for whoever reads it (nothing here does); the host group's own port is bound by rank 0 (the system picks
+	# it) and published through a file, so no port is chosen before somebody holds it (grid.FilePortCell)
+	with socket.socket() as s:
 		s.bind(("127.0.0.1", 0))
-		t.bind(("127.0.0.1", 0))
-		port, hostPort = s.getsockname()[1], t.getsockname()[1]
+		port = s.getsockname()[1]
+	scratch = tempfile.mkdtemp(prefix="puzzle_bench_")
 
 	procs = []
 	for rank in range(args.gpus):
 		env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-				   MASTER_PORT=str(port), PUZZLE_MI355_PORT=str(hostPort),
+				   MASTER_PORT=str(port), PUZZLE_MI355_PORT_FILE=os.path.join(scratch, "hostgroup.port"),
 				   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
 		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-	codes = [p.wait() for p in procs]
-	sys.exit(max(codes))
+	# a rank that dies leaves the others waiting in the host group or inside a collective: stop them, report its status
+	import time
+	codes = [None] * len(procs)
+	while any(c is None for c in codes):
+		for i, p in enumerate(procs):
+			if codes[i] is None:
+				codes[i] = p.poll()
+		if any(c not in (None, 0) for c in codes):
+			for i, p in enumerate(procs):
+				if codes[i] is None:
+					p.terminate()
+					codes[i] = p.wait()
+			break
+		time.sleep(0.05)
+	import shutil
+	shutil.rmtree(scratch, ignore_errors=True)
+	sys.exit(max(abs(c) for c in codes))
 
 
 def convLayers(net):

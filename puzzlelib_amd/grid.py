@@ -1027,9 +1027,34 @@ def nodeFromEnv(bucketBytes=25 << 20):
 	# refuses two ranks on one device unless it is built/configured to allow it)
 	local = int(os.environ.get("PUZZLE_MI355_DEVICE", local))
 
-	# MASTER_PORT itself belongs to the launcher's rendezvous store; the host group takes the next port unless told otherwise
+	# MASTER_PORT itself belongs to the launcher's rendezvous store; the host group takes the next port unless told otherwise.
+	# PUZZLE_MI355_PORT_FILE (bench.py's own launcher): rank 0 binds a port the system picks and writes it there, the others read
+	# it — no port is chosen before somebody holds it
+	portFile = os.environ.get("PUZZLE_MI355_PORT_FILE")
 	port = int(os.environ.get("PUZZLE_MI355_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
-	return connectNode(rank, world, local, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, bucketBytes)
+	return connectNode(rank, world, local, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, bucketBytes,
+					   portCell=None if portFile is None else FilePortCell(portFile))
+
+
+class FilePortCell:
+	"""the `portCell` of connectNode for ranks that share nothing but the file system: .value reads / writes the port in a file"""
+
+	def __init__(self, path):
+		self.path = path
+
+	@property
+	def value(self):
+		try:
+			return int(open(self.path).read().strip() or 0)
+		except (OSError, ValueError):
+			return 0
+
+	@value.setter
+	def value(self, port):
+		tmp = "%s.%d" % (self.path, os.getpid())
+		with open(tmp, "w") as f:
+			f.write(str(int(port)))
+		os.replace(tmp, self.path)
 
 
 def connectNode(rank, world, device, addr, port, bucketBytes=25 << 20, portCell=None):
