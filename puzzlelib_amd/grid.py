@@ -814,10 +814,12 @@ class ArenaWatcher:
 		self.listening = on
 
 	def onIssue(self, name, args):
-		if self.busy:
+		if self.busy or name.startswith("pz_comm_"):  # (the exchange's own calls carry the arena's base address, not a gradient write)
 			return
 		import ctypes
 		base, end = self.base, self.base + self.end
+		if name == "pz_memset_d32" and args[0] == base and int(args[2]) * 4 >= self.end:
+			return                                    # the step's deferred zero fill, run by the first write barrier: not the write itself
 		for arg in args:
 			if type(arg) is int:
 				if base <= arg < end:
